@@ -1,0 +1,160 @@
+/*
+ * speck_c_api.h -- C-ABI boundary of the MI355X-native SpGEMM backend
+ * (libspeck_amd.so).  Plain pointers and sizes only; every pointer inside a
+ * speck_dcsr is a DEVICE pointer (HIP), exactly as in the reference's dCSR<T>.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the upstream GPUPeople/spECK tree).
+ */
+#ifndef SPECK_C_API_H
+#define SPECK_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (the reference printf()s and returns; include/common.h:19-33,
+ *      source/GPU/Multiply.cu:57-97 -- a C ABI reports instead) ---- */
+enum {
+    SPECK_OK = 0,
+    SPECK_ERR_INVALID = 1,        /* null pointers / inconsistent sizes */
+    SPECK_ERR_DIM_LIMIT = 2,      /* rows(A) or cols(B) > 2^27, source/GPU/Multiply.cu:57-66 */
+    SPECK_ERR_HIP = 3,            /* a HIP runtime call failed */
+    SPECK_ERR_OOM = 4,            /* device allocation failed, source/GPU/Multiply.cu:594-599 */
+    SPECK_ERR_NNZ_OVERFLOW = 5,   /* nnz(C) does not fit the u32 row_offsets of dCSR */
+    SPECK_ERR_NO_DEVICE = 6,
+    SPECK_ERR_IO = 7
+};
+
+/* ---- device CSR: field-for-field the reference's dCSR<T> / dCSRNoDealloc<T>
+ *      (include/dCSR.h:9-35): rows, cols, nnz, data, row_offsets, col_ids.
+ *      row_offsets has rows+1 entries; they may be ABSOLUTE offsets into
+ *      col_ids/data of a larger matrix (a row-range view used for sharding). ---- */
+typedef struct speck_dcsr {
+    uint64_t rows, cols, nnz;
+    void *data;             /* double* or float*  (device) */
+    uint32_t *row_offsets;  /* device */
+    uint32_t *col_ids;      /* device */
+} speck_dcsr;
+
+/* ---- per-stage timings: the reference's Timings (include/Timings.h:4-18),
+ *      milliseconds, same field names/order ---- */
+typedef struct speck_timings {
+    int32_t measureAll;
+    int32_t measureCompleteTime;
+    float init, countProducts, loadBalanceCounting, globalMapsCounting, spGEMMCounting, allocC,
+        loadBalanceNumeric, globalMapsNumeric, spGEMMNumeric, sorting, cleanup, complete;
+} speck_timings;
+
+/* ---- what the last multiply did (drives bench.py's roofline object) ---- */
+#define SPECK_NUM_SYM_BINS 6
+#define SPECK_NUM_NUM_BINS 8
+typedef struct speck_stats {
+    uint64_t sum_products;                       /* P, u64 (reference: u32, Multiply.cu:237) */
+    uint64_t nnz_c;
+    uint32_t max_row_ops;                        /* maxComputationsPerRow, Multiply.cu:252 */
+    uint32_t max_row_nnz_c;                      /* maxElementsPerRow, Multiply.cu:615 */
+    uint32_t sym_bin_rows[SPECK_NUM_SYM_BINS];   /* rows per symbolic kernel class */
+    uint32_t num_bin_rows[SPECK_NUM_NUM_BINS];   /* rows per numeric kernel class */
+    uint64_t num_bin_bytes[SPECK_NUM_NUM_BINS];  /* algorithmic bytes per numeric class */
+    uint64_t sym_bin_bytes[SPECK_NUM_SYM_BINS];
+    float num_bin_ms[SPECK_NUM_NUM_BINS];        /* HIP-event ms of each numeric kernel launch */
+    float sym_bin_ms[SPECK_NUM_SYM_BINS];
+    float analysis_ms, scan_ms;
+    int32_t kernel_events_valid;                 /* 1 if *_ms were recorded for the last call */
+    int32_t numeric_reruns;                      /* optimistic-capacity misses */
+} speck_stats;
+
+typedef struct speck_config speck_config; /* opaque; reference: spECKConfig, include/spECKConfig.h:8-53 */
+
+/* spECKConfig::initialize(device) -- include/spECKConfig.h:15-32: queries the
+ * device (CU count, LDS limits), creates 6 streams and 4 events, and (new) a
+ * grow-only scratch arena reused across calls. */
+int speck_config_create(int device, speck_config **out);
+/* spECKConfig::cleanup() -- include/spECKConfig.h:34-43 */
+int speck_config_destroy(speck_config *cfg);
+/* spECKConfig::{sm,maxStaticSharedMemoryPerBlock,maxDynamicSharedMemoryPerBlock} */
+int speck_config_info(const speck_config *cfg, int *sm, int *max_static_lds, int *max_dynamic_lds);
+/* Run the pipeline on a caller-owned stream (e.g. torch's current stream); NULL restores streams[0]. */
+int speck_config_set_stream(speck_config *cfg, void *hip_stream);
+/* Tunables (thresholds the reference hard-codes in Multiply.cu:128-131,321-324); name -> value. */
+int speck_config_set_option(speck_config *cfg, const char *name, int64_t value);
+/* Record HIP events around every kernel of the next calls (fills speck_stats.*_ms). */
+int speck_config_profile_kernels(speck_config *cfg, int enable);
+int speck_last_stats(const speck_config *cfg, speck_stats *out);
+
+/* spECK::MultiplyspECK<double,...>(A, B, matOut, config, timings) --
+ * include/Multiply.h:15-16, source/GPU/Multiply.cu:51-1128.
+ * Ownership as in the reference: A,B caller-owned, read-only; C is
+ * allocated by the callee and freed by the caller (speck_dcsr_free); if
+ * C->rows == A->rows and C->row_offsets != NULL that buffer is reused; data/col_ids are
+ * re-allocated only when C->nnz != nnz(C).  On error C is left untouched. */
+int speck_multiply_f64(speck_config *cfg, const speck_dcsr *A, const speck_dcsr *B, speck_dcsr *C,
+                       speck_timings *timings);
+/* the <float,...> instantiation, source/GPU/Multiply.cu:1130 */
+int speck_multiply_f32(speck_config *cfg, const speck_dcsr *A, const speck_dcsr *B, speck_dcsr *C,
+                       speck_timings *timings);
+
+/* ---- staged entry points (each a prefix of the pipeline; used by the parity
+ *      tests and by the row-shard partitioner) ---- */
+/* readOperations -- include/common.cuh:321-459, launch source/GPU/Multiply.cu:239-252.
+ * d_* are device arrays of A->rows u32 (any may be NULL); h_* are host scalars. */
+int speck_analysis(speck_config *cfg, const speck_dcsr *A, const speck_dcsr *B, uint32_t *d_row_ops,
+                   uint32_t *d_row_max_ops, uint32_t *d_row_col_min, uint32_t *d_row_col_max,
+                   uint64_t *h_sum_products, uint32_t *h_max_row_ops);
+/* analysis + binning + symbolic + scan (source/GPU/Multiply.cu:239-575):
+ * d_row_offsets (A->rows+1 u32, device) receives C's row offsets; *h_nnz_c = nnz(C). */
+int speck_symbolic(speck_config *cfg, const speck_dcsr *A, const speck_dcsr *B,
+                   uint32_t *d_row_offsets, uint64_t *h_nnz_c);
+/* Row-shard boundaries with equal sum of per-row products:
+ * h_bounds[parts+1], h_bounds[0]=0, h_bounds[parts]=A->rows. */
+int speck_partition_rows(speck_config *cfg, const speck_dcsr *A, const speck_dcsr *B, int parts,
+                         uint64_t *h_bounds);
+
+/* ---- dCSR memory helpers: dCSR<T>::alloc / reset / convert(),
+ *      include/dCSR.h:19-47, source/dCSR.cpp:25-115 ---- */
+int speck_dcsr_alloc(speck_dcsr *m, uint64_t rows, uint64_t cols, uint64_t nnz, int alloc_offsets,
+                     size_t value_size);
+int speck_dcsr_free(speck_dcsr *m);
+int speck_dcsr_upload(speck_dcsr *dst, uint64_t rows, uint64_t cols, uint64_t nnz,
+                      const uint32_t *h_row_offsets, const uint32_t *h_col_ids, const void *h_data,
+                      size_t value_size);
+int speck_dcsr_download(const speck_dcsr *src, uint32_t *h_row_offsets, uint32_t *h_col_ids,
+                        void *h_data, size_t value_size);
+/* spECK::Compare(ref, cmp, compare_data) -- include/Compare.h:5-6, source/GPU/Compare.cu:11-82;
+ * stricter: offsets + col ids bit-exact; values |x-y| <= rel_tol*max(|x|,|y|) when compare_data.
+ * *h_mismatches = number of differing rows (0 = equal). */
+int speck_compare_f64(speck_config *cfg, const speck_dcsr *ref, const speck_dcsr *cmp,
+                      int compare_data, double rel_tol, uint64_t *h_mismatches);
+/* Order-preserving transpose (source/GPU/Transpose.cu:10-117; DataLoader.cpp:65-69 for rows!=cols). */
+int speck_transpose_f64(speck_config *cfg, const speck_dcsr *A, speck_dcsr *At);
+
+/* ---- host-side synthetic inputs and on-disk formats ---- */
+typedef struct speck_host_csr speck_host_csr; /* opaque host CSR<double>, include/CSR.h */
+/* kind: "uniform" (config #1), "scircuit", "webbase", "mac_econ", "cant", "nlpkkt";
+ * scale multiplies the row count (1.0 = the SuiteSparse dimensions). */
+int speck_gen_matrix(const char *kind, double scale, uint64_t seed, int signed_values,
+                     speck_host_csr **out);
+/* loadMTX + convert(COO->CSR) -- source/COO.cpp:53-164, source/CSR.cpp:173-212 */
+int speck_load_mtx(const char *path, speck_host_csr **out);
+/* loadCSR / storeCSR (.hicsr) -- source/CSR.cpp:88-137 */
+int speck_load_hicsr(const char *path, speck_host_csr **out);
+int speck_store_hicsr(const speck_host_csr *m, const char *path);
+/* DataLoader: "<path>d_.hicsr" cache, else .mtx then write cache -- source/DataLoader.cpp:24-58 */
+int speck_load_matrix(const char *path, int write_cache, speck_host_csr **out);
+int speck_host_csr_dims(const speck_host_csr *m, uint64_t *rows, uint64_t *cols, uint64_t *nnz);
+int speck_host_csr_copy(const speck_host_csr *m, uint32_t *row_offsets, uint32_t *col_ids, double *data);
+int speck_host_csr_from_arrays(uint64_t rows, uint64_t cols, uint64_t nnz, const uint32_t *row_offsets,
+                               const uint32_t *col_ids, const double *data, speck_host_csr **out);
+int speck_host_csr_free(speck_host_csr *m);
+
+const char *speck_status_string(int status);
+const char *speck_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,83 @@
+"""Row-sharded SpGEMM across the GPUs of one node (new functionality; the reference is
+single-GPU -- SURVEY.md 8e).
+
+Rows of C are independent: rank p multiplies the contiguous row range [b_p, b_{p+1}) of A
+(balanced by the analysis pass' per-row product counts) with a replicated B, then ONE
+exchange step concatenates the shards: an all_gather of the shard sizes followed by a
+gatherv of col_ids / data / per-row nnz to the root.  RCCL has no gatherv
+(rccl.h: ncclGather/ncclAllGather are equal-count), so it is a batch of point-to-point
+send/recv -- each peer->root transfer rides exactly one xGMI link.
+
+Works with any torch.distributed backend ("nccl" == RCCL on ROCm, "gloo" on CPU for tests).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def balanced_bounds(row_ops, parts):
+    """Contiguous row ranges with ~equal sum(row_ops + 1). Same rule as speck_partition_rows."""
+    m = len(row_ops)
+    cost = np.asarray(row_ops, dtype=np.uint64) + np.uint64(1)
+    total = int(cost.sum())
+    run = np.cumsum(cost, dtype=np.uint64)
+    bounds = [0]
+    for p in range(1, parts):
+        # first row count i such that run[i-1] * parts >= total * p
+        target = -(-total * p // parts)
+        i = int(np.searchsorted(run, target, side="left")) + 1
+        bounds.append(min(max(i, bounds[-1]), m))
+    bounds.append(m)
+    return bounds
+
+
+def gatherv_csr(row_nnz, col_ids, data, root=0, group=None):
+    """Concatenate per-rank CSR shards on `root`.
+
+    row_nnz : int64/uint32 tensor [rows_p]   nnz of each local C row
+    col_ids : int32 tensor [nnz_p] (u32 bit pattern), data : float tensor [nnz_p]
+    Returns (row_offsets[int64, rows+1], col_ids, data) on root, None elsewhere.
+    """
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    dev = col_ids.device
+    sizes = torch.tensor([row_nnz.numel(), col_ids.numel()], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = torch.stack(all_sizes).cpu().numpy()
+    rows_p, nnz_p = all_sizes[:, 0], all_sizes[:, 1]
+    row_nnz = row_nnz.to(torch.int32).contiguous()
+
+    if rank != root:
+        ops = []
+        for t in (row_nnz, col_ids, data):
+            if t.numel():
+                ops.append(dist.P2POp(dist.isend, t, root, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return None
+
+    total_rows, total_nnz = int(rows_p.sum()), int(nnz_p.sum())
+    out_cnt = torch.empty(total_rows, dtype=torch.int32, device=dev)
+    out_col = torch.empty(total_nnz, dtype=col_ids.dtype, device=dev)
+    out_val = torch.empty(total_nnz, dtype=data.dtype, device=dev)
+    r_off = np.concatenate([[0], np.cumsum(rows_p)])
+    n_off = np.concatenate([[0], np.cumsum(nnz_p)])
+    ops = []
+    for p in range(world):
+        rs, ns = slice(int(r_off[p]), int(r_off[p + 1])), slice(int(n_off[p]), int(n_off[p + 1]))
+        if p == root:
+            out_cnt[rs] = row_nnz
+            out_col[ns] = col_ids
+            out_val[ns] = data
+            continue
+        for dst, sl in ((out_cnt, rs), (out_col, ns), (out_val, ns)):
+            if sl.stop > sl.start:
+                ops.append(dist.P2POp(dist.irecv, dst[sl], p, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    row_offsets = torch.zeros(total_rows + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(out_cnt.to(torch.int64), 0, out=row_offsets[1:])
+    return row_offsets, out_col, out_val

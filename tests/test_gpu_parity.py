@@ -1,0 +1,311 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Bar: row_offsets and col_ids bit-exact; fp64 values within 1e-12 relative -- stated
+rigorously as |c - c_ref| <= 1e-12 * sum|a*b| per entry (any summation order satisfies
+it; the plain relative form is asserted too wherever no cancellation is possible).
+"""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import speck_amd as sa
+from speck_amd import _lib
+from conftest import csr_from_dense, random_csr
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL64 = 1e-12
+TOL32 = 2e-5
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    c = sa.spECKConfig.initialize(0)
+    yield c
+    c.cleanup()
+
+
+def to_sa(h):
+    return sa.HostCSR(h.rows, h.cols, h.row_offsets, h.col_ids, h.data)
+
+
+def fast_random_csr(rows, cols, k, seed, signed=True, jitter=True):
+    """Vectorised random CSR: ~k distinct sorted columns per row."""
+    rng = np.random.default_rng(seed)
+    kk = rng.integers(max(1, k // 2), k + 1, size=rows) if jitter else np.full(rows, k)
+    c = np.sort(rng.integers(0, cols, size=(rows, k), dtype=np.int64), axis=1)
+    keep = np.ones((rows, k), dtype=bool)
+    keep[:, 1:] = c[:, 1:] != c[:, :-1]
+    keep &= np.arange(k)[None, :] < kk[:, None]
+    cnt = keep.sum(axis=1)
+    ro = np.zeros(rows + 1, dtype=np.uint32)
+    ro[1:] = np.cumsum(cnt)
+    ci = c[keep].astype(np.uint32)
+    v = 0.5 + rng.random(ci.size)
+    if signed:
+        v *= rng.choice([-1.0, 1.0], size=ci.size)
+    return po.HostCSR(rows, cols, ro, ci, v)
+
+
+def check(cfg, A, B, expect_classes=None, tol=TOL64, C_reuse=None):
+    dA, dB = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B))
+    dC = C_reuse if C_reuse is not None else sa.dCSR(A.data.dtype)
+    sa.MultiplyspECK(dA, dB, dC, cfg)
+    st = cfg.last_stats()
+    R, ab = po.spgemm(A, B)
+    got = dC.to_host()
+    assert got.rows == R.rows and got.cols == R.cols and got.nnz == R.nnz
+    assert (got.row_offsets == R.row_offsets).all(), "row_offsets differ"
+    assert (got.col_ids == R.col_ids).all(), "col_ids differ"
+    err = np.abs(got.data.astype(np.float64) - R.data.astype(np.float64))
+    bound = tol * ab.astype(np.float64) + 1e-300
+    assert (err <= bound).all(), f"max err/bound {np.max(err / bound)}"
+    assert st["nnz_c"] == R.nnz
+    if expect_classes:
+        for kind, name in expect_classes:
+            rows = st["sym_bin_rows" if kind == "sym" else "num_bin_rows"][name]
+            assert rows > 0, f"case did not exercise {kind}:{name}: {st}"
+    return dC, st, R
+
+
+def test_smoke_entry_runs():
+    import __graft_entry__ as g
+    g.smoke()
+
+
+def test_loaded_library_is_the_in_tree_hip_build():
+    maps = open("/proc/self/maps").read()
+    assert _lib.LIB_PATH in maps
+
+
+def test_tiny_cases(cfg):
+    for case in json.load(open(os.path.join(G, "tiny_cases.json"))):
+        A, B = csr_from_dense(case["a"]), csr_from_dense(case["b"])
+        dC, _, R = check(cfg, A, B)
+        pat = np.array(case["pattern"])
+        assert dC.nnz == int(pat.sum()), case["name"]
+
+
+def test_golden_synth10k(cfg):
+    g = json.load(open(os.path.join(G, "synth10k.json")))
+    A = po.gen_uniform(g["n"], g["seed"])
+    dC, st, R = check(cfg, A, A)
+    got = dC.to_host()
+    assert st["sum_products"] == g["P"] and dC.nnz == g["nnzC"]
+    assert hashlib.sha256(got.col_ids.tobytes()).hexdigest()[:16] == g["sha_c_col_ids"]
+    assert hashlib.sha256(got.row_offsets.tobytes()).hexdigest()[:16] == g["sha_c_row_offsets"]
+    # positive values: no cancellation, plain relative tolerance holds
+    assert np.max(np.abs(got.data - R.data) / np.abs(R.data)) <= TOL64
+    assert st["max_row_nnz_c"] == g["max_row_nnzC"] and st["max_row_ops"] == g["max_row_ops"]
+
+
+def test_early_outs(cfg):
+    # nnzA * nnzB == 0 -> matOut.nnz = 0, nothing allocated (Multiply.cu:67-70)
+    A = po.HostCSR(3, 3, np.zeros(4, np.uint32), np.zeros(0, np.uint32), np.zeros(0))
+    B = random_csr(3, 3, 2, 1)
+    dC = sa.dCSR()
+    sa.MultiplyspECK(sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), dC, cfg)
+    assert dC.nnz == 0
+    # P == 0 with nnz > 0: every referenced B row is empty (Multiply.cu:256-261)
+    A = csr_from_dense([[1, 0, 0], [1, 0, 0]])
+    B = csr_from_dense([[0, 0], [0, 0], [1, 1]])
+    dC = sa.dCSR()
+    sa.MultiplyspECK(sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), dC, cfg)
+    assert dC.nnz == 0 and dC.rows == 2 and dC.cols == 2
+
+
+def test_dimension_limit_and_invalid(cfg):
+    L = _lib.load()
+    A, B, C_ = _lib.DCsr(), _lib.DCsr(), _lib.DCsr()
+    A.rows, A.cols, A.nnz = (1 << 27) + 1, 4, 1
+    B.rows, B.cols, B.nnz = 4, 4, 1
+    assert L.speck_multiply_f64(cfg._h, ctypes.byref(A), ctypes.byref(B), ctypes.byref(C_), None) == 2
+    A.rows, B.cols = 4, (1 << 27) + 1
+    assert L.speck_multiply_f64(cfg._h, ctypes.byref(A), ctypes.byref(B), ctypes.byref(C_), None) == 2
+    B.cols, A.cols = 4, 5   # inner dimensions disagree
+    assert L.speck_multiply_f64(cfg._h, ctypes.byref(A), ctypes.byref(B), ctypes.byref(C_), None) == 1
+    assert C_.nnz == 0 and not C_.data          # C untouched on error
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_small_rows_wave_and_direct(cfg, seed):
+    A = random_csr(700, 500, 3, seed, empty_row_frac=0.15)
+    B = random_csr(500, 600, 4, seed + 50, empty_row_frac=0.15)
+    check(cfg, A, B, [("sym", "wave"), ("num", "wave"), ("num", "direct")])
+
+
+def test_hash_classes_h1_h2(cfg):
+    A = fast_random_csr(600, 4000, 20, 1)
+    B = fast_random_csr(4000, 30000, 30, 2)
+    check(cfg, A, B, [("sym", "hash1k"), ("num", "hash512"), ("num", "hash2k")])
+
+
+def test_hash_classes_h2_h3(cfg):
+    A = fast_random_csr(200, 6000, 64, 3)
+    B = fast_random_csr(6000, 300000, 64, 4)
+    # range ~300k columns: H3 needs three 128Ki-column sort windows
+    check(cfg, A, B, [("sym", "hash8k"), ("num", "hash8k")])
+
+
+def test_symbolic_h3_and_dense_multiwindow(cfg):
+    A = fast_random_csr(48, 5000, 150, 5, jitter=False)
+    B = fast_random_csr(5000, 2000000, 150, 6, jitter=False)
+    cfg.set_option("sym_bitmap_ratio", 0)      # keep the bitmap out: exercise the 128 KiB hash set
+    try:
+        check(cfg, A, B, [("sym", "hash32k"), ("num", "dense16k")])
+    finally:
+        cfg.set_option("sym_bitmap_ratio", 32)
+
+
+def test_symbolic_bitmap_multiwindow_heavy_rows(cfg):
+    # ops > 26214 per row and 2.5M columns: three 1Mi-column bitmap windows
+    A = fast_random_csr(24, 4000, 300, 7, jitter=False)
+    B = fast_random_csr(4000, 2500000, 110, 8, jitter=False)
+    check(cfg, A, B, [("sym", "bitmap1m"), ("num", "dense16k")])
+
+
+def test_banded_dense_and_bitmap_classes(cfg):
+    A = to_po(sa.gen_matrix("cant", 0.05, 3, signed=True))
+    _, st, _ = check(cfg, A, A, [("sym", "bitmap256k"), ("num", "dense4k")])
+    cfg.set_option("num_dense_ratio", 0)       # same input through the hash + rank-sort kernel
+    try:
+        check(cfg, A, A, [("num", "hash512")])
+    finally:
+        cfg.set_option("num_dense_ratio", 16)
+
+
+def to_po(m):
+    return po.HostCSR(m.rows, m.cols, m.row_offsets, m.col_ids, m.data)
+
+
+def test_exact_cancellation_is_structural(cfg):
+    # every product pair cancels: values 0.0, entries kept
+    a = np.zeros((40, 40))
+    b = np.zeros((40, 40))
+    for i in range(40):
+        a[i, i] = 1.0
+        a[i, (i + 1) % 40] = 1.0
+        b[i, (i * 7) % 40] = 2.0 if i % 2 == 0 else -2.0
+        b[i, (i * 7 + 3) % 40] = 1.0
+    for i in range(0, 40, 2):
+        b[(i + 1) % 40, (i * 7) % 40] = -2.0
+    check(cfg, csr_from_dense(a), csr_from_dense(b))
+
+
+def test_matout_reuse_rules(cfg):
+    A = fast_random_csr(500, 500, 8, 11)
+    dA = sa.dCSR.from_host(to_sa(A))
+    dC = sa.dCSR()
+    sa.MultiplyspECK(dA, dA, dC, cfg)
+    p = (dC._c.row_offsets, dC._c.col_ids, dC._c.data)
+    sa.MultiplyspECK(dA, dA, dC, cfg)          # same nnz: all three buffers are reused
+    assert (dC._c.row_offsets, dC._c.col_ids, dC._c.data) == p
+    first = dC.to_host()
+    B = fast_random_csr(500, 500, 5, 12)       # different nnz(C): data/col_ids re-allocated
+    check(cfg, A, B, C_reuse=dC)
+    check(cfg, A, A, C_reuse=dC)
+    again = dC.to_host()
+    assert (again.col_ids == first.col_ids).all()
+    A2 = fast_random_csr(300, 500, 5, 13)      # different row count: new row_offsets
+    check(cfg, A2, A, C_reuse=dC)
+
+
+def test_row_shards_concatenate(cfg):
+    A = to_po(sa.gen_matrix("scircuit", 0.05, 5, signed=True))
+    dA = sa.dCSR.from_host(to_sa(A))
+    dC = sa.dCSR()
+    sa.MultiplyspECK(dA, dA, dC, cfg)
+    full = dC.to_host()
+    bounds = sa.partition_rows(dA, dA, cfg, 4)
+    assert bounds[0] == 0 and bounds[-1] == A.rows and bounds == sorted(bounds)
+    an = po.analysis(A, A)
+    from speck_amd.sharding import balanced_bounds
+    assert bounds == balanced_bounds(an["row_ops"], 4)
+    cols, cnts, vals = [], [], []
+    for p in range(4):
+        dS = sa.dCSR()
+        sa.MultiplyspECK(dA.row_view(bounds[p], bounds[p + 1]), dA, dS, cfg)
+        s = dS.to_host()
+        cols.append(s.col_ids)
+        vals.append(s.data)
+        cnts.append(np.diff(s.row_offsets.astype(np.int64)))
+    assert (np.concatenate(cols) == full.col_ids).all()
+    assert (np.concatenate(cnts) == np.diff(full.row_offsets.astype(np.int64))).all()
+    R, ab = po.spgemm(A, A)
+    assert (np.abs(np.concatenate(vals) - R.data) <= TOL64 * ab + 1e-300).all()
+
+
+def test_stage_entry_points(cfg):
+    A = random_csr(900, 700, 5, 21, empty_row_frac=0.1)
+    B = random_csr(700, 800, 6, 22, empty_row_frac=0.1)
+    dA, dB = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B))
+    got, ref = sa.analysis(dA, dB, cfg), po.analysis(A, B)
+    for k in ("row_ops", "row_max_ops", "row_col_min", "row_col_max"):
+        assert (got[k] == ref[k]).all(), k
+    assert got["sum_products"] == ref["sum_products"] and got["max_row_ops"] == ref["max_row_ops"]
+    ro, nnz = sa.symbolic(dA, dB, cfg)
+    cnt, total = po.symbolic(A, B)
+    po.lib().orc_exclusive_scan(cnt, A.rows)
+    assert nnz == total and (ro == cnt).all()
+
+
+def test_float32_instantiation(cfg):
+    A = fast_random_csr(400, 3000, 12, 31)
+    B = fast_random_csr(3000, 5000, 20, 32)
+    A32 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float32))
+    B32 = po.HostCSR(B.rows, B.cols, B.row_offsets, B.col_ids, B.data.astype(np.float32))
+    check(cfg, A32, B32, tol=TOL32)
+
+
+def test_repeated_runs_give_identical_structure(cfg):
+    A = to_po(sa.gen_matrix("webbase", 0.02, 9, signed=True))
+    dA = sa.dCSR.from_host(to_sa(A))
+    outs = []
+    for _ in range(3):
+        dC = sa.dCSR()
+        sa.MultiplyspECK(dA, dA, dC, cfg)
+        outs.append(dC.to_host())
+    for o in outs[1:]:
+        assert (o.row_offsets == outs[0].row_offsets).all() and (o.col_ids == outs[0].col_ids).all()
+        assert np.allclose(o.data, outs[0].data, rtol=1e-9, atol=1e-9)
+
+
+def test_compare_and_transpose(cfg):
+    A = random_csr(300, 450, 6, 41)
+    dA = sa.dCSR.from_host(to_sa(A))
+    dT = sa.transpose(dA, cfg)
+    T = dT.to_host()
+    R = po.transpose(A)
+    assert (T.row_offsets == R.row_offsets).all() and (T.col_ids == R.col_ids).all()
+    assert (T.data == R.data).all()
+    dC1, dC2 = sa.dCSR(), sa.dCSR()
+    sa.MultiplyspECK(dA, dT, dC1, cfg)
+    sa.MultiplyspECK(dA, dT, dC2, cfg)
+    assert sa.compare(dC1, dC2, cfg, compare_data=True, rel_tol=1e-9)
+    A2 = random_csr(300, 450, 6, 42)
+    dC3 = sa.dCSR()
+    sa.MultiplyspECK(sa.dCSR.from_host(to_sa(A2)), dT, dC3, cfg)
+    assert not sa.compare(dC1, dC3, cfg)
+    check(cfg, A, R)
+
+
+@pytest.mark.parametrize("kind,scale", [("scircuit", 1.0), ("mac_econ", 1.0), ("cant", 0.25),
+                                        ("webbase", 0.1), ("nlpkkt", 0.002)])
+def test_suitesparse_standins_full_parity(cfg, kind, scale):
+    A = to_po(sa.gen_matrix(kind, scale, 1, signed=True))
+    dC, st, R = check(cfg, A, A)
+    # size-independent properties: sorted rows, row-sum identity (C*1 == A*(A*1))
+    ones = np.ones(A.cols)
+    S = A.to_scipy()
+    lhs = dC.to_host()
+    csum = np.add.reduceat(np.concatenate([lhs.data, [0.0]]),
+                           np.minimum(lhs.row_offsets[:-1], lhs.nnz).astype(np.int64))
+    csum[np.diff(lhs.row_offsets.astype(np.int64)) == 0] = 0.0
+    ref = S @ (S @ ones)
+    scale_ = np.abs(S) @ (np.abs(S) @ ones) + 1e-300
+    assert np.max(np.abs(csum - ref) / scale_) < 1e-11

@@ -1,0 +1,116 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the header
+declares, its generators and on-disk formats match the oracle / the reference's own code.
+No compute entry point is called here (there is no GPU in the build container)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import speck_amd
+from speck_amd import _lib
+from oracle import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "speck_c_api.h")).read()
+    declared = set(re.findall(r"\b(speck_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.declared_symbols())
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in _lib.load().speck_version()
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.DCsr) == 48                   # 3 x u64 + 3 pointers
+    assert ctypes.sizeof(_lib.CTimings) == 8 + 12 * 4       # 2 flags + 12 floats
+    assert _lib.load().speck_status_string(2).decode().startswith("matrix dimension")
+
+
+def test_missing_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(speck_amd.SpeckError):
+        speck_amd.spECKConfig.initialize(0)
+
+
+def test_uniform_generator_is_config1():
+    g = json.load(open(os.path.join(G, "synth10k.json")))
+    A = speck_amd.gen_matrix("uniform", 1.0, 42)
+    O = po.gen_uniform(10000, 42)
+    assert A.nnz == g["nnzA"]
+    assert (A.row_offsets == O.row_offsets).all() and (A.col_ids == O.col_ids).all()
+    assert (A.data == O.data).all()
+
+
+@pytest.mark.parametrize("kind,scale", [("scircuit", 0.05), ("webbase", 0.01), ("mac_econ", 0.05),
+                                        ("cant", 0.05), ("nlpkkt", 0.0005)])
+def test_standins_are_valid_sorted_csr(kind, scale):
+    A = speck_amd.gen_matrix(kind, scale, 7, signed=True)
+    B = speck_amd.gen_matrix(kind, scale, 7, signed=True)
+    assert (A.col_ids == B.col_ids).all() and (A.data == B.data).all()  # deterministic
+    assert A.rows == A.cols and A.row_offsets[0] == 0 and A.row_offsets[-1] == len(A.col_ids)
+    for r in range(A.rows):
+        c = A.col_ids[A.row_offsets[r]:A.row_offsets[r + 1]].astype(np.int64)
+        assert (np.diff(c) > 0).all() and (len(c) == 0 or c[-1] < A.cols)
+    assert (np.abs(A.data) >= 0.5).all() and (np.abs(A.data) < 1.5).all() and (A.data < 0).any()
+
+
+def test_mtx_reader_matches_reference_loader():
+    meta = json.load(open(os.path.join(G, "formats.json")))
+    for name, m in meta.items():
+        A = speck_amd.load_mtx(os.path.join(G, "formats", name))
+        assert (A.rows, A.cols, A.nnz) == (m["rows"], m["cols"], m["nnz"]), name
+        assert list(A.row_offsets) == m["row_offsets"], name
+        assert list(A.col_ids) == m["col_ids"], name
+        assert list(A.data) == m["data"], name
+
+
+def test_hicsr_reads_reference_bytes_and_roundtrips(tmp_path):
+    meta = json.load(open(os.path.join(G, "formats.json")))
+    for name, m in meta.items():
+        ref_file = os.path.join(G, "formats", m["hicsr"])
+        A = speck_amd.load_hicsr(ref_file)
+        assert list(A.row_offsets) == m["row_offsets"] and list(A.col_ids) == m["col_ids"]
+        assert list(A.data) == m["data"]
+        out = tmp_path / (name + ".hicsr")
+        speck_amd.store_hicsr(A, out)
+        ours, theirs = open(out, "rb").read(), open(ref_file, "rb").read()
+        assert len(ours) == len(theirs) == 96 + 12 * m["nnz"] + 4 * (m["rows"] + 1)
+        # identical except the struct padding the reference leaves uninitialised
+        # (7 bytes after the magic, 7 bytes after State::transpose)
+        keep = [i for i in range(len(ours)) if not (9 <= i < 16 or 89 <= i < 96)]
+        assert bytes(ours[i] for i in keep) == bytes(theirs[i] for i in keep), name
+
+
+def test_cache_rule_of_the_data_loader(tmp_path):
+    src = os.path.join(G, "formats", "general_real.mtx")
+    dst = tmp_path / "m.mtx"
+    dst.write_text(open(src).read())
+    A = speck_amd.load_matrix(dst)
+    assert os.path.exists(str(dst) + "d_.hicsr")          # DataLoader.cpp:9-26 file name
+    dst.unlink()
+    B = speck_amd.load_matrix(dst)                          # served from the cache
+    assert (A.col_ids == B.col_ids).all() and (A.data == B.data).all()
+
+
+def test_reference_binary_reads_our_hicsr(tmp_path):
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_formats")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    A = speck_amd.gen_matrix("mac_econ", 0.002, 3, signed=True)
+    path = tmp_path / "x.hicsr"
+    speck_amd.store_hicsr(A, path)
+    dump = subprocess.check_output([ref, "dump", str(path)]).decode().split("\n")
+    assert [int(x) for x in dump[0].split()] == [A.rows, A.cols, A.nnz]
+    assert [int(x) for x in dump[1].split()] == list(A.row_offsets)
+    assert [int(x) for x in dump[2].split()] == list(A.col_ids)
+    assert [float(x) for x in dump[3].split()] == list(A.data)
