@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- SpGEMM GFLOP/s (2 * intermediate products / s) for A*A, the metric of BASELINE.json.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload scircuit|...]
+
+One "step" = one complete MultiplyspECK call (analysis -> binning -> symbolic -> scan ->
+numeric, output matrix reused across steps exactly like the reference's benchmark loop,
+source/Executor.cpp:43-72) with A and B already resident in HBM.  For N > 1 (launched by
+torch.distributed.run, one rank per GPU) rows of A are sharded by the analysis pass'
+product counts, B is replicated, and the step ends with ONE exchange: the gatherv of the
+C shards to rank 0 over RCCL (speck_amd/sharding.py).  Weak scaling: the matrix has
+N x the rows of the 1-GPU workload, so per-GPU work stays fixed.
+
+SuiteSparse files are not available offline: the workload is the structure-matched
+synthetic stand-in of SURVEY.md 8d ("scircuit" = BASELINE.json configs[1]); a real .mtx is
+used instead when --mtx points at one.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: the HIP runtime torch bundles is the one the process shares)
+import torch.distributed as dist  # noqa: E402
+
+import speck_amd as sa  # noqa: E402
+from speck_amd.api import NUM_CLASS_NAMES  # noqa: E402
+from speck_amd.sharding import gatherv_csr  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class _DevArray:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (zero copy)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr=typestr, data=(int(ptr), False),
+                                             version=2, strides=None)
+
+
+def shard_tensors(dC):
+    n, rows = dC.nnz, dC.rows
+    ro = torch.as_tensor(_DevArray(dC._c.row_offsets, rows + 1, "<i4"), device="cuda")
+    col = torch.as_tensor(_DevArray(dC._c.col_ids, max(n, 1), "<i4"), device="cuda")[:n]
+    val = torch.as_tensor(_DevArray(dC._c.data, max(n, 1), "<f8"), device="cuda")[:n]
+    return ro, col, val
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="scircuit")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--mtx", default=None, help="real MatrixMarket file instead of the stand-in")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gatherv exchange")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n_gpus = world
+    assert n_gpus == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    # ---- workload (same on every rank: deterministic generator, B replicated)
+    if args.mtx:
+        A = sa.load_matrix(args.mtx, write_cache=False)
+        data_label, wl_name = "suitesparse", os.path.basename(args.mtx)
+    else:
+        A = sa.gen_matrix(args.workload, args.scale * n_gpus, args.seed, signed=True)
+        data_label, wl_name = "synthetic", f"{args.workload}-like A*A (SURVEY 8d stand-in)"
+    assert A.rows == A.cols, "A*A needs a square matrix (use the transpose for rectangular inputs)"
+    dev = torch.device("cuda", local_rank)
+    t_ro = torch.from_numpy(A.row_offsets.view(np.int32)).to(dev)
+    t_col = torch.from_numpy(A.col_ids.view(np.int32)).to(dev)
+    t_val = torch.from_numpy(A.data).to(dev)
+    dA = sa.dCSR.from_device(A.rows, A.cols, A.nnz, t_ro.data_ptr(), t_col.data_ptr(), t_val.data_ptr(),
+                             keep=(t_ro, t_col, t_val), host_row_offsets=A.row_offsets)
+    cfg = sa.spECKConfig.initialize(local_rank)
+
+    if n_gpus > 1:
+        bounds = sa.partition_rows(dA, dA, cfg, n_gpus)
+        mine = dA.row_view(bounds[rank], bounds[rank + 1])
+    else:
+        bounds = [0, A.rows]
+        mine = dA
+    dC = sa.dCSR()
+    timings = sa.Timings()
+
+    def step():
+        sa.MultiplyspECK(mine, dA, dC, cfg, timings)
+        if n_gpus > 1 and not args.no_gather:
+            torch.cuda.synchronize()
+            ro, col, val = shard_tensors(dC)
+            return gatherv_csr(ro[1:] - ro[:-1], col, val, root=0)
+        return None
+
+    # ---- warm-up; find the dominant numeric kernel (per-kernel HIP events on the pipeline stream)
+    cfg.profile_kernels(1)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    st = cfg.last_stats()
+    P_local, nnzc_local = st["sum_products"], st["nnz_c"]
+    dominant = max(NUM_CLASS_NAMES, key=lambda k: st["num_bin_ms"][k])
+
+    def barrier():
+        if n_gpus > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps
+    kernel_ms = {k: 0.0 for k in NUM_CLASS_NAMES}
+    sym_ms = num_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        s = cfg.last_stats()            # events were recorded on the pipeline's stream
+        for k in NUM_CLASS_NAMES:
+            kernel_ms[k] += s["num_bin_ms"][k]
+        sym_ms += s["analysis_ms"] + s["scan_ms"] + sum(s["sym_bin_ms"].values())
+        num_ms += sum(s["num_bin_ms"].values())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if n_gpus > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        pp = torch.tensor([P_local, nnzc_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(pp)
+        P_total, nnzc_total = int(pp[0].item()), int(pp[1].item())
+    else:
+        P_total, nnzc_total = P_local, nnzc_local
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    gflops = 2.0 * P_total / (elapsed / args.steps) / 1e9
+
+    if rank == 0:
+        dom_ms = kernel_ms[dominant] / args.steps
+        dom_bytes = st["num_bin_bytes"][dominant]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"{args.workload}:num_{dominant}")
+        out = {
+            "metric": "SpGEMM GFLOP/s (2*flops_intermediate/s), A*A",
+            "value": round(gflops, 3),
+            "unit": "GFLOP/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": data_label,
+            "config": {
+                "workload": wl_name, "rows": A.rows, "nnzA": A.nnz, "products": P_total,
+                "nnzC": nnzc_total, "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",
+                "gather": bool(n_gpus > 1 and not args.no_gather),
+            },
+            "phases_ms": {"symbolic": round(sym_ms / args.steps, 4), "numeric": round(num_ms / args.steps, 4)},
+            "roofline": {
+                "bound": "hbm", "kernel": f"numeric:{dominant}",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
+                "numeric_phase_frac": round(
+                    sum(st["num_bin_bytes"].values()) / max(num_ms / args.steps * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+            },
+            "kernels_ms": {k: round(v / args.steps, 5) for k, v in kernel_ms.items() if v > 0},
+            "rows_per_class": {k: v for k, v in st["num_bin_rows"].items() if v},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, P_total)
+        print(json.dumps(out), flush=True)
+
+    cfg.cleanup()
+    if n_gpus > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(A, P):
+    """The oracle (row-parallel Gustavson, symbolic + numeric, all host cores) timed on the same
+    workload; bounded to ~10-30 s of CPU work."""
+    from oracle import pyoracle as po
+    H = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data)
+    cores = po.max_threads()
+    sample = "full workload"
+    if P > 4e9:  # keep the CPU leg bounded: a leading row block of the same matrix
+        rows = max(1, int(A.rows * 4e9 / P))
+        Hs = H.row_slice(0, rows)
+        sample = f"first {rows} of {A.rows} rows"
+    else:
+        Hs = H
+    po.spgemm(Hs, H, threads=0, with_abs=False)  # warm-up (page faults)
+    reps, t_total, Ps = 0, 0.0, po.analysis(Hs, H)["sum_products"]
+    while reps < 3 or (t_total < 5.0 and reps < 20):
+        t0 = time.perf_counter()
+        po.spgemm(Hs, H, threads=0, with_abs=False)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    return {"value": round(2.0 * Ps * reps / t_total / 1e9, 3), "unit": "GFLOP/s", "cores": cores,
+            "kind": "port", "sample": f"{sample}, {reps} runs, symbolic+numeric"}
+
+
+if __name__ == "__main__":
+    main()
