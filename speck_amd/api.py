@@ -15,8 +15,8 @@ import numpy as np
 from . import _lib
 from ._lib import CStats, CTimings, DCsr, NUM_NUM_BINS, NUM_SYM_BINS
 
-SYM_CLASS_NAMES = ["wave", "hash1k", "hash8k", "hash32k", "bitmap256k", "bitmap1m"]
-NUM_CLASS_NAMES = ["direct", "wave", "hash512", "hash2k", "hash8k", "dense4k", "dense16k", "global"]
+SYM_CLASS_NAMES = ["g16", "wave256", "wave1k", "block4k", "block16k", "block32k", "bitmap256k", "bitmap1m"]
+NUM_CLASS_NAMES = ["direct", "g16", "wave128", "wave512", "block2k", "block8k", "dense4k", "dense16k", "global"]
 
 
 class SpeckError(RuntimeError):

@@ -1,4 +1,4 @@
-// device_common.hpp -- shared device helpers for the gfx950 SpGEMM kernels.
+// device_common.hpp -- shared definitions for the gfx950 SpGEMM kernels.
 // wave64 everywhere: a "wave" below is 64 lanes, ballots are 64-bit.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -12,6 +12,7 @@ using u8 = uint8_t;
 
 constexpr u32 kEmptyKey = 0xFFFFFFFFu;
 constexpr int kWave = 64;
+constexpr int kMaxClasses = 12;  // array extent of every per-class table
 
 // Trivially-copyable CSR view handed to kernels (reference: dCSRNoDealloc<T>,
 // include/dCSR.h:24-35).  row_offsets may be absolute offsets of a row-range view.
@@ -24,41 +25,53 @@ struct CsrView {
 };
 
 // ---- kernel classes ("bins") --------------------------------------------------
-// Symbolic classes, chosen from the analysis pass' per-row upper bound `ops`
-// (= exact product count), the A-row length and the reachable column range.
+// A row is processed by a GROUP of lanes: 16 lanes of a wave, a whole 64-lane wave, or a
+// workgroup.  Small rows dominate SuiteSparse-like inputs and every row is a chain of four
+// dependent global loads (A.rowptr -> A.col -> B.rowptr -> B.col/val), so throughput is
+// "rows in flight / chain latency": small rows get small groups.
+// Symbolic classes: chosen from the analysis pass' per-row upper bound `ops` (= exact
+// product count), the A-row length and the reachable column range.
 enum SymClass : u8 {
-    SYM_WAVE = 0,  // one wave per row, 128-key LDS set per wave
-    SYM_H1 = 1,    // workgroup hash set, 1024 keys
-    SYM_H2 = 2,    // workgroup hash set, 8192 keys
-    SYM_H3 = 3,    // workgroup hash set, 32768 keys (128 KiB of LDS)
-    SYM_BM1 = 4,   // column bitmap, 256 Ki columns per window
-    SYM_BM2 = 5,   // column bitmap, 1 Mi columns per window (128 KiB of LDS), multi-window
+    SYM_G16 = 0,    // 16 lanes per row, 64-key LDS set       (ops <= 51)
+    SYM_W256 = 1,   // one wave per row, 256-key set          (ops <= 204)
+    SYM_W1K = 2,    // one wave per row, 1024-key set         (ops <= 819)
+    SYM_B4K = 3,    // workgroup(256) per row, 4096-key set   (ops <= 3276)
+    SYM_B16K = 4,   // workgroup(512) per row, 16384-key set  (ops <= 13107)
+    SYM_B32K = 5,   // workgroup(1024) per row, 32768-key set (ops <= 26214), 128 KiB LDS
+    SYM_BM1 = 6,    // column bitmap, workgroup(256), 256 Ki columns per window
+    SYM_BM2 = 7,    // column bitmap, workgroup(1024), 1 Mi columns per window, multi-window
+    SYM_CLASSES = 8,
     SYM_NONE = 0xFF  // resolved by the analysis kernel itself (empty / single-entry A rows)
 };
-// Numeric classes, chosen from the EXACT nnz of the C row (symbolic result).
+// Numeric classes: chosen from the EXACT nnz of the C row (symbolic result).
 enum NumClass : u8 {
-    NUM_DIRECT = 0,  // A row has one entry: C row = a * B row (already sorted)
-    NUM_WAVE = 1,    // one wave per row, 128-entry LDS table per wave
-    NUM_H1 = 2,      // workgroup hash, 512 entries, in-place rank sort
-    NUM_H2 = 3,      // workgroup hash, 2048 entries, bitmap-rank sort
-    NUM_H3 = 4,      // workgroup hash, 8192 entries, bitmap-rank sort
-    NUM_D1 = 5,      // dense column-window accumulator, narrow column range
-    NUM_D2 = 6,      // dense column-window accumulator, 16 Ki columns/window, multi-window
-    NUM_G = 7,       // global-memory hash spill (heavy rows, wide column range)
+    NUM_DIRECT = 0,  // A row has one entry: C row = a * B row (already sorted); 16 lanes/row
+    NUM_G16 = 1,     // 16 lanes per row, 64-entry table, rank sort        (nnz <= 42)
+    NUM_W128 = 2,    // wave per row, 128-entry table, rank sort           (nnz <= 85)
+    NUM_W512 = 3,    // wave per row, 512-entry table, 2-level bitmap sort (nnz <= 341)
+    NUM_B2K = 4,     // workgroup(256), 2048-entry table, bitmap sort      (nnz <= 1365)
+    NUM_B8K = 5,     // workgroup(512), 8192-entry table, bitmap sort      (nnz <= 5461)
+    NUM_D1 = 6,      // dense column-window accumulator, narrow column range, workgroup(256)
+    NUM_D2 = 7,      // dense accumulator, 16 Ki columns/window, multi-window, workgroup(1024)
+    NUM_G = 8,       // global-memory hash spill (heavy rows with a very wide column range)
+    NUM_CLASSES = 9,
     NUM_NONE = 0xFF
 };
 
-constexpr u32 kSymWaveCap = 128, kSymWaveMaxOps = 102;
-constexpr u32 kSymH1Cap = 1024, kSymH1MaxOps = 819;
-constexpr u32 kSymH2Cap = 8192, kSymH2MaxOps = 6553;
-constexpr u32 kSymH3Cap = 32768, kSymH3MaxOps = 26214;
+constexpr u32 kSymG16Cap = 64, kSymG16MaxOps = 51;
+constexpr u32 kSymW256Cap = 256, kSymW256MaxOps = 204;
+constexpr u32 kSymW1KCap = 1024, kSymW1KMaxOps = 819;
+constexpr u32 kSymB4KCap = 4096, kSymB4KMaxOps = 3276;
+constexpr u32 kSymB16KCap = 16384, kSymB16KMaxOps = 13107;
+constexpr u32 kSymB32KCap = 32768, kSymB32KMaxOps = 26214;
 constexpr u32 kSymBm1Words = 8192;    // 32 KiB  -> 262144 columns
 constexpr u32 kSymBm2Words = 32768;   // 128 KiB -> 1048576 columns per window
 
-constexpr u32 kNumWaveCap = 128, kNumWaveMaxNnz = 85;
-constexpr u32 kNumH1Cap = 512, kNumH1MaxNnz = 341;
-constexpr u32 kNumH2Cap = 2048, kNumH2MaxNnz = 1365;
-constexpr u32 kNumH3Cap = 8192, kNumH3MaxNnz = 5461;
+constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = 42;
+constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = 85;
+constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = 341;
+constexpr u32 kNumB2KCap = 2048, kNumB2KMaxNnz = 1365;
+constexpr u32 kNumB8KCap = 8192, kNumB8KMaxNnz = 5461;
 constexpr u32 kNumD1Cols = 4096;
 constexpr u32 kNumD2Cols = 16384;
 
@@ -67,21 +80,23 @@ struct ClassifyParams {
     u32 sym_bitmap_ratio;   // use a bitmap when range <= ratio * ops (and ops > wave limit)
     u32 num_dense_ratio;    // use D1 when range <= kNumD1Cols and range <= ratio * nnz
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
-    u32 reserved;
+    u32 want_bytes;         // accumulate the per-class algorithmic byte counts (profiling)
 };
 
 __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u32 cmax,
                                                 const ClassifyParams& p)
 {
     if (ops == 0 || len_a <= 1) return SYM_NONE;
-    if (ops <= kSymWaveMaxOps) return SYM_WAVE;
+    if (ops <= kSymG16MaxOps) return SYM_G16;
+    if (ops <= kSymW256MaxOps) return SYM_W256;
     const u64 range = u64(cmax) - u64(cmin) + 1;
     const bool bitmap_ok = range <= u64(p.sym_bitmap_ratio) * ops;
     if (bitmap_ok && range <= u64(kSymBm1Words) * 32) return SYM_BM1;
-    if (ops <= kSymH1MaxOps) return SYM_H1;
-    if (ops <= kSymH2MaxOps) return SYM_H2;
+    if (ops <= kSymW1KMaxOps) return SYM_W1K;
+    if (ops <= kSymB4KMaxOps) return SYM_B4K;
+    if (ops <= kSymB16KMaxOps) return SYM_B16K;
     if (bitmap_ok) return SYM_BM2;
-    if (ops <= kSymH3MaxOps) return SYM_H3;
+    if (ops <= kSymB32KMaxOps) return SYM_B32K;
     return SYM_BM2;
 }
 
@@ -90,12 +105,13 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 nnz, u32 cmin, u32
 {
     if (nnz == 0) return NUM_NONE;
     if (len_a == 1) return NUM_DIRECT;
-    if (nnz <= kNumWaveMaxNnz) return NUM_WAVE;
+    if (nnz <= kNumG16MaxNnz) return NUM_G16;
+    if (nnz <= kNumW128MaxNnz) return NUM_W128;
     const u64 range = u64(cmax) - u64(cmin) + 1;
     if (range <= kNumD1Cols && range <= u64(p.num_dense_ratio) * nnz) return NUM_D1;
-    if (nnz <= kNumH1MaxNnz) return NUM_H1;
-    if (nnz <= kNumH2MaxNnz) return NUM_H2;
-    if (nnz <= kNumH3MaxNnz) return NUM_H3;
+    if (nnz <= kNumW512MaxNnz) return NUM_W512;
+    if (nnz <= kNumB2KMaxNnz) return NUM_B2K;
+    if (nnz <= kNumB8KMaxNnz) return NUM_B8K;
     const u64 passes = (range + kNumD2Cols - 1) / kNumD2Cols;
     if (passes > p.num_global_passes) return NUM_G;
     return NUM_D2;
@@ -115,6 +131,13 @@ __host__ __device__ inline u64 symbolic_row_bytes(u32 len_a, u32 ops)
     return 8ull + 12ull * len_a + 4ull * ops + 4ull;
 }
 
+// Per-class row list description, shared by the symbolic and the numeric phase.
+struct BinTable {
+    u32 count[kMaxClasses];
+    u32 offset[kMaxClasses + 1];
+    u64 bytes[kMaxClasses];
+};
+
 // Device-side statistics block; one per config, zeroed at the start of a call.
 struct DeviceStats {
     u64 sum_products;
@@ -122,17 +145,19 @@ struct DeviceStats {
     u32 max_row_ops;
     u32 max_row_nnz_c;
     u32 nnz_overflow;
-    u32 capacity_miss;   // numeric kernels saw nnz_c > capacity of the reused C buffers
-    u32 sym_count[8];
-    u32 num_count[8];
-    u32 sym_offset[9];
-    u32 num_offset[9];
-    u32 sym_cursor[8];
-    u32 num_cursor[8];
-    u64 sym_bytes[8];
-    u64 num_bytes[8];
-    u32 gmap_next;       // global-hash spill pool cursor
+    u32 capacity_miss;
+    BinTable sym;
+    BinTable num;
+};
+
+// What every analysis / scan-apply block leaves behind for the single-block stats kernel
+// (plain stores: ~12 ns per same-line global atomic would otherwise dominate these kernels).
+struct BlockPartial {
+    u64 products;
+    u32 max_val;
     u32 pad;
+    u32 count[kMaxClasses];
+    u64 bytes[kMaxClasses];
 };
 
 #ifdef __HIPCC__
@@ -160,12 +185,6 @@ __device__ __forceinline__ u32 wave_reduce_max(u32 v)
     for (int off = 32; off > 0; off >>= 1) v = max(v, (u32)__shfl_xor((int)v, off, 64));
     return v;
 }
-__device__ __forceinline__ u32 wave_reduce_min(u32 v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, (u32)__shfl_xor((int)v, off, 64));
-    return v;
-}
 // inclusive scan across the 64 lanes
 __device__ __forceinline__ u32 wave_inclusive_scan(u32 v)
 {
@@ -189,17 +208,6 @@ __device__ __forceinline__ u32 hash_slot(u32 key)
     static_assert((CAP & (CAP - 1)) == 0, "capacity must be a power of two");
     constexpr int bits = __builtin_ctz(CAP);
     return (key * 0x9E3779B1u) >> (32 - bits);
-}
-
-// log2 of the lane-group width that walks one B row: the smallest power of two
-// >= the average B-row length of this A row, clamped to [min_shift, max_shift].
-// (Role of the reference's getThreadShiftNew, include/common.cuh:509-555, re-derived
-// for 64-lane waves: a group never spans waves.)
-__device__ __forceinline__ u32 pick_group_shift(u32 ops, u32 len_a, u32 min_shift, u32 max_shift)
-{
-    const u32 avg = (ops + len_a - 1) / (len_a ? len_a : 1);
-    u32 s = avg <= 1 ? 0 : 32 - __clz(avg - 1);
-    return s < min_shift ? min_shift : (s > max_shift ? max_shift : s);
 }
 
 // Block-wide exclusive scan of one u32 per thread (THREADS multiple of 64).

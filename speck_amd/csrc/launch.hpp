@@ -4,18 +4,23 @@
 
 namespace speck {
 
+u32 analysis_blocks(u32 m);
+u32 scan_tiles(u32 m);
+size_t scan_scratch_bytes(u32 m);
+
+// analysis (+ stats fold + ordered scatter of the symbolic classes when sym_cls != nullptr)
 void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32* b_ro,
                      const u32* b_col, u32 m, u64 nnz_a, u32* row_ops, u32* row_max_ops,
-                     u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts, DeviceStats* st,
-                     const ClassifyParams& cp, int max_blocks);
+                     u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
+                     BlockPartial* partials, u32* blk_base, u32* bin_rows, DeviceStats* st,
+                     const ClassifyParams& cp);
 
-void launch_binning(hipStream_t s, const u8* cls, u32 m, DeviceStats* st, int numeric, u32* bin_rows,
-                    int max_blocks);
-
-size_t scan_scratch_bytes(u32 m);
+// exclusive scan of the row counts (+ numeric classification, stats fold, ordered scatter
+// when num_cls != nullptr)
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, u64* tile_sums, const u32* a_ro,
                  const u32* row_ops, const u32* row_col_min, const u32* row_col_max, u8* num_cls,
-                 DeviceStats* st, const ClassifyParams& cp, u32 vsize);
+                 BlockPartial* partials, u32* blk_base, u32* bin_rows, DeviceStats* st,
+                 const ClassifyParams& cp, u32 vsize);
 
 // Everything a symbolic / numeric kernel needs besides the matrices.
 struct RowWork {
@@ -35,6 +40,8 @@ template <typename T>
 void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& A, const CsrView<T>& B,
                     const RowWork& w, const u32* c_ro, u32* c_col, T* c_val, u64 c_capacity,
                     DeviceStats* st_mut, int cu_count);
+
+u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block);
 
 // LDS bytes a class needs (for occupancy-aware grid sizing and DESIGN.md tables)
 u32 symbolic_lds_bytes(int cls);

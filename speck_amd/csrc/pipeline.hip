@@ -48,7 +48,11 @@ struct speck_config {
     DeviceStats* h_stats = nullptr;  // pinned
     ClassifyParams cp{};
     bool profile_kernels = false;
-    std::vector<hipEvent_t> kev;  // kernel event pool
+    std::vector<hipEvent_t> kev;  // kernel event pool (timing)
+    std::vector<hipStream_t> aux;  // one stream per kernel class: classes run concurrently
+    std::vector<hipEvent_t> aux_done;
+    hipEvent_t fork = nullptr;
+    bool concurrent_classes = true;
     speck_stats last{};
 };
 
@@ -87,7 +91,11 @@ struct Scratch {
     u32 *row_ops, *row_max_ops, *row_col_min, *row_col_max, *bin_rows;
     u8* cls;
     u64* tile_sums;
+    BlockPartial* partials;
+    u32* blk_base;
 };
+
+u32 partial_blocks(u32 m) { return std::max(analysis_blocks(m), scan_tiles(m)); }
 
 size_t scratch_bytes(u32 m)
 {
@@ -95,6 +103,8 @@ size_t scratch_bytes(u32 m)
     b += 5 * Carver::need(m, 4);
     b += Carver::need(m, 1);
     b += Carver::need(scan_scratch_bytes(m), 1);
+    b += Carver::need(partial_blocks(m), sizeof(BlockPartial));
+    b += Carver::need(size_t(partial_blocks(m)) * kMaxClasses, 4);
     return b + 4096;
 }
 
@@ -109,6 +119,8 @@ Scratch carve(speck_config* c, u32 m)
     s.bin_rows = cv.take<u32>(m);
     s.cls = cv.take<u8>(m);
     s.tile_sums = reinterpret_cast<u64*>(cv.take<u8>(scan_scratch_bytes(m)));
+    s.partials = cv.take<BlockPartial>(partial_blocks(m));
+    s.blk_base = cv.take<u32>(size_t(partial_blocks(m)) * kMaxClasses);
     return s;
 }
 
@@ -168,30 +180,72 @@ int run_analysis(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DeviceStats), s));
     launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, classify ? sc.cls : nullptr,
-                    counts, c->d_stats, c->cp, c->sm * 8);
-    if (classify) launch_binning(s, sc.cls, m, c->d_stats, 0, sc.bin_rows, c->sm * 8);
+                    counts, sc.partials, sc.blk_base, sc.bin_rows, c->d_stats, c->cp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SPECK_OK;
 }
 
-int run_symbolic_kernels(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
-                         const Scratch& sc, u32* counts, size_t* ev_idx)
+// Launch one kernel per non-empty class.  The classes are independent (disjoint rows), so each
+// runs on its own stream between a fork and a join event on the pipeline stream: the
+// latency-bound heavy-row kernels (few workgroups) overlap the throughput-bound small-row ones
+// (the reference does the same with its 6 streams, source/GPU/Multiply.cu:494-553, but relies on
+// legacy default-stream ordering; here the dependencies are explicit events).
+struct ClassTiming {
+    int cls;
+    size_t ev;
+};
+
+template <typename LaunchFn>
+int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, const u32* counts,
+                size_t* ev_idx, std::vector<ClassTiming>* timing, LaunchFn&& launch)
 {
-    RowWork w{sc.bin_rows, sc.row_ops, sc.row_col_min, sc.row_col_max, c->d_stats};
-    // heaviest classes first: they have the longest tails
-    static const int order[SPECK_NUM_SYM_BINS] = {SYM_BM2, SYM_H3, SYM_H2, SYM_BM1, SYM_H1, SYM_WAVE};
-    for (int cls : order) {
-        const u32 cnt = c->h_stats->sym_count[cls];
+    bool forked = false;
+    size_t used = 0;
+    for (int i = 0; i < n_order; ++i) {
+        const int cls = order[i];
+        const u32 cnt = counts[cls];
         if (!cnt) continue;
-        if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, (*ev_idx)++), s);
-        launch_symbolic(s, cls, cnt, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, w, counts,
-                        c->sm);
-        if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, (*ev_idx)++), s);
+        hipStream_t ks = s;
+        if (c->concurrent_classes && used < c->aux.size()) {
+            if (!forked) {
+                HIP_TRY(hipEventRecord(c->fork, s));
+                forked = true;
+            }
+            ks = c->aux[used];
+            HIP_TRY(hipStreamWaitEvent(ks, c->fork, 0));
+        }
+        if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, *ev_idx), ks);
+        launch(ks, cls, cnt);
+        if (c->profile_kernels) {
+            (void)hipEventRecord(kernel_event(c, *ev_idx + 1), ks);
+            timing->push_back({cls, *ev_idx});
+            *ev_idx += 2;
+        }
+        if (ks != s) {
+            HIP_TRY(hipEventRecord(c->aux_done[used], ks));
+            HIP_TRY(hipStreamWaitEvent(s, c->aux_done[used], 0));
+            ++used;
+        }
     }
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
+}
+
+int run_symbolic_kernels(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
+                         const Scratch& sc, u32* counts, size_t* ev_idx,
+                         std::vector<ClassTiming>* timing)
+{
+    RowWork w{sc.bin_rows, sc.row_ops, sc.row_col_min, sc.row_col_max, c->d_stats};
+    // heaviest classes first: they have the longest tails
+    static const int order[SYM_CLASSES] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_B4K,
+                                           SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
+    return run_classes(c, s, order, SYM_CLASSES, c->h_stats->sym.count, ev_idx, timing,
+                       [&](hipStream_t ks, int cls, u32 cnt) {
+                           launch_symbolic(ks, cls, cnt, A->row_offsets, A->col_ids, B->row_offsets,
+                                           B->col_ids, w, counts, c->sm);
+                       });
 }
 
 template <typename T>
@@ -267,17 +321,20 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     t->globalMapsCounting = 0.f;
 
     // ---- SYMBOLIC (Multiply.cu:488-554)
-    const size_t ev_sym0 = ev;
-    rc = run_symbolic_kernels(c, s, A, B, sc, c_ro, &ev);
+    std::vector<ClassTiming> sym_timing, num_timing;
+    rc = run_symbolic_kernels(c, s, A, B, sc, c_ro, &ev, &sym_timing);
     if (rc != SPECK_OK) return fail(rc);
-    const size_t ev_sym1 = ev;
+    for (int i = 0; i < SPECK_NUM_SYM_BINS; ++i) {  // h_stats is overwritten by the next read-back
+        c->last.sym_bin_rows[i] = c->h_stats->sym.count[i];
+        c->last.sym_bin_bytes[i] = c->h_stats->sym.bytes[i];
+    }
 
     // ---- SCAN + numeric classification/binning (Multiply.cu:570-575, 615-682)
+    const size_t ev_scan = ev;
     if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, ev++), s);
     launch_scan(s, c_ro, m, sc.tile_sums, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
-                sc.cls, c->d_stats, c->cp, (u32)sizeof(T));
+                sc.cls, sc.partials, sc.blk_base, sc.bin_rows, c->d_stats, c->cp, (u32)sizeof(T));
     if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, ev++), s);
-    launch_binning(s, sc.cls, m, c->d_stats, 1, sc.bin_rows, c->sm * 8);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -327,21 +384,14 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
     RowWork w{sc.bin_rows, sc.row_ops, sc.row_col_min, sc.row_col_max, c->d_stats};
-    static const int order[SPECK_NUM_NUM_BINS] = {NUM_G,  NUM_D2,   NUM_H3,    NUM_H2,
-                                                  NUM_D1, NUM_H1,   NUM_WAVE,  NUM_DIRECT};
-    const size_t ev_num0 = ev;
-    int num_order_used[SPECK_NUM_NUM_BINS];
-    int num_used = 0;
-    for (int cls : order) {
-        const u32 cnt = c->h_stats->num_count[cls];
-        if (!cnt) continue;
-        if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, ev++), s);
-        launch_numeric<T>(s, cls, cnt, Av, Bv, w, c_ro, c_col, static_cast<T*>(c_val), nnz_c,
-                          c->d_stats, c->sm);
-        if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, ev++), s);
-        num_order_used[num_used++] = cls;
-    }
-    HIP_TRY(hipGetLastError());
+    static const int order[NUM_CLASSES] = {NUM_G,   NUM_D2,   NUM_B8K,  NUM_B2K,   NUM_D1,
+                                           NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
+    rc = run_classes(c, s, order, NUM_CLASSES, c->h_stats->num.count, &ev, &num_timing,
+                     [&](hipStream_t ks, int cls, u32 cnt) {
+                         launch_numeric<T>(ks, cls, cnt, Av, Bv, w, c_ro, c_col, static_cast<T*>(c_val),
+                                           nnz_c, c->d_stats, c->sm);
+                     });
+    if (rc != SPECK_OK) return rc;
     if (t->measureAll) {
         HIP_TRY(hipStreamSynchronize(s));
     }
@@ -357,13 +407,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     }
 
     // ---- stats for the harness
-    for (int i = 0; i < SPECK_NUM_SYM_BINS; ++i) {
-        c->last.sym_bin_rows[i] = c->h_stats->sym_count[i];
-        c->last.sym_bin_bytes[i] = c->h_stats->sym_bytes[i];
-    }
     for (int i = 0; i < SPECK_NUM_NUM_BINS; ++i) {
-        c->last.num_bin_rows[i] = c->h_stats->num_count[i];
-        c->last.num_bin_bytes[i] = c->h_stats->num_bytes[i];
+        c->last.num_bin_rows[i] = c->h_stats->num.count[i];
+        c->last.num_bin_bytes[i] = c->h_stats->num.bytes[i];
     }
     if (c->profile_kernels) {
         HIP_TRY(hipStreamSynchronize(s));
@@ -373,20 +419,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             return v;
         };
         c->last.analysis_ms = ms(0);
-        size_t e = ev_sym0;
-        static const int sorder[SPECK_NUM_SYM_BINS] = {SYM_BM2, SYM_H3, SYM_H2, SYM_BM1, SYM_H1, SYM_WAVE};
-        for (int cls : sorder) {
-            if (!c->h_stats->sym_count[cls]) continue;
-            c->last.sym_bin_ms[cls] = ms(e);
-            e += 2;
-        }
-        (void)ev_sym1;
-        c->last.scan_ms = ms(e);
-        e = ev_num0;
-        for (int i = 0; i < num_used; ++i) {
-            c->last.num_bin_ms[num_order_used[i]] = ms(e);
-            e += 2;
-        }
+        c->last.scan_ms = ms(ev_scan);
+        for (const auto& ct : sym_timing) c->last.sym_bin_ms[ct.cls] = ms(ct.ev);
+        for (const auto& ct : num_timing) c->last.num_bin_ms[ct.cls] = ms(ct.ev);
         c->last.kernel_events_valid = 1;
     }
     if (t->measureAll) {
@@ -436,12 +471,21 @@ int speck_config_create(int device, speck_config** out)
     HIP_TRY(hipEventCreate(&c->completeEnd));
     HIP_TRY(hipEventCreate(&c->individualStart));
     HIP_TRY(hipEventCreate(&c->individualEnd));
+    for (int i = 0; i < kMaxClasses; ++i) {
+        hipStream_t s;
+        hipEvent_t e;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->aux.push_back(s);
+        c->aux_done.push_back(e);
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(DeviceStats)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stats), sizeof(DeviceStats), hipHostMallocDefault));
     c->cp.sym_bitmap_ratio = 32;
     c->cp.num_dense_ratio = 16;
     c->cp.num_global_passes = 0xFFFFFFFFu;
-    c->cp.reserved = 0;
+    c->cp.want_bytes = 0;
     *out = c;
     return SPECK_OK;
 }
@@ -456,6 +500,9 @@ int speck_config_destroy(speck_config* c)
     (void)hipEventDestroy(c->individualStart);
     (void)hipEventDestroy(c->individualEnd);
     for (auto e : c->kev) (void)hipEventDestroy(e);
+    for (auto s : c->aux) (void)hipStreamDestroy(s);
+    for (auto e : c->aux_done) (void)hipEventDestroy(e);
+    if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->arena) (void)hipFree(c->arena);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
@@ -487,6 +534,8 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     if (n == "sym_bitmap_ratio") c->cp.sym_bitmap_ratio = (u32)value;
     else if (n == "num_dense_ratio") c->cp.num_dense_ratio = (u32)value;
     else if (n == "num_global_passes") c->cp.num_global_passes = (u32)value;
+    else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
+    else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
     else return SPECK_ERR_INVALID;
     return SPECK_OK;
 }
@@ -539,7 +588,9 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
         }
         return SPECK_OK;
     }
-    Scratch sc{};
+    rc = ensure_arena(c, scratch_bytes(m));
+    if (rc != SPECK_OK) return rc;
+    Scratch sc = carve(c, m);  // partials / blk_base come from the arena, row arrays from the caller
     sc.row_ops = d_row_ops;
     sc.row_max_ops = d_row_max_ops;
     sc.row_col_min = d_row_col_min;
@@ -574,11 +625,12 @@ int speck_symbolic(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     size_t ev = 0;
     const bool prof = c->profile_kernels;
     c->profile_kernels = false;
-    rc = run_symbolic_kernels(c, s, A, B, sc, d_row_offsets, &ev);
+    std::vector<ClassTiming> timing;
+    rc = run_symbolic_kernels(c, s, A, B, sc, d_row_offsets, &ev, &timing);
     c->profile_kernels = prof;
     if (rc != SPECK_OK) return rc;
     launch_scan(s, d_row_offsets, m, sc.tile_sums, A->row_offsets, sc.row_ops, sc.row_col_min,
-                sc.row_col_max, nullptr, c->d_stats, c->cp, 8);
+                sc.row_col_max, nullptr, sc.partials, sc.blk_base, sc.bin_rows, c->d_stats, c->cp, 8);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -1,0 +1,229 @@
+// row_groups.hpp -- the lane-group abstraction shared by the symbolic and numeric kernels.
+//
+// A row of C is produced by a GROUP: SubWave<16> (16 lanes of a wave), SubWave<64> (a wave) or
+// Block<THREADS> (a workgroup).  All groups run the same three steps:
+//   1. stage the A row's metadata in LDS: for each entry a_ik the inclusive prefix of
+//      nnz(B_k), the B-row start rebased to that prefix, and a_ik itself;
+//   2. walk the FLATTENED product space p in [0, ops): lane -> p, the owning A entry is found
+//      by a (hinted) binary search in the LDS prefix; consecutive lanes read consecutive
+//      B entries (coalesced) and every lane has the same amount of work whatever the B-row
+//      length distribution is (the reference balances this with getThreadShiftNew,
+//      include/common.cuh:509-555, which assumes near-uniform B rows);
+//   3. the loads of product p+stride are issued before product p is accumulated, so the
+//      dependent chain LDS-search -> global load -> LDS atomic of successive products overlaps.
+#pragma once
+#include "device_common.hpp"
+
+namespace speck {
+
+// ---- group policies -------------------------------------------------------------
+template <int L>
+struct SubWave {
+    static_assert(L == 8 || L == 16 || L == 32 || L == 64, "sub-wave width");
+    static constexpr int SIZE = L;
+    static constexpr bool kIsBlock = false;
+    u32 lane;       // index inside the group
+    u32 base_lane;  // wave lane of group lane 0
+    __device__ __forceinline__ SubWave()
+    {
+        const u32 wl = lane_id();
+        lane = wl & (L - 1);
+        base_lane = wl & ~u32(L - 1);
+    }
+    __device__ __forceinline__ void sync() const { wave_lds_fence(); }
+    __device__ __forceinline__ u32 inclusive_scan(u32 v, u32* total, u32* /*scratch*/) const
+    {
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) {
+            const u32 t = (u32)__shfl_up((int)v, off, L);
+            if (lane >= (u32)off) v += t;
+        }
+        *total = (u32)__shfl((int)v, L - 1, L);
+        return v;
+    }
+    __device__ __forceinline__ u32 reduce_add(u32 v, u32* /*scratch*/) const
+    {
+#pragma unroll
+        for (int off = L >> 1; off > 0; off >>= 1) v += (u32)__shfl_xor((int)v, off, L);
+        return v;
+    }
+    // bit i of the result <=> group lane i voted true
+    __device__ __forceinline__ u64 ballot(bool p) const
+    {
+        const u64 m = __ballot(p);
+        if (L == 64) return m;
+        return (m >> base_lane) & ((1ull << (L & 63)) - 1ull);
+    }
+    // contiguous slice of [0,total) walked by this lane: start, stride, end
+    __device__ __forceinline__ void product_range(u32 total, u32& p0, u32& step, u32& end) const
+    {
+        p0 = lane;
+        step = L;
+        end = total;
+    }
+};
+
+template <int THREADS>
+struct Block {
+    static constexpr int SIZE = THREADS;
+    static constexpr bool kIsBlock = true;
+    u32 lane;
+    __device__ __forceinline__ Block() : lane(threadIdx.x) {}
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ u32 inclusive_scan(u32 v, u32* total, u32* scratch) const
+    {
+        return block_exclusive_scan<THREADS>(v, scratch, total) + v;
+    }
+    __device__ __forceinline__ u32 reduce_add(u32 v, u32* scratch) const
+    {
+        v = wave_reduce_add(v);
+        __syncthreads();
+        if (lane_id() == 0) scratch[threadIdx.x >> 6] = v;
+        __syncthreads();
+        u32 s = 0;
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) s += scratch[w];
+        __syncthreads();
+        return s;
+    }
+    // every wave owns a contiguous, 64-aligned slice of the product space and strides by 64
+    // inside it: coalesced, and the owning A entry only moves forward (cheap hinted search)
+    __device__ __forceinline__ void product_range(u32 total, u32& p0, u32& step, u32& end) const
+    {
+        constexpr u32 NW = THREADS / 64;
+        const u32 per_wave = (((total + NW - 1) / NW) + 63u) & ~63u;
+        const u32 w = threadIdx.x >> 6;
+        const u32 lo = w * per_wave;
+        p0 = lo + lane_id();
+        step = 64;
+        end = min(total, lo + per_wave);
+    }
+};
+
+// Per-group LDS staging area for one chunk of A entries (SIZE entries).
+template <typename T>
+struct RowMeta {
+    u32* incl;  // inclusive prefix of B-row lengths
+    u32* off;   // B-row start minus exclusive prefix: ib = off[s] + p  (u32 wrap-around)
+    T* av;      // a_ik (unused by the symbolic kernels: pass nullptr)
+};
+
+template <int SIZE, typename T>
+constexpr u32 row_meta_bytes(bool with_values)
+{
+    return SIZE * (8 + (with_values ? (u32)sizeof(T) : 0));
+}
+
+// Smallest s in [lo, cnt) with incl[s] > p.  `lo` is a lower bound carried between calls.
+__device__ __forceinline__ u32 owner_search(const u32* incl, u32 lo, u32 cnt, u32 p)
+{
+    if (incl[lo] > p) return lo;
+    u32 hi = cnt - 1;
+    ++lo;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (incl[mid] > p) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// Walk all products of row [a0,a1) of A.  f(col, value) for WITH_VALUES, f(col) otherwise.
+template <bool WITH_VALUES, class G, typename T, typename F>
+__device__ __forceinline__ void for_each_product(const G& g, const CsrView<T>& A, const CsrView<T>& B,
+                                                 u32 a0, u32 a1, const RowMeta<T>& m, u32* scratch,
+                                                 F&& f)
+{
+    for (u32 chunk = a0; chunk < a1; chunk += G::SIZE) {
+        const u32 cnt = min((u32)G::SIZE, a1 - chunk);
+        u32 len = 0, bs = 0;
+        T av = T(0);
+        if (g.lane < cnt) {
+            const u32 k = A.col_ids[chunk + g.lane];
+            if (WITH_VALUES) av = A.data[chunk + g.lane];
+            bs = B.row_offsets[k];
+            len = B.row_offsets[k + 1] - bs;
+        }
+        u32 total;
+        const u32 incl = g.inclusive_scan(len, &total, scratch);
+        if (g.lane < cnt) {
+            m.incl[g.lane] = incl;
+            m.off[g.lane] = bs - (incl - len);
+            if (WITH_VALUES) m.av[g.lane] = av;
+        }
+        g.sync();
+        u32 p, step, end;
+        g.product_range(total, p, step, end);
+        if (p < end) {
+            u32 s = owner_search(m.incl, 0, cnt, p);
+            u32 ib = m.off[s] + p;
+            u32 c = B.col_ids[ib];
+            T v = T(0);
+            if (WITH_VALUES) v = m.av[s] * B.data[ib];
+            while (true) {
+                const u32 pn = p + step;
+                const bool more = pn < end;
+                u32 cn = 0;
+                T vn = T(0);
+                if (more) {  // issue the next product's loads before touching the accumulator
+                    s = owner_search(m.incl, s, cnt, pn);
+                    const u32 ibn = m.off[s] + pn;
+                    cn = B.col_ids[ibn];
+                    if (WITH_VALUES) vn = m.av[s] * B.data[ibn];
+                }
+                if constexpr (WITH_VALUES) f(c, v); else f(c);
+                if (!more) break;
+                p = pn;
+                c = cn;
+                v = vn;
+            }
+        }
+        g.sync();
+    }
+}
+
+// ---- LDS open-addressed structures ------------------------------------------------
+template <u32 CAP>
+__device__ __forceinline__ u32 set_insert(u32* tab, u32 key)
+{
+    u32 slot = hash_slot<CAP>(key);
+    while (true) {
+        const u32 old = atomicCAS(&tab[slot], kEmptyKey, key);
+        if (old == kEmptyKey) return 1;
+        if (old == key) return 0;
+        slot = (slot + 1) & (CAP - 1);
+    }
+}
+
+template <u32 CAP, typename T>
+__device__ __forceinline__ void table_accumulate(u32* keys, T* vals, u32 key, T prod)
+{
+    u32 slot = hash_slot<CAP>(key);
+    while (true) {
+        const u32 old = atomicCAS(&keys[slot], kEmptyKey, key);
+        if (old == kEmptyKey || old == key) break;
+        slot = (slot + 1) & (CAP - 1);
+    }
+    atomicAdd(&vals[slot], prod);
+}
+
+// Exclusive prefix of popcounts over bm[0..nwords) into pref[]; returns the total.
+// Every lane owns a contiguous run of words.
+template <class G>
+__device__ __forceinline__ u32 bitmap_prefix(const G& g, const u32* bm, u32* pref, u32 nwords,
+                                             u32* scratch)
+{
+    const u32 wpt = (nwords + G::SIZE - 1) / G::SIZE;
+    const u32 w_begin = min(g.lane * wpt, nwords), w_end = min(w_begin + wpt, nwords);
+    u32 local = 0;
+    for (u32 i = w_begin; i < w_end; ++i) local += __popc(bm[i]);
+    u32 total;
+    u32 run = g.inclusive_scan(local, &total, scratch) - local;
+    for (u32 i = w_begin; i < w_end; ++i) {
+        pref[i] = run;
+        run += __popc(bm[i]);
+    }
+    g.sync();
+    return total;
+}
+
+}  // namespace speck

@@ -1,123 +1,78 @@
-// symbolic.hip -- symbolic phase for gfx950: nnz of every C row (distinct columns
-// reached by the row; structural, values are never read).
+// symbolic.hip -- symbolic phase for gfx950: nnz of every C row (distinct columns reached by
+// the row; structural, values are never read).
 // Role of the reference's spGEMMCountLauncher / denseSpGEMMCount
 // (include/GPU/spECK_HashSpGEMM.cuh:1797-1853, 1681-1711) and HashMapNoValue
 // (include/HashMap.cuh:136-229); designed for 64-lane waves and 160 KiB of LDS:
-//   SYM_WAVE : one wave per row, private 128-key LDS set, no workgroup barrier
-//   SYM_H1-3 : one workgroup per row, power-of-two key set (4 / 32 / 128 KiB)
-//   SYM_BM1-2: column bitmap (1 bit per column) -- one ds_or per product, no probing;
-//              128 KiB of LDS cover 1 Mi columns per window, so the heaviest rows
-//              never need a global-memory spill in this phase.
+//   SYM_G16        : 16 lanes per row (4 rows per wave), 64-key set, no barrier
+//   SYM_W256/W1K   : one wave per row, 256 / 1024-key set, no workgroup barrier
+//   SYM_B4K/16K/32K: one workgroup per row, 16 / 64 / 128 KiB key set
+//   SYM_BM1/BM2    : column bitmap (1 bit per column): one ds_or per product, no probing;
+//                    128 KiB of LDS cover 1 Mi columns per window, so the heaviest rows never
+//                    need a global-memory spill in this phase.
 // Algorithmic bytes per row: 8 + 12*lenA + 4*ops + 4 (device_common.hpp).
 #include "device_common.hpp"
 #include "launch.hpp"
+#include "row_groups.hpp"
 
 namespace speck {
 
-template <u32 CAP>
-__device__ __forceinline__ u32 set_insert(u32* tab, u32 key)
+template <class G, int THREADS>
+constexpr u32 sym_scratch_words()
 {
-    u32 slot = hash_slot<CAP>(key);
-    while (true) {
-        const u32 old = atomicCAS(&tab[slot], kEmptyKey, key);
-        if (old == kEmptyKey) return 1;
-        if (old == key) return 0;
-        slot = (slot + 1) & (CAP - 1);
-    }
+    return G::kIsBlock ? (THREADS / 64 + 2) : 0;
 }
 
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void sym_wave_kernel(const u32* __restrict__ a_ro,
-                                                           const u32* __restrict__ a_col,
-                                                           const u32* __restrict__ b_ro,
-                                                           const u32* __restrict__ b_col, RowWork w,
-                                                           u32* __restrict__ counts)
+// LDS per group: key set + A-row staging (+ scan scratch for workgroup groups)
+template <class G, u32 CAP, int THREADS>
+constexpr u32 sym_group_lds()
 {
-    constexpr int NW = THREADS / 64;
-    __shared__ u32 s_tab[NW][kSymWaveCap];
-    const u32 lane = lane_id(), wid = threadIdx.x >> 6;
-    u32* tab = s_tab[wid];
-    const u32 off = w.st->sym_offset[SYM_WAVE], count = w.st->sym_count[SYM_WAVE];
-    const u32 nwaves = gridDim.x * NW;
-    for (u32 idx = blockIdx.x * NW + wid; idx < count; idx += nwaves) {
-        const u32 row = w.bin_rows[off + idx];
-        tab[lane] = kEmptyKey;
-        tab[lane + 64] = kEmptyKey;
-        const u32 a0 = a_ro[row], a1 = a_ro[row + 1];
-        const u32 shift = pick_group_shift(w.row_ops[row], a1 - a0, 0, 6);
-        const u32 G = 1u << shift, gl = lane & (G - 1), gsub = lane >> shift, ngroups = 64u >> shift;
-        wave_lds_fence();
-        u32 cnt = 0;
-        for (u32 ia = a0 + gsub; ia < a1; ia += ngroups) {
-            const u32 k = a_col[ia];
-            const u32 bs = b_ro[k], be = b_ro[k + 1];
-            for (u32 ib = bs + gl; ib < be; ib += G) cnt += set_insert<kSymWaveCap>(tab, b_col[ib]);
-        }
-        cnt = wave_reduce_add(cnt);
-        if (lane == 0) counts[row] = cnt;
-        wave_lds_fence();
-    }
+    return (CAP + 2 * G::SIZE + sym_scratch_words<G, THREADS>() + 3u) / 4u * 16u;
 }
 
-template <u32 CAP, int THREADS>
-__global__ __launch_bounds__(THREADS) void sym_hash_kernel(const u32* __restrict__ a_ro,
-                                                           const u32* __restrict__ a_col,
-                                                           const u32* __restrict__ b_ro,
-                                                           const u32* __restrict__ b_col, RowWork w,
-                                                           u32* __restrict__ counts, int cls)
+template <class G, u32 CAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void sym_hash_kernel(CsrView<float> A, CsrView<float> B,
+                                                           RowWork w, u32* __restrict__ counts,
+                                                           int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32* tab = reinterpret_cast<u32*>(smem);
-    u32* s_cnt = tab + CAP;
-    constexpr u32 kLog2Threads = __builtin_ctz((u32)THREADS);
-    const u32 off = w.st->sym_offset[cls], count = w.st->sym_count[cls];
-    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    constexpr u32 NG = THREADS / G::SIZE;
+    constexpr u32 kGroupBytes = sym_group_lds<G, CAP, THREADS>();
+    const G g;
+    const u32 gid = G::kIsBlock ? 0u : threadIdx.x / G::SIZE;
+    u32* tab = reinterpret_cast<u32*>(smem + gid * kGroupBytes);
+    RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr};
+    u32* scratch = tab + CAP + 2 * G::SIZE;
+    const u32 off = w.st->sym.offset[cls], count = w.st->sym.count[cls];
+    for (u32 idx = blockIdx.x * NG + gid; idx < count; idx += gridDim.x * NG) {
         const u32 row = w.bin_rows[off + idx];
-        uint4* tab4 = reinterpret_cast<uint4*>(tab);
-        for (u32 i = threadIdx.x; i < CAP / 4; i += THREADS)
-            tab4[i] = make_uint4(kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey);
-        if (threadIdx.x == 0) *s_cnt = 0;
-        __syncthreads();
-        const u32 a0 = a_ro[row], a1 = a_ro[row + 1];
-        const u32 shift = pick_group_shift(w.row_ops[row], a1 - a0, 0, kLog2Threads);
-        const u32 G = 1u << shift, gl = threadIdx.x & (G - 1), gsub = threadIdx.x >> shift,
-                  ngroups = (u32)THREADS >> shift;
+        for (u32 i = g.lane; i < CAP; i += G::SIZE) tab[i] = kEmptyKey;
+        g.sync();
         u32 cnt = 0;
-        for (u32 ia = a0 + gsub; ia < a1; ia += ngroups) {
-            const u32 k = a_col[ia];
-            const u32 bs = b_ro[k], be = b_ro[k + 1];
-            for (u32 ib = bs + gl; ib < be; ib += G) cnt += set_insert<CAP>(tab, b_col[ib]);
-        }
-        cnt = wave_reduce_add(cnt);
-        if (lane_id() == 0 && cnt) atomicAdd(s_cnt, cnt);
-        __syncthreads();
-        if (threadIdx.x == 0) counts[row] = *s_cnt;
-        __syncthreads();
+        for_each_product<false>(g, A, B, A.row_offsets[row], A.row_offsets[row + 1], meta, scratch,
+                                [&](u32 c) { cnt += set_insert<CAP>(tab, c); });
+        cnt = g.reduce_add(cnt, scratch);
+        if (g.lane == 0) counts[row] = cnt;
+        g.sync();
     }
 }
 
 template <u32 WORDS, int THREADS>
-__global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(const u32* __restrict__ a_ro,
-                                                             const u32* __restrict__ a_col,
-                                                             const u32* __restrict__ b_ro,
-                                                             const u32* __restrict__ b_col,
+__global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(CsrView<float> A, CsrView<float> B,
                                                              RowWork w, u32* __restrict__ counts,
                                                              int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = Block<THREADS>;
+    const G g;
     u32* bm = reinterpret_cast<u32*>(smem);
-    u32* s_cnt = bm + WORDS;
-    constexpr u32 kLog2Threads = __builtin_ctz((u32)THREADS);
+    RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr};
+    u32* scratch = bm + WORDS + 2 * THREADS;
     constexpr u64 kWindowCols = u64(WORDS) * 32;
-    const u32 off = w.st->sym_offset[cls], count = w.st->sym_count[cls];
+    const u32 off = w.st->sym.offset[cls], count = w.st->sym.count[cls];
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
         const u32 row = w.bin_rows[off + idx];
-        const u32 a0 = a_ro[row], a1 = a_ro[row + 1];
+        const u32 a0 = A.row_offsets[row], a1 = A.row_offsets[row + 1];
         const u32 cmin = w.row_col_min[row], cmax = w.row_col_max[row];
-        const u32 shift = pick_group_shift(w.row_ops[row], a1 - a0, 0, kLog2Threads);
-        const u32 G = 1u << shift, gl = threadIdx.x & (G - 1), gsub = threadIdx.x >> shift,
-                  ngroups = (u32)THREADS >> shift;
-        if (threadIdx.x == 0) *s_cnt = 0;
         u32 total = 0;
         for (u64 w0 = cmin; w0 <= cmax; w0 += kWindowCols) {
             const u64 left = u64(cmax) - w0 + 1;
@@ -126,35 +81,29 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(const u32* __restri
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             __syncthreads();
             const u32 base = (u32)w0;
-            for (u32 ia = a0 + gsub; ia < a1; ia += ngroups) {
-                const u32 k = a_col[ia];
-                const u32 bs = b_ro[k], be = b_ro[k + 1];
-                for (u32 ib = bs + gl; ib < be; ib += G) {
-                    const u32 d = b_col[ib] - base;  // wraps to a huge value when left of the window
-                    if (d < ncols) atomicOr(&bm[d >> 5], 1u << (d & 31));
-                }
-            }
-            __syncthreads();
+            for_each_product<false>(g, A, B, a0, a1, meta, scratch, [&](u32 c) {
+                const u32 d = c - base;  // wraps to a huge value when left of the window
+                if (d < ncols) atomicOr(&bm[d >> 5], 1u << (d & 31));
+            });
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) total += __popc(bm[i]);
             __syncthreads();
         }
-        total = wave_reduce_add(total);
-        if (lane_id() == 0 && total) atomicAdd(s_cnt, total);
-        __syncthreads();
-        if (threadIdx.x == 0) counts[row] = *s_cnt;
-        __syncthreads();
+        total = g.reduce_add(total, scratch);
+        if (threadIdx.x == 0) counts[row] = total;
     }
 }
 
 u32 symbolic_lds_bytes(int cls)
 {
     switch (cls) {
-        case SYM_WAVE: return 4 * kSymWaveCap * 4;
-        case SYM_H1: return kSymH1Cap * 4 + 16;
-        case SYM_H2: return kSymH2Cap * 4 + 16;
-        case SYM_H3: return kSymH3Cap * 4 + 16;
-        case SYM_BM1: return kSymBm1Words * 4 + 16;
-        case SYM_BM2: return kSymBm2Words * 4 + 16;
+        case SYM_G16: return 16 * sym_group_lds<SubWave<16>, kSymG16Cap, 256>();
+        case SYM_W256: return 4 * sym_group_lds<SubWave<64>, kSymW256Cap, 256>();
+        case SYM_W1K: return 4 * sym_group_lds<SubWave<64>, kSymW1KCap, 256>();
+        case SYM_B4K: return sym_group_lds<Block<256>, kSymB4KCap, 256>();
+        case SYM_B16K: return sym_group_lds<Block<512>, kSymB16KCap, 512>();
+        case SYM_B32K: return sym_group_lds<Block<1024>, kSymB32KCap, 1024>();
+        case SYM_BM1: return (kSymBm1Words + 2 * 256 + 8) * 4;
+        case SYM_BM2: return (kSymBm2Words + 2 * 1024 + 24) * 4;
     }
     return 0;
 }
@@ -163,63 +112,58 @@ template <typename K>
 static void set_dyn_lds(K kernel, u32 bytes)
 {
     // kernels above 64 KiB of LDS need the opt-in (a workgroup may own all 160 KiB on gfx950)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-static u32 grid_for(u32 count, u32 lds, int cu_count, u32 rows_per_block)
+u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block)
 {
     u32 per_cu = lds ? (160u * 1024u) / lds : 8;
-    if (per_cu > 8) per_cu = 8;
+    const u32 by_threads = 2048u / (u32)threads;
+    if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
-    const u64 cap = u64(cu_count) * per_cu * 16;  // 16 rounds of resident workgroups, then stride
+    const u64 cap = u64(cu_count) * per_cu * 8;  // 8 rounds of resident workgroups, then stride
     u64 need = (u64(count) + rows_per_block - 1) / rows_per_block;
     if (need > cap) need = cap;
     return need ? (u32)need : 1u;
+}
+
+template <class G, u32 CAP, int THREADS>
+static void launch_sym_hash(hipStream_t s, int cls, u32 count, const CsrView<float>& A,
+                            const CsrView<float>& B, const RowWork& w, u32* counts, int cu_count)
+{
+    auto k = sym_hash_kernel<G, CAP, THREADS>;
+    const u32 lds = symbolic_lds_bytes(cls);
+    set_dyn_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3(grid_for(count, lds, THREADS, cu_count, THREADS / G::SIZE)),
+                       dim3(THREADS), lds, s, A, B, w, counts, cls);
 }
 
 void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u32* a_col,
                      const u32* b_ro, const u32* b_col, const RowWork& w, u32* counts, int cu_count)
 {
     if (count == 0) return;
+    const CsrView<float> A{a_ro, a_col, nullptr, 0, 0}, B{b_ro, b_col, nullptr, 0, 0};
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
-        case SYM_WAVE: {
-            constexpr int T = 256;
-            hipLaunchKernelGGL(sym_wave_kernel<T>, dim3(grid_for(count, lds, cu_count, T / 64)),
-                               dim3(T), 0, s, a_ro, a_col, b_ro, b_col, w, counts);
-            break;
-        }
-        case SYM_H1: {
-            auto k = sym_hash_kernel<kSymH1Cap, 256>;
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, cu_count, 1)), dim3(256), lds, s, a_ro,
-                               a_col, b_ro, b_col, w, counts, cls);
-            break;
-        }
-        case SYM_H2: {
-            auto k = sym_hash_kernel<kSymH2Cap, 512>;
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, cu_count, 1)), dim3(512), lds, s, a_ro,
-                               a_col, b_ro, b_col, w, counts, cls);
-            break;
-        }
-        case SYM_H3: {
-            auto k = sym_hash_kernel<kSymH3Cap, 1024>;
-            set_dyn_lds(k, lds);
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, cu_count, 1)), dim3(1024), lds, s, a_ro,
-                               a_col, b_ro, b_col, w, counts, cls);
-            break;
-        }
+        case SYM_G16: launch_sym_hash<SubWave<16>, kSymG16Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
+        case SYM_W256: launch_sym_hash<SubWave<64>, kSymW256Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
+        case SYM_W1K: launch_sym_hash<SubWave<64>, kSymW1KCap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
+        case SYM_B4K: launch_sym_hash<Block<256>, kSymB4KCap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
+        case SYM_B16K: launch_sym_hash<Block<512>, kSymB16KCap, 512>(s, cls, count, A, B, w, counts, cu_count); break;
+        case SYM_B32K: launch_sym_hash<Block<1024>, kSymB32KCap, 1024>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_BM1: {
             auto k = sym_bitmap_kernel<kSymBm1Words, 256>;
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, cu_count, 1)), dim3(256), lds, s, a_ro,
-                               a_col, b_ro, b_col, w, counts, cls);
+            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, A, B,
+                               w, counts, cls);
             break;
         }
         case SYM_BM2: {
             auto k = sym_bitmap_kernel<kSymBm2Words, 1024>;
             set_dyn_lds(k, lds);
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, cu_count, 1)), dim3(1024), lds, s, a_ro,
-                               a_col, b_ro, b_col, w, counts, cls);
+            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A,
+                               B, w, counts, cls);
             break;
         }
     }

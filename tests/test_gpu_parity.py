@@ -136,20 +136,36 @@ def test_dimension_limit_and_invalid(cfg):
 def test_random_small_rows_wave_and_direct(cfg, seed):
     A = random_csr(700, 500, 3, seed, empty_row_frac=0.15)
     B = random_csr(500, 600, 4, seed + 50, empty_row_frac=0.15)
-    check(cfg, A, B, [("sym", "wave"), ("num", "wave"), ("num", "direct")])
+    check(cfg, A, B, [("sym", "g16"), ("num", "g16"), ("num", "direct")])
 
 
-def test_hash_classes_h1_h2(cfg):
+def test_wave_classes(cfg):
+    A = fast_random_csr(900, 3000, 10, 61)
+    B = fast_random_csr(3000, 20000, 12, 62)
+    check(cfg, A, B, [("sym", "wave256"), ("num", "wave128"), ("num", "g16")])
+
+
+def test_hash_classes_wave1k_wave512_block2k(cfg):
     A = fast_random_csr(600, 4000, 20, 1)
     B = fast_random_csr(4000, 30000, 30, 2)
-    check(cfg, A, B, [("sym", "hash1k"), ("num", "hash512"), ("num", "hash2k")])
+    check(cfg, A, B, [("sym", "wave1k"), ("num", "wave512"), ("num", "block2k")])
 
 
-def test_hash_classes_h2_h3(cfg):
+def test_hash_classes_block16k(cfg):
+    A = fast_random_csr(100, 5000, 100, 71, jitter=False)
+    B = fast_random_csr(5000, 300000, 100, 72, jitter=False)
+    cfg.set_option("sym_bitmap_ratio", 0)
+    try:
+        check(cfg, A, B, [("sym", "block16k"), ("num", "dense16k")])
+    finally:
+        cfg.set_option("sym_bitmap_ratio", 32)
+
+
+def test_hash_classes_block4k_block8k(cfg):
     A = fast_random_csr(200, 6000, 64, 3)
     B = fast_random_csr(6000, 300000, 64, 4)
-    # range ~300k columns: H3 needs three 128Ki-column sort windows
-    check(cfg, A, B, [("sym", "hash8k"), ("num", "hash8k")])
+    # range ~300k columns: wide enough for the two-level bitmap sort
+    check(cfg, A, B, [("sym", "block4k"), ("num", "block8k")])
 
 
 def test_symbolic_h3_and_dense_multiwindow(cfg):
@@ -157,7 +173,7 @@ def test_symbolic_h3_and_dense_multiwindow(cfg):
     B = fast_random_csr(5000, 2000000, 150, 6, jitter=False)
     cfg.set_option("sym_bitmap_ratio", 0)      # keep the bitmap out: exercise the 128 KiB hash set
     try:
-        check(cfg, A, B, [("sym", "hash32k"), ("num", "dense16k")])
+        check(cfg, A, B, [("sym", "block32k"), ("num", "dense16k")])
     finally:
         cfg.set_option("sym_bitmap_ratio", 32)
 
@@ -174,7 +190,7 @@ def test_banded_dense_and_bitmap_classes(cfg):
     _, st, _ = check(cfg, A, A, [("sym", "bitmap256k"), ("num", "dense4k")])
     cfg.set_option("num_dense_ratio", 0)       # same input through the hash + rank-sort kernel
     try:
-        check(cfg, A, A, [("num", "hash512")])
+        check(cfg, A, A, [("num", "wave512")])
     finally:
         cfg.set_option("num_dense_ratio", 16)
 
