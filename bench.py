@@ -109,20 +109,33 @@ def main():
             return gatherv_csr(ro[1:] - ro[:-1], col, val, root=0)
         return None
 
-    # ---- warm-up; find the dominant numeric kernel (per-kernel HIP events on the pipeline stream)
+    # ---- pre-pass (untimed, eager path with per-kernel HIP events on each kernel's own stream):
+    #      algorithmic bytes per class, per-class / per-phase ms, the dominant numeric kernel
     cfg.profile_kernels(1)
     cfg.set_option("collect_bytes", 1)   # per-class algorithmic bytes: one call is enough
     step()
     torch.cuda.synchronize()
     st = cfg.last_stats()
     cfg.set_option("collect_bytes", 0)
-    for _ in range(max(args.warmup - 1, 1)):
+    prof_steps = 5
+    kernel_ms = {k: 0.0 for k in NUM_CLASS_NAMES}
+    sym_ms = num_ms = 0.0
+    for _ in range(prof_steps):
+        step()
+        s = cfg.last_stats()
+        for k in NUM_CLASS_NAMES:
+            kernel_ms[k] += s["num_bin_ms"][k] / prof_steps
+        sym_ms += (s["analysis_ms"] + s["scan_ms"] + max(s["sym_bin_ms"].values())) / prof_steps
+        num_ms += max(s["num_bin_ms"].values()) / prof_steps
+    P_local, nnzc_local = st["sum_products"], st["nnz_c"]
+    dominant = max(NUM_CLASS_NAMES, key=lambda k: kernel_ms[k])
+    cfg.profile_kernels(0)
+    # the timed region replays a captured hipGraph; the dominant kernel stays bracketed by two
+    # HIP events on its own stream inside that graph
+    cfg.set_option("time_num_class", NUM_CLASS_NAMES.index(dominant))
+    for _ in range(max(args.warmup, 2)):
         step()
     torch.cuda.synchronize()
-    st_t = cfg.last_stats()
-    st["num_bin_ms"] = st_t["num_bin_ms"]
-    P_local, nnzc_local = st["sum_products"], st["nnz_c"]
-    dominant = max(NUM_CLASS_NAMES, key=lambda k: st["num_bin_ms"][k])
 
     def barrier():
         if n_gpus > 1:
@@ -130,19 +143,18 @@ def main():
         torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps
-    kernel_ms = {k: 0.0 for k in NUM_CLASS_NAMES}
-    sym_ms = num_ms = 0.0
+    dom_live_ms, dom_live_n = 0.0, 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        s = cfg.last_stats()            # events were recorded on the pipeline's stream
-        for k in NUM_CLASS_NAMES:
-            kernel_ms[k] += s["num_bin_ms"][k]
-        sym_ms += s["analysis_ms"] + s["scan_ms"] + sum(s["sym_bin_ms"].values())
-        num_ms += sum(s["num_bin_ms"].values())
+        s = cfg.last_stats()
+        if s["kernel_events_valid"]:
+            dom_live_ms += s["num_bin_ms"][dominant]
+            dom_live_n += 1
     barrier()
     elapsed = time.perf_counter() - t0
+    replays = cfg.last_stats()["graph_replays"]
     if n_gpus > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -157,7 +169,8 @@ def main():
     gflops = 2.0 * P_total / (elapsed / args.steps) / 1e9
 
     if rank == 0:
-        dom_ms = kernel_ms[dominant] / args.steps
+        live = dom_live_n > 0 and dom_live_ms > 0
+        dom_ms = dom_live_ms / dom_live_n if live else kernel_ms[dominant]
         dom_bytes = st["num_bin_bytes"][dominant]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
@@ -182,17 +195,21 @@ def main():
                 "nnzC": nnzc_total, "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",
                 "gather": bool(n_gpus > 1 and not args.no_gather),
             },
-            "phases_ms": {"symbolic": round(sym_ms / args.steps, 4), "numeric": round(num_ms / args.steps, 4)},
+            "phases_ms": {"symbolic": round(sym_ms, 4), "numeric": round(num_ms, 4),
+                          "note": "untimed profiled pre-pass; classes run concurrently (max over classes)"},
             "roofline": {
                 "bound": "hbm", "kernel": f"numeric:{dominant}",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
+                "timed_with": ("HIP events around the kernel inside the replayed graph, timed region"
+                               if live else "HIP events, profiled pre-pass (eager)"),
                 "numeric_phase_frac": round(
-                    sum(st["num_bin_bytes"].values()) / max(num_ms / args.steps * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                    sum(st["num_bin_bytes"].values()) / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
             },
-            "kernels_ms": {k: round(v / args.steps, 5) for k, v in kernel_ms.items() if v > 0},
+            "kernels_ms": {k: round(v, 5) for k, v in kernel_ms.items() if v > 0},
             "rows_per_class": {k: v for k, v in st["num_bin_rows"].items() if v},
+            "graph_replays": replays,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, P_total)

@@ -65,7 +65,9 @@ typedef struct speck_stats {
     float sym_bin_ms[SPECK_NUM_SYM_BINS];
     float analysis_ms, scan_ms;
     int32_t kernel_events_valid;                 /* 1 if *_ms were recorded for the last call */
-    int32_t numeric_reruns;                      /* optimistic-capacity misses */
+    int32_t numeric_reruns;                      /* replayed sequences rejected by the device-side checks */
+    int32_t graph_replays;                       /* multiplies served by a replayed hipGraph (cumulative) */
+    int32_t graph_captures;
 } speck_stats;
 
 typedef struct speck_config speck_config; /* opaque; reference: spECKConfig, include/spECKConfig.h:8-53 */

@@ -30,7 +30,8 @@ class CStats(C.Structure):
                 ("num_bin_bytes", C.c_uint64 * NUM_NUM_BINS), ("sym_bin_bytes", C.c_uint64 * NUM_SYM_BINS),
                 ("num_bin_ms", C.c_float * NUM_NUM_BINS), ("sym_bin_ms", C.c_float * NUM_SYM_BINS),
                 ("analysis_ms", C.c_float), ("scan_ms", C.c_float),
-                ("kernel_events_valid", C.c_int32), ("numeric_reruns", C.c_int32)]
+                ("kernel_events_valid", C.c_int32), ("numeric_reruns", C.c_int32),
+                ("graph_replays", C.c_int32), ("graph_captures", C.c_int32)]
 
 
 # every symbol include/speck_c_api.h declares, with its ctypes signature

@@ -272,7 +272,8 @@ class spECKConfig:
             sym_bin_ms=dict(zip(SYM_CLASS_NAMES, list(s.sym_bin_ms))),
             num_bin_ms=dict(zip(NUM_CLASS_NAMES, list(s.num_bin_ms))),
             analysis_ms=float(s.analysis_ms), scan_ms=float(s.scan_ms),
-            kernel_events_valid=bool(s.kernel_events_valid), numeric_reruns=int(s.numeric_reruns))
+            kernel_events_valid=bool(s.kernel_events_valid), numeric_reruns=int(s.numeric_reruns),
+            graph_replays=int(s.graph_replays), graph_captures=int(s.graph_captures))
 
 
 def MultiplyspECK(A, B, matOut, config, timings=None):

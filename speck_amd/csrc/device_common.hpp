@@ -81,6 +81,8 @@ struct ClassifyParams {
     u32 num_dense_ratio;    // use D1 when range <= kNumD1Cols and range <= ratio * nnz
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
     u32 want_bytes;         // accumulate the per-class algorithmic byte counts (profiling)
+    u32 sym_allowed;        // classes whose kernels are part of this launch sequence; a row
+    u32 num_allowed;        //   outside them raises DeviceStats::capacity_miss (graph replay)
 };
 
 __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u32 cmax,
@@ -145,9 +147,22 @@ struct DeviceStats {
     u32 max_row_ops;
     u32 max_row_nnz_c;
     u32 nnz_overflow;
-    u32 capacity_miss;
+    u32 capacity_miss;       // nnz(C) of this call does not fit the C buffers baked into the launch
     BinTable sym;
     BinTable num;
+    u32 sym_queue[kMaxClasses];  // next unclaimed row of each workgroup-per-row class
+    u32 num_queue[kMaxClasses];
+};
+
+// One row of work as the class kernels see it: written in class order by the scatter kernels,
+// read with a single 32-byte load (the next row's record is fetched while the current one runs).
+struct __attribute__((aligned(32))) RowRec {
+    u32 row;         // row of A / C
+    u32 a0, a1;      // bounds of the A row (absolute offsets into A.col_ids / A.data)
+    u32 base;        // first entry of the C row (numeric phase)
+    u32 cmin, cmax;  // column range reachable by the row (analysis)
+    u32 ops;         // intermediate products of the row
+    u32 nnz;         // nnz of the C row (numeric phase)
 };
 
 // What every analysis / scan-apply block leaves behind for the single-block stats kernel

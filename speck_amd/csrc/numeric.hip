@@ -15,6 +15,7 @@
 // the occupied buckets; level 2 holds one 32-bit mask per OCCUPIED bucket (<= nnz words).
 // O(nnz + range/1024) LDS operations instead of a comparison sort (the reference uses an
 // O(nnz^2) rank sort below 500 entries and cub::BlockRadixSort above, :813-865, 1856-1925).
+// The sort scratch aliases the hash table: by then every lane holds its slots in registers.
 // The product a*b is rounded first and then added with an LDS atomic (ds_add_f64), as the
 // reference does (spECK_HashSpGEMM.cuh:157-165) -- no FMA across the add.
 // Algorithmic bytes per row: 8 + 20*lenA + 12*ops + 4 + 12*nnz for fp64 (device_common.hpp).
@@ -27,29 +28,29 @@ namespace speck {
 // ------------------------------------------------------------------ NUM_DIRECT
 template <typename T, int THREADS>
 __global__ __launch_bounds__(THREADS) void num_direct_kernel(CsrView<T> A, CsrView<T> B, RowWork w,
-                                                             const u32* __restrict__ c_ro,
                                                              u32* __restrict__ c_col,
                                                              T* __restrict__ c_val)
 {
     constexpr u32 L = 16, NG = THREADS / L;
+    if (w.st->capacity_miss) return;
     const u32 lane = threadIdx.x & (L - 1), gid = threadIdx.x / L;
-    const u32 off = w.st->num.offset[NUM_DIRECT], count = w.st->num.count[NUM_DIRECT];
+    const u32 count = w.st->num.count[NUM_DIRECT];
+    const RowRec* recs = w.recs + w.st->num.offset[NUM_DIRECT];
     for (u32 idx = blockIdx.x * NG + gid; idx < count; idx += gridDim.x * NG) {
-        const u32 row = w.bin_rows[off + idx];
-        const u32 ia = A.row_offsets[row];
-        const u32 k = A.col_ids[ia];
-        const T av = A.data[ia];
-        const u32 bs = B.row_offsets[k], be = B.row_offsets[k + 1];
-        const u32 base = c_ro[row];
-        for (u32 j = lane; j < be - bs; j += L) {
-            c_col[base + j] = B.col_ids[bs + j];
-            c_val[base + j] = av * B.data[bs + j];
+        const RowRec rec = recs[idx];
+        const u32 k = A.col_ids[rec.a0];
+        const T av = A.data[rec.a0];
+        const u32 bs = B.row_offsets[k];
+        for (u32 j = lane; j < rec.nnz; j += L) {
+            c_col[rec.base + j] = B.col_ids[bs + j];
+            c_val[rec.base + j] = av * B.data[bs + j];
         }
     }
 }
 
 // ------------------------------------------------------------------ sorting back-ends
 // Rank sort for tiny tables: every lane owns OWN = CAP/SIZE slots (registers).
+// `ckeys` may alias the table: all slots are in registers before the first write.
 template <class G, typename T, u32 CAP>
 __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, const T* vals,
                                                  u32* ckeys, u32 base, u32* __restrict__ c_col,
@@ -58,12 +59,16 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
     constexpr u32 OWN = CAP / G::SIZE;
     u32 k[OWN];
     T v[OWN];
-    u32 run = 0;
-    const u64 lt = (1ull << g.lane) - 1ull;
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j) {
         k[j] = keys[j * G::SIZE + g.lane];
         v[j] = vals[j * G::SIZE + g.lane];
+    }
+    g.sync();
+    u32 run = 0;
+    const u64 lt = (1ull << g.lane) - 1ull;
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j) {
         const u64 mask = g.ballot(k[j] != kEmptyKey);
         if (k[j] != kEmptyKey) ckeys[run + __popcll(mask & lt)] = k[j];
         run += __popcll(mask);
@@ -87,7 +92,8 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
         }
 }
 
-// Two-level bitmap sort (see the header comment).  S: LDS scratch of max(2*W1, 2*NMAX) words.
+// Two-level bitmap sort (see the header comment).  S: LDS scratch of max(2*W1, 2*NMAX) words;
+// it may alias the table (slots are loaded into registers first).
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX>
 __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, const T* vals, u32* S,
                                                    u32* scan_scratch, u32 cmin, u32 cmax, u32 base,
@@ -103,6 +109,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
         v[j] = vals[j * G::SIZE + g.lane];
         brank[j] = 0;
     }
+    g.sync();
     u32* l1 = S;
     u32* l1pref = S + W1;
     u32* masks = S;
@@ -161,57 +168,68 @@ constexpr u32 scan_scratch_words()
 {
     return G::kIsBlock ? (THREADS / 64 + 2) : 0;
 }
-template <u32 CAP, u32 W1, u32 NMAX, int MODE>
-constexpr u32 sort_scratch_words()
-{
-    return MODE == SORT_RANK ? (NMAX + 8) : (2 * W1 > 2 * NMAX ? 2 * W1 : 2 * NMAX);
-}
-// LDS bytes of one group, 16-byte granular
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
+// LDS bytes of one group, 16-byte granular: table (values, keys) | a_ik | prefix | offsets | scan
+template <class G, typename T, u32 CAP, int THREADS>
 constexpr u32 num_group_lds()
 {
-    const u32 words = CAP + 2 * G::SIZE + scan_scratch_words<G, THREADS>() + 4 +
-                      sort_scratch_words<CAP, W1, NMAX, MODE>();
-    return (CAP + G::SIZE) * (u32)sizeof(T) + (words + 3u) / 4u * 16u;
+    const u32 words = 2 * G::SIZE + scan_scratch_words<G, THREADS>();
+    return CAP * ((u32)sizeof(T) + 4u) + G::SIZE * (u32)sizeof(T) + (words + 3u) / 4u * 16u;
 }
 
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void num_hash_kernel(CsrView<T> A, CsrView<T> B, RowWork w,
-                                                           const u32* __restrict__ c_ro,
                                                            u32* __restrict__ c_col,
                                                            T* __restrict__ c_val, int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 NG = THREADS / G::SIZE;
-    constexpr u32 kGroupBytes = num_group_lds<G, T, CAP, W1, NMAX, MODE, THREADS>();
+    constexpr u32 kGroupBytes = num_group_lds<G, T, CAP, THREADS>();
+    // the sort scratch (rank: NMAX+8 words, bitmap: max(2*W1, 2*NMAX) words) fits in the table
+    static_assert((MODE == SORT_RANK ? NMAX + 8 : (2 * W1 > 2 * NMAX ? 2 * W1 : 2 * NMAX)) * 4 <=
+                      CAP * (sizeof(T) + 4),
+                  "sort scratch must fit in the table it aliases");
     const G g;
     const u32 gid = G::kIsBlock ? 0u : threadIdx.x / G::SIZE;
     unsigned char* mine = smem + gid * kGroupBytes;
     T* vals = reinterpret_cast<T*>(mine);
-    T* m_av = vals + CAP;
-    u32* keys = reinterpret_cast<u32*>(m_av + G::SIZE);
-    RowMeta<T> meta{keys + CAP, keys + CAP + G::SIZE, m_av};
-    u32* scan_scratch = keys + CAP + 2 * G::SIZE;
-    // 16-byte aligned start of the sort scratch
-    u32* S = keys + ((CAP + 2 * G::SIZE + scan_scratch_words<G, THREADS>() + 3u) & ~3u);
-    const u32 off = w.st->num.offset[cls], count = w.st->num.count[cls];
-    for (u32 idx = blockIdx.x * NG + gid; idx < count; idx += gridDim.x * NG) {
-        const u32 row = w.bin_rows[off + idx];
+    u32* keys = reinterpret_cast<u32*>(vals + CAP);
+    T* m_av = reinterpret_cast<T*>(keys + CAP);
+    u32* m_incl = reinterpret_cast<u32*>(m_av + G::SIZE);
+    RowMeta<T> meta{m_incl, m_incl + G::SIZE, m_av};
+    u32* scan_scratch = m_incl + 2 * G::SIZE;
+    u32* S = reinterpret_cast<u32*>(mine);
+    if (w.st->capacity_miss) return;
+    const u32 count = w.st->num.count[cls];
+    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    u32 idx = blockIdx.x * NG + gid;
+    const u32 stride = gridDim.x * NG;
+    RowRec next{};
+    if (!G::kIsBlock && idx < count) next = recs[idx];
+    while (true) {
+        if constexpr (G::kIsBlock) idx = next_queued_row(w.queue + cls, scan_scratch + THREADS / 64 + 1);
+        if (idx >= count) break;
+        RowRec rec;
+        if constexpr (G::kIsBlock) {
+            rec = recs[idx];
+        } else {
+            rec = next;  // fetched while the previous row was being processed
+            if (idx + stride < count) next = recs[idx + stride];
+        }
         for (u32 i = g.lane; i < CAP; i += G::SIZE) {
             keys[i] = kEmptyKey;
             vals[i] = T(0);
         }
         g.sync();
-        for_each_product<true>(g, A, B, A.row_offsets[row], A.row_offsets[row + 1], meta, scan_scratch,
+        for_each_product<true>(g, A, B, rec.a0, rec.a1, meta, scan_scratch,
                                [&](u32 c, T p) { table_accumulate<CAP>(keys, vals, c, p); });
-        const u32 base = c_ro[row];
         if constexpr (MODE == SORT_RANK) {
-            emit_rank_sorted<G, T, CAP>(g, keys, vals, S, base, c_col, c_val);
+            emit_rank_sorted<G, T, CAP>(g, keys, vals, S, rec.base, c_col, c_val);
         } else {
-            emit_bitmap_sorted<G, T, CAP, W1, NMAX>(g, keys, vals, S, scan_scratch, w.row_col_min[row],
-                                                    w.row_col_max[row], base, c_col, c_val);
+            emit_bitmap_sorted<G, T, CAP, W1, NMAX>(g, keys, vals, S, scan_scratch, rec.cmin, rec.cmax,
+                                                    rec.base, c_col, c_val);
         }
         g.sync();
+        if constexpr (!G::kIsBlock) idx += stride;
     }
 }
 
@@ -224,7 +242,6 @@ constexpr u32 num_dense_lds()
 
 template <typename T, u32 WCOLS, int THREADS>
 __global__ __launch_bounds__(THREADS) void num_dense_kernel(CsrView<T> A, CsrView<T> B, RowWork w,
-                                                            const u32* __restrict__ c_ro,
                                                             u32* __restrict__ c_col,
                                                             T* __restrict__ c_val, int cls)
 {
@@ -238,22 +255,23 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(CsrView<T> A, CsrVie
     u32* pref = bm + WORDS;
     RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av};
     u32* scratch = pref + WORDS + 2 * THREADS;
-    const u32 off = w.st->num.offset[cls], count = w.st->num.count[cls];
-    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const u32 row = w.bin_rows[off + idx];
-        const u32 a0 = A.row_offsets[row], a1 = A.row_offsets[row + 1];
-        const u32 cmin = w.row_col_min[row], cmax = w.row_col_max[row];
-        const u32 base = c_ro[row];
+    if (w.st->capacity_miss) return;
+    const u32 count = w.st->num.count[cls];
+    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    while (true) {
+        const u32 idx = next_queued_row(w.queue + cls, scratch + THREADS / 64 + 1);
+        if (idx >= count) break;
+        const RowRec rec = recs[idx];
         u32 emitted = 0;
-        for (u64 w0 = cmin; w0 <= cmax; w0 += WCOLS) {
-            const u64 left = u64(cmax) - w0 + 1;
+        for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += WCOLS) {
+            const u64 left = u64(rec.cmax) - w0 + 1;
             const u32 ncols = left < WCOLS ? (u32)left : WCOLS;
             const u32 nwords = (ncols + 31) >> 5;
             const u32 wbase = (u32)w0;
             for (u32 i = threadIdx.x; i < ncols; i += THREADS) vals[i] = T(0);
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             __syncthreads();
-            for_each_product<true>(g, A, B, a0, a1, meta, scratch, [&](u32 c, T p) {
+            for_each_product<true>(g, A, B, rec.a0, rec.a1, meta, scratch, [&](u32 c, T p) {
                 const u32 d = c - wbase;
                 if (d < ncols) {
                     atomicAdd(&vals[d], p);
@@ -265,8 +283,8 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(CsrView<T> A, CsrVie
                 const u32 word = bm[d >> 5];
                 if (word & (1u << (d & 31))) {
                     const u32 r = emitted + pref[d >> 5] + __popc(word & ((1u << (d & 31)) - 1u));
-                    c_col[base + r] = wbase + d;
-                    c_val[base + r] = vals[d];
+                    c_col[rec.base + r] = wbase + d;
+                    c_val[rec.base + r] = vals[d];
                 }
             }
             emitted += total;
@@ -285,11 +303,11 @@ u32 numeric_lds_bytes_t(int cls)
 {
     switch (cls) {
         case NUM_DIRECT: return 0;
-        case NUM_G16: return 16 * num_group_lds<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>();
-        case NUM_W128: return 4 * num_group_lds<SubWave<64>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>();
-        case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>();
-        case NUM_B2K: return num_group_lds<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256>();
-        case NUM_B8K: return num_group_lds<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512>();
+        case NUM_G16: return 16 * num_group_lds<SubWave<16>, T, kNumG16Cap, 256>();
+        case NUM_W128: return 4 * num_group_lds<SubWave<64>, T, kNumW128Cap, 256>();
+        case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, 256>();
+        case NUM_B2K: return num_group_lds<Block<256>, T, kNumB2KCap, 256>();
+        case NUM_B8K: return num_group_lds<Block<512>, T, kNumB8KCap, 512>();
         case NUM_D1: return num_dense_lds<T, kNumD1Cols, 256>();
         case NUM_D2: return num_dense_lds<T, kNumD2Cols, 1024>();
     }
@@ -309,23 +327,20 @@ static void set_dyn_lds(K kernel, u32 bytes)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block);
-
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
 static void launch_num_hash(hipStream_t s, int cls, u32 count, const CsrView<T>& A, const CsrView<T>& B,
-                            const RowWork& w, const u32* c_ro, u32* c_col, T* c_val, int cu_count)
+                            const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
     auto k = num_hash_kernel<G, T, CAP, W1, NMAX, MODE, THREADS>;
     const u32 lds = numeric_lds_bytes_t<T>(cls);
     set_dyn_lds(k, lds);
     hipLaunchKernelGGL(k, dim3(grid_for(count, lds, THREADS, cu_count, THREADS / G::SIZE)),
-                       dim3(THREADS), lds, s, A, B, w, c_ro, c_col, c_val, cls);
+                       dim3(THREADS), lds, s, A, B, w, c_col, c_val, cls);
 }
 
 template <typename T>
 void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& A, const CsrView<T>& B,
-                    const RowWork& w, const u32* c_ro, u32* c_col, T* c_val, u64 /*c_capacity*/,
-                    DeviceStats* /*st_mut*/, int cu_count)
+                    const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
     if (count == 0) return;
     const u32 lds = numeric_lds_bytes_t<T>(cls);
@@ -333,51 +348,49 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& A, cons
         case NUM_DIRECT: {
             constexpr int TH = 256;
             hipLaunchKernelGGL((num_direct_kernel<T, TH>), dim3(grid_for(count, 0, TH, cu_count, TH / 16)),
-                               dim3(TH), 0, s, A, B, w, c_ro, c_col, c_val);
+                               dim3(TH), 0, s, A, B, w, c_col, c_val);
             break;
         }
         case NUM_G16:
             launch_num_hash<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
-                s, cls, count, A, B, w, c_ro, c_col, c_val, cu_count);
+                s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_W128:
             launch_num_hash<SubWave<64>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
-                s, cls, count, A, B, w, c_ro, c_col, c_val, cu_count);
+                s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_W512:
             launch_num_hash<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
-                s, cls, count, A, B, w, c_ro, c_col, c_val, cu_count);
+                s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_B2K:
             launch_num_hash<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256>(
-                s, cls, count, A, B, w, c_ro, c_col, c_val, cu_count);
+                s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_B8K:
             launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512>(
-                s, cls, count, A, B, w, c_ro, c_col, c_val, cu_count);
+                s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_D1: {
             auto k = num_dense_kernel<T, kNumD1Cols, 256>;
             set_dyn_lds(k, lds);
             hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, A, B, w,
-                               c_ro, c_col, c_val, cls);
+                               c_col, c_val, cls);
             break;
         }
         case NUM_D2: {
             auto k = num_dense_kernel<T, kNumD2Cols, 1024>;
             set_dyn_lds(k, lds);
             hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,
-                               w, c_ro, c_col, c_val, cls);
+                               w, c_col, c_val, cls);
             break;
         }
     }
 }
 
 template void launch_numeric<double>(hipStream_t, int, u32, const CsrView<double>&,
-                                     const CsrView<double>&, const RowWork&, const u32*, u32*,
-                                     double*, u64, DeviceStats*, int);
+                                     const CsrView<double>&, const RowWork&, u32*, double*, int);
 template void launch_numeric<float>(hipStream_t, int, u32, const CsrView<float>&,
-                                    const CsrView<float>&, const RowWork&, const u32*, u32*, float*,
-                                    u64, DeviceStats*, int);
+                                    const CsrView<float>&, const RowWork&, u32*, float*, int);
 
 }  // namespace speck

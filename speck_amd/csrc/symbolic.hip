@@ -42,17 +42,31 @@ __global__ __launch_bounds__(THREADS) void sym_hash_kernel(CsrView<float> A, Csr
     u32* tab = reinterpret_cast<u32*>(smem + gid * kGroupBytes);
     RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr};
     u32* scratch = tab + CAP + 2 * G::SIZE;
-    const u32 off = w.st->sym.offset[cls], count = w.st->sym.count[cls];
-    for (u32 idx = blockIdx.x * NG + gid; idx < count; idx += gridDim.x * NG) {
-        const u32 row = w.bin_rows[off + idx];
+    const u32 count = w.st->sym.count[cls];
+    const RowRec* recs = w.recs + w.st->sym.offset[cls];
+    u32 idx = blockIdx.x * NG + gid;
+    const u32 stride = gridDim.x * NG;
+    RowRec next{};
+    if (!G::kIsBlock && idx < count) next = recs[idx];
+    while (true) {
+        if constexpr (G::kIsBlock) idx = next_queued_row(w.queue + cls, scratch + THREADS / 64 + 1);
+        if (idx >= count) break;
+        RowRec rec;
+        if constexpr (G::kIsBlock) {
+            rec = recs[idx];
+        } else {
+            rec = next;  // fetched while the previous row was being processed
+            if (idx + stride < count) next = recs[idx + stride];
+        }
         for (u32 i = g.lane; i < CAP; i += G::SIZE) tab[i] = kEmptyKey;
         g.sync();
         u32 cnt = 0;
-        for_each_product<false>(g, A, B, A.row_offsets[row], A.row_offsets[row + 1], meta, scratch,
+        for_each_product<false>(g, A, B, rec.a0, rec.a1, meta, scratch,
                                 [&](u32 c) { cnt += set_insert<CAP>(tab, c); });
         cnt = g.reduce_add(cnt, scratch);
-        if (g.lane == 0) counts[row] = cnt;
+        if (g.lane == 0) counts[rec.row] = cnt;
         g.sync();
+        if constexpr (!G::kIsBlock) idx += stride;
     }
 }
 
@@ -68,20 +82,21 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(CsrView<float> A, C
     RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr};
     u32* scratch = bm + WORDS + 2 * THREADS;
     constexpr u64 kWindowCols = u64(WORDS) * 32;
-    const u32 off = w.st->sym.offset[cls], count = w.st->sym.count[cls];
-    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const u32 row = w.bin_rows[off + idx];
-        const u32 a0 = A.row_offsets[row], a1 = A.row_offsets[row + 1];
-        const u32 cmin = w.row_col_min[row], cmax = w.row_col_max[row];
+    const u32 count = w.st->sym.count[cls];
+    const RowRec* recs = w.recs + w.st->sym.offset[cls];
+    while (true) {
+        const u32 idx = next_queued_row(w.queue + cls, scratch + THREADS / 64 + 1);
+        if (idx >= count) break;
+        const RowRec rec = recs[idx];
         u32 total = 0;
-        for (u64 w0 = cmin; w0 <= cmax; w0 += kWindowCols) {
-            const u64 left = u64(cmax) - w0 + 1;
+        for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += kWindowCols) {
+            const u64 left = u64(rec.cmax) - w0 + 1;
             const u32 ncols = left < kWindowCols ? (u32)left : (u32)kWindowCols;
             const u32 nwords = (ncols + 31) >> 5;
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             __syncthreads();
             const u32 base = (u32)w0;
-            for_each_product<false>(g, A, B, a0, a1, meta, scratch, [&](u32 c) {
+            for_each_product<false>(g, A, B, rec.a0, rec.a1, meta, scratch, [&](u32 c) {
                 const u32 d = c - base;  // wraps to a huge value when left of the window
                 if (d < ncols) atomicOr(&bm[d >> 5], 1u << (d & 31));
             });
@@ -89,7 +104,7 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(CsrView<float> A, C
             __syncthreads();
         }
         total = g.reduce_add(total, scratch);
-        if (threadIdx.x == 0) counts[row] = total;
+        if (threadIdx.x == 0) counts[rec.row] = total;
     }
 }
 
@@ -123,7 +138,9 @@ u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block)
     const u32 by_threads = 2048u / (u32)threads;
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
-    const u64 cap = u64(cu_count) * per_cu * 8;  // 8 rounds of resident workgroups, then stride
+    // sub-wave classes: 4 rounds of resident workgroups, then a static stride;
+    // workgroup-per-row classes (rows_per_block == 1): the resident set, rows come from a queue
+    const u64 cap = u64(cu_count) * per_cu * (rows_per_block > 1 ? 4 : 1);
     u64 need = (u64(count) + rows_per_block - 1) / rows_per_block;
     if (need > cap) need = cap;
     return need ? (u32)need : 1u;
@@ -140,11 +157,11 @@ static void launch_sym_hash(hipStream_t s, int cls, u32 count, const CsrView<flo
                        dim3(THREADS), lds, s, A, B, w, counts, cls);
 }
 
-void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u32* a_col,
-                     const u32* b_ro, const u32* b_col, const RowWork& w, u32* counts, int cu_count)
+void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_col, const u32* b_ro,
+                     const u32* b_col, const RowWork& w, u32* counts, int cu_count)
 {
     if (count == 0) return;
-    const CsrView<float> A{a_ro, a_col, nullptr, 0, 0}, B{b_ro, b_col, nullptr, 0, 0};
+    const CsrView<float> A{nullptr, a_col, nullptr, 0, 0}, B{b_ro, b_col, nullptr, 0, 0};
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
         case SYM_G16: launch_sym_hash<SubWave<16>, kSymG16Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
