@@ -24,7 +24,8 @@ oracle:
 
 apps: $(LIB)
 	@if [ -f apps/runspECK.cpp ]; then \
-	  $(HIPCC) $(HIPFLAGS) -x hip apps/runspECK.cpp -o apps/runspECK -Lspeck_amd -lspeck_amd -Wl,-rpath,'$$ORIGIN/../speck_amd'; fi
+	  $(HIPCC) $(HIPFLAGS) -x hip apps/runspECK.cpp -o apps/runspECK -Lspeck_amd -lspeck_amd \
+	      -L/opt/rocm/lib -lrocsparse -Wl,-rpath,'$$ORIGIN/../speck_amd' -Wl,-rpath,/opt/rocm/lib; fi
 
 clean:
 	rm -f $(OBJS) $(LIB) apps/runspECK

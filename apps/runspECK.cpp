@@ -1,0 +1,264 @@
+// runspECK -- the reference's benchmark driver (source/runspECK.cpp:13-32, source/Executor.cpp:13-81,
+// source/RunConfig.cpp:8-23, source/DataLoader.cpp:24-75) on top of the MI355X backend.
+//
+//   runspECK <matrix.mtx | gen:<kind>[:scale[:seed]]> [config.ini]
+//
+// Same behaviour: loads "<path>d_.hicsr" if present, else the .mtx (and writes the cache);
+// B = A when square, else A^T; IterationsWarmUp + IterationsExecution calls of
+// spECK::MultiplyspECK<double,4,1024,DYN,STATIC> with the SAME matOut and config; prints
+//   var-SpGEMM -> NNZ: <nnz(C)>
+//   var-SpGEMM SpGEMM: <mean complete ms> ms
+// INI keys honoured (the six the reference reads, Executor.cpp:15-29, RunConfig.cpp:22):
+// IterationsWarmUp, IterationsExecution, TrackIndividualTimes, TrackCompleteTimes,
+// CompareResult, InputFile.  CompareResult checks C against rocSPARSE SpGEMM (the reference
+// checks against cuSPARSE, Executor.cpp:29-40): row lengths and column ids bit-exact, values 1e-10.
+// "gen:" inputs are the synthetic SuiteSparse stand-ins (no network in the build image).
+#include <hip/hip_runtime.h>
+#include <rocsparse/rocsparse.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "CSR.h"
+#include "Compare.h"
+#include "Multiply.h"
+#include "Transpose.h"
+
+namespace {
+
+std::map<std::string, std::string> read_ini(const char* path)
+{
+    std::map<std::string, std::string> kv;
+    std::ifstream f(path);
+    std::string line;
+    while (std::getline(f, line)) {
+        const size_t c = line.find_first_of(";#");
+        if (c != std::string::npos) line = line.substr(0, c);
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos) continue;
+        auto trim = [](std::string s) {
+            const char* ws = " \t\r\n";
+            const size_t b = s.find_first_not_of(ws);
+            if (b == std::string::npos) return std::string();
+            return s.substr(b, s.find_last_not_of(ws) - b + 1);
+        };
+        kv[trim(line.substr(0, eq))] = trim(line.substr(eq + 1));
+    }
+    return kv;
+}
+int get_int(const std::map<std::string, std::string>& kv, const char* k, int def)
+{
+    auto it = kv.find(k);
+    return it == kv.end() ? def : std::atoi(it->second.c_str());
+}
+bool get_bool(const std::map<std::string, std::string>& kv, const char* k, bool def)
+{
+    auto it = kv.find(k);
+    if (it == kv.end()) return def;
+    std::string v = it->second;
+    std::transform(v.begin(), v.end(), v.begin(), ::tolower);
+    return v == "true" || v == "1" || v == "yes" || v == "on";
+}
+
+#define RS(expr)                                                                   \
+    do {                                                                           \
+        rocsparse_status _s = (expr);                                              \
+        if (_s != rocsparse_status_success) {                                      \
+            std::printf("rocSPARSE error %d at %s:%d\n", (int)_s, __FILE__, __LINE__); \
+            return false;                                                          \
+        }                                                                          \
+    } while (0)
+
+// C_ref = A*B with rocSPARSE (generic SpGEMM + csrsort), into a dCSR<double>.
+bool rocsparse_reference(const dCSR<double>& A, const dCSR<double>& B, dCSR<double>& C)
+{
+    rocsparse_handle h;
+    RS(rocsparse_create_handle(&h));
+    const double alpha = 1.0, beta = 0.0;
+    C.alloc(A.rows, B.cols, 0, true);
+    rocsparse_spmat_descr dA, dB, dC, dD;
+    RS(rocsparse_create_csr_descr(&dA, A.rows, A.cols, A.nnz, A.row_offsets, A.col_ids, A.data,
+                                  rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero,
+                                  rocsparse_datatype_f64_r));
+    RS(rocsparse_create_csr_descr(&dB, B.rows, B.cols, B.nnz, B.row_offsets, B.col_ids, B.data,
+                                  rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero,
+                                  rocsparse_datatype_f64_r));
+    RS(rocsparse_create_csr_descr(&dC, A.rows, B.cols, 0, C.row_offsets, nullptr, nullptr, rocsparse_indextype_i32,
+                                  rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    RS(rocsparse_create_csr_descr(&dD, A.rows, B.cols, 0, nullptr, nullptr, nullptr, rocsparse_indextype_i32,
+                                  rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    size_t bytes = 0;
+    RS(rocsparse_spgemm(h, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, &beta, dD, dC,
+                        rocsparse_datatype_f64_r, rocsparse_spgemm_alg_default, rocsparse_spgemm_stage_buffer_size,
+                        &bytes, nullptr));
+    void* buf = nullptr;
+    if (hipMalloc(&buf, bytes ? bytes : 16) != hipSuccess) return false;
+    RS(rocsparse_spgemm(h, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, &beta, dD, dC,
+                        rocsparse_datatype_f64_r, rocsparse_spgemm_alg_default, rocsparse_spgemm_stage_nnz, &bytes,
+                        buf));
+    int64_t r, c, nnz;
+    RS(rocsparse_spmat_get_size(dC, &r, &c, &nnz));
+    unsigned int* ro = C.row_offsets;
+    C.row_offsets = nullptr;
+    C.alloc(A.rows, B.cols, (size_t)nnz, false);
+    C.row_offsets = ro;
+    RS(rocsparse_csr_set_pointers(dC, C.row_offsets, C.col_ids, C.data));
+    RS(rocsparse_spgemm(h, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, &beta, dD, dC,
+                        rocsparse_datatype_f64_r, rocsparse_spgemm_alg_default, rocsparse_spgemm_stage_compute, &bytes,
+                        buf));
+    // ascending column ids per row (our contract; rocSPARSE does not promise it)
+    rocsparse_mat_descr md;
+    RS(rocsparse_create_mat_descr(&md));
+    size_t sbytes = 0;
+    RS(rocsparse_csrsort_buffer_size(h, (rocsparse_int)A.rows, (rocsparse_int)B.cols, (rocsparse_int)nnz,
+                                     (const rocsparse_int*)C.row_offsets, (const rocsparse_int*)C.col_ids, &sbytes));
+    void* sbuf = nullptr;
+    rocsparse_int* perm = nullptr;
+    double* sorted = nullptr;
+    if (hipMalloc(&sbuf, sbytes ? sbytes : 16) != hipSuccess) return false;
+    if (hipMalloc((void**)&perm, (nnz ? nnz : 1) * sizeof(rocsparse_int)) != hipSuccess) return false;
+    if (hipMalloc((void**)&sorted, (nnz ? nnz : 1) * sizeof(double)) != hipSuccess) return false;
+    RS(rocsparse_create_identity_permutation(h, (rocsparse_int)nnz, perm));
+    RS(rocsparse_csrsort(h, (rocsparse_int)A.rows, (rocsparse_int)B.cols, (rocsparse_int)nnz, md,
+                         (const rocsparse_int*)C.row_offsets, (rocsparse_int*)C.col_ids, perm, sbuf));
+    RS(rocsparse_dgthr(h, (rocsparse_int)nnz, C.data, sorted, perm, rocsparse_index_base_zero));
+    (void)hipMemcpy(C.data, sorted, nnz * sizeof(double), hipMemcpyDeviceToDevice);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(buf);
+    (void)hipFree(sbuf);
+    (void)hipFree(perm);
+    (void)hipFree(sorted);
+    rocsparse_destroy_mat_descr(md);
+    rocsparse_destroy_spmat_descr(dA);
+    rocsparse_destroy_spmat_descr(dB);
+    rocsparse_destroy_spmat_descr(dC);
+    rocsparse_destroy_spmat_descr(dD);
+    rocsparse_destroy_handle(h);
+    return true;
+}
+
+CSR<double> load_input(const std::string& path)
+{
+    if (path.rfind("gen:", 0) == 0) {
+        std::stringstream ss(path.substr(4));
+        std::string kind, tok;
+        std::getline(ss, kind, ':');
+        double scale = 1.0;
+        uint64_t seed = 1;
+        if (std::getline(ss, tok, ':')) scale = std::atof(tok.c_str());
+        if (std::getline(ss, tok, ':')) seed = std::strtoull(tok.c_str(), nullptr, 10);
+        speck_host_csr* h = nullptr;
+        if (speck_gen_matrix(kind.c_str(), scale, seed, 1, &h) != SPECK_OK) throw std::runtime_error("unknown generator");
+        return speck_detail::from_handle<double>(h);
+    }
+    // DataLoader.cpp:24-58
+    const std::string csrPath = path + "d_" + ".hicsr";
+    try {
+        std::cout << "trying to load csr file \"" << csrPath << "\"\n";
+        CSR<double> m = loadCSR<double>(csrPath.c_str());
+        std::cout << "successfully loaded: \"" << csrPath << "\"\n";
+        return m;
+    } catch (std::exception& ex) {
+        std::cout << "could not load csr file:\n\t" << ex.what() << "\n";
+    }
+    std::cout << "trying to load mtx file \"" << path << "\"\n";
+    CSR<double> m = loadMTXasCSR<double>(path.c_str());
+    std::cout << "successfully loaded and converted: \"" << csrPath << "\"\n";
+    try {
+        std::cout << "write csr file for future use\n";
+        storeCSR(m, csrPath.c_str());
+    } catch (std::exception& ex) {
+        std::cout << ex.what() << std::endl;
+    }
+    return m;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[])
+{
+    if (argc < 2) {
+        std::printf("no .mtx file path set. please call using 'runspECK /path/to/matrix.mtx [config.ini]'");
+        return -1;
+    }
+    std::map<std::string, std::string> ini;
+    if (argc > 2) ini = read_ini(argv[2]);
+    std::string filePath = argv[1];
+    if (ini.count("InputFile")) filePath = ini["InputFile"];  // RunConfig.cpp:22
+
+    const int iterationsWarmup = get_int(ini, "IterationsWarmUp", 5);
+    const int iterationsExecution = get_int(ini, "IterationsExecution", 10);
+    const bool measureAll = get_bool(ini, "TrackIndividualTimes", false);
+    const bool measureCompleteTimes = get_bool(ini, "TrackCompleteTimes", true);
+    const bool compareResult = get_bool(ini, "CompareResult", false);
+
+    try {
+        CSR<double> cpuA = load_input(filePath);
+        std::cout << "Matrix: " << cpuA.rows << "x" << cpuA.cols << ": " << cpuA.nnz << " nonzeros\n";
+        dCSR<double> gpuA, gpuB, dCsrHiRes, dCsrReference;
+        convert(gpuA, cpuA, 0);
+        if (gpuA.rows != gpuA.cols)
+            spECK::Transpose(gpuA, gpuB);  // DataLoader.cpp:65-69
+        else
+            convert(gpuB, cpuA, 0);
+
+        auto config = spECK::spECKConfig::initialize(0);
+        if (compareResult && !rocsparse_reference(gpuA, gpuB, dCsrReference)) {
+            std::printf("Error: rocSPARSE reference failed\n");
+            return 2;
+        }
+        Timings timings, warmupTimings, benchTimings;
+        int errors = 0;
+        auto one = [&](Timings& acc) {
+            timings = Timings();
+            timings.measureAll = measureAll;
+            timings.measureCompleteTime = measureCompleteTimes;
+            spECK::MultiplyspECK<double, 4, 1024, spECK_DYNAMIC_MEM_PER_BLOCK, spECK_STATIC_MEM_PER_BLOCK>(
+                gpuA, gpuB, dCsrHiRes, config, timings);
+            acc += timings;
+            if (compareResult && dCsrHiRes.data != nullptr && dCsrHiRes.col_ids != nullptr) {
+                speck_dcsr a = dCsrReference.raw(), b = dCsrHiRes.raw();
+                uint64_t bad = 1;
+                speck_compare_f64(nullptr, &a, &b, 0, 0.0, &bad);
+                uint64_t badv = 1;
+                speck_compare_f64(nullptr, &a, &b, 1, 1e-10, &badv);
+                if (bad != 0) {
+                    std::printf("Error: Matrix incorrect\n");
+                    ++errors;
+                } else if (badv != 0) {
+                    std::printf("Note: %llu rows differ from rocSPARSE by more than 1e-10 relative (values only)\n",
+                                (unsigned long long)badv);
+                }
+            }
+        };
+        for (int i = 0; i < iterationsWarmup; ++i) one(warmupTimings);
+        for (int i = 0; i < iterationsExecution; ++i) one(benchTimings);
+        benchTimings /= (float)iterationsExecution;
+
+        std::cout << std::setw(20) << "var-SpGEMM -> NNZ: " << dCsrHiRes.nnz << std::endl;
+        std::cout << std::setw(20) << "var-SpGEMM SpGEMM: " << benchTimings.complete << " ms" << std::endl;
+        speck_stats st;
+        speck_last_stats(config.handle, &st);
+        if (benchTimings.complete > 0)
+            std::cout << std::setw(20) << "var-SpGEMM GFLOPS: " << 2.0 * (double)st.sum_products / (benchTimings.complete * 1e6)
+                      << std::endl;
+        if (compareResult) std::cout << "compare vs rocSPARSE: " << (errors ? "FAILED" : "ok") << std::endl;
+        config.cleanup();
+        return errors ? 3 : 0;
+    } catch (std::exception& ex) {
+        std::cout << ex.what() << std::endl;
+        return 1;
+    } catch (const char* msg) {
+        std::cout << msg << std::endl;
+        return 1;
+    }
+}

@@ -128,7 +128,9 @@ def main():
         sym_ms += (s["analysis_ms"] + s["scan_ms"] + max(s["sym_bin_ms"].values())) / prof_steps
         num_ms += max(s["num_bin_ms"].values()) / prof_steps
     P_local, nnzc_local = st["sum_products"], st["nnz_c"]
-    dominant = max(NUM_CLASS_NAMES, key=lambda k: kernel_ms[k])
+    # dominant kernel = the numeric class that moves the most algorithmic bytes (under
+    # concurrency a starved small class can span the whole phase, so "longest" would mislead)
+    dominant = max(NUM_CLASS_NAMES, key=lambda k: st["num_bin_bytes"][k])
     cfg.profile_kernels(0)
     # the timed region replays a captured hipGraph; the dominant kernel stays bracketed by two
     # HIP events on its own stream inside that graph

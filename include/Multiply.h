@@ -1,0 +1,42 @@
+// Multiply.h -- the reference's public entry point (include/Multiply.h:13-20) over the C ABI.
+//   spECK::MultiplyspECK<T, BLOCKS_PER_SM, THREADS_PER_BLOCK, MAX_DYNAMIC_SHARED, MAX_STATIC_SHARED>
+//       (A, B, matOut, config, timings)
+// The four integer template arguments are accepted for source compatibility with callers such as
+// the reference's Executor.cpp:48; this backend sizes its kernels for gfx950 (160 KiB LDS) itself.
+#pragma once
+
+#include <cstdio>
+
+#include "Timings.h"
+#include "dCSR.h"
+#include "spECKConfig.h"
+
+static constexpr int spECK_STATIC_MEM_PER_BLOCK{65536};
+static constexpr int spECK_DYNAMIC_MEM_PER_BLOCK{163840};
+
+namespace spECK {
+template <typename DataType, int BLOCKS_PER_SM, int THREADS_PER_BLOCK, int MAX_DYNAMIC_SHARED, int MAX_STATIC_SHARED>
+void MultiplyspECKImplementation(const dCSR<DataType>& A, const dCSR<DataType>& B, dCSR<DataType>& matOut,
+                                 spECKConfig& config, Timings& timings)
+{
+    speck_dcsr a = A.raw(), b = B.raw(), c = matOut.raw();
+    speck_timings t = timings.to_c();
+    const int rc = sizeof(DataType) == 8 ? speck_multiply_f64(config.handle, &a, &b, &c, &t)
+                                         : speck_multiply_f32(config.handle, &a, &b, &c, &t);
+    if (rc != SPECK_OK) {
+        // the reference printf()s and returns, leaving matOut untouched (Multiply.cu:57-97)
+        std::printf("ERROR: %s\n", speck_status_string(rc));
+        return;
+    }
+    matOut.adopt(c);
+    timings.from_c(t);
+}
+
+template <typename DataType, int BLOCKS_PER_SM, int THREADS_PER_BLOCK, int MAX_DYNAMIC_SHARED, int MAX_STATIC_SHARED>
+void MultiplyspECK(const dCSR<DataType>& A, const dCSR<DataType>& B, dCSR<DataType>& matOut, spECKConfig& config,
+                   Timings& timings)
+{
+    MultiplyspECKImplementation<DataType, BLOCKS_PER_SM, THREADS_PER_BLOCK, MAX_DYNAMIC_SHARED, MAX_STATIC_SHARED>(
+        A, B, matOut, config, timings);
+}
+}  // namespace spECK

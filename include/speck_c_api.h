@@ -126,6 +126,10 @@ int speck_dcsr_upload(speck_dcsr *dst, uint64_t rows, uint64_t cols, uint64_t nn
                       size_t value_size);
 int speck_dcsr_download(const speck_dcsr *src, uint32_t *h_row_offsets, uint32_t *h_col_ids,
                         void *h_data, size_t value_size);
+/* overwrite the contents of an existing device matrix in place (same rows / nnz, same device
+ * pointers); any of the host arrays may be NULL */
+int speck_dcsr_update(speck_dcsr *dst, const uint32_t *h_row_offsets, const uint32_t *h_col_ids,
+                      const void *h_data, size_t value_size);
 /* spECK::Compare(ref, cmp, compare_data) -- include/Compare.h:5-6, source/GPU/Compare.cu:11-82;
  * stricter: offsets + col ids bit-exact; values |x-y| <= rel_tol*max(|x|,|y|) when compare_data.
  * *h_mismatches = number of differing rows (0 = equal). */

@@ -55,6 +55,7 @@ _SIGS = {
     "speck_dcsr_upload": (C.c_int, [_P(DCsr), C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_size_t]),
     "speck_dcsr_download": (C.c_int, [_P(DCsr), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "speck_dcsr_update": (C.c_int, [_P(DCsr), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "speck_compare_f64": (C.c_int, [C.c_void_p, _P(DCsr), _P(DCsr), C.c_int, C.c_double, _P(C.c_uint64)]),
     "speck_transpose_f64": (C.c_int, [C.c_void_p, _P(DCsr), _P(DCsr)]),
     "speck_gen_matrix": (C.c_int, [C.c_char_p, C.c_double, C.c_uint64, C.c_int, _P(C.c_void_p)]),

@@ -12,7 +12,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 nnz_a, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, u32* blk_base, RowRec* recs, DeviceStats* st,
-                     const ClassifyParams& cp);
+                     const ClassifyParams& cp, u32* b_start, u32* b_len);
 
 // exclusive scan of the row counts (+ numeric classification, stats fold, ordered scatter of the
 // numeric row records when num_cls != nullptr).  tile_off: scan_tiles(m) u32 of scratch.
@@ -26,13 +26,15 @@ struct RowWork {
     const RowRec* recs;     // row records grouped by class (device)
     const DeviceStats* st;  // offsets/counts live here (device)
     u32* queue;             // per-class work-queue heads (device), zeroed per call
+    const u32* b_start;     // per A entry (relative to the first entry of the A view):
+    const u32* b_len;       //   start / length of the referenced B row, written by the analysis
 };
 
 // Launch the symbolic kernel of class `cls`.  `count` is an UPPER BOUND of the class' row count
 // (the rows of A): the grid depends only on it, the kernels read the real count from the
 // device-side stats block, so the launch sequence is static and can be captured in a hipGraph.
-void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_col, const u32* b_ro,
-                     const u32* b_col, const RowWork& w, u32* counts, int cu_count);
+void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u32* b_start,
+                     const u32* b_len, const u32* b_col, const RowWork& w, u32* counts, int cu_count);
 
 // Launch the numeric kernel of class `cls` (same convention for `count`).
 template <typename T>

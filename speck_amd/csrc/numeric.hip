@@ -27,23 +27,23 @@ namespace speck {
 
 // ------------------------------------------------------------------ NUM_DIRECT
 template <typename T, int THREADS>
-__global__ __launch_bounds__(THREADS) void num_direct_kernel(CsrView<T> A, CsrView<T> B, RowWork w,
+__global__ __launch_bounds__(THREADS) void num_direct_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                              u32* __restrict__ c_col,
                                                              T* __restrict__ c_val)
 {
     constexpr u32 L = 16, NG = THREADS / L;
     if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
     const u32 lane = threadIdx.x & (L - 1), gid = threadIdx.x / L;
     const u32 count = w.st->num.count[NUM_DIRECT];
     const RowRec* recs = w.recs + w.st->num.offset[NUM_DIRECT];
     for (u32 idx = blockIdx.x * NG + gid; idx < count; idx += gridDim.x * NG) {
         const RowRec rec = recs[idx];
-        const u32 k = A.col_ids[rec.a0];
-        const T av = A.data[rec.a0];
-        const u32 bs = B.row_offsets[k];
+        const T av = src.a_val[rec.a0];
+        const u32 bs = src.b_start[rec.a0];
         for (u32 j = lane; j < rec.nnz; j += L) {
-            c_col[rec.base + j] = B.col_ids[bs + j];
-            c_val[rec.base + j] = av * B.data[bs + j];
+            c_col[rec.base + j] = src.b_col[bs + j];
+            c_val[rec.base + j] = av * src.b_val[bs + j];
         }
     }
 }
@@ -177,7 +177,7 @@ constexpr u32 num_group_lds()
 }
 
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
-__global__ __launch_bounds__(THREADS) void num_hash_kernel(CsrView<T> A, CsrView<T> B, RowWork w,
+__global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                            u32* __restrict__ c_col,
                                                            T* __restrict__ c_val, int cls)
 {
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(CsrView<T> A, CsrView
     u32* scan_scratch = m_incl + 2 * G::SIZE;
     u32* S = reinterpret_cast<u32*>(mine);
     if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
     u32 idx = blockIdx.x * NG + gid;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(CsrView<T> A, CsrView
             vals[i] = T(0);
         }
         g.sync();
-        for_each_product<true>(g, A, B, rec.a0, rec.a1, meta, scan_scratch,
+        for_each_product<true>(g, src, rec.a0, rec.a1, meta, scan_scratch,
                                [&](u32 c, T p) { table_accumulate<CAP>(keys, vals, c, p); });
         if constexpr (MODE == SORT_RANK) {
             emit_rank_sorted<G, T, CAP>(g, keys, vals, S, rec.base, c_col, c_val);
@@ -241,7 +242,7 @@ constexpr u32 num_dense_lds()
 }
 
 template <typename T, u32 WCOLS, int THREADS>
-__global__ __launch_bounds__(THREADS) void num_dense_kernel(CsrView<T> A, CsrView<T> B, RowWork w,
+__global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                             u32* __restrict__ c_col,
                                                             T* __restrict__ c_val, int cls)
 {
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(CsrView<T> A, CsrVie
     RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av};
     u32* scratch = pref + WORDS + 2 * THREADS;
     if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
     while (true) {
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(CsrView<T> A, CsrVie
             for (u32 i = threadIdx.x; i < ncols; i += THREADS) vals[i] = T(0);
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             __syncthreads();
-            for_each_product<true>(g, A, B, rec.a0, rec.a1, meta, scratch, [&](u32 c, T p) {
+            for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch, [&](u32 c, T p) {
                 const u32 d = c - wbase;
                 if (d < ncols) {
                     atomicAdd(&vals[d], p);
@@ -328,7 +330,7 @@ static void set_dyn_lds(K kernel, u32 bytes)
 }
 
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
-static void launch_num_hash(hipStream_t s, int cls, u32 count, const CsrView<T>& A, const CsrView<T>& B,
+static void launch_num_hash(hipStream_t s, int cls, u32 count, const ProductSrc<T>& A, const u32* B,
                             const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
     auto k = num_hash_kernel<G, T, CAP, W1, NMAX, MODE, THREADS>;
@@ -339,10 +341,13 @@ static void launch_num_hash(hipStream_t s, int cls, u32 count, const CsrView<T>&
 }
 
 template <typename T>
-void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& A, const CsrView<T>& B,
+void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, const CsrView<T>& Bv,
                     const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
     if (count == 0) return;
+    // (A, B) below = (product source, A.row_offsets): the kernels rebase the per-entry arrays
+    const ProductSrc<T> A{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data};
+    const u32* B = Av.row_offsets;
     const u32 lds = numeric_lds_bytes_t<T>(cls);
     switch (cls) {
         case NUM_DIRECT: {

@@ -133,13 +133,14 @@ struct Scratch {
     u32* tile_off;
     BlockPartial* partials;
     u32* blk_base;
+    u32 *b_start, *b_len;  // per A entry: the referenced B row (written by the analysis)
 };
 
 u32 partial_blocks(u32 m) { return std::max(analysis_blocks(m), scan_tiles(m)); }
 
-size_t scratch_bytes(u32 m)
+size_t scratch_bytes(u32 m, u64 nnz_a)
 {
-    size_t b = 0;
+    size_t b = 2 * Carver::need(nnz_a, 4);
     b += 4 * Carver::need(m, 4);
     b += Carver::need(m, sizeof(RowRec));
     b += Carver::need(m, 1);
@@ -149,10 +150,12 @@ size_t scratch_bytes(u32 m)
     return b + 4096;
 }
 
-Scratch carve(speck_config* c, u32 m)
+Scratch carve(speck_config* c, u32 m, u64 nnz_a)
 {
     Carver cv(c->arena);
     Scratch s;
+    s.b_start = cv.take<u32>(nnz_a);
+    s.b_len = cv.take<u32>(nnz_a);
     s.recs = cv.take<RowRec>(m);
     s.row_ops = cv.take<u32>(m);
     s.row_max_ops = cv.take<u32>(m);
@@ -290,16 +293,16 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     }
     launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials,
-                    sc.blk_base, sc.recs, c->d_stats, cp);
+                    sc.blk_base, sc.recs, c->d_stats, cp, sc.b_start, sc.b_len);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
-    RowWork w{sc.recs, c->d_stats, c->d_stats->sym_queue};
+    RowWork w{sc.recs, c->d_stats, c->d_stats->sym_queue, sc.b_start, sc.b_len};
     // heaviest classes first: they have the longest tails
     static const int order[SYM_CLASSES] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_B4K,
                                            SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
     int rc = run_classes(c, s, order, SYM_CLASSES, sym_mask, tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr,
                          [&](hipStream_t ks, int cls) {
-                             launch_symbolic(ks, cls, m, A->col_ids, B->row_offsets, B->col_ids, w, c_ro,
-                                             c->sm);
+                             launch_symbolic(ks, cls, m, A->row_offsets, sc.b_start, sc.b_len, B->col_ids,
+                                             w, c_ro, c->sm);
                          });
     if (rc != SPECK_OK) return rc;
     if (timed) {
@@ -323,7 +326,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     CsrView<T> Av{A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
-    RowWork w{sc.recs, c->d_stats, c->d_stats->num_queue};
+    RowWork w{sc.recs, c->d_stats, c->d_stats->num_queue, sc.b_start, sc.b_len};
     static const int order[NUM_CLASSES] = {NUM_G,    NUM_D2,   NUM_B8K, NUM_B2K,   NUM_D1,
                                            NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
     return run_classes(c, s, order, NUM_CLASSES, num_mask, tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr,
@@ -448,9 +451,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     };
     StageTimer st(c, t->measureAll != 0, s);
 
-    rc = ensure_arena(c, scratch_bytes(m));
+    rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
-    Scratch sc = carve(c, m);
+    Scratch sc = carve(c, m, A->nnz);
 
     // ------------------------------------------------------------------ replay path
     // Same buffers as a previous call, C already allocated for the expected nnz: replay the
@@ -770,9 +773,9 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
         }
         return SPECK_OK;
     }
-    rc = ensure_arena(c, scratch_bytes(m));
+    rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
-    Scratch sc = carve(c, m);  // partials / blk_base come from the arena, row arrays from the caller
+    Scratch sc = carve(c, m, A->nnz);  // partials / blk_base come from the arena, row arrays from the caller
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DeviceStats), s));
     launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, d_row_ops,
                     d_row_max_ops, d_row_col_min, d_row_col_max, nullptr, nullptr, sc.partials,
@@ -780,7 +783,7 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
                         ClassifyParams cp = c->cp;
                         cp.sym_allowed = cp.num_allowed = 0xFFFFFFFFu;
                         return cp;
-                    }());
+                    }(), nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return rc;
@@ -804,9 +807,9 @@ int speck_symbolic(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
         if (h_nnz_c) *h_nnz_c = 0;
         return SPECK_OK;
     }
-    rc = ensure_arena(c, scratch_bytes(m));
+    rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
-    Scratch sc = carve(c, m);
+    Scratch sc = carve(c, m, A->nnz);
     rc = enqueue_front(c, s, A, B, sc, d_row_offsets, 8, ~0ull, kAllSym, kAllNum, false, nullptr);
     if (rc != SPECK_OK) return rc;
     rc = read_stats(c, s);
@@ -824,9 +827,9 @@ int speck_partition_rows(speck_config* c, const speck_dcsr* A, const speck_dcsr*
     int rc = check_inputs(A, B);
     if (rc != SPECK_OK) return rc;
     const u32 m = (u32)A->rows;
-    rc = ensure_arena(c, scratch_bytes(m));
+    rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
-    Scratch sc = carve(c, m);
+    Scratch sc = carve(c, m, A->nnz);
     u64 P = 0;
     rc = speck_analysis(c, A, B, sc.row_ops, nullptr, nullptr, nullptr, &P, nullptr);
     if (rc != SPECK_OK) return rc;
@@ -897,6 +900,19 @@ int speck_dcsr_download(const speck_dcsr* src, uint32_t* h_row_offsets, uint32_t
     }
     if (h_row_offsets && src->row_offsets)
         HIP_TRY(hipMemcpy(h_row_offsets, src->row_offsets, (src->rows + 1) * 4, hipMemcpyDeviceToHost));
+    return SPECK_OK;
+}
+
+int speck_dcsr_update(speck_dcsr* dst, const uint32_t* h_row_offsets, const uint32_t* h_col_ids,
+                      const void* h_data, size_t value_size)
+{
+    if (!dst) return SPECK_ERR_INVALID;
+    if (dst->nnz) {
+        if (h_data) HIP_TRY(hipMemcpy(dst->data, h_data, dst->nnz * value_size, hipMemcpyHostToDevice));
+        if (h_col_ids) HIP_TRY(hipMemcpy(dst->col_ids, h_col_ids, dst->nnz * 4, hipMemcpyHostToDevice));
+    }
+    if (h_row_offsets && dst->row_offsets)
+        HIP_TRY(hipMemcpy(dst->row_offsets, h_row_offsets, (dst->rows + 1) * 4, hipMemcpyHostToDevice));
     return SPECK_OK;
 }
 

@@ -140,21 +140,41 @@ __device__ __forceinline__ u32 owner_search(const u32* incl, u32 lo, u32 cnt, u3
     return lo;
 }
 
+// Where the products of a row come from.  b_start / b_len hold, per entry of A, the first entry
+// and the length of the B row it references: the analysis pass reads B.row_offsets for every A
+// entry anyway and writes them out (8 B per A entry), so the symbolic and numeric kernels load
+// them coalesced next to a_ik instead of gathering B.row_offsets behind A.col_ids -- one
+// dependent global round trip less per row.  Both are indexed by (absolute A entry - e_base).
+template <typename T>
+struct ProductSrc {
+    const u32* __restrict__ b_start;
+    const u32* __restrict__ b_len;
+    const T* __restrict__ a_val;
+    const u32* __restrict__ b_col;
+    const T* __restrict__ b_val;
+    // rebase the per-entry arrays so that they can be indexed with absolute A entries
+    __device__ __forceinline__ void rebase(const u32* a_row_offsets)
+    {
+        const u32 e_base = a_row_offsets[0];
+        b_start -= e_base;
+        b_len -= e_base;
+    }
+};
+
 // Walk all products of row [a0,a1) of A.  f(col, value) for WITH_VALUES, f(col) otherwise.
 template <bool WITH_VALUES, class G, typename T, typename F>
-__device__ __forceinline__ void for_each_product(const G& g, const CsrView<T>& A, const CsrView<T>& B,
-                                                 u32 a0, u32 a1, const RowMeta<T>& m, u32* scratch,
-                                                 F&& f)
+__device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>& src, u32 a0, u32 a1,
+                                                 const RowMeta<T>& m, u32* scratch, F&& f)
 {
     for (u32 chunk = a0; chunk < a1; chunk += G::SIZE) {
         const u32 cnt = min((u32)G::SIZE, a1 - chunk);
         u32 len = 0, bs = 0;
         T av = T(0);
         if (g.lane < cnt) {
-            const u32 k = A.col_ids[chunk + g.lane];
-            if (WITH_VALUES) av = A.data[chunk + g.lane];
-            bs = B.row_offsets[k];
-            len = B.row_offsets[k + 1] - bs;
+            const u32 e = chunk + g.lane;
+            if (WITH_VALUES) av = src.a_val[e];
+            bs = src.b_start[e];
+            len = src.b_len[e];
         }
         u32 total;
         const u32 incl = g.inclusive_scan(len, &total, scratch);
@@ -181,9 +201,9 @@ __device__ __forceinline__ void for_each_product(const G& g, const CsrView<T>& A
                 if (pu < end) {
                     s = owner_search(m.incl, s, cnt, pu);
                     const u32 ib = m.off[s] + pu;
-                    c[u] = B.col_ids[ib];
+                    c[u] = src.b_col[ib];
                     if (WITH_VALUES) {
-                        bv[u] = B.data[ib];
+                        bv[u] = src.b_val[ib];
                         av_[u] = m.av[s];
                     }
                 }

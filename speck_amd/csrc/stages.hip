@@ -43,10 +43,11 @@ __global__ __launch_bounds__(kChunk) void analysis_kernel(
     const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* __restrict__ row_ops,
     u32* __restrict__ row_max_ops, u32* __restrict__ row_col_min, u32* __restrict__ row_col_max,
     u8* __restrict__ sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
-    ClassifyParams cp)
+    ClassifyParams cp, u32* __restrict__ b_start, u32* __restrict__ b_len)
 {
     constexpr int NW = kChunk / 64;
     constexpr int U = 4;
+    const u32 e_base = a_ro[0];  // A may be a row-range view with absolute offsets
     __shared__ u32 s_ro[kChunk + 1];
     __shared__ u64 s_ops[kChunk];
     __shared__ u32 s_mx[kChunk], s_cmin[kChunk], s_cmax[kChunk];
@@ -86,6 +87,10 @@ __global__ __launch_bounds__(kChunk) void analysis_kernel(
                 const u32 k = ok[u] ? a_col[e] : 0u;
                 bs[u] = ok[u] ? b_ro[k] : 0u;
                 be[u] = ok[u] ? b_ro[k + 1] : 0u;
+                if (ok[u] && b_start) {  // hand the B-row bounds to the symbolic / numeric kernels
+                    b_start[e - e_base] = bs[u];
+                    b_len[e - e_base] = be[u] - bs[u];
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -492,13 +497,13 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 /*nnz_a*/, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, u32* blk_base, RowRec* recs, DeviceStats* st,
-                     const ClassifyParams& cp)
+                     const ClassifyParams& cp, u32* b_start, u32* b_len)
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
     hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kChunk), 0, s, a_ro, a_col, b_ro, b_col, m,
                        rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                       partials, cp);
+                       partials, cp, b_start, b_len);
     hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(1024), 0, s, partials, blocks, 0, st, blk_base,
                        cp.sym_allowed, (u32*)nullptr, ~0ull);
     if (sym_cls)

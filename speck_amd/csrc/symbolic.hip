@@ -30,7 +30,7 @@ constexpr u32 sym_group_lds()
 }
 
 template <class G, u32 CAP, int THREADS>
-__global__ __launch_bounds__(THREADS) void sym_hash_kernel(CsrView<float> A, CsrView<float> B,
+__global__ __launch_bounds__(THREADS) void sym_hash_kernel(ProductSrc<float> src, const u32* a_ro,
                                                            RowWork w, u32* __restrict__ counts,
                                                            int cls)
 {
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(THREADS) void sym_hash_kernel(CsrView<float> A, Csr
     constexpr u32 NG = THREADS / G::SIZE;
     constexpr u32 kGroupBytes = sym_group_lds<G, CAP, THREADS>();
     const G g;
+    src.rebase(a_ro);
     const u32 gid = G::kIsBlock ? 0u : threadIdx.x / G::SIZE;
     u32* tab = reinterpret_cast<u32*>(smem + gid * kGroupBytes);
     RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr};
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(THREADS) void sym_hash_kernel(CsrView<float> A, Csr
         for (u32 i = g.lane; i < CAP; i += G::SIZE) tab[i] = kEmptyKey;
         g.sync();
         u32 cnt = 0;
-        for_each_product<false>(g, A, B, rec.a0, rec.a1, meta, scratch,
+        for_each_product<false>(g, src, rec.a0, rec.a1, meta, scratch,
                                 [&](u32 c) { cnt += set_insert<CAP>(tab, c); });
         cnt = g.reduce_add(cnt, scratch);
         if (g.lane == 0) counts[rec.row] = cnt;
@@ -71,13 +72,14 @@ __global__ __launch_bounds__(THREADS) void sym_hash_kernel(CsrView<float> A, Csr
 }
 
 template <u32 WORDS, int THREADS>
-__global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(CsrView<float> A, CsrView<float> B,
+__global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> src, const u32* a_ro,
                                                              RowWork w, u32* __restrict__ counts,
                                                              int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = Block<THREADS>;
     const G g;
+    src.rebase(a_ro);
     u32* bm = reinterpret_cast<u32*>(smem);
     RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr};
     u32* scratch = bm + WORDS + 2 * THREADS;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(CsrView<float> A, C
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             __syncthreads();
             const u32 base = (u32)w0;
-            for_each_product<false>(g, A, B, rec.a0, rec.a1, meta, scratch, [&](u32 c) {
+            for_each_product<false>(g, src, rec.a0, rec.a1, meta, scratch, [&](u32 c) {
                 const u32 d = c - base;  // wraps to a huge value when left of the window
                 if (d < ncols) atomicOr(&bm[d >> 5], 1u << (d & 31));
             });
@@ -147,8 +149,8 @@ u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block)
 }
 
 template <class G, u32 CAP, int THREADS>
-static void launch_sym_hash(hipStream_t s, int cls, u32 count, const CsrView<float>& A,
-                            const CsrView<float>& B, const RowWork& w, u32* counts, int cu_count)
+static void launch_sym_hash(hipStream_t s, int cls, u32 count, const ProductSrc<float>& A,
+                            const u32* B, const RowWork& w, u32* counts, int cu_count)
 {
     auto k = sym_hash_kernel<G, CAP, THREADS>;
     const u32 lds = symbolic_lds_bytes(cls);
@@ -157,11 +159,13 @@ static void launch_sym_hash(hipStream_t s, int cls, u32 count, const CsrView<flo
                        dim3(THREADS), lds, s, A, B, w, counts, cls);
 }
 
-void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_col, const u32* b_ro,
-                     const u32* b_col, const RowWork& w, u32* counts, int cu_count)
+void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u32* b_start,
+                     const u32* b_len, const u32* b_col, const RowWork& w, u32* counts, int cu_count)
 {
     if (count == 0) return;
-    const CsrView<float> A{nullptr, a_col, nullptr, 0, 0}, B{b_ro, b_col, nullptr, 0, 0};
+    // (A, B) below = (product source, A.row_offsets): the kernels rebase the per-entry arrays
+    const ProductSrc<float> A{b_start, b_len, nullptr, b_col, nullptr};
+    const u32* B = a_ro;
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
         case SYM_G16: launch_sym_hash<SubWave<16>, kSymG16Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;

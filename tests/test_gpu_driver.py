@@ -1,0 +1,62 @@
+"""The runspECK driver (reference source/Executor.cpp:13-81) end to end on the GPU, including its
+CompareResult path -- here against rocSPARSE SpGEMM, the stand-in for the reference's cuSPARSE check."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "apps", "runspECK")
+
+
+def run(args, cwd):
+    assert os.path.exists(EXE), "apps/runspECK missing: run `make` / __graft_entry__.build()"
+    p = subprocess.run([EXE] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    return p.returncode, p.stdout.decode()
+
+
+def write_ini(path, **kv):
+    with open(path, "w") as f:
+        for k, v in kv.items():
+            f.write(f"{k}={v}\n")
+
+
+@pytest.mark.parametrize("spec", ["gen:scircuit:0.1:3", "gen:cant:0.05:3", "gen:webbase:0.02:3"])
+def test_driver_matches_rocsparse(tmp_path, spec):
+    ini = tmp_path / "config.ini"
+    write_ini(ini, TrackCompleteTimes="true", TrackIndividualTimes="false", CompareResult="true",
+              IterationsWarmUp=2, IterationsExecution=3)
+    rc, out = run([spec, str(ini)], tmp_path)
+    assert rc == 0, out
+    assert "compare vs rocSPARSE: ok" in out, out
+    assert "Error: Matrix incorrect" not in out
+    m = re.search(r"var-SpGEMM -> NNZ: (\d+)", out)
+    assert m and int(m.group(1)) > 0
+    m = re.search(r"var-SpGEMM SpGEMM: ([0-9.eE+-]+) ms", out)
+    assert m and float(m.group(1)) > 0
+
+
+def test_driver_mtx_cache_and_rectangular(tmp_path):
+    src = os.path.join(ROOT, "tests", "golden", "formats", "general_real.mtx")   # 4 x 5: B = A^T
+    mtx = tmp_path / "m.mtx"
+    shutil.copy(src, mtx)
+    ini = tmp_path / "config.ini"
+    write_ini(ini, CompareResult="true", IterationsWarmUp=1, IterationsExecution=2)
+    rc, out = run([str(mtx), str(ini)], tmp_path)
+    assert rc == 0, out
+    assert "Matrix: 4x5: 7 nonzeros" in out
+    assert os.path.exists(str(mtx) + "d_.hicsr")                  # DataLoader.cpp cache file name
+    assert "compare vs rocSPARSE: ok" in out
+    rc, out2 = run([str(mtx), str(ini)], tmp_path)                # second run is served by the cache
+    assert rc == 0 and "successfully loaded: " in out2
+
+
+def test_driver_individual_times_table(tmp_path):
+    ini = tmp_path / "config.ini"
+    write_ini(ini, TrackIndividualTimes="true", IterationsWarmUp=1, IterationsExecution=1)
+    rc, out = run(["gen:mac_econ:0.05:1", str(ini)], tmp_path)
+    assert rc == 0, out
+    assert "spECK      numeric kernel = " in out and "spECK     counting kernel = " in out
