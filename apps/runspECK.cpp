@@ -92,9 +92,14 @@ bool rocsparse_reference(const dCSR<double>& A, const dCSR<double>& B, dCSR<doub
     RS(rocsparse_create_csr_descr(&dB, B.rows, B.cols, B.nnz, B.row_offsets, B.col_ids, B.data,
                                   rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero,
                                   rocsparse_datatype_f64_r));
-    RS(rocsparse_create_csr_descr(&dC, A.rows, B.cols, 0, C.row_offsets, nullptr, nullptr, rocsparse_indextype_i32,
+    // nnz = 0 placeholders need valid pointers: C.alloc(.., 0, ..) keeps one element of each
+    (void)hipMemset(C.row_offsets, 0, (A.rows + 1) * sizeof(unsigned int));
+    RS(rocsparse_create_csr_descr(&dC, A.rows, B.cols, 0, C.row_offsets, C.col_ids, C.data, rocsparse_indextype_i32,
                                   rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
-    RS(rocsparse_create_csr_descr(&dD, A.rows, B.cols, 0, nullptr, nullptr, nullptr, rocsparse_indextype_i32,
+    unsigned int* d_ro = nullptr;  // D is empty (beta = 0) but needs its own zeroed row offsets
+    if (hipMalloc((void**)&d_ro, (A.rows + 1) * sizeof(unsigned int)) != hipSuccess) return false;
+    (void)hipMemset(d_ro, 0, (A.rows + 1) * sizeof(unsigned int));
+    RS(rocsparse_create_csr_descr(&dD, A.rows, B.cols, 0, d_ro, C.col_ids, C.data, rocsparse_indextype_i32,
                                   rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
     size_t bytes = 0;
     RS(rocsparse_spgemm(h, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, &beta, dD, dC,
@@ -134,6 +139,7 @@ bool rocsparse_reference(const dCSR<double>& A, const dCSR<double>& B, dCSR<doub
     (void)hipMemcpy(C.data, sorted, nnz * sizeof(double), hipMemcpyDeviceToDevice);
     (void)hipDeviceSynchronize();
     (void)hipFree(buf);
+    (void)hipFree(d_ro);
     (void)hipFree(sbuf);
     (void)hipFree(perm);
     (void)hipFree(sorted);

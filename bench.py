@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--mtx", default=None, help="real MatrixMarket file instead of the stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gatherv exchange")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (tuning)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,6 +92,9 @@ def main():
     dA = sa.dCSR.from_device(A.rows, A.cols, A.nnz, t_ro.data_ptr(), t_col.data_ptr(), t_val.data_ptr(),
                              keep=(t_ro, t_col, t_val), host_row_offsets=A.row_offsets)
     cfg = sa.spECKConfig.initialize(local_rank)
+    for o in args.opt:
+        name, value = o.split("=")
+        cfg.set_option(name, int(value))
 
     if n_gpus > 1:
         bounds = sa.partition_rows(dA, dA, cfg, n_gpus)

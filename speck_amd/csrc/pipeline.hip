@@ -568,7 +568,10 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     rc = enqueue_back<T>(c, s, A, B, sc, c_ro, c_col, static_cast<T*>(c_val), num_mask,
                          c->h_stats->num.count, &tm);
     if (rc != SPECK_OK) return rc;
-    if (t->measureAll) HIP_TRY(hipStreamSynchronize(s));
+    // The reference may return before its kernels finish when measureCompleteTime is off
+    // (Multiply.cu:1082-1085) and relies on blocking streams to order later copies.  The
+    // pipeline streams here are non-blocking, so the call always returns with C complete.
+    HIP_TRY(hipStreamSynchronize(s));
     t->spGEMMNumeric = st.lap();
     t->sorting = 0.f;  // sorting is fused into the numeric kernels
     t->cleanup = 0.f;  // nothing to free: the arena persists
