@@ -150,14 +150,16 @@ def main():
 
     # ---- timed region: exactly K steps
     dom_live_ms, dom_live_n = 0.0, 0
+    live_ok = bool(cfg.last_stats()["kernel_events_valid"])  # do the in-graph events deliver times?
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        s = cfg.last_stats()
-        if s["kernel_events_valid"]:
-            dom_live_ms += s["num_bin_ms"][dominant]
-            dom_live_n += 1
+        if live_ok:
+            s = cfg.last_stats()
+            if s["kernel_events_valid"]:
+                dom_live_ms += s["num_bin_ms"][dominant]
+                dom_live_n += 1
     barrier()
     elapsed = time.perf_counter() - t0
     replays = cfg.last_stats()["graph_replays"]

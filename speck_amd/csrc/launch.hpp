@@ -11,15 +11,14 @@ u32 scan_tiles(u32 m);
 void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32* b_ro,
                      const u32* b_col, u32 m, u64 nnz_a, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
-                     BlockPartial* partials, u32* blk_base, RowRec* recs, DeviceStats* st,
-                     const ClassifyParams& cp, u32* b_start, u32* b_len);
+                     BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
+                     u32* b_start, u32* b_len);
 
 // exclusive scan of the row counts (+ numeric classification, stats fold, ordered scatter of the
 // numeric row records when num_cls != nullptr).  tile_off: scan_tiles(m) u32 of scratch.
-void launch_scan(hipStream_t s, u32* counts_inout, u32 m, u32* tile_off, const u32* a_ro,
-                 const u32* row_ops, const u32* row_col_min, const u32* row_col_max, u8* num_cls,
-                 BlockPartial* partials, u32* blk_base, RowRec* recs, DeviceStats* st,
-                 const ClassifyParams& cp, u32 vsize, u64 exact_nnz);
+void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
+                 const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
+                 RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz);
 
 // Everything a symbolic / numeric kernel needs besides the matrices.
 struct RowWork {

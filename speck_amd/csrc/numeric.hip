@@ -205,17 +205,10 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, co
     u32 idx = blockIdx.x * NG + gid;
     const u32 stride = gridDim.x * NG;
     RowRec next{};
-    if (!G::kIsBlock && idx < count) next = recs[idx];
-    while (true) {
-        if constexpr (G::kIsBlock) idx = next_queued_row(w.queue + cls, scan_scratch + THREADS / 64 + 1);
-        if (idx >= count) break;
-        RowRec rec;
-        if constexpr (G::kIsBlock) {
-            rec = recs[idx];
-        } else {
-            rec = next;  // fetched while the previous row was being processed
-            if (idx + stride < count) next = recs[idx + stride];
-        }
+    if (idx < count) next = recs[idx];
+    while (idx < count) {
+        const RowRec rec = next;  // fetched while the previous row was being processed
+        if (idx + stride < count) next = recs[idx + stride];
         for (u32 i = g.lane; i < CAP; i += G::SIZE) {
             keys[i] = kEmptyKey;
             vals[i] = T(0);
@@ -230,7 +223,7 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, co
                                                     rec.base, c_col, c_val);
         }
         g.sync();
-        if constexpr (!G::kIsBlock) idx += stride;
+        idx += stride;
     }
 }
 
@@ -260,10 +253,11 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
     src.rebase(a_ro);
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
-    while (true) {
-        const u32 idx = next_queued_row(w.queue + cls, scratch + THREADS / 64 + 1);
-        if (idx >= count) break;
-        const RowRec rec = recs[idx];
+    RowRec next{};
+    if (blockIdx.x < count) next = recs[blockIdx.x];
+    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const RowRec rec = next;  // fetched while the previous row was being processed
+        if (idx + gridDim.x < count) next = recs[idx + gridDim.x];
         u32 emitted = 0;
         for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += WCOLS) {
             const u64 left = u64(rec.cmax) - w0 + 1;

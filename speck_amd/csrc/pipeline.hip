@@ -292,8 +292,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
     launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
-                    sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials,
-                    sc.blk_base, sc.recs, c->d_stats, cp, sc.b_start, sc.b_len);
+                    sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
+                    c->d_stats, cp, sc.b_start, sc.b_len);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     RowWork w{sc.recs, c->d_stats, c->d_stats->sym_queue, sc.b_start, sc.b_len};
     // heaviest classes first: they have the longest tails
@@ -309,9 +309,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         tm->ev_scan = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
-    launch_scan(s, c_ro, m, sc.tile_off, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
-                classify_numeric ? sc.cls : nullptr, sc.partials, sc.blk_base, sc.recs, c->d_stats, cp,
-                vsize, exact_nnz);
+    launch_scan(s, c_ro, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
+                classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -781,8 +780,8 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     Scratch sc = carve(c, m, A->nnz);  // partials / blk_base come from the arena, row arrays from the caller
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DeviceStats), s));
     launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, d_row_ops,
-                    d_row_max_ops, d_row_col_min, d_row_col_max, nullptr, nullptr, sc.partials,
-                    sc.blk_base, sc.recs, c->d_stats, [&] {
+                    d_row_max_ops, d_row_col_min, d_row_col_max, nullptr, nullptr, sc.partials, sc.recs,
+                    c->d_stats, [&] {
                         ClassifyParams cp = c->cp;
                         cp.sym_allowed = cp.num_allowed = 0xFFFFFFFFu;
                         return cp;

@@ -12,6 +12,8 @@
 // No kernel here issues a global atomic: same-cache-line device atomics cost ~12 ns each on
 // MI355X and serialise, so every block leaves a BlockPartial behind (plain stores) and one
 // single-block kernel folds them.
+#include <type_traits>
+
 #include "device_common.hpp"
 #include "launch.hpp"
 
@@ -178,101 +180,140 @@ __global__ __launch_bounds__(kChunk) void analysis_kernel(
 }
 
 // --------------------------------------------------------------------------------
-// Fold the block partials: totals, per-class offsets and, per block, the base of each class
-// inside the record array.  One workgroup, one wave per class (wave-level scans, no barriers
-// inside).  For the numeric phase it also scans the per-tile nnz sums (the middle step of the
-// row_offsets scan) and checks the assumptions of a replayed launch sequence.
+// Folding the block partials.  There is no separate "stats" kernel: every block of the two
+// scatter kernels folds the (<= ~1k) partials itself -- a few coalesced loads and wave
+// reductions, ~2 us, all blocks in parallel -- instead of waiting for a single-workgroup
+// kernel (~12 us of dependent latency plus a kernel boundary).  Block 0 publishes the totals
+// to the DeviceStats block that the class kernels and the host read.
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void stats_kernel(const BlockPartial* __restrict__ parts, u32 nb,
-                                                     int numeric, DeviceStats* __restrict__ st,
-                                                     u32* __restrict__ blk_base, u32 allowed_mask,
-                                                     u32* __restrict__ tile_off, u64 exact_nnz)
+struct Fold {
+    u32 prefix[kMaxClasses];  // rows of each class in the blocks before mine
+    u32 total[kMaxClasses];   // rows of each class in all blocks
+    u64 sum_prefix, sum_total;  // products (analysis) / nnz (numeric) before mine / overall
+    u32 max_val;
+};
+
+template <int THREADS, int NCLS>
+__device__ __forceinline__ void fold_partials(const BlockPartial* __restrict__ parts, u32 nb,
+                                              u32 my_block, Fold* s_fold /*LDS*/, u64* s_bytes /*LDS*/,
+                                              bool want_bytes)
 {
-    __shared__ u32 s_total[kMaxClasses];
-    __shared__ u64 s_bytes[kMaxClasses];
-    const u32 lane = lane_id(), w = threadIdx.x >> 6;
-    if (w < kMaxClasses) {
-        u32 carry = 0;
-        u64 bytes = 0;
-        for (u32 base = 0; base < nb; base += 64) {
-            const u32 i = base + lane;
-            const u32 v = i < nb ? parts[i].count[w] : 0;
-            if (i < nb) bytes += parts[i].bytes[w];
-            const u32 incl = wave_inclusive_scan(v);
-            if (i < nb) blk_base[size_t(i) * kMaxClasses + w] = carry + incl - v;
-            carry += (u32)__shfl((int)incl, 63, 64);
-        }
-        bytes = wave_reduce_add(bytes);
-        if (lane == 0) {
-            s_total[w] = carry;
-            s_bytes[w] = bytes;
-        }
-    } else if (w == kMaxClasses) {
-        if (!numeric) {
-            u64 p = 0;
-            for (u32 i = lane; i < nb; i += 64) p += parts[i].products;
-            p = wave_reduce_add(p);
-            if (lane == 0) st->sum_products = p;
-        } else {
-            // exclusive scan of the per-tile nnz sums -> offset of each tile's first row
-            u64 carry = 0;
-            for (u32 base = 0; base < nb; base += 64) {
-                const u32 i = base + lane;
-                const u64 v = i < nb ? parts[i].products : 0;
-                u64 incl = v;
+    constexpr int NW = THREADS / 64;
+    __shared__ u32 s_pre[NW][NCLS], s_tot[NW][NCLS], s_mx[NW];
+    __shared__ u64 s_sp[NW], s_st[NW], s_by[NW][NCLS];
+    u32 pre[NCLS], tot[NCLS];
+    u64 by[NCLS];
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const u64 t = __shfl_up(incl, off, 64);
-                    if (lane >= (u32)off) incl += t;
-                }
-                if (i < nb) tile_off[i] = (u32)(carry + incl - v);
-                carry += __shfl(incl, 63, 64);
-            }
-            if (lane == 0) {
-                st->nnz_c = carry;
-                if (carry > 0xFFFFFFFFull) st->nnz_overflow = 1;
-                if (exact_nnz != ~0ull && carry != exact_nnz) st->capacity_miss = 1;
-            }
+    for (int c = 0; c < NCLS; ++c) pre[c] = tot[c] = 0, by[c] = 0;
+    u64 sp = 0, stt = 0;
+    u32 mx = 0;
+    for (u32 b = threadIdx.x; b < nb; b += THREADS) {
+        const bool before = b < my_block;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) {
+            const u32 v = parts[b].count[c];
+            tot[c] += v;
+            if (before) pre[c] += v;
+            if (want_bytes) by[c] += parts[b].bytes[c];
         }
-    } else if (w == kMaxClasses + 1) {
-        u32 mx = 0;
-        for (u32 i = lane; i < nb; i += 64) mx = max(mx, parts[i].max_val);
-        mx = wave_reduce_max(mx);
+        const u64 p = parts[b].products;
+        stt += p;
+        if (before) sp += p;
+        mx = max(mx, parts[b].max_val);
+    }
+    const u32 wid = threadIdx.x >> 6, lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+        const u32 a = wave_reduce_add(pre[c]), t = wave_reduce_add(tot[c]);
+        const u64 y = want_bytes ? wave_reduce_add(by[c]) : 0ull;
         if (lane == 0) {
-            if (numeric) st->max_row_nnz_c = mx; else st->max_row_ops = mx;
+            s_pre[wid][c] = a;
+            s_tot[wid][c] = t;
+            s_by[wid][c] = y;
         }
+    }
+    sp = wave_reduce_add(sp);
+    stt = wave_reduce_add(stt);
+    mx = wave_reduce_max(mx);
+    if (lane == 0) {
+        s_sp[wid] = sp;
+        s_st[wid] = stt;
+        s_mx[wid] = mx;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        BinTable& t = numeric ? st->num : st->sym;
-        u32 run = 0;
-        for (int c = 0; c < kMaxClasses; ++c) {
-            t.count[c] = s_total[c];
-            t.offset[c] = run;
-            t.bytes[c] = s_bytes[c];
-            run += s_total[c];
-            // a replayed launch sequence only carries the kernels of `allowed_mask`
-            if (s_total[c] && !((allowed_mask >> c) & 1u)) st->capacity_miss = 1;
-        }
-        t.offset[kMaxClasses] = run;
+    if (threadIdx.x < kMaxClasses) {
+        u32 a = 0, t = 0;
+        u64 y = 0;
+        if (threadIdx.x < NCLS)
+            for (int w = 0; w < NW; ++w) {
+                a += s_pre[w][threadIdx.x];
+                t += s_tot[w][threadIdx.x];
+                y += s_by[w][threadIdx.x];
+            }
+        s_fold->prefix[threadIdx.x] = a;
+        s_fold->total[threadIdx.x] = t;
+        s_bytes[threadIdx.x] = y;
     }
+    if (threadIdx.x == 0) {
+        u64 a = 0, t = 0;
+        u32 m = 0;
+        for (int w = 0; w < NW; ++w) {
+            a += s_sp[w];
+            t += s_st[w];
+            m = max(m, s_mx[w]);
+        }
+        s_fold->sum_prefix = a;
+        s_fold->sum_total = t;
+        s_fold->max_val = m;
+    }
+    __syncthreads();
+}
+
+// class offsets = exclusive scan of the class totals (tiny, every thread computes what it needs)
+__device__ __forceinline__ u32 class_offset(const Fold& f, u32 cls)
+{
+    u32 run = 0;
+    for (u32 c = 0; c < cls; ++c) run += f.total[c];
+    return run;
+}
+
+__device__ __forceinline__ void publish_bins(BinTable& t, const Fold& f, const u64* bytes, u32 allowed_mask,
+                                             DeviceStats* st)
+{
+    u32 run = 0;
+    for (int c = 0; c < kMaxClasses; ++c) {
+        t.count[c] = f.total[c];
+        t.offset[c] = run;
+        t.bytes[c] = bytes[c];
+        run += f.total[c];
+        // a replayed launch sequence only carries the kernels of `allowed_mask`
+        if (f.total[c] && !((allowed_mask >> c) & 1u)) st->capacity_miss = 1;
+    }
+    t.offset[kMaxClasses] = run;
 }
 
 // Ordered scatter for the symbolic phase: block b re-reads the classes of its rows and writes
-// each row's record at class_offset + block_base + rank (rank from ballots, ascending rows).
+// each row's record at class_offset + rows-before-my-block + rank (ballots, ascending rows).
 __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
-    const u8* __restrict__ cls, u32 m, u32 rows_per_block, const DeviceStats* __restrict__ st,
-    const u32* __restrict__ blk_base, const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
-    const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
-    RowRec* __restrict__ recs)
+    const u8* __restrict__ cls, u32 m, u32 rows_per_block, DeviceStats* __restrict__ st,
+    const BlockPartial* __restrict__ parts, u32 nb, const u32* __restrict__ a_ro,
+    const u32* __restrict__ row_ops, const u32* __restrict__ row_col_min,
+    const u32* __restrict__ row_col_max, RowRec* __restrict__ recs, ClassifyParams cp)
 {
     constexpr int NW = kChunk / 64;
+    __shared__ Fold s_fold;
+    __shared__ u64 s_bytes[kMaxClasses];
     __shared__ u32 s_wcnt[SYM_CLASSES][NW];
     __shared__ u32 s_run[SYM_CLASSES];
     const u32 lane = lane_id(), wid = threadIdx.x >> 6;
-    if (threadIdx.x < SYM_CLASSES)
-        s_run[threadIdx.x] = st->sym.offset[threadIdx.x] +
-                             blk_base[size_t(blockIdx.x) * kMaxClasses + threadIdx.x];
+    fold_partials<kChunk, SYM_CLASSES>(parts, nb, blockIdx.x, &s_fold, s_bytes, cp.want_bytes != 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->sum_products = s_fold.sum_total;
+        st->max_row_ops = s_fold.max_val;
+        publish_bins(st->sym, s_fold, s_bytes, cp.sym_allowed, st);
+    }
+    if (!cls) return;
+    if (threadIdx.x < SYM_CLASSES) s_run[threadIdx.x] = class_offset(s_fold, threadIdx.x) + s_fold.prefix[threadIdx.x];
     __syncthreads();
     const u32 row_begin = blockIdx.x * rows_per_block;
     const u32 row_end = min(m, row_begin + rows_per_block);
@@ -315,15 +356,16 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
 // row_offsets scan, fused with the numeric classification and scatter.  Tile = 2048 rows,
 // thread t owns 8 consecutive rows.
 //   num_count_kernel : per tile  nnz sum + class histogram (+ max row nnz), class per row
-//   stats_kernel     : scan of the tile sums, class offsets / per-tile class bases
-//   num_apply_kernel : row_offsets = tile offset + local scan (in place) and the RowRec of
+//   num_apply_kernel : folds the tile partials (tile offset = nnz before my tile, class bases),
+//                      row_offsets = tile offset + local scan (in place) and the RowRec of
 //                      every row at its class position (ascending rows inside a class)
 // Traffic: 8(m+1) B for the scan itself + 4m re-read of the counts + 33 m for
 // classes and records.
 // --------------------------------------------------------------------------------
 constexpr int kScanThreads = 256;
-constexpr int kScanItems = 8;
-constexpr int kScanTile = kScanThreads * kScanItems;
+// rows per thread: chosen by the host so that the tile count stays <= ~1024 (every block of
+// num_apply_kernel folds all tile partials) while small inputs still get >= ~300 blocks
+static inline int scan_items(u32 m) { return m <= (1u << 19) ? 2 : (m <= (1u << 21) ? 8 : 32); }
 constexpr int kFieldBits = 12;  // per-class counters packed 5 per u64 (<= 512 per wave)
 
 __device__ __forceinline__ void packed_add(u64& lo, u64& hi, u32 cls)
@@ -335,6 +377,7 @@ __device__ __forceinline__ u32 packed_get(u64 lo, u64 hi, u32 cls)
     return (u32)((cls < 5 ? lo >> (kFieldBits * cls) : hi >> (kFieldBits * (cls - 5))) & 0xFFFu);
 }
 
+template <int ITEMS>
 __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
     const u32* __restrict__ counts, u32 m, const u32* __restrict__ a_ro,
     const u32* __restrict__ row_ops, const u32* __restrict__ row_col_min,
@@ -348,11 +391,11 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
     __shared__ u32 s_max[NW];
     if (threadIdx.x < kMaxClasses) s_bytes[threadIdx.x] = 0;
     __syncthreads();
-    const u64 base = u64(blockIdx.x) * kScanTile + u64(threadIdx.x) * kScanItems;
+    const u64 base = u64(blockIdx.x) * (kScanThreads * ITEMS) + u64(threadIdx.x) * ITEMS;
     u64 tsum = 0, packed_lo = 0, packed_hi = 0;
     u32 my_max = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const u64 row = base + i;
         if (row < m) {
             const u32 c = counts[row];
@@ -401,43 +444,56 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
     }
 }
 
+template <int ITEMS>
 __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
-    u32* __restrict__ counts_inout, u32 m, const u32* __restrict__ tile_off,
-    const DeviceStats* __restrict__ st, const u32* __restrict__ blk_base,
-    const u8* __restrict__ num_cls, const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
+    u32* __restrict__ counts_inout, u32 m, DeviceStats* __restrict__ st,
+    const BlockPartial* __restrict__ parts, u32 nb, const u8* __restrict__ num_cls,
+    const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
     const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
-    RowRec* __restrict__ recs)
+    RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz)
 {
     constexpr int NW = kScanThreads / 64;
+    __shared__ Fold s_fold;
+    __shared__ u64 s_bytes[kMaxClasses];
     __shared__ u32 s_scan[NW + 1];
     __shared__ u64 s_wlo[NW], s_whi[NW];
     const u32 lane = lane_id(), wid = threadIdx.x >> 6;
-    const u64 base = u64(blockIdx.x) * kScanTile + u64(threadIdx.x) * kScanItems;
-    u32 c[kScanItems];
+    fold_partials<kScanThreads, NUM_CLASSES>(parts, nb, blockIdx.x, &s_fold, s_bytes, cp.want_bytes != 0);
+    const u64 nnz_c = s_fold.sum_total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->nnz_c = nnz_c;
+        st->max_row_nnz_c = s_fold.max_val;
+        if (nnz_c > 0xFFFFFFFFull) st->nnz_overflow = 1;
+        // the C buffers of a replayed launch sequence were allocated for exactly `exact_nnz`
+        if (exact_nnz != ~0ull && nnz_c != exact_nnz) st->capacity_miss = 1;
+        publish_bins(st->num, s_fold, s_bytes, num_cls ? cp.num_allowed : 0xFFFFFFFFu, st);
+    }
+    const u64 base = u64(blockIdx.x) * (kScanThreads * ITEMS) + u64(threadIdx.x) * ITEMS;
+    u32 c[ITEMS];
     u32 tsum = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         c[i] = (base + i) < m ? counts_inout[base + i] : 0;
         tsum += c[i];
     }
     u32 total;
     const u32 excl = block_exclusive_scan<kScanThreads>(tsum, s_scan, &total);
-    u32 run = tile_off[blockIdx.x] + excl;
-    u32 off[kScanItems];
+    u32 run = (u32)s_fold.sum_prefix + excl;
+    u32 off[ITEMS];
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         off[i] = run;
         if (base + i < m) counts_inout[base + i] = run;
         run += c[i];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts_inout[m] = (u32)st->nnz_c;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts_inout[m] = (u32)nnz_c;
     if (!num_cls) return;
 
     // class of my 8 rows, packed per-thread histogram, exclusive scan over the threads
-    u8 cls[kScanItems];
+    u8 cls[ITEMS];
     u64 plo = 0, phi = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         cls[i] = (base + i) < m ? num_cls[base + i] : (u8)NUM_NONE;
         if (cls[i] != NUM_NONE) packed_add(plo, phi, cls[i]);
     }
@@ -462,12 +518,12 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     }
     u64 used_lo = 0, used_hi = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const u64 row = base + i;
         if (cls[i] == NUM_NONE) continue;
         const u32 k = cls[i];
-        const u32 pos = st->num.offset[k] + blk_base[size_t(blockIdx.x) * kMaxClasses + k] +
-                        packed_get(blo, bhi, k) + packed_get(used_lo, used_hi, k);
+        const u32 pos = class_offset(s_fold, k) + s_fold.prefix[k] + packed_get(blo, bhi, k) +
+                        packed_get(used_lo, used_hi, k);
         packed_add(used_lo, used_hi, k);
         RowRec r;
         r.row = (u32)row;
@@ -491,38 +547,44 @@ u32 analysis_blocks(u32 m)
     row_chunking(m, &r, &b);
     return b;
 }
-u32 scan_tiles(u32 m) { return cdiv(m ? m : 1, kScanTile); }
+u32 scan_tiles(u32 m) { return cdiv(m ? m : 1, kScanThreads * scan_items(m)); }
 
 void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32* b_ro,
                      const u32* b_col, u32 m, u64 /*nnz_a*/, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
-                     BlockPartial* partials, u32* blk_base, RowRec* recs, DeviceStats* st,
-                     const ClassifyParams& cp, u32* b_start, u32* b_len)
+                     BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
+                     u32* b_start, u32* b_len)
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
     hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kChunk), 0, s, a_ro, a_col, b_ro, b_col, m,
                        rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                        partials, cp, b_start, b_len);
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(1024), 0, s, partials, blocks, 0, st, blk_base,
-                       cp.sym_allowed, (u32*)nullptr, ~0ull);
-    if (sym_cls)
-        hipLaunchKernelGGL(sym_scatter_kernel, dim3(blocks), dim3(kChunk), 0, s, sym_cls, m,
-                           rows_per_block, st, blk_base, a_ro, row_ops, row_col_min, row_col_max, recs);
+    // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
+    hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,
+                       (const u8*)sym_cls, m, rows_per_block, st, (const BlockPartial*)partials, blocks, a_ro,
+                       (const u32*)row_ops, (const u32*)row_col_min, (const u32*)row_col_max, recs, cp);
 }
 
-void launch_scan(hipStream_t s, u32* counts_inout, u32 m, u32* tile_off, const u32* a_ro,
-                 const u32* row_ops, const u32* row_col_min, const u32* row_col_max, u8* num_cls,
-                 BlockPartial* partials, u32* blk_base, RowRec* recs, DeviceStats* st,
-                 const ClassifyParams& cp, u32 vsize, u64 exact_nnz)
+void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
+                 const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
+                 RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz)
 {
     const u32 tiles = scan_tiles(m);
-    hipLaunchKernelGGL(num_count_kernel, dim3(tiles), dim3(kScanThreads), 0, s, counts_inout, m, a_ro,
-                       row_ops, row_col_min, row_col_max, num_cls, partials, cp, vsize);
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(1024), 0, s, partials, tiles, 1, st, blk_base,
-                       num_cls ? cp.num_allowed : 0xFFFFFFFFu, tile_off, exact_nnz);
-    hipLaunchKernelGGL(num_apply_kernel, dim3(tiles), dim3(kScanThreads), 0, s, counts_inout, m, tile_off,
-                       st, blk_base, (const u8*)num_cls, a_ro, row_ops, row_col_min, row_col_max, recs);
+    auto go = [&](auto items) {
+        constexpr int I = decltype(items)::value;
+        hipLaunchKernelGGL(num_count_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s,
+                           (const u32*)counts_inout, m, a_ro, row_ops, row_col_min, row_col_max, num_cls,
+                           partials, cp, vsize);
+        hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts_inout, m, st,
+                           (const BlockPartial*)partials, tiles, (const u8*)num_cls, a_ro, row_ops,
+                           row_col_min, row_col_max, recs, cp, exact_nnz);
+    };
+    switch (scan_items(m)) {
+        case 2: go(std::integral_constant<int, 2>{}); break;
+        case 8: go(std::integral_constant<int, 8>{}); break;
+        default: go(std::integral_constant<int, 32>{}); break;
+    }
 }
 
 }  // namespace speck

@@ -48,17 +48,10 @@ __global__ __launch_bounds__(THREADS) void sym_hash_kernel(ProductSrc<float> src
     u32 idx = blockIdx.x * NG + gid;
     const u32 stride = gridDim.x * NG;
     RowRec next{};
-    if (!G::kIsBlock && idx < count) next = recs[idx];
-    while (true) {
-        if constexpr (G::kIsBlock) idx = next_queued_row(w.queue + cls, scratch + THREADS / 64 + 1);
-        if (idx >= count) break;
-        RowRec rec;
-        if constexpr (G::kIsBlock) {
-            rec = recs[idx];
-        } else {
-            rec = next;  // fetched while the previous row was being processed
-            if (idx + stride < count) next = recs[idx + stride];
-        }
+    if (idx < count) next = recs[idx];
+    while (idx < count) {
+        const RowRec rec = next;  // fetched while the previous row was being processed
+        if (idx + stride < count) next = recs[idx + stride];
         for (u32 i = g.lane; i < CAP; i += G::SIZE) tab[i] = kEmptyKey;
         g.sync();
         u32 cnt = 0;
@@ -67,7 +60,7 @@ __global__ __launch_bounds__(THREADS) void sym_hash_kernel(ProductSrc<float> src
         cnt = g.reduce_add(cnt, scratch);
         if (g.lane == 0) counts[rec.row] = cnt;
         g.sync();
-        if constexpr (!G::kIsBlock) idx += stride;
+        idx += stride;
     }
 }
 
@@ -86,10 +79,11 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> s
     constexpr u64 kWindowCols = u64(WORDS) * 32;
     const u32 count = w.st->sym.count[cls];
     const RowRec* recs = w.recs + w.st->sym.offset[cls];
-    while (true) {
-        const u32 idx = next_queued_row(w.queue + cls, scratch + THREADS / 64 + 1);
-        if (idx >= count) break;
-        const RowRec rec = recs[idx];
+    RowRec next{};
+    if (blockIdx.x < count) next = recs[blockIdx.x];
+    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const RowRec rec = next;  // fetched while the previous row was being processed
+        if (idx + gridDim.x < count) next = recs[idx + gridDim.x];
         u32 total = 0;
         for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += kWindowCols) {
             const u64 left = u64(rec.cmax) - w0 + 1;
