@@ -27,6 +27,8 @@ struct RowWork {
     u32* queue;             // per-class work-queue heads (device), zeroed per call
     const u32* b_start;     // per A entry (relative to the first entry of the A view):
     const u32* b_len;       //   start / length of the referenced B row, written by the analysis
+    u32* gkeys;             // global-memory spill pool of the NUM_G class: 2*nnz(C) keys ...
+    void* gvals;            //   ... and values (nullptr when no row needs it)
 };
 
 // Launch the symbolic kernel of class `cls`.  `count` is an UPPER BOUND of the class' row count

@@ -19,6 +19,8 @@
 // The product a*b is rounded first and then added with an LDS atomic (ds_add_f64), as the
 // reference does (spECK_HashSpGEMM.cuh:157-165) -- no FMA across the add.
 // Algorithmic bytes per row: 8 + 20*lenA + 12*ops + 4 + 12*nnz for fp64 (device_common.hpp).
+#include <type_traits>
+
 #include "device_common.hpp"
 #include "launch.hpp"
 #include "row_groups.hpp"
@@ -215,7 +217,9 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, co
         }
         g.sync();
         for_each_product<true>(g, src, rec.a0, rec.a1, meta, scan_scratch,
-                               [&](u32 c, T p) { table_accumulate<CAP>(keys, vals, c, p); });
+                               [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
+                                   table_accumulate_batch<CAP>(keys, vals, c, p, n);
+                               });
         if constexpr (MODE == SORT_RANK) {
             emit_rank_sorted<G, T, CAP>(g, keys, vals, S, rec.base, c_col, c_val);
         } else {
@@ -267,13 +271,17 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
             for (u32 i = threadIdx.x; i < ncols; i += THREADS) vals[i] = T(0);
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             __syncthreads();
-            for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch, [&](u32 c, T p) {
-                const u32 d = c - wbase;
-                if (d < ncols) {
-                    atomicAdd(&vals[d], p);
-                    atomicOr(&bm[d >> 5], 1u << (d & 31));
-                }
-            });
+            for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch,
+                                   [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
+#pragma unroll
+                                       for (int u = 0; u < kBatch; ++u) {
+                                           const u32 d = c[u] - wbase;
+                                           if ((u32)u < n && d < ncols) {
+                                               atomicAdd(&vals[d], p[u]);
+                                               atomicOr(&bm[d >> 5], 1u << (d & 31));
+                                           }
+                                       }
+                                   });
             const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);
             for (u32 d = threadIdx.x; d < ncols; d += THREADS) {
                 const u32 word = bm[d >> 5];
@@ -289,7 +297,136 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
     }
 }
 
+// ------------------------------------------------------------------ NUM_G
+// Global-memory spill for heavy rows whose column range would need many dense windows
+// (role of the reference's global hash maps, include/HashMap.cuh:112-134 and
+// spECK_HashSpGEMM.cuh:25-36; the reference hard-disables the numeric one, Multiply.cu:699-700,
+// and falls back to multi-window dense rows instead).
+// The table of row i lives in a pool sized 2*nnz(C): slots [2*base_i, 2*base_i + 2*nnz_i), load
+// factor 1/2 from the EXACT nnz, so it can never fill.  One workgroup owns a row from
+// initialisation to emission, so no inter-workgroup protocol is needed: all table traffic during
+// accumulation is L2 atomics (global_atomic_cmpswap + global_atomic_add_f64), and the emission
+// reads it back with agent-scope loads that bypass this CU's L1.
+// Sorted output: the distinct keys are ranked with an LDS column bitmap (512 Ki columns per
+// window) -- prefix popcount, no comparisons.
+template <typename V>
+__device__ __forceinline__ V load_l2(const V* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T, int THREADS, u32 BMW>
+constexpr u32 num_global_lds()
+{
+    return THREADS * (u32)sizeof(T) + (2 * BMW + 2 * THREADS + THREADS / 64 + 2 + 3) / 4 * 16;
+}
+
+template <typename T, int THREADS, u32 BMW>
+__global__ __launch_bounds__(THREADS) void num_global_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                             u32* __restrict__ c_col,
+                                                             T* __restrict__ c_val, int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = Block<THREADS>;
+    using Bits = typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned int>::type;
+    const G g;
+    T* m_av = reinterpret_cast<T*>(smem);
+    u32* bm = reinterpret_cast<u32*>(m_av + THREADS);
+    u32* pref = bm + BMW;
+    RowMeta<T> meta{pref + BMW, pref + BMW + THREADS, m_av};
+    u32* scratch = pref + BMW + 2 * THREADS;
+    if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
+    u32* gkeys = w.gkeys;
+    T* gvals = static_cast<T*>(w.gvals);
+    constexpr u64 kWindowCols = u64(BMW) * 32;
+    const u32 count = w.st->num.count[cls];
+    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    RowRec next{};
+    if (blockIdx.x < count) next = recs[blockIdx.x];
+    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const RowRec rec = next;
+        if (idx + gridDim.x < count) next = recs[idx + gridDim.x];
+        const u32 cap = 2u * rec.nnz;
+        const size_t t0 = 2 * size_t(rec.base);
+        for (u32 i = threadIdx.x; i < cap; i += THREADS) {
+            gkeys[t0 + i] = kEmptyKey;
+            gvals[t0 + i] = T(0);
+        }
+        __syncthreads();  // the table is initialised (stores are acknowledged by L2) before any atomic
+        for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch,
+                               [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
+                                   u32 slot[kBatch], old[kBatch];
+#pragma unroll
+                                   for (int u = 0; u < kBatch; ++u) {  // kBatch L2 atomics in flight
+                                       slot[u] = __umulhi(c[u] * 0x9E3779B1u, cap);
+                                       old[u] = kEmptyKey;
+                                       if ((u32)u < n) old[u] = atomicCAS(&gkeys[t0 + slot[u]], kEmptyKey, c[u]);
+                                   }
+#pragma unroll
+                                   for (int u = 0; u < kBatch; ++u) {
+                                       if ((u32)u >= n) continue;
+                                       while (old[u] != kEmptyKey && old[u] != c[u]) {
+                                           slot[u] = slot[u] + 1 == cap ? 0u : slot[u] + 1;
+                                           old[u] = atomicCAS(&gkeys[t0 + slot[u]], kEmptyKey, c[u]);
+                                       }
+                                       unsafeAtomicAdd(&gvals[t0 + slot[u]], p[u]);
+                                   }
+                               });
+        __syncthreads();
+        u32 emitted = 0;
+        for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += kWindowCols) {
+            const u64 left = u64(rec.cmax) - w0 + 1;
+            const u32 ncols = left < kWindowCols ? (u32)left : (u32)kWindowCols;
+            const u32 nwords = (ncols + 31) >> 5;
+            const u32 wbase = (u32)w0;
+            for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
+            __syncthreads();
+            constexpr int kScan = 8;  // independent L2 loads in flight per thread
+            for (u32 i0 = threadIdx.x; i0 < cap; i0 += THREADS * kScan) {
+                u32 k[kScan];
+#pragma unroll
+                for (int u = 0; u < kScan; ++u) {
+                    const u32 i = i0 + u * THREADS;
+                    k[u] = i < cap ? load_l2(&gkeys[t0 + i]) : kEmptyKey;
+                }
+#pragma unroll
+                for (int u = 0; u < kScan; ++u) {
+                    const u32 d = k[u] - wbase;
+                    if (k[u] != kEmptyKey && d < ncols) atomicOr(&bm[d >> 5], 1u << (d & 31));
+                }
+            }
+            __syncthreads();
+            const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);
+            for (u32 i0 = threadIdx.x; i0 < cap; i0 += THREADS * kScan) {
+                u32 k[kScan];
+                Bits raw[kScan];
+#pragma unroll
+                for (int u = 0; u < kScan; ++u) {
+                    const u32 i = i0 + u * THREADS;
+                    k[u] = i < cap ? load_l2(&gkeys[t0 + i]) : kEmptyKey;
+                    raw[u] = i < cap ? load_l2(reinterpret_cast<const Bits*>(&gvals[t0 + i])) : Bits(0);
+                }
+#pragma unroll
+                for (int u = 0; u < kScan; ++u) {
+                    const u32 d = k[u] - wbase;
+                    if (k[u] != kEmptyKey && d < ncols) {
+                        const u32 r = emitted + pref[d >> 5] + __popc(bm[d >> 5] & ((1u << (d & 31)) - 1u));
+                        T val;
+                        __builtin_memcpy(&val, &raw[u], sizeof(T));
+                        c_col[rec.base + r] = k[u];
+                        c_val[rec.base + r] = val;
+                    }
+                }
+            }
+            emitted += total;
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------ launchers
+constexpr u32 kNumGBmWords = 16384;  // 512 Ki columns per sort window of the global-spill class
 constexpr u32 kW512W1 = 256;   // 256 Ki columns per sort window
 constexpr u32 kB2KW1 = 512;    // 512 Ki columns per sort window
 constexpr u32 kB8KW1 = 512;
@@ -306,6 +443,7 @@ u32 numeric_lds_bytes_t(int cls)
         case NUM_B8K: return num_group_lds<Block<512>, T, kNumB8KCap, 512>();
         case NUM_D1: return num_dense_lds<T, kNumD1Cols, 256>();
         case NUM_D2: return num_dense_lds<T, kNumD2Cols, 1024>();
+        case NUM_G: return num_global_lds<T, 1024, kNumGBmWords>();
     }
     return 0;
 }
@@ -379,6 +517,13 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
         }
         case NUM_D2: {
             auto k = num_dense_kernel<T, kNumD2Cols, 1024>;
+            set_dyn_lds(k, lds);
+            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,
+                               w, c_col, c_val, cls);
+            break;
+        }
+        case NUM_G: {
+            auto k = num_global_kernel<T, 1024, kNumGBmWords>;
             set_dyn_lds(k, lds);
             hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,
                                w, c_col, c_val, cls);

@@ -79,6 +79,8 @@ struct speck_config {
     GraphKey last_key;                         // ... and what it ran on
     bool last_key_valid = false;
     int graph_replays = 0, graph_captures = 0, graph_misses = 0;
+    void* gpool = nullptr;    // global-memory spill pool (NUM_G rows): keys then values
+    size_t gpool_bytes = 0, gpool_vals_off = 0;
     int time_num_class = -1;  // numeric class bracketed by tev0/tev1 in replayed sequences
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
     speck_stats last{};
@@ -295,7 +297,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
                     c->d_stats, cp, sc.b_start, sc.b_len);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
-    RowWork w{sc.recs, c->d_stats, c->d_stats->sym_queue, sc.b_start, sc.b_len};
+    RowWork w{sc.recs, c->d_stats, c->d_stats->sym_queue, sc.b_start, sc.b_len, nullptr, nullptr};
     // heaviest classes first: they have the longest tails
     static const int order[SYM_CLASSES] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_B4K,
                                            SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
@@ -325,7 +327,9 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     CsrView<T> Av{A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
-    RowWork w{sc.recs, c->d_stats, c->d_stats->num_queue, sc.b_start, sc.b_len};
+    RowWork w{sc.recs, c->d_stats, c->d_stats->num_queue, sc.b_start, sc.b_len,
+              static_cast<u32*>(c->gpool),
+              c->gpool ? static_cast<void*>(static_cast<unsigned char*>(c->gpool) + c->gpool_vals_off) : nullptr};
     static const int order[NUM_CLASSES] = {NUM_G,    NUM_D2,   NUM_B8K, NUM_B2K,   NUM_D1,
                                            NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
     return run_classes(c, s, order, NUM_CLASSES, num_mask, tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr,
@@ -564,6 +568,24 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     // NUMERIC (Multiply.cu:835-1014) + in-kernel sort (Multiply.cu:1028-1043)
     const u32 num_mask = mask_of(c->h_stats->num.count, NUM_CLASSES);
+    if (num_mask >> NUM_G & 1u) {
+        // global-memory spill pool of the heavy rows (role of the reference's global maps,
+        // Multiply.cu:357-427): 2*nnz(C) keys + values, grow-only
+        const size_t need = 2 * size_t(nnz_c) * (4 + sizeof(T)) + 256;
+        if (need > c->gpool_bytes) {
+            drop_graph(c);
+            if (c->gpool) (void)hipFree(c->gpool);
+            c->gpool = nullptr;
+            c->gpool_bytes = 0;
+            if (hipMalloc(&c->gpool, need + need / 8) != hipSuccess) {
+                (void)hipGetLastError();
+                return SPECK_ERR_OOM;
+            }
+            c->gpool_bytes = need + need / 8;
+        }
+        c->gpool_vals_off = (2 * size_t(nnz_c) * 4 + 255) & ~size_t(255);
+    }
+    t->globalMapsNumeric = st.lap();
     rc = enqueue_back<T>(c, s, A, B, sc, c_ro, c_col, static_cast<T*>(c_val), num_mask,
                          c->h_stats->num.count, &tm);
     if (rc != SPECK_OK) return rc;
@@ -657,7 +679,7 @@ int speck_config_create(int device, speck_config** out)
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stats), sizeof(DeviceStats), hipHostMallocDefault));
     c->cp.sym_bitmap_ratio = 32;
     c->cp.num_dense_ratio = 16;
-    c->cp.num_global_passes = 0xFFFFFFFFu;
+    c->cp.num_global_passes = 4;  // heavy rows: dense windows up to 64 Ki columns, else global spill
     c->cp.want_bytes = 0;
     *out = c;
     return SPECK_OK;
@@ -679,6 +701,7 @@ int speck_config_destroy(speck_config* c)
     for (auto e : c->aux_done) (void)hipEventDestroy(e);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->gpool) (void)hipFree(c->gpool);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     delete c;

@@ -208,41 +208,67 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
                     }
                 }
             }
+            // the valid products of a batch are a prefix (p + u*step is increasing in u)
+            u32 nvalid = 0;
+            T prod[kBatch];
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
-                if (p + u * step < end) {
-                    if constexpr (WITH_VALUES) f(c[u], av_[u] * bv[u]); else f(c[u]);
-                }
+                nvalid += (p + u * step < end) ? 1u : 0u;
+                prod[u] = av_[u] * bv[u];  // rounded product, added later (no FMA across the add)
             }
+            f(c, prod, nvalid);
             p += kBatch * step;
         }
         g.sync();
     }
 }
 
-// ---- LDS open-addressed structures ------------------------------------------------
+// ---- open-addressed structures (LDS or global memory) ---------------------------------
+// Batched forms: the first compare-and-swap of the kBatch products are issued back to back
+// (independent atomics in flight); only a collision enters the probing loop.
 template <u32 CAP>
-__device__ __forceinline__ u32 set_insert(u32* tab, u32 key)
+__device__ __forceinline__ u32 set_insert_batch(u32* tab, const u32 (&key)[kBatch], u32 nvalid)
 {
-    u32 slot = hash_slot<CAP>(key);
-    while (true) {
-        const u32 old = atomicCAS(&tab[slot], kEmptyKey, key);
-        if (old == kEmptyKey) return 1;
-        if (old == key) return 0;
-        slot = (slot + 1) & (CAP - 1);
+    u32 slot[kBatch], old[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+        slot[u] = hash_slot<CAP>(key[u]);
+        old[u] = kEmptyKey;
+        if ((u32)u < nvalid) old[u] = atomicCAS(&tab[slot[u]], kEmptyKey, key[u]);
     }
+    u32 added = 0;
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+        if ((u32)u >= nvalid) continue;
+        while (old[u] != kEmptyKey && old[u] != key[u]) {
+            slot[u] = (slot[u] + 1) & (CAP - 1);
+            old[u] = atomicCAS(&tab[slot[u]], kEmptyKey, key[u]);
+        }
+        added += old[u] == kEmptyKey ? 1u : 0u;
+    }
+    return added;
 }
 
 template <u32 CAP, typename T>
-__device__ __forceinline__ void table_accumulate(u32* keys, T* vals, u32 key, T prod)
+__device__ __forceinline__ void table_accumulate_batch(u32* keys, T* vals, const u32 (&key)[kBatch],
+                                                       const T (&prod)[kBatch], u32 nvalid)
 {
-    u32 slot = hash_slot<CAP>(key);
-    while (true) {
-        const u32 old = atomicCAS(&keys[slot], kEmptyKey, key);
-        if (old == kEmptyKey || old == key) break;
-        slot = (slot + 1) & (CAP - 1);
+    u32 slot[kBatch], old[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+        slot[u] = hash_slot<CAP>(key[u]);
+        old[u] = kEmptyKey;
+        if ((u32)u < nvalid) old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
     }
-    atomicAdd(&vals[slot], prod);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+        if ((u32)u >= nvalid) continue;
+        while (old[u] != kEmptyKey && old[u] != key[u]) {
+            slot[u] = (slot[u] + 1) & (CAP - 1);
+            old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
+        }
+        atomicAdd(&vals[slot[u]], prod[u]);
+    }
 }
 
 // Exclusive prefix of popcounts over bm[0..nwords) into pref[]; returns the total.

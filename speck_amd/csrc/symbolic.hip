@@ -56,7 +56,9 @@ __global__ __launch_bounds__(THREADS) void sym_hash_kernel(ProductSrc<float> src
         g.sync();
         u32 cnt = 0;
         for_each_product<false>(g, src, rec.a0, rec.a1, meta, scratch,
-                                [&](u32 c) { cnt += set_insert<CAP>(tab, c); });
+                                [&](const u32(&c)[kBatch], const float(&)[kBatch], u32 n) {
+                                    cnt += set_insert_batch<CAP>(tab, c, n);
+                                });
         cnt = g.reduce_add(cnt, scratch);
         if (g.lane == 0) counts[rec.row] = cnt;
         g.sync();
@@ -92,10 +94,14 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> s
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             __syncthreads();
             const u32 base = (u32)w0;
-            for_each_product<false>(g, src, rec.a0, rec.a1, meta, scratch, [&](u32 c) {
-                const u32 d = c - base;  // wraps to a huge value when left of the window
-                if (d < ncols) atomicOr(&bm[d >> 5], 1u << (d & 31));
-            });
+            for_each_product<false>(g, src, rec.a0, rec.a1, meta, scratch,
+                                    [&](const u32(&c)[kBatch], const float(&)[kBatch], u32 n) {
+#pragma unroll
+                                        for (int u = 0; u < kBatch; ++u) {
+                                            const u32 d = c[u] - base;  // wraps when left of the window
+                                            if ((u32)u < n && d < ncols) atomicOr(&bm[d >> 5], 1u << (d & 31));
+                                        }
+                                    });
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) total += __popc(bm[i]);
             __syncthreads();
         }

@@ -156,7 +156,7 @@ def test_hash_classes_block16k(cfg):
     B = fast_random_csr(5000, 300000, 100, 72, jitter=False)
     cfg.set_option("sym_bitmap_ratio", 0)
     try:
-        check(cfg, A, B, [("sym", "block16k"), ("num", "dense16k")])
+        check(cfg, A, B, [("sym", "block16k"), ("num", "global")])   # 300k columns: global spill
     finally:
         cfg.set_option("sym_bitmap_ratio", 32)
 
@@ -173,16 +173,28 @@ def test_symbolic_h3_and_dense_multiwindow(cfg):
     B = fast_random_csr(5000, 2000000, 150, 6, jitter=False)
     cfg.set_option("sym_bitmap_ratio", 0)      # keep the bitmap out: exercise the 128 KiB hash set
     try:
+        cfg.set_option("num_global_passes", 1 << 30)   # force the multi-window dense path (123 windows)
         check(cfg, A, B, [("sym", "block32k"), ("num", "dense16k")])
+        cfg.set_option("num_global_passes", 4)         # default: the same rows through the global spill
+        check(cfg, A, B, [("sym", "block32k"), ("num", "global")])
     finally:
         cfg.set_option("sym_bitmap_ratio", 32)
+        cfg.set_option("num_global_passes", 4)
 
 
 def test_symbolic_bitmap_multiwindow_heavy_rows(cfg):
     # ops > 26214 per row and 2.5M columns: three 1Mi-column bitmap windows
     A = fast_random_csr(24, 4000, 300, 7, jitter=False)
     B = fast_random_csr(4000, 2500000, 110, 8, jitter=False)
-    check(cfg, A, B, [("sym", "bitmap1m"), ("num", "dense16k")])
+    # numeric: ~33k nnz per row over 2.5M columns -> global spill, five 512Ki-column sort windows
+    check(cfg, A, B, [("sym", "bitmap1m"), ("num", "global")])
+
+
+def test_heavy_rows_with_narrow_range_stay_dense(cfg):
+    # > 5461 nnz per row but only 40k columns: 3 dense windows beat the global spill
+    A = fast_random_csr(40, 3000, 200, 81, jitter=False)
+    B = fast_random_csr(3000, 40000, 90, 82, jitter=False)
+    check(cfg, A, B, [("num", "dense16k")])
 
 
 def test_banded_dense_and_bitmap_classes(cfg):
