@@ -51,7 +51,7 @@ typedef struct speck_timings {
 
 /* ---- what the last multiply did (drives bench.py's roofline object) ---- */
 #define SPECK_NUM_SYM_BINS 8
-#define SPECK_NUM_NUM_BINS 9
+#define SPECK_NUM_NUM_BINS 10
 typedef struct speck_stats {
     uint64_t sum_products;                       /* P, u64 (reference: u32, Multiply.cu:237) */
     uint64_t nnz_c;
@@ -64,6 +64,7 @@ typedef struct speck_stats {
     float num_bin_ms[SPECK_NUM_NUM_BINS];        /* HIP-event ms of each numeric kernel launch */
     float sym_bin_ms[SPECK_NUM_SYM_BINS];
     float analysis_ms, scan_ms;
+    float sym_light_ms, num_light_ms;            /* the merged launch of all 256-thread classes */
     int32_t kernel_events_valid;                 /* 1 if *_ms were recorded for the last call */
     int32_t numeric_reruns;                      /* replayed sequences rejected by the device-side checks */
     int32_t graph_replays;                       /* multiplies served by a replayed hipGraph (cumulative) */

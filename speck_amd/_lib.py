@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspeck_amd.so")
 
 NUM_SYM_BINS = 8
-NUM_NUM_BINS = 9
+NUM_NUM_BINS = 10
 
 
 class DCsr(C.Structure):
@@ -30,6 +30,7 @@ class CStats(C.Structure):
                 ("num_bin_bytes", C.c_uint64 * NUM_NUM_BINS), ("sym_bin_bytes", C.c_uint64 * NUM_SYM_BINS),
                 ("num_bin_ms", C.c_float * NUM_NUM_BINS), ("sym_bin_ms", C.c_float * NUM_SYM_BINS),
                 ("analysis_ms", C.c_float), ("scan_ms", C.c_float),
+                ("sym_light_ms", C.c_float), ("num_light_ms", C.c_float),
                 ("kernel_events_valid", C.c_int32), ("numeric_reruns", C.c_int32),
                 ("graph_replays", C.c_int32), ("graph_captures", C.c_int32)]
 

@@ -16,7 +16,8 @@ from . import _lib
 from ._lib import CStats, CTimings, DCsr, NUM_NUM_BINS, NUM_SYM_BINS
 
 SYM_CLASS_NAMES = ["g16", "wave256", "wave1k", "block4k", "block16k", "block32k", "bitmap256k", "bitmap1m"]
-NUM_CLASS_NAMES = ["direct", "g16", "wave128", "wave512", "block2k", "block8k", "dense4k", "dense16k", "global"]
+NUM_CLASS_NAMES = ["direct", "g16", "wave128", "wave512", "block2k", "block8k", "dense4k", "dense16k", "global",
+                   "wave1k"]
 
 
 class SpeckError(RuntimeError):
@@ -272,6 +273,7 @@ class spECKConfig:
             sym_bin_ms=dict(zip(SYM_CLASS_NAMES, list(s.sym_bin_ms))),
             num_bin_ms=dict(zip(NUM_CLASS_NAMES, list(s.num_bin_ms))),
             analysis_ms=float(s.analysis_ms), scan_ms=float(s.scan_ms),
+            sym_light_ms=float(s.sym_light_ms), num_light_ms=float(s.num_light_ms),
             kernel_events_valid=bool(s.kernel_events_valid), numeric_reruns=int(s.numeric_reruns),
             graph_replays=int(s.graph_replays), graph_captures=int(s.graph_captures))
 

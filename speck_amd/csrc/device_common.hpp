@@ -54,7 +54,9 @@ enum NumClass : u8 {
     NUM_D1 = 6,      // dense column-window accumulator, narrow column range, workgroup(256)
     NUM_D2 = 7,      // dense accumulator, 16 Ki columns/window, multi-window, workgroup(1024)
     NUM_G = 8,       // global-memory hash spill (heavy rows with a very wide column range)
-    NUM_CLASSES = 9,
+    NUM_W1K = 9,     // wave per row, 1024-entry table, 2-level bitmap sort (nnz <= 682): no
+                     //   workgroup barriers, 2.4x less LDS per row than NUM_B2K
+    NUM_CLASSES = 10,
     NUM_NONE = 0xFF
 };
 
@@ -70,6 +72,7 @@ constexpr u32 kSymBm2Words = 32768;   // 128 KiB -> 1048576 columns per window
 constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = 42;
 constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = 85;
 constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = 341;
+constexpr u32 kNumW1KCap = 1024, kNumW1KMaxNnz = 682;
 constexpr u32 kNumB2KCap = 2048, kNumB2KMaxNnz = 1365;
 constexpr u32 kNumB8KCap = 8192, kNumB8KMaxNnz = 5461;
 constexpr u32 kNumD1Cols = 4096;
@@ -112,6 +115,7 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 nnz, u32 cmin, u32
     const u64 range = u64(cmax) - u64(cmin) + 1;
     if (range <= kNumD1Cols && range <= u64(p.num_dense_ratio) * nnz) return NUM_D1;
     if (nnz <= kNumW512MaxNnz) return NUM_W512;
+    if (nnz <= kNumW1KMaxNnz) return NUM_W1K;
     if (nnz <= kNumB2KMaxNnz) return NUM_B2K;
     if (nnz <= kNumB8KMaxNnz) return NUM_B8K;
     const u64 passes = (range + kNumD2Cols - 1) / kNumD2Cols;

@@ -31,6 +31,24 @@ struct RowWork {
     void* gvals;            //   ... and values (nullptr when no row needs it)
 };
 
+// Block ranges of the classes inside a merged ("light") launch: class slot k owns the blocks
+// [first[k], first[k+1]).
+struct ClassGrid {
+    u32 first[8];
+};
+constexpr u32 kSymLightMask = (1u << SYM_BM1) | (1u << SYM_B4K) | (1u << SYM_W1K) | (1u << SYM_W256) | (1u << SYM_G16);
+constexpr u32 kNumLightMask = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W128) |
+                              (1u << NUM_G16) | (1u << NUM_DIRECT);
+
+// One launch for all 256-thread classes in `mask`.  counts_hint[cls] sizes each class' block range
+// (the kernels read the real counts on the device and stride, so a stale hint only costs speed).
+void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, const u32* a_ro,
+                           const u32* b_start, const u32* b_len, const u32* b_col, const RowWork& w,
+                           u32* counts, int cu_count);
+template <typename T>
+void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const CsrView<T>& A,
+                          const CsrView<T>& B, const RowWork& w, u32* c_col, T* c_val, int cu_count);
+
 // Launch the symbolic kernel of class `cls`.  `count` is an UPPER BOUND of the class' row count
 // (the rows of A): the grid depends only on it, the kernels read the real count from the
 // device-side stats block, so the launch sequence is static and can be captured in a hipGraph.

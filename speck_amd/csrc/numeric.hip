@@ -29,17 +29,15 @@ namespace speck {
 
 // ------------------------------------------------------------------ NUM_DIRECT
 template <typename T, int THREADS>
-__global__ __launch_bounds__(THREADS) void num_direct_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
-                                                             u32* __restrict__ c_col,
-                                                             T* __restrict__ c_val)
+__device__ __forceinline__ void num_direct_body(const ProductSrc<T>& src, const RowWork& w,
+                                                u32* __restrict__ c_col, T* __restrict__ c_val, u32 bidx,
+                                                u32 nblk)
 {
     constexpr u32 L = 16, NG = THREADS / L;
-    if (w.st->capacity_miss) return;
-    src.rebase(a_ro);
     const u32 lane = threadIdx.x & (L - 1), gid = threadIdx.x / L;
     const u32 count = w.st->num.count[NUM_DIRECT];
     const RowRec* recs = w.recs + w.st->num.offset[NUM_DIRECT];
-    for (u32 idx = blockIdx.x * NG + gid; idx < count; idx += gridDim.x * NG) {
+    for (u32 idx = bidx * NG + gid; idx < count; idx += nblk * NG) {
         const RowRec rec = recs[idx];
         const T av = src.a_val[rec.a0];
         const u32 bs = src.b_start[rec.a0];
@@ -179,11 +177,10 @@ constexpr u32 num_group_lds()
 }
 
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
-__global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
-                                                           u32* __restrict__ c_col,
-                                                           T* __restrict__ c_val, int cls)
+__device__ __forceinline__ void num_hash_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
+                                              u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
+                                              u32 bidx, u32 nblk)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 NG = THREADS / G::SIZE;
     constexpr u32 kGroupBytes = num_group_lds<G, T, CAP, THREADS>();
     // the sort scratch (rank: NMAX+8 words, bitmap: max(2*W1, 2*NMAX) words) fits in the table
@@ -200,12 +197,10 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, co
     RowMeta<T> meta{m_incl, m_incl + G::SIZE, m_av};
     u32* scan_scratch = m_incl + 2 * G::SIZE;
     u32* S = reinterpret_cast<u32*>(mine);
-    if (w.st->capacity_miss) return;
-    src.rebase(a_ro);
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
-    u32 idx = blockIdx.x * NG + gid;
-    const u32 stride = gridDim.x * NG;
+    u32 idx = bidx * NG + gid;
+    const u32 stride = nblk * NG;
     RowRec next{};
     if (idx < count) next = recs[idx];
     while (idx < count) {
@@ -239,11 +234,10 @@ constexpr u32 num_dense_lds()
 }
 
 template <typename T, u32 WCOLS, int THREADS>
-__global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
-                                                            u32* __restrict__ c_col,
-                                                            T* __restrict__ c_val, int cls)
+__device__ __forceinline__ void num_dense_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
+                                               u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
+                                               u32 bidx, u32 nblk)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 WORDS = WCOLS / 32;
     using G = Block<THREADS>;
     const G g;
@@ -253,15 +247,13 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
     u32* pref = bm + WORDS;
     RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av};
     u32* scratch = pref + WORDS + 2 * THREADS;
-    if (w.st->capacity_miss) return;
-    src.rebase(a_ro);
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
     RowRec next{};
-    if (blockIdx.x < count) next = recs[blockIdx.x];
-    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    if (bidx < count) next = recs[bidx];
+    for (u32 idx = bidx; idx < count; idx += nblk) {
         const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + gridDim.x < count) next = recs[idx + gridDim.x];
+        if (idx + nblk < count) next = recs[idx + nblk];
         u32 emitted = 0;
         for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += WCOLS) {
             const u64 left = u64(rec.cmax) - w0 + 1;
@@ -295,6 +287,76 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
             __syncthreads();
         }
     }
+}
+
+// ------------------------------------------------------------------ kernels
+// Stand-alone kernels (one class per launch) and the merged "light" kernel: all classes whose
+// workgroups are 256 threads wide and need <= ~40 KiB of LDS share ONE launch -- block ranges map
+// to classes (ClassGrid), heaviest class first.  One launch instead of up to six removes the
+// cross-queue fork/join hand-offs (~15 us each on MI355X) and lets the dispatcher interleave
+// workgroups of different classes on a CU.
+template <typename T, int THREADS>
+__global__ __launch_bounds__(THREADS) void num_direct_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                             u32* __restrict__ c_col,
+                                                             T* __restrict__ c_val)
+{
+    if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
+    num_direct_body<T, THREADS>(src, w, c_col, c_val, blockIdx.x, gridDim.x);
+}
+
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                           u32* __restrict__ c_col,
+                                                           T* __restrict__ c_val, int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
+    num_hash_body<G, T, CAP, W1, NMAX, MODE, THREADS>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
+}
+
+template <typename T, u32 WCOLS, int THREADS>
+__global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                            u32* __restrict__ c_col,
+                                                            T* __restrict__ c_val, int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
+    num_dense_body<T, WCOLS, THREADS>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
+}
+
+constexpr u32 kW512W1 = 256;   // 256 Ki columns per sort window
+constexpr u32 kB2KW1 = 512;    // 512 Ki columns per sort window
+constexpr u32 kB8KW1 = 512;
+
+template <typename T>
+__global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                        u32* __restrict__ c_col, T* __restrict__ c_val,
+                                                        ClassGrid cg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
+    const u32 b = blockIdx.x;
+    // launch order (ClassGrid slots): D1, B2K, W512, W128, G16, DIRECT
+    if (b < cg.first[1])
+        num_dense_body<T, kNumD1Cols, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0]);
+    else if (b < cg.first[2])
+        num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256>(
+            smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1]);
+    else if (b < cg.first[3])
+        num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
+            smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2]);
+    else if (b < cg.first[4])
+        num_hash_body<SubWave<64>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[3], cg.first[4] - cg.first[3]);
+    else if (b < cg.first[5])
+        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
+    else
+        num_direct_body<T, 256>(src, w, c_col, c_val, b - cg.first[5], cg.first[6] - cg.first[5]);
 }
 
 // ------------------------------------------------------------------ NUM_G
@@ -427,9 +489,6 @@ __global__ __launch_bounds__(THREADS) void num_global_kernel(ProductSrc<T> src, 
 
 // ------------------------------------------------------------------ launchers
 constexpr u32 kNumGBmWords = 16384;  // 512 Ki columns per sort window of the global-spill class
-constexpr u32 kW512W1 = 256;   // 256 Ki columns per sort window
-constexpr u32 kB2KW1 = 512;    // 512 Ki columns per sort window
-constexpr u32 kB8KW1 = 512;
 
 template <typename T>
 u32 numeric_lds_bytes_t(int cls)
@@ -439,6 +498,7 @@ u32 numeric_lds_bytes_t(int cls)
         case NUM_G16: return 16 * num_group_lds<SubWave<16>, T, kNumG16Cap, 256>();
         case NUM_W128: return 4 * num_group_lds<SubWave<64>, T, kNumW128Cap, 256>();
         case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, 256>();
+        case NUM_W1K: return 4 * num_group_lds<SubWave<64>, T, kNumW1KCap, 256>();
         case NUM_B2K: return num_group_lds<Block<256>, T, kNumB2KCap, 256>();
         case NUM_B8K: return num_group_lds<Block<512>, T, kNumB8KCap, 512>();
         case NUM_D1: return num_dense_lds<T, kNumD1Cols, 256>();
@@ -473,6 +533,26 @@ static void launch_num_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
 }
 
 template <typename T>
+void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const CsrView<T>& Av,
+                          const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count)
+{
+    static const int slots[6] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
+    static const u32 rows_per_block[6] = {1, 1, 4, 4, 16, 16};
+    u32 lds = 0;
+    for (int k = 0; k < 6; ++k)
+        if (mask >> slots[k] & 1u) lds = lds > numeric_lds_bytes_t<T>(slots[k]) ? lds : numeric_lds_bytes_t<T>(slots[k]);
+    ClassGrid cg{};
+    for (int k = 0; k < 6; ++k) {
+        const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
+        cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
+    }
+    if (cg.first[6] == 0) return;
+    const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data};
+    hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[6]), dim3(256), lds, s, src, Av.row_offsets, w,
+                       c_col, c_val, cg);
+}
+
+template <typename T>
 void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, const CsrView<T>& Bv,
                     const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
@@ -498,6 +578,10 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             break;
         case NUM_W512:
             launch_num_hash<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
+                s, cls, count, A, B, w, c_col, c_val, cu_count);
+            break;
+        case NUM_W1K:
+            launch_num_hash<SubWave<64>, T, kNumW1KCap, kW512W1, kNumW1KMaxNnz, SORT_BITMAP, 256>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_B2K:
@@ -532,6 +616,10 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
     }
 }
 
+template void launch_numeric_light<double>(hipStream_t, const u32*, u32, const CsrView<double>&,
+                                           const CsrView<double>&, const RowWork&, u32*, double*, int);
+template void launch_numeric_light<float>(hipStream_t, const u32*, u32, const CsrView<float>&,
+                                          const CsrView<float>&, const RowWork&, u32*, float*, int);
 template void launch_numeric<double>(hipStream_t, int, u32, const CsrView<double>&,
                                      const CsrView<double>&, const RowWork&, u32*, double*, int);
 template void launch_numeric<float>(hipStream_t, int, u32, const CsrView<float>&,

@@ -68,6 +68,8 @@ struct speck_config {
     std::vector<hipEvent_t> aux_done;
     hipEvent_t fork = nullptr;
     bool concurrent_classes = true;
+    bool merge_light = true;  // all 256-thread classes of a phase in one launch
+    u32 last_sym_counts[kMaxClasses] = {}, last_num_counts[kMaxClasses] = {};
 
     // captured launch sequence of the last repeated call
     bool use_graph = true;
@@ -225,15 +227,17 @@ struct ClassTiming {
     size_t ev;
 };
 
+constexpr int kLightItem = -1;  // pseudo class: the merged launch of all 256-thread classes
+
 template <typename LaunchFn>
-int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u32 mask,
+int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u32 mask, u32 light_mask,
                 size_t* ev_idx, std::vector<ClassTiming>* timing, LaunchFn&& launch)
 {
     bool forked = false;
     size_t used = 0;
     for (int i = 0; i < n_order; ++i) {
         const int cls = order[i];
-        if (!(mask >> cls & 1u)) continue;
+        if (cls == kLightItem ? !(mask & light_mask) : !(mask >> cls & 1u)) continue;
         hipStream_t ks = s;
         if (c->concurrent_classes && used < c->aux.size()) {
             if (!forked) {
@@ -281,7 +285,7 @@ struct Timing {
 // decision: `sym_mask` only prunes kernels of classes known to be empty (eager path: all).
 int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
                   const Scratch& sc, u32* c_ro, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
-                  bool classify_numeric, Timing* tm)
+                  bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr)
 {
     const u32 m = (u32)A->rows;
     ClassifyParams cp = c->cp;
@@ -299,12 +303,21 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     RowWork w{sc.recs, c->d_stats, c->d_stats->sym_queue, sc.b_start, sc.b_len, nullptr, nullptr};
     // heaviest classes first: they have the longest tails
-    static const int order[SYM_CLASSES] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_B4K,
-                                           SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
-    int rc = run_classes(c, s, order, SYM_CLASSES, sym_mask, tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr,
+    u32 all_m[kMaxClasses];
+    for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
+    const u32* hint = sym_hint ? sym_hint : all_m;
+    static const int merged[4] = {SYM_BM2, SYM_B32K, SYM_B16K, kLightItem};
+    static const int separate[SYM_CLASSES] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_B4K,
+                                              SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
+    int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 4 : (int)SYM_CLASSES, sym_mask,
+                         kSymLightMask, tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr,
                          [&](hipStream_t ks, int cls) {
-                             launch_symbolic(ks, cls, m, A->row_offsets, sc.b_start, sc.b_len, B->col_ids,
-                                             w, c_ro, c->sm);
+                             if (cls == kLightItem)
+                                 launch_symbolic_light(ks, hint, sym_mask & kSymLightMask, A->row_offsets, sc.b_start,
+                                                       sc.b_len, B->col_ids, w, c_ro, c->sm);
+                             else
+                                 launch_symbolic(ks, cls, hint[cls], A->row_offsets, sc.b_start, sc.b_len,
+                                                 B->col_ids, w, c_ro, c->sm);
                          });
     if (rc != SPECK_OK) return rc;
     if (timed) {
@@ -330,16 +343,24 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     RowWork w{sc.recs, c->d_stats, c->d_stats->num_queue, sc.b_start, sc.b_len,
               static_cast<u32*>(c->gpool),
               c->gpool ? static_cast<void*>(static_cast<unsigned char*>(c->gpool) + c->gpool_vals_off) : nullptr};
-    static const int order[NUM_CLASSES] = {NUM_G,    NUM_D2,   NUM_B8K, NUM_B2K,   NUM_D1,
-                                           NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
-    return run_classes(c, s, order, NUM_CLASSES, num_mask, tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr,
+    u32 all_m[kMaxClasses];
+    for (auto& x : all_m) x = m;
+    const u32* hint = counts ? counts : all_m;
+    static const int merged[5] = {NUM_G, NUM_D2, NUM_B8K, NUM_W1K, kLightItem};
+    static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K,  NUM_B2K, NUM_W1K,
+                                              NUM_D1, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
+    return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 5 : (int)NUM_CLASSES, num_mask,
+                       kNumLightMask, tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr,
                        [&](hipStream_t ks, int cls) {
-                           // one class may be bracketed by timing events even inside a captured
+                           // one launch may be bracketed by timing events even inside a captured
                            // sequence (bench.py: the dominant kernel, timed live in the timed region)
                            const bool bracket = !tm && cls == c->time_num_class && c->tev0;
                            if (bracket) (void)hipEventRecord(c->tev0, ks);
-                           launch_numeric<T>(ks, cls, counts ? counts[cls] : m, Av, Bv, w, c_col, c_val,
-                                             c->sm);
+                           if (cls == kLightItem)
+                               launch_numeric_light<T>(ks, hint, num_mask & kNumLightMask, Av, Bv, w, c_col, c_val,
+                                                       c->sm);
+                           else
+                               launch_numeric<T>(ks, cls, hint[cls], Av, Bv, w, c_col, c_val, c->sm);
                            if (bracket) (void)hipEventRecord(c->tev1, ks);
                        });
 }
@@ -394,10 +415,10 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     drop_graph(c);
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
-                           c->last_num_mask, true, nullptr);
+                           c->last_num_mask, true, nullptr, c->last_sym_counts);
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
-                             c->last_num_mask, nullptr, nullptr);
+                             c->last_num_mask, c->last_num_counts, nullptr);
     hipError_t e = rc == SPECK_OK ? hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats),
                                                    hipMemcpyDeviceToHost, s)
                                   : hipErrorUnknown;
@@ -600,6 +621,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // remember what this call ran on: an identical next call is captured and replayed
     c->last_sym_mask = mask_of(c->h_stats->sym.count, SYM_CLASSES);
     c->last_num_mask = num_mask;
+    std::memcpy(c->last_sym_counts, c->h_stats->sym.count, sizeof(c->last_sym_counts));
+    std::memcpy(c->last_num_counts, c->h_stats->num.count, sizeof(c->last_num_counts));
     c->last_key = make_key<T>(c, A, B, C, s);
     c->last_key_valid = true;
 
@@ -615,8 +638,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         };
         c->last.analysis_ms = ms(tm.ev_analysis);
         c->last.scan_ms = ms(tm.ev_scan);
-        for (const auto& ct : tm.sym) c->last.sym_bin_ms[ct.cls] = ms(ct.ev);
-        for (const auto& ct : tm.num) c->last.num_bin_ms[ct.cls] = ms(ct.ev);
+        for (const auto& ct : tm.sym) (ct.cls == kLightItem ? c->last.sym_light_ms : c->last.sym_bin_ms[ct.cls]) = ms(ct.ev);
+        for (const auto& ct : tm.num) (ct.cls == kLightItem ? c->last.num_light_ms : c->last.num_bin_ms[ct.cls]) = ms(ct.ev);
         c->last.kernel_events_valid = 1;
     }
     if (t->measureAll) {
@@ -735,6 +758,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
     else if (n == "use_graph") c->use_graph = value != 0;
+    else if (n == "merge_light") {
+        c->merge_light = value != 0;
+        drop_graph(c);
+    }
     else if (n == "time_num_class") {
         if (!c->tev0) {
             HIP_TRY(hipEventCreate(&c->tev0));

@@ -30,23 +30,21 @@ constexpr u32 sym_group_lds()
 }
 
 template <class G, u32 CAP, int THREADS>
-__global__ __launch_bounds__(THREADS) void sym_hash_kernel(ProductSrc<float> src, const u32* a_ro,
-                                                           RowWork w, u32* __restrict__ counts,
-                                                           int cls)
+__device__ __forceinline__ void sym_hash_body(unsigned char* smem, const ProductSrc<float>& src,
+                                              const RowWork& w, u32* __restrict__ counts, int cls, u32 bidx,
+                                              u32 nblk)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 NG = THREADS / G::SIZE;
     constexpr u32 kGroupBytes = sym_group_lds<G, CAP, THREADS>();
     const G g;
-    src.rebase(a_ro);
     const u32 gid = G::kIsBlock ? 0u : threadIdx.x / G::SIZE;
     u32* tab = reinterpret_cast<u32*>(smem + gid * kGroupBytes);
     RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr};
     u32* scratch = tab + CAP + 2 * G::SIZE;
     const u32 count = w.st->sym.count[cls];
     const RowRec* recs = w.recs + w.st->sym.offset[cls];
-    u32 idx = blockIdx.x * NG + gid;
-    const u32 stride = gridDim.x * NG;
+    u32 idx = bidx * NG + gid;
+    const u32 stride = nblk * NG;
     RowRec next{};
     if (idx < count) next = recs[idx];
     while (idx < count) {
@@ -67,14 +65,12 @@ __global__ __launch_bounds__(THREADS) void sym_hash_kernel(ProductSrc<float> src
 }
 
 template <u32 WORDS, int THREADS>
-__global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> src, const u32* a_ro,
-                                                             RowWork w, u32* __restrict__ counts,
-                                                             int cls)
+__device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const ProductSrc<float>& src,
+                                                const RowWork& w, u32* __restrict__ counts, int cls, u32 bidx,
+                                                u32 nblk)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = Block<THREADS>;
     const G g;
-    src.rebase(a_ro);
     u32* bm = reinterpret_cast<u32*>(smem);
     RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr};
     u32* scratch = bm + WORDS + 2 * THREADS;
@@ -82,10 +78,10 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> s
     const u32 count = w.st->sym.count[cls];
     const RowRec* recs = w.recs + w.st->sym.offset[cls];
     RowRec next{};
-    if (blockIdx.x < count) next = recs[blockIdx.x];
-    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    if (bidx < count) next = recs[bidx];
+    for (u32 idx = bidx; idx < count; idx += nblk) {
         const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + gridDim.x < count) next = recs[idx + gridDim.x];
+        if (idx + nblk < count) next = recs[idx + nblk];
         u32 total = 0;
         for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += kWindowCols) {
             const u64 left = u64(rec.cmax) - w0 + 1;
@@ -108,6 +104,48 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> s
         total = g.reduce_add(total, scratch);
         if (threadIdx.x == 0) counts[rec.row] = total;
     }
+}
+
+// ------------------------------------------------------------------ kernels
+// Stand-alone kernels (one class per launch) and the merged "light" kernel (see numeric.hip):
+// every 256-thread class shares one launch, block ranges map to classes, heaviest first.
+template <class G, u32 CAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void sym_hash_kernel(ProductSrc<float> src, const u32* a_ro,
+                                                           RowWork w, u32* __restrict__ counts,
+                                                           int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    src.rebase(a_ro);
+    sym_hash_body<G, CAP, THREADS>(smem, src, w, counts, cls, blockIdx.x, gridDim.x);
+}
+
+template <u32 WORDS, int THREADS>
+__global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> src, const u32* a_ro,
+                                                             RowWork w, u32* __restrict__ counts,
+                                                             int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    src.rebase(a_ro);
+    sym_bitmap_body<WORDS, THREADS>(smem, src, w, counts, cls, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
+                                                        u32* __restrict__ counts, ClassGrid cg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    src.rebase(a_ro);
+    const u32 b = blockIdx.x;
+    // launch order (ClassGrid slots): BM1, B4K, W1K, W256, G16
+    if (b < cg.first[1])
+        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0]);
+    else if (b < cg.first[2])
+        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1]);
+    else if (b < cg.first[3])
+        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2]);
+    else if (b < cg.first[4])
+        sym_hash_body<SubWave<64>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3]);
+    else
+        sym_hash_body<SubWave<16>, kSymG16Cap, 256>(smem, src, w, counts, SYM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
 }
 
 u32 symbolic_lds_bytes(int cls)
@@ -157,6 +195,25 @@ static void launch_sym_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
     set_dyn_lds(k, lds);
     hipLaunchKernelGGL(k, dim3(grid_for(count, lds, THREADS, cu_count, THREADS / G::SIZE)),
                        dim3(THREADS), lds, s, A, B, w, counts, cls);
+}
+
+void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, const u32* a_ro,
+                           const u32* b_start, const u32* b_len, const u32* b_col, const RowWork& w,
+                           u32* counts, int cu_count)
+{
+    static const int slots[5] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_G16};
+    static const u32 rows_per_block[5] = {1, 1, 4, 4, 16};
+    u32 lds = 0;
+    for (int k = 0; k < 5; ++k)
+        if (mask >> slots[k] & 1u) lds = lds > symbolic_lds_bytes(slots[k]) ? lds : symbolic_lds_bytes(slots[k]);
+    ClassGrid cg{};
+    for (int k = 0; k < 5; ++k) {
+        const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
+        cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
+    }
+    if (cg.first[5] == 0) return;
+    const ProductSrc<float> src{b_start, b_len, nullptr, b_col, nullptr};
+    hipLaunchKernelGGL(sym_light_kernel, dim3(cg.first[5]), dim3(256), lds, s, src, a_ro, w, counts, cg);
 }
 
 void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u32* b_start,
