@@ -3,6 +3,9 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := speck_amd/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+ifdef PHASE_CLOCKS
+HIPFLAGS += -DSPECK_PHASE_CLOCKS
+endif
 HIP_SRCS := $(wildcard $(CSRC)/*.hip)
 CPP_SRCS := $(wildcard $(CSRC)/*.cpp)
 OBJS := $(HIP_SRCS:.hip=.o) $(CPP_SRCS:.cpp=.o)

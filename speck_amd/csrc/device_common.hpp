@@ -191,29 +191,54 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename V>
-__device__ __forceinline__ V wave_reduce_add(V v)
+// Scans and reductions move data with DPP modifiers (row_shr inside the 16-lane rows, then
+// row_bcast15 / row_bcast31 across rows): pure VALU, no ds_bpermute traffic through the LDS
+// crossbar -- the class kernels are bound by VALU and LDS instruction issue, not by HBM.
+// Lanes without a source keep `old` (the identity of the operation).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ u32 dpp_move(u32 old, u32 v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
-__device__ __forceinline__ u32 wave_reduce_max(u32 v)
+constexpr int kDppRowShr = 0x110, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+// inclusive scan inside every 16-lane row
+__device__ __forceinline__ u32 row16_inclusive_scan(u32 v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, (u32)__shfl_xor((int)v, off, 64));
+    v += dpp_move<kDppRowShr + 1>(0, v);
+    v += dpp_move<kDppRowShr + 2>(0, v);
+    v += dpp_move<kDppRowShr + 4>(0, v);
+    v += dpp_move<kDppRowShr + 8>(0, v);
     return v;
 }
 // inclusive scan across the 64 lanes
 __device__ __forceinline__ u32 wave_inclusive_scan(u32 v)
 {
-    const u32 lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        u32 t = (u32)__shfl_up((int)v, off, 64);
-        if (lane >= (u32)off) v += t;
-    }
+    v = row16_inclusive_scan(v);
+    v += dpp_move<kDppRowBcast15, 0xA>(0, v);
+    v += dpp_move<kDppRowBcast31, 0xC>(0, v);
     return v;
+}
+__device__ __forceinline__ u32 wave_reduce_add(u32 v)
+{
+    return (u32)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
+}
+__device__ __forceinline__ u64 wave_reduce_add(u64 v)
+{
+    // per-half sums of the low words cannot overflow a u64 accumulated from 64 lanes
+    const u32 lo = (u32)v, hi = (u32)(v >> 32);
+    const u64 s_lo16 = wave_reduce_add(lo & 0xFFFFu), s_hi16 = wave_reduce_add(lo >> 16);
+    return (u64(wave_reduce_add(hi)) << 32) + (s_hi16 << 16) + s_lo16;
+}
+__device__ __forceinline__ u32 wave_reduce_max(u32 v)
+{
+    v = max(v, dpp_move<kDppRowShr + 1>(0, v));
+    v = max(v, dpp_move<kDppRowShr + 2>(0, v));
+    v = max(v, dpp_move<kDppRowShr + 4>(0, v));
+    v = max(v, dpp_move<kDppRowShr + 8>(0, v));
+    v = max(v, dpp_move<kDppRowBcast15, 0xA>(0, v));
+    v = max(v, dpp_move<kDppRowBcast31, 0xC>(0, v));
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ u64 lanemask_lt()
 {

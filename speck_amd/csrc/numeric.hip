@@ -97,10 +97,12 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX>
 __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, const T* vals, u32* S,
                                                    u32* scan_scratch, u32 cmin, u32 cmax, u32 base,
-                                                   u32* __restrict__ c_col, T* __restrict__ c_val)
+                                                   u32* __restrict__ c_col, T* __restrict__ c_val,
+                                                   int cls = 0)
 {
     constexpr u32 OWN = CAP / G::SIZE;
     constexpr u64 kWindowCols = u64(W1) * 1024;
+    PHASE_BEGIN(cls);
     u32 k[OWN], brank[OWN];
     T v[OWN];
 #pragma unroll
@@ -110,6 +112,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
         brank[j] = 0;
     }
     g.sync();
+    PHASE_MARK(3);
     u32* l1 = S;
     u32* l1pref = S + W1;
     u32* masks = S;
@@ -128,7 +131,9 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
             if (k[j] != kEmptyKey && d < ncols) atomicOr(&l1[d >> 10], 1u << ((d >> 5) & 31));
         }
         g.sync();
+        PHASE_MARK(4);
         const u32 nocc = bitmap_prefix(g, l1, l1pref, nw1, scan_scratch);
+        PHASE_MARK(5);
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
             const u32 d = k[j] - wbase;
@@ -136,6 +141,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
                 brank[j] = l1pref[d >> 10] + __popc(l1[d >> 10] & ((1u << ((d >> 5) & 31)) - 1u));
         }
         g.sync();  // level-1 arrays are dead from here: the masks alias them
+        PHASE_MARK(6);
         for (u32 i = g.lane; i < nocc; i += G::SIZE) masks[i] = 0;
         g.sync();
 #pragma unroll
@@ -144,7 +150,9 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
             if (k[j] != kEmptyKey && d < ncols) atomicOr(&masks[brank[j]], 1u << (d & 31));
         }
         g.sync();
+        PHASE_MARK(7);
         const u32 total = bitmap_prefix(g, masks, mpref, nocc, scan_scratch);
+        PHASE_MARK(8);
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
             const u32 d = k[j] - wbase;
@@ -157,6 +165,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
         }
         emitted += total;
         g.sync();
+        PHASE_MARK(9);
     }
 }
 
@@ -172,7 +181,7 @@ constexpr u32 scan_scratch_words()
 template <class G, typename T, u32 CAP, int THREADS>
 constexpr u32 num_group_lds()
 {
-    const u32 words = 2 * G::SIZE + scan_scratch_words<G, THREADS>();
+    const u32 words = 2 * G::SIZE + scan_scratch_words<G, THREADS>() + win_words<G>();
     return CAP * ((u32)sizeof(T) + 4u) + G::SIZE * (u32)sizeof(T) + (words + 3u) / 4u * 16u;
 }
 
@@ -194,8 +203,8 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     u32* keys = reinterpret_cast<u32*>(vals + CAP);
     T* m_av = reinterpret_cast<T*>(keys + CAP);
     u32* m_incl = reinterpret_cast<u32*>(m_av + G::SIZE);
-    RowMeta<T> meta{m_incl, m_incl + G::SIZE, m_av};
     u32* scan_scratch = m_incl + 2 * G::SIZE;
+    RowMeta<T> meta{m_incl, m_incl + G::SIZE, m_av, scan_scratch + scan_scratch_words<G, THREADS>()};
     u32* S = reinterpret_cast<u32*>(mine);
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
@@ -204,6 +213,7 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     RowRec next{};
     if (idx < count) next = recs[idx];
     while (idx < count) {
+        PHASE_BEGIN(cls);
         const RowRec rec = next;  // fetched while the previous row was being processed
         if (idx + stride < count) next = recs[idx + stride];
         for (u32 i = g.lane; i < CAP; i += G::SIZE) {
@@ -211,17 +221,20 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
             vals[i] = T(0);
         }
         g.sync();
+        PHASE_MARK(0);
         for_each_product<true>(g, src, rec.a0, rec.a1, meta, scan_scratch,
                                [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
                                    table_accumulate_batch<CAP>(keys, vals, c, p, n);
-                               });
+                               }, cls);
+        PHASE_MARK(1);
         if constexpr (MODE == SORT_RANK) {
             emit_rank_sorted<G, T, CAP>(g, keys, vals, S, rec.base, c_col, c_val);
         } else {
             emit_bitmap_sorted<G, T, CAP, W1, NMAX>(g, keys, vals, S, scan_scratch, rec.cmin, rec.cmax,
-                                                    rec.base, c_col, c_val);
+                                                    rec.base, c_col, c_val, cls);
         }
         g.sync();
+        PHASE_MARK(2);
         idx += stride;
     }
 }
@@ -230,7 +243,8 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
 template <typename T, u32 WCOLS, int THREADS>
 constexpr u32 num_dense_lds()
 {
-    return (WCOLS + THREADS) * (u32)sizeof(T) + (2 * (WCOLS / 32) + 2 * THREADS + THREADS / 64 + 2 + 3) / 4 * 16;
+    return (WCOLS + THREADS) * (u32)sizeof(T) +
+           (2 * (WCOLS / 32) + 2 * THREADS + THREADS / 64 + 2 + win_words<Block<THREADS>>() + 3) / 4 * 16;
 }
 
 template <typename T, u32 WCOLS, int THREADS>
@@ -245,8 +259,8 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
     T* m_av = vals + WCOLS;
     u32* bm = reinterpret_cast<u32*>(m_av + THREADS);
     u32* pref = bm + WORDS;
-    RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av};
     u32* scratch = pref + WORDS + 2 * THREADS;
+    RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av, scratch + THREADS / 64 + 2};
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
     RowRec next{};
@@ -380,7 +394,8 @@ __device__ __forceinline__ V load_l2(const V* p)
 template <typename T, int THREADS, u32 BMW>
 constexpr u32 num_global_lds()
 {
-    return THREADS * (u32)sizeof(T) + (2 * BMW + 2 * THREADS + THREADS / 64 + 2 + 3) / 4 * 16;
+    return THREADS * (u32)sizeof(T) +
+           (2 * BMW + 2 * THREADS + THREADS / 64 + 2 + win_words<Block<THREADS>>() + 3) / 4 * 16;
 }
 
 template <typename T, int THREADS, u32 BMW>
@@ -395,8 +410,8 @@ __global__ __launch_bounds__(THREADS) void num_global_kernel(ProductSrc<T> src, 
     T* m_av = reinterpret_cast<T*>(smem);
     u32* bm = reinterpret_cast<u32*>(m_av + THREADS);
     u32* pref = bm + BMW;
-    RowMeta<T> meta{pref + BMW, pref + BMW + THREADS, m_av};
     u32* scratch = pref + BMW + 2 * THREADS;
+    RowMeta<T> meta{pref + BMW, pref + BMW + THREADS, m_av, scratch + THREADS / 64 + 2};
     if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     u32* gkeys = w.gkeys;
@@ -615,6 +630,23 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
         }
     }
 }
+
+}  // namespace speck
+#ifdef SPECK_PHASE_CLOCKS
+// out: kMaxClasses*16 u64 (class-major); the device counters are reset.
+extern "C" int speck_debug_phase_clocks(unsigned long long* out)
+{
+    constexpr int n = speck::kMaxClasses * 16;
+    static unsigned long long all[speck::kPhaseSlots * n];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(speck::g_phase_clk), sizeof(all)) != hipSuccess) return 3;
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    for (int s = 0; s < speck::kPhaseSlots; ++s)
+        for (int i = 0; i < n; ++i) out[i] += all[s * n + i];
+    for (auto& x : all) x = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(speck::g_phase_clk), all, sizeof(all)) == hipSuccess ? 0 : 3;
+}
+#endif
+namespace speck {
 
 template void launch_numeric_light<double>(hipStream_t, const u32*, u32, const CsrView<double>&,
                                            const CsrView<double>&, const RowWork&, u32*, double*, int);

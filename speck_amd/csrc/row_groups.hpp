@@ -16,10 +16,31 @@
 
 namespace speck {
 
+// Opt-in phase clocks (make PHASE_CLOCKS=1): cycles (s_memtime) a row spends in each phase of the
+// hash kernels, summed per class by the first lane of every group.  Read and reset through
+// speck_debug_phase_clocks(); scripts/phase_clocks.py prints the table.
+#ifdef SPECK_PHASE_CLOCKS
+constexpr int kPhaseSlots = 1024;  // spread over block ids: same-address atomics would serialise
+static __device__ unsigned long long g_phase_clk[kPhaseSlots * kMaxClasses * 16];
+#define PHASE_BEGIN(cls_) \
+    long long pc_t_ = clock64(); \
+    const int pc_cls_ = (cls_)
+#define PHASE_MARK(i_) \
+    do { \
+        const long long pc_n_ = clock64(); \
+        if (g.lane == 0) atomicAdd(&g_phase_clk[(blockIdx.x % kPhaseSlots) * kMaxClasses * 16 + pc_cls_ * 16 + (i_)], (unsigned long long)(pc_n_ - pc_t_)); \
+        pc_t_ = pc_n_; \
+    } while (0)
+#else
+#define PHASE_BEGIN(cls_)
+#define PHASE_MARK(i_)
+#endif
+
+
 // ---- group policies -------------------------------------------------------------
 template <int L>
 struct SubWave {
-    static_assert(L == 8 || L == 16 || L == 32 || L == 64, "sub-wave width");
+    static_assert(L == 16 || L == 64, "sub-wave width");
     static constexpr int SIZE = L;
     static constexpr bool kIsBlock = false;
     u32 lane;       // index inside the group
@@ -33,19 +54,21 @@ struct SubWave {
     __device__ __forceinline__ void sync() const { wave_lds_fence(); }
     __device__ __forceinline__ u32 inclusive_scan(u32 v, u32* total, u32* /*scratch*/) const
     {
-#pragma unroll
-        for (int off = 1; off < L; off <<= 1) {
-            const u32 t = (u32)__shfl_up((int)v, off, L);
-            if (lane >= (u32)off) v += t;
+        if constexpr (L == 64) {
+            v = wave_inclusive_scan(v);
+            *total = (u32)__builtin_amdgcn_readlane((int)v, 63);
+        } else {
+            v = row16_inclusive_scan(v);
+            // lane 15 of the own 16-lane row: ds_swizzle bit mode, lane' = (lane & 0x10) | 0x0F
+            *total = (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (0x0F << 5));
         }
-        *total = (u32)__shfl((int)v, L - 1, L);
         return v;
     }
-    __device__ __forceinline__ u32 reduce_add(u32 v, u32* /*scratch*/) const
+    __device__ __forceinline__ u32 reduce_add(u32 v, u32* scratch) const
     {
-#pragma unroll
-        for (int off = L >> 1; off > 0; off >>= 1) v += (u32)__shfl_xor((int)v, off, L);
-        return v;
+        u32 total;
+        inclusive_scan(v, &total, scratch);
+        return total;
     }
     // bit i of the result <=> group lane i voted true
     __device__ __forceinline__ u64 ballot(bool p) const
@@ -117,6 +140,7 @@ struct RowMeta {
     u32* incl;  // inclusive prefix of B-row lengths
     u32* off;   // B-row start minus exclusive prefix: ib = off[s] + p  (u32 wrap-around)
     T* av;      // a_ik (unused by the symbolic kernels: pass nullptr)
+    u32* win;   // win_words<G>() words of owner-window scratch (wave and workgroup groups)
 };
 
 template <int SIZE, typename T>
@@ -126,19 +150,6 @@ constexpr u32 row_meta_bytes(bool with_values)
 }
 
 constexpr int kBatch = 4;  // products per lane fetched before accumulating (memory-level parallelism)
-
-// Smallest s in [lo, cnt) with incl[s] > p.  `lo` is a lower bound carried between calls.
-__device__ __forceinline__ u32 owner_search(const u32* incl, u32 lo, u32 cnt, u32 p)
-{
-    if (incl[lo] > p) return lo;
-    u32 hi = cnt - 1;
-    ++lo;
-    while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (incl[mid] > p) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
 
 // Where the products of a row come from.  b_start / b_len hold, per entry of A, the first entry
 // and the length of the B row it references: the analysis pass reads B.row_offsets for every A
@@ -161,20 +172,144 @@ struct ProductSrc {
     }
 };
 
-// Walk all products of row [a0,a1) of A.  f(col, value) for WITH_VALUES, f(col) otherwise.
+// ---- product -> owning A entry ---------------------------------------------------------
+// Product p of a staged chunk belongs to the smallest entry s with incl[s] > p.
+//
+// Sub-wave groups (16 lanes): a per-lane binary search over <= 16 entries; the kBatch searches of
+// a lane advance in lock step so a round costs one LDS round trip.
+template <bool WITH_VALUES, typename T>
+__device__ __forceinline__ void fetch_batch(const ProductSrc<T>& src, const RowMeta<T>& m, u32 cnt, u32 p,
+                                            u32 step, u32 end, u32& s, u32 (&c)[kBatch],
+                                            T (&bv)[kBatch], T (&av)[kBatch])
+{
+    u32 lo[kBatch], hi[kBatch];
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+        const u32 pu = p + u * step;
+        lo[u] = hi[u] = s;
+        if (pu < end) {
+            if (m.incl[s] <= pu) {
+                lo[u] = s + 1;
+                hi[u] = cnt - 1;
+            }
+        }
+        more |= lo[u] < hi[u];
+    }
+    while (more) {
+        more = false;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const u32 mid = (lo[u] + hi[u]) >> 1;
+            const bool act = lo[u] < hi[u];
+            const bool gt = m.incl[mid] > p + u * step;
+            hi[u] = (act && gt) ? mid : hi[u];
+            lo[u] = (act && !gt) ? mid + 1 : lo[u];
+            more |= lo[u] < hi[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+        const u32 pu = p + u * step;
+        c[u] = kEmptyKey;
+        bv[u] = T(0);
+        av[u] = T(0);
+        if (pu < end) {
+            const u32 ib = m.off[lo[u]] + pu;
+            c[u] = src.b_col[ib];
+            if (WITH_VALUES) {
+                bv[u] = src.b_val[ib];
+                av[u] = m.av[lo[u]];
+            }
+            s = lo[u];
+        }
+    }
+}
+
+// Wave and workgroup groups: a wave walks a contiguous slice of the product space in windows of
+// kBatch*64 products, lane l taking products base + 64u + l.  The owners of a whole window are
+// found cooperatively instead of by 256 binary searches (which made these kernels VALU- and
+// LDS-issue bound): the entries from s0 = owner(base) on drop a count at the window position
+// where their products END (incl[e] - base; 16-bit counters, two per LDS word -- empty B rows
+// share a position), and the owner of position i is s0 + the number of ends at positions <= i:
+// one LDS read and one DPP scan per 64 products.  s0 is carried from window to window.
+constexpr u32 kWinProducts = kBatch * 64;
+constexpr u32 kWinWords = kWinProducts / 2;  // LDS words per wave
+
+template <class G>
+constexpr u32 win_words()
+{
+    return G::SIZE >= 64 ? (G::SIZE / 64) * kWinWords : 0;
+}
+
+// owner(p), the same for all lanes of the wave (broadcast LDS reads, scalar control flow)
+__device__ __forceinline__ u32 uniform_owner(const u32* incl, u32 cnt, u32 p)
+{
+    u32 lo = 0, hi = cnt - 1;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        const u32 v = (u32)__builtin_amdgcn_readfirstlane((int)incl[mid]);
+        if (v > p) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void window_owners(const u32* incl, u32* win, u32 cnt, u32 base, u32& s0,
+                                              u32 (&own)[kBatch])
+{
+    const u32 l = lane_id();
+    reinterpret_cast<uint2*>(win)[l] = make_uint2(0u, 0u);
+    wave_lds_fence();
+    u32 sw = s0, at_end = 0;
+    bool again;
+    do {
+        const u32 e = sw + l;
+        const u32 b = e < cnt ? incl[e] - base : 0xFFFFFFFFu;  // >= 1: incl[s0] > base
+        if (b < kWinProducts) atomicAdd(&win[b >> 1], 1u << ((b & 1u) * 16u));
+        at_end += (u32)__popcll(__ballot(b == kWinProducts));
+        again = (u32)__builtin_amdgcn_readlane((int)b, 63) <= kWinProducts;
+        sw += 64;
+    } while (again);
+    wave_lds_fence();
+    u32 carry = s0;
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+        const u32 pos = u * 64 + l;
+        const u32 x = (win[pos >> 1] >> ((pos & 1u) * 16u)) & 0xFFFFu;
+        const u32 inc = wave_inclusive_scan(x);
+        own[u] = carry + inc;
+        carry += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    s0 = carry + at_end;
+    wave_lds_fence();
+}
+
+// Walk all products of row [a0,a1) of A.  f(cols[kBatch], products[kBatch], nvalid).
 template <bool WITH_VALUES, class G, typename T, typename F>
 __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>& src, u32 a0, u32 a1,
-                                                 const RowMeta<T>& m, u32* scratch, F&& f)
+                                                 const RowMeta<T>& m, u32* scratch, F&& f,
+                                                 int dbg_cls = kMaxClasses - 1)
 {
+    PHASE_BEGIN(dbg_cls);
+    u32 nlen = 0, nbs = 0;
+    T nav = T(0);
+    if (a0 + g.lane < a1) {
+        const u32 e = a0 + g.lane;
+        if (WITH_VALUES) nav = src.a_val[e];
+        nbs = src.b_start[e];
+        nlen = src.b_len[e];
+    }
     for (u32 chunk = a0; chunk < a1; chunk += G::SIZE) {
         const u32 cnt = min((u32)G::SIZE, a1 - chunk);
-        u32 len = 0, bs = 0;
-        T av = T(0);
-        if (g.lane < cnt) {
-            const u32 e = chunk + g.lane;
-            if (WITH_VALUES) av = src.a_val[e];
-            bs = src.b_start[e];
-            len = src.b_len[e];
+        const u32 len = nlen, bs = nbs;
+        const T av = nav;
+        // the next chunk's entries are fetched while this chunk's products are walked
+        nlen = 0;
+        if (chunk + G::SIZE + g.lane < a1) {
+            const u32 e = chunk + G::SIZE + g.lane;
+            if (WITH_VALUES) nav = src.a_val[e];
+            nbs = src.b_start[e];
+            nlen = src.b_len[e];
         }
         u32 total;
         const u32 incl = g.inclusive_scan(len, &total, scratch);
@@ -184,42 +319,63 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
             if (WITH_VALUES) m.av[g.lane] = av;
         }
         g.sync();
+        PHASE_MARK(10);
         u32 p, step, end;
         g.product_range(total, p, step, end);
-        u32 s = 0;
-        // kBatch products per lane are fetched back to back (independent gathers in flight)
-        // before any of them touches the accumulator.
-        while (p < end) {
-            u32 c[kBatch];
-            T bv[kBatch], av_[kBatch];
+        if constexpr (G::SIZE >= 64) {
+            const u32 l = lane_id();
+            u32 base = (u32)__builtin_amdgcn_readfirstlane((int)(p - l));
+            const u32 wend = (u32)__builtin_amdgcn_readfirstlane((int)end);
+            u32* win = m.win + (G::kIsBlock ? (threadIdx.x >> 6) * kWinWords : 0u);
+            u32 s0 = 0;
+            if (base < wend) s0 = uniform_owner(m.incl, cnt, base);
+            PHASE_MARK(11);
+            while (base < wend) {
+                u32 own[kBatch];
+                window_owners(m.incl, win, cnt, base, s0, own);
+                u32 c[kBatch];
+                T prod[kBatch];
+                u32 nvalid = 0;
 #pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                const u32 pu = p + u * step;
-                c[u] = kEmptyKey;
-                bv[u] = T(0);
-                av_[u] = T(0);
-                if (pu < end) {
-                    s = owner_search(m.incl, s, cnt, pu);
-                    const u32 ib = m.off[s] + pu;
-                    c[u] = src.b_col[ib];
-                    if (WITH_VALUES) {
-                        bv[u] = src.b_val[ib];
-                        av_[u] = m.av[s];
+                for (int u = 0; u < kBatch; ++u) {
+                    const u32 pu = base + u * 64 + l;
+                    c[u] = kEmptyKey;
+                    T bv = T(0), a = T(0);
+                    if (pu < wend) {
+                        const u32 ib = m.off[own[u]] + pu;
+                        c[u] = src.b_col[ib];
+                        if (WITH_VALUES) {
+                            bv = src.b_val[ib];
+                            a = m.av[own[u]];
+                        }
+                        ++nvalid;  // the valid products of a lane are a prefix in u
                     }
+                    prod[u] = a * bv;  // rounded product, added later (no FMA across the add)
                 }
+                f(c, prod, nvalid);
+                base += kWinProducts;
             }
-            // the valid products of a batch are a prefix (p + u*step is increasing in u)
-            u32 nvalid = 0;
-            T prod[kBatch];
+        } else {
+            u32 s = 0;
+            PHASE_MARK(11);
+            while (p < end) {
+                u32 c[kBatch];
+                T bv[kBatch], av_[kBatch];
+                fetch_batch<WITH_VALUES>(src, m, cnt, p, step, end, s, c, bv, av_);
+                u32 nvalid = 0;
+                T prod[kBatch];
 #pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                nvalid += (p + u * step < end) ? 1u : 0u;
-                prod[u] = av_[u] * bv[u];  // rounded product, added later (no FMA across the add)
+                for (int u = 0; u < kBatch; ++u) {
+                    nvalid += (p + u * step < end) ? 1u : 0u;
+                    prod[u] = av_[u] * bv[u];
+                }
+                f(c, prod, nvalid);
+                p += kBatch * step;
             }
-            f(c, prod, nvalid);
-            p += kBatch * step;
         }
+        PHASE_MARK(12);
         g.sync();
+        PHASE_MARK(13);
     }
 }
 

@@ -26,7 +26,7 @@ constexpr u32 sym_scratch_words()
 template <class G, u32 CAP, int THREADS>
 constexpr u32 sym_group_lds()
 {
-    return (CAP + 2 * G::SIZE + sym_scratch_words<G, THREADS>() + 3u) / 4u * 16u;
+    return (CAP + 2 * G::SIZE + sym_scratch_words<G, THREADS>() + win_words<G>() + 3u) / 4u * 16u;
 }
 
 template <class G, u32 CAP, int THREADS>
@@ -39,8 +39,8 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
     const G g;
     const u32 gid = G::kIsBlock ? 0u : threadIdx.x / G::SIZE;
     u32* tab = reinterpret_cast<u32*>(smem + gid * kGroupBytes);
-    RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr};
     u32* scratch = tab + CAP + 2 * G::SIZE;
+    RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr, scratch + sym_scratch_words<G, THREADS>()};
     const u32 count = w.st->sym.count[cls];
     const RowRec* recs = w.recs + w.st->sym.offset[cls];
     u32 idx = bidx * NG + gid;
@@ -72,8 +72,8 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
     using G = Block<THREADS>;
     const G g;
     u32* bm = reinterpret_cast<u32*>(smem);
-    RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr};
     u32* scratch = bm + WORDS + 2 * THREADS;
+    RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr, scratch + THREADS / 64 + 2};
     constexpr u64 kWindowCols = u64(WORDS) * 32;
     const u32 count = w.st->sym.count[cls];
     const RowRec* recs = w.recs + w.st->sym.offset[cls];
@@ -157,8 +157,8 @@ u32 symbolic_lds_bytes(int cls)
         case SYM_B4K: return sym_group_lds<Block<256>, kSymB4KCap, 256>();
         case SYM_B16K: return sym_group_lds<Block<512>, kSymB16KCap, 512>();
         case SYM_B32K: return sym_group_lds<Block<1024>, kSymB32KCap, 1024>();
-        case SYM_BM1: return (kSymBm1Words + 2 * 256 + 8) * 4;
-        case SYM_BM2: return (kSymBm2Words + 2 * 1024 + 24) * 4;
+        case SYM_BM1: return (kSymBm1Words + 2 * 256 + 8 + win_words<Block<256>>()) * 4;
+        case SYM_BM2: return (kSymBm2Words + 2 * 1024 + 24 + win_words<Block<1024>>()) * 4;
     }
     return 0;
 }

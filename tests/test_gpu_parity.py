@@ -148,7 +148,27 @@ def test_wave_classes(cfg):
 def test_hash_classes_wave1k_wave512_block2k(cfg):
     A = fast_random_csr(600, 4000, 20, 1)
     B = fast_random_csr(4000, 30000, 30, 2)
-    check(cfg, A, B, [("sym", "wave1k"), ("num", "wave512"), ("num", "block2k")])
+    check(cfg, A, B, [("sym", "wave1k"), ("num", "wave512"), ("num", "wave1k")])
+    A = fast_random_csr(300, 4000, 44, 3)
+    B = fast_random_csr(4000, 30000, 40, 4)
+    check(cfg, A, B, [("sym", "block4k"), ("num", "wave1k"), ("num", "block2k")])
+
+
+def test_empty_b_rows_and_long_a_rows(cfg):
+    """B rows of length zero share a position in the owner windows; A rows longer than a group
+    are staged in several chunks."""
+    rng = np.random.default_rng(5)
+    B = fast_random_csr(3000, 9000, 6, 6)
+    ro = B.row_offsets.astype(np.int64)
+    ln = np.diff(ro)
+    ln[rng.random(3000) < 0.6] = 0          # 60 % of the B rows become empty
+    keep = np.concatenate([np.arange(ro[i], ro[i] + ln[i]) for i in range(3000)]).astype(np.int64)
+    nro = np.zeros(3001, dtype=np.uint32)
+    nro[1:] = np.cumsum(ln)
+    B2 = po.HostCSR(3000, 9000, nro, B.col_ids[keep], B.data[keep])
+    for k in (3, 40, 300, 1500):            # A rows up to 1500 entries: 3 chunks of a 512 workgroup
+        A = fast_random_csr(200, 3000, k, 7 + k)
+        check(cfg, A, B2)
 
 
 def test_hash_classes_block16k(cfg):
