@@ -10,7 +10,7 @@ import speck_amd as sa
 from speck_amd import _lib
 
 PHASES = ["init", "products", "sort(total)", "s:load", "s:l1 build", "s:l1 prefix", "s:rank", "s:l2 build",
-          "s:l2 prefix", "s:emit", "p:meta+scan", "p:search+issue", "p:wait+accumulate", "p:sync"]
+          "s:l2 prefix", "s:emit", "p:meta+scan", "p:search+issue", "p:accumulate", "p:sync", "p:owner windows", "p:gather"]
 
 
 def main():

@@ -18,7 +18,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 // numeric row records when num_cls != nullptr).  tile_off: scan_tiles(m) u32 of scratch.
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
-                 RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz);
+                 RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
+                 DeviceStats* host_mirror = nullptr);
 
 // Everything a symbolic / numeric kernel needs besides the matrices.
 struct RowWork {
@@ -61,6 +62,8 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& A, cons
                     const RowWork& w, u32* c_col, T* c_val, int cu_count);
 
 u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block);
+// resident-set multiples a class grid may reach before its workgroups start striding over rows
+void set_grid_rounds(u32 block_classes, u32 subwave_classes);
 
 // LDS bytes a class needs (for occupancy-aware grid sizing and DESIGN.md tables)
 u32 symbolic_lds_bytes(int cls);

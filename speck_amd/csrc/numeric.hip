@@ -51,18 +51,23 @@ __device__ __forceinline__ void num_direct_body(const ProductSrc<T>& src, const 
 // ------------------------------------------------------------------ sorting back-ends
 // Rank sort for tiny tables: every lane owns OWN = CAP/SIZE slots (registers).
 // `ckeys` may alias the table: all slots are in registers before the first write.
+// `cap_row` (a power of two, SIZE <= cap_row <= CAP) slots of the table are in use.
 template <class G, typename T, u32 CAP>
 __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, const T* vals,
-                                                 u32* ckeys, u32 base, u32* __restrict__ c_col,
-                                                 T* __restrict__ c_val)
+                                                 u32* ckeys, u32 cap_row, u32 base,
+                                                 u32* __restrict__ c_col, T* __restrict__ c_val)
 {
     constexpr u32 OWN = CAP / G::SIZE;
     u32 k[OWN];
     T v[OWN];
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j) {
-        k[j] = keys[j * G::SIZE + g.lane];
-        v[j] = vals[j * G::SIZE + g.lane];
+        k[j] = kEmptyKey;
+        v[j] = T(0);
+        if (j * G::SIZE < cap_row) {
+            k[j] = keys[j * G::SIZE + g.lane];
+            v[j] = vals[j * G::SIZE + g.lane];
+        }
     }
     g.sync();
     u32 run = 0;
@@ -79,10 +84,19 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j) r[j] = 0;
     const uint4* ck4 = reinterpret_cast<const uint4*>(ckeys);
-    for (u32 q = 0; q < (run + 3) / 4; ++q) {
-        const uint4 x = ck4[q];  // same address for the whole group: LDS broadcast
+    // most rows of these classes are far smaller than the class limit: when every group of the
+    // wave uses a single slot per lane, only that slot is ranked
+    if (__ballot(cap_row > (u32)G::SIZE) == 0) {
+        for (u32 q = 0; q < (run + 3) / 4; ++q) {
+            const uint4 x = ck4[q];  // same address for the whole group: LDS broadcast
+            r[0] += (x.x < k[0]) + (x.y < k[0]) + (x.z < k[0]) + (x.w < k[0]);
+        }
+    } else {
+        for (u32 q = 0; q < (run + 3) / 4; ++q) {
+            const uint4 x = ck4[q];
 #pragma unroll
-        for (u32 j = 0; j < OWN; ++j) r[j] += (x.x < k[j]) + (x.y < k[j]) + (x.z < k[j]) + (x.w < k[j]);
+            for (u32 j = 0; j < OWN; ++j) r[j] += (x.x < k[j]) + (x.y < k[j]) + (x.z < k[j]) + (x.w < k[j]);
+        }
     }
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j)
@@ -96,20 +110,26 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
 // it may alias the table (slots are loaded into registers first).
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX>
 __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, const T* vals, u32* S,
-                                                   u32* scan_scratch, u32 cmin, u32 cmax, u32 base,
-                                                   u32* __restrict__ c_col, T* __restrict__ c_val,
-                                                   int cls = 0)
+                                                   u32* scan_scratch, u32 cap_row, u32 cmin, u32 cmax,
+                                                   u32 base, u32* __restrict__ c_col,
+                                                   T* __restrict__ c_val, int cls = 0)
 {
     constexpr u32 OWN = CAP / G::SIZE;
     constexpr u64 kWindowCols = u64(W1) * 1024;
     PHASE_BEGIN(cls);
     u32 k[OWN], brank[OWN];
     T v[OWN];
+    // slots j*SIZE + lane: only the first cap_row / SIZE of them exist for this row (the guards
+    // below are uniform for the group, whole iterations are skipped)
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j) {
-        k[j] = keys[j * G::SIZE + g.lane];
-        v[j] = vals[j * G::SIZE + g.lane];
+        k[j] = kEmptyKey;
+        v[j] = T(0);
         brank[j] = 0;
+        if (j * G::SIZE < cap_row) {
+            k[j] = keys[j * G::SIZE + g.lane];
+            v[j] = vals[j * G::SIZE + g.lane];
+        }
     }
     g.sync();
     PHASE_MARK(3);
@@ -127,6 +147,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
         g.sync();
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
+            if (j * G::SIZE >= cap_row) continue;
             const u32 d = k[j] - wbase;
             if (k[j] != kEmptyKey && d < ncols) atomicOr(&l1[d >> 10], 1u << ((d >> 5) & 31));
         }
@@ -136,6 +157,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
         PHASE_MARK(5);
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
+            if (j * G::SIZE >= cap_row) continue;
             const u32 d = k[j] - wbase;
             if (k[j] != kEmptyKey && d < ncols)
                 brank[j] = l1pref[d >> 10] + __popc(l1[d >> 10] & ((1u << ((d >> 5) & 31)) - 1u));
@@ -146,6 +168,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
         g.sync();
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
+            if (j * G::SIZE >= cap_row) continue;
             const u32 d = k[j] - wbase;
             if (k[j] != kEmptyKey && d < ncols) atomicOr(&masks[brank[j]], 1u << (d & 31));
         }
@@ -155,6 +178,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
         PHASE_MARK(8);
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
+            if (j * G::SIZE >= cap_row) continue;
             const u32 d = k[j] - wbase;
             if (k[j] != kEmptyKey && d < ncols) {
                 const u32 r = emitted + mpref[brank[j]] +
@@ -216,7 +240,13 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         PHASE_BEGIN(cls);
         const RowRec rec = next;  // fetched while the previous row was being processed
         if (idx + stride < count) next = recs[idx + stride];
-        for (u32 i = g.lane; i < CAP; i += G::SIZE) {
+        // table of this row: the smallest power of two >= 1.5 nnz (load <= 2/3), at least one slot
+        // per lane; the class limit guarantees it fits (nnz <= 2/3 CAP)
+        u32 bits = 32u - (u32)__clz((int)max(rec.nnz + (rec.nnz >> 1), 2u) - 1);
+        bits = min(max(bits, (u32)__builtin_ctz(G::SIZE)), (u32)__builtin_ctz(CAP));
+        if constexpr (G::SIZE >= 64) bits = (u32)__builtin_amdgcn_readfirstlane((int)bits);
+        const u32 cap_row = 1u << bits;
+        for (u32 i = g.lane; i < cap_row; i += G::SIZE) {
             keys[i] = kEmptyKey;
             vals[i] = T(0);
         }
@@ -224,14 +254,14 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         PHASE_MARK(0);
         for_each_product<true>(g, src, rec.a0, rec.a1, meta, scan_scratch,
                                [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
-                                   table_accumulate_batch<CAP>(keys, vals, c, p, n);
+                                   table_accumulate_batch(keys, vals, bits, c, p, n);
                                }, cls);
         PHASE_MARK(1);
         if constexpr (MODE == SORT_RANK) {
-            emit_rank_sorted<G, T, CAP>(g, keys, vals, S, rec.base, c_col, c_val);
+            emit_rank_sorted<G, T, CAP>(g, keys, vals, S, cap_row, rec.base, c_col, c_val);
         } else {
-            emit_bitmap_sorted<G, T, CAP, W1, NMAX>(g, keys, vals, S, scan_scratch, rec.cmin, rec.cmax,
-                                                    rec.base, c_col, c_val, cls);
+            emit_bitmap_sorted<G, T, CAP, W1, NMAX>(g, keys, vals, S, scan_scratch, cap_row, rec.cmin,
+                                                    rec.cmax, rec.base, c_col, c_val, cls);
         }
         g.sync();
         PHASE_MARK(2);

@@ -60,7 +60,8 @@ struct speck_config {
     void* arena = nullptr;
     size_t arena_bytes = 0;
     DeviceStats* d_stats = nullptr;
-    DeviceStats* h_stats = nullptr;  // pinned
+    DeviceStats* h_stats = nullptr;  // pinned, mapped
+    DeviceStats* h_stats_dev = nullptr;  // device address of h_stats
     ClassifyParams cp{};
     bool profile_kernels = false;
     std::vector<hipEvent_t> kev;   // kernel event pool (timing)
@@ -235,11 +236,19 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
 {
     bool forked = false;
     size_t used = 0;
+    auto active = [&](int cls) { return cls == kLightItem ? (mask & light_mask) != 0 : (mask >> cls & 1u) != 0; };
+    // The last active item stays on the pipeline stream: a fork costs its branch 10-20 us of
+    // cross-queue latency, a join on an already finished branch almost nothing -- so a phase with
+    // one kernel pays no event at all, and the merged light launch (usually the longest) starts
+    // at once while the heavy-row kernels start late on their side streams and still finish first.
+    int last_active = -1;
+    for (int i = 0; i < n_order; ++i)
+        if (active(order[i])) last_active = i;
     for (int i = 0; i < n_order; ++i) {
         const int cls = order[i];
-        if (cls == kLightItem ? !(mask & light_mask) : !(mask >> cls & 1u)) continue;
+        if (!active(cls)) continue;
         hipStream_t ks = s;
-        if (c->concurrent_classes && used < c->aux.size()) {
+        if (c->concurrent_classes && used < c->aux.size() && i != last_active) {
             if (!forked) {
                 HIP_TRY(hipEventRecord(c->fork, s));
                 forked = true;
@@ -257,10 +266,10 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
         }
         if (ks != s) {
             HIP_TRY(hipEventRecord(c->aux_done[used], ks));
-            HIP_TRY(hipStreamWaitEvent(s, c->aux_done[used], 0));
             ++used;
         }
     }
+    for (size_t k = 0; k < used; ++k) HIP_TRY(hipStreamWaitEvent(s, c->aux_done[k], 0));
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
 }
@@ -285,13 +294,13 @@ struct Timing {
 // decision: `sym_mask` only prunes kernels of classes known to be empty (eager path: all).
 int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
                   const Scratch& sc, u32* c_ro, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
-                  bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr)
+                  bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr,
+                  DeviceStats* host_mirror = nullptr)
 {
     const u32 m = (u32)A->rows;
     ClassifyParams cp = c->cp;
     cp.sym_allowed = sym_mask;
     cp.num_allowed = num_mask;
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DeviceStats), s));
     const bool timed = c->profile_kernels && tm;
     if (timed) {
         tm->ev_analysis = tm->ev;
@@ -325,7 +334,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
     launch_scan(s, c_ro, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
-                classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz);
+                classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
+                host_mirror);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -415,13 +425,12 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     drop_graph(c);
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
-                           c->last_num_mask, true, nullptr, c->last_sym_counts);
+                           c->last_num_mask, true, nullptr, c->last_sym_counts, c->h_stats_dev);
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
                              c->last_num_mask, c->last_num_counts, nullptr);
-    hipError_t e = rc == SPECK_OK ? hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats),
-                                                   hipMemcpyDeviceToHost, s)
-                                  : hipErrorUnknown;
+    // no copy node: the scan kernel mirrors the statistics block into pinned host memory
+    hipError_t e = rc == SPECK_OK ? hipSuccess : hipErrorUnknown;
     hipGraph_t g = nullptr;
     hipError_t e2 = hipStreamEndCapture(s, &g);
     if (rc != SPECK_OK || e != hipSuccess || e2 != hipSuccess || !g) {
@@ -699,7 +708,8 @@ int speck_config_create(int device, speck_config** out)
     }
     HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(DeviceStats)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stats), sizeof(DeviceStats), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stats), sizeof(DeviceStats), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_stats_dev), c->h_stats, 0));
     c->cp.sym_bitmap_ratio = 32;
     c->cp.num_dense_ratio = 16;
     c->cp.num_global_passes = 4;  // heavy rows: dense windows up to 64 Ki columns, else global spill
@@ -758,6 +768,14 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
     else if (n == "use_graph") c->use_graph = value != 0;
+    else if (n == "grid_rounds_block") {
+        set_grid_rounds((u32)value, 0);
+        drop_graph(c);
+    }
+    else if (n == "grid_rounds_sub") {
+        set_grid_rounds(0, (u32)value);
+        drop_graph(c);
+    }
     else if (n == "merge_light") {
         c->merge_light = value != 0;
         drop_graph(c);

@@ -31,9 +31,11 @@ static __device__ unsigned long long g_phase_clk[kPhaseSlots * kMaxClasses * 16]
         if (g.lane == 0) atomicAdd(&g_phase_clk[(blockIdx.x % kPhaseSlots) * kMaxClasses * 16 + pc_cls_ * 16 + (i_)], (unsigned long long)(pc_n_ - pc_t_)); \
         pc_t_ = pc_n_; \
     } while (0)
+#define PHASE_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define PHASE_BEGIN(cls_)
 #define PHASE_MARK(i_)
+#define PHASE_WAIT_VMEM()
 #endif
 
 
@@ -303,14 +305,6 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
         const u32 cnt = min((u32)G::SIZE, a1 - chunk);
         const u32 len = nlen, bs = nbs;
         const T av = nav;
-        // the next chunk's entries are fetched while this chunk's products are walked
-        nlen = 0;
-        if (chunk + G::SIZE + g.lane < a1) {
-            const u32 e = chunk + G::SIZE + g.lane;
-            if (WITH_VALUES) nav = src.a_val[e];
-            nbs = src.b_start[e];
-            nlen = src.b_len[e];
-        }
         u32 total;
         const u32 incl = g.inclusive_scan(len, &total, scratch);
         if (g.lane < cnt) {
@@ -319,6 +313,15 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
             if (WITH_VALUES) m.av[g.lane] = av;
         }
         g.sync();
+        // the next chunk's entries are fetched while this chunk's products are walked (issued
+        // here, with no older load pending, so that no wait is placed right behind them)
+        nlen = 0;
+        if (chunk + G::SIZE + g.lane < a1) {
+            const u32 e = chunk + G::SIZE + g.lane;
+            if (WITH_VALUES) nav = src.a_val[e];
+            nbs = src.b_start[e];
+            nlen = src.b_len[e];
+        }
         PHASE_MARK(10);
         u32 p, step, end;
         g.product_range(total, p, step, end);
@@ -333,26 +336,34 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
             while (base < wend) {
                 u32 own[kBatch];
                 window_owners(m.incl, win, cnt, base, s0, own);
+                PHASE_MARK(14);
                 u32 c[kBatch];
-                T prod[kBatch];
+                T bv[kBatch], a[kBatch], prod[kBatch];
                 u32 nvalid = 0;
+                // all kBatch gathers are issued before the first product is formed
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
                     const u32 pu = base + u * 64 + l;
                     c[u] = kEmptyKey;
-                    T bv = T(0), a = T(0);
+                    bv[u] = T(0);
+                    a[u] = T(0);
                     if (pu < wend) {
                         const u32 ib = m.off[own[u]] + pu;
                         c[u] = src.b_col[ib];
                         if (WITH_VALUES) {
-                            bv = src.b_val[ib];
-                            a = m.av[own[u]];
+                            bv[u] = src.b_val[ib];
+                            a[u] = m.av[own[u]];
                         }
                         ++nvalid;  // the valid products of a lane are a prefix in u
                     }
-                    prod[u] = a * bv;  // rounded product, added later (no FMA across the add)
                 }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u)
+                    prod[u] = a[u] * bv[u];  // rounded product, added later (no FMA across the add)
+                PHASE_WAIT_VMEM();
+                PHASE_MARK(15);
                 f(c, prod, nvalid);
+                PHASE_MARK(12);
                 base += kWinProducts;
             }
         } else {
@@ -405,14 +416,17 @@ __device__ __forceinline__ u32 set_insert_batch(u32* tab, const u32 (&key)[kBatc
     return added;
 }
 
-template <u32 CAP, typename T>
-__device__ __forceinline__ void table_accumulate_batch(u32* keys, T* vals, const u32 (&key)[kBatch],
+// The table of a row uses the first 2^bits slots of the class' arrays (bits chosen per row from
+// its exact nnz: every later pass over the slots costs LDS and VALU issue per SLOT, not per key).
+template <typename T>
+__device__ __forceinline__ void table_accumulate_batch(u32* keys, T* vals, u32 bits, const u32 (&key)[kBatch],
                                                        const T (&prod)[kBatch], u32 nvalid)
 {
+    const u32 mask = (1u << bits) - 1u;
     u32 slot[kBatch], old[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
-        slot[u] = hash_slot<CAP>(key[u]);
+        slot[u] = (key[u] * 0x9E3779B1u) >> (32u - bits);
         old[u] = kEmptyKey;
         if ((u32)u < nvalid) old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
     }
@@ -420,7 +434,7 @@ __device__ __forceinline__ void table_accumulate_batch(u32* keys, T* vals, const
     for (int u = 0; u < kBatch; ++u) {
         if ((u32)u >= nvalid) continue;
         while (old[u] != kEmptyKey && old[u] != key[u]) {
-            slot[u] = (slot[u] + 1) & (CAP - 1);
+            slot[u] = (slot[u] + 1) & mask;
             old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
         }
         atomicAdd(&vals[slot[u]], prod[u]);

@@ -45,10 +45,14 @@ __global__ __launch_bounds__(kChunk) void analysis_kernel(
     const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* __restrict__ row_ops,
     u32* __restrict__ row_max_ops, u32* __restrict__ row_col_min, u32* __restrict__ row_col_max,
     u8* __restrict__ sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
-    ClassifyParams cp, u32* __restrict__ b_start, u32* __restrict__ b_len)
+    ClassifyParams cp, u32* __restrict__ b_start, u32* __restrict__ b_len, DeviceStats* __restrict__ st)
 {
     constexpr int NW = kChunk / 64;
     constexpr int U = 4;
+    // the statistics block of this call starts from zero (no memset node in the launch sequence;
+    // nothing reads or writes it before the scatter kernel that follows)
+    if (blockIdx.x == 0)
+        for (u32 i = threadIdx.x; i < sizeof(DeviceStats) / 4; i += kChunk) reinterpret_cast<u32*>(st)[i] = 0;
     const u32 e_base = a_ro[0];  // A may be a row-range view with absolute offsets
     __shared__ u32 s_ro[kChunk + 1];
     __shared__ u64 s_ops[kChunk];
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     const BlockPartial* __restrict__ parts, u32 nb, const u8* __restrict__ num_cls,
     const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
     const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
-    RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz)
+    RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz, DeviceStats* __restrict__ host_mirror)
 {
     constexpr int NW = kScanThreads / 64;
     __shared__ Fold s_fold;
@@ -467,6 +471,13 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
         // the C buffers of a replayed launch sequence were allocated for exactly `exact_nnz`
         if (exact_nnz != ~0ull && nnz_c != exact_nnz) st->capacity_miss = 1;
         publish_bins(st->num, s_fold, s_bytes, num_cls ? cp.num_allowed : 0xFFFFFFFFu, st);
+        // everything the host needs is final here: write it straight into pinned host memory
+        // instead of a copy node at the end of the launch sequence
+        if (host_mirror) {
+            const u64* src = reinterpret_cast<const u64*>(st);
+            u64* dst = reinterpret_cast<u64*>(host_mirror);
+            for (u32 i = 0; i < sizeof(DeviceStats) / 8; ++i) dst[i] = src[i];
+        }
     }
     const u64 base = u64(blockIdx.x) * (kScanThreads * ITEMS) + u64(threadIdx.x) * ITEMS;
     u32 c[ITEMS];
@@ -559,7 +570,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
     row_chunking(m, &rows_per_block, &blocks);
     hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kChunk), 0, s, a_ro, a_col, b_ro, b_col, m,
                        rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                       partials, cp, b_start, b_len);
+                       partials, cp, b_start, b_len, st);
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,
                        (const u8*)sym_cls, m, rows_per_block, st, (const BlockPartial*)partials, blocks, a_ro,
@@ -568,7 +579,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
-                 RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz)
+                 RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
+                 DeviceStats* host_mirror)
 {
     const u32 tiles = scan_tiles(m);
     auto go = [&](auto items) {
@@ -578,7 +590,7 @@ void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const
                            partials, cp, vsize);
         hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts_inout, m, st,
                            (const BlockPartial*)partials, tiles, (const u8*)num_cls, a_ro, row_ops,
-                           row_col_min, row_col_max, recs, cp, exact_nnz);
+                           row_col_min, row_col_max, recs, cp, exact_nnz, host_mirror);
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;

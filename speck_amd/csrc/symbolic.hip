@@ -172,6 +172,13 @@ static void set_dyn_lds(K kernel, u32 bytes)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+static u32 g_grid_rounds_block = 1, g_grid_rounds_sub = 4;
+void set_grid_rounds(u32 block_classes, u32 subwave_classes)
+{
+    if (block_classes) g_grid_rounds_block = block_classes;
+    if (subwave_classes) g_grid_rounds_sub = subwave_classes;
+}
+
 u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block)
 {
     u32 per_cu = lds ? (160u * 1024u) / lds : 8;
@@ -180,7 +187,12 @@ u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block)
     if (per_cu < 1) per_cu = 1;
     // sub-wave classes: 4 rounds of resident workgroups, then a static stride;
     // workgroup-per-row classes (rows_per_block == 1): the resident set, rows come from a queue
-    const u64 cap = u64(cu_count) * per_cu * (rows_per_block > 1 ? 4 : 1);
+    // Workgroups that fit several times into a CU are cheap to dispatch one row at a time (the
+    // hardware dispatcher balances rows of very different cost); a workgroup that owns most of
+    // the LDS would starve behind smaller ones, so those classes keep a resident set and stride.
+    u32 rounds = rows_per_block > 1 ? g_grid_rounds_sub : g_grid_rounds_block;
+    if (rows_per_block == 1 && g_grid_rounds_block == 1 && lds <= 48u * 1024u) rounds = 16;
+    const u64 cap = u64(cu_count) * per_cu * rounds;
     u64 need = (u64(count) + rows_per_block - 1) / rows_per_block;
     if (need > cap) need = cap;
     return need ? (u32)need : 1u;
