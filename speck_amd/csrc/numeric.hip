@@ -452,6 +452,7 @@ __global__ __launch_bounds__(THREADS) void num_global_kernel(ProductSrc<T> src, 
     RowRec next{};
     if (blockIdx.x < count) next = recs[blockIdx.x];
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        PHASE_BEGIN(cls);
         const RowRec rec = next;
         if (idx + gridDim.x < count) next = recs[idx + gridDim.x];
         const u32 cap = 2u * rec.nnz;
@@ -461,6 +462,7 @@ __global__ __launch_bounds__(THREADS) void num_global_kernel(ProductSrc<T> src, 
             gvals[t0 + i] = T(0);
         }
         __syncthreads();  // the table is initialised (stores are acknowledged by L2) before any atomic
+        PHASE_MARK(0);
         for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch,
                                [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
                                    u32 slot[kBatch], old[kBatch];
@@ -479,8 +481,9 @@ __global__ __launch_bounds__(THREADS) void num_global_kernel(ProductSrc<T> src, 
                                        }
                                        unsafeAtomicAdd(&gvals[t0 + slot[u]], p[u]);
                                    }
-                               });
+                               }, cls);
         __syncthreads();
+        PHASE_MARK(1);
         u32 emitted = 0;
         for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += kWindowCols) {
             const u64 left = u64(rec.cmax) - w0 + 1;
@@ -529,6 +532,7 @@ __global__ __launch_bounds__(THREADS) void num_global_kernel(ProductSrc<T> src, 
             emitted += total;
             __syncthreads();
         }
+        PHASE_MARK(2);
     }
 }
 
