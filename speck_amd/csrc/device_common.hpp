@@ -83,6 +83,7 @@ struct ClassifyParams {
     u32 sym_bitmap_ratio;   // use a bitmap when range <= ratio * ops (and ops > wave limit)
     u32 num_dense_ratio;    // use D1 when range <= kNumD1Cols and range <= ratio * nnz
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
+    u32 num_wave1k;         // rows of 342..682 nnz: wave-per-row class (else they join NUM_B2K)
     u32 want_bytes;         // accumulate the per-class algorithmic byte counts (profiling)
     u32 sym_allowed;        // classes whose kernels are part of this launch sequence; a row
     u32 num_allowed;        //   outside them raises DeviceStats::capacity_miss (graph replay)
@@ -115,7 +116,7 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 nnz, u32 cmin, u32
     const u64 range = u64(cmax) - u64(cmin) + 1;
     if (range <= kNumD1Cols && range <= u64(p.num_dense_ratio) * nnz) return NUM_D1;
     if (nnz <= kNumW512MaxNnz) return NUM_W512;
-    if (nnz <= kNumW1KMaxNnz) return NUM_W1K;
+    if (p.num_wave1k && nnz <= kNumW1KMaxNnz) return NUM_W1K;
     if (nnz <= kNumB2KMaxNnz) return NUM_B2K;
     if (nnz <= kNumB8KMaxNnz) return NUM_B8K;
     const u64 passes = (range + kNumD2Cols - 1) / kNumD2Cols;

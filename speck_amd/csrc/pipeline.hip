@@ -410,7 +410,7 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
     k.num[0] = A->rows; k.num[1] = A->nnz; k.num[2] = B->rows; k.num[3] = B->cols; k.num[4] = C->nnz;
     k.num[5] = sizeof(T);
     k.num[6] = (u64(c->cp.sym_bitmap_ratio) << 32) | c->cp.num_dense_ratio;
-    k.num[7] = (u64(c->cp.num_global_passes) << 32) | (u64(c->cp.want_bytes) << 1) |
+    k.num[7] = (u64(c->cp.num_global_passes) << 32) | (u64(c->cp.num_wave1k) << 2) | (u64(c->cp.want_bytes) << 1) |
                (c->concurrent_classes ? 1u : 0u);
     k.num[7] ^= reinterpret_cast<u64>(s);
     return k;
@@ -713,6 +713,7 @@ int speck_config_create(int device, speck_config** out)
     c->cp.sym_bitmap_ratio = 32;
     c->cp.num_dense_ratio = 16;
     c->cp.num_global_passes = 4;  // heavy rows: dense windows up to 64 Ki columns, else global spill
+    c->cp.num_wave1k = 0;  // measured: one launch (and fork/join) less beats the barrier-free rows
     c->cp.want_bytes = 0;
     *out = c;
     return SPECK_OK;
@@ -765,6 +766,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     if (n == "sym_bitmap_ratio") c->cp.sym_bitmap_ratio = (u32)value;
     else if (n == "num_dense_ratio") c->cp.num_dense_ratio = (u32)value;
     else if (n == "num_global_passes") c->cp.num_global_passes = (u32)value;
+    else if (n == "num_wave1k") {
+        c->cp.num_wave1k = value != 0;
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
     else if (n == "use_graph") c->use_graph = value != 0;

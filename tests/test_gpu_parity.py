@@ -148,10 +148,16 @@ def test_wave_classes(cfg):
 def test_hash_classes_wave1k_wave512_block2k(cfg):
     A = fast_random_csr(600, 4000, 20, 1)
     B = fast_random_csr(4000, 30000, 30, 2)
-    check(cfg, A, B, [("sym", "wave1k"), ("num", "wave512"), ("num", "wave1k")])
-    A = fast_random_csr(300, 4000, 44, 3)
-    B = fast_random_csr(4000, 30000, 40, 4)
-    check(cfg, A, B, [("sym", "block4k"), ("num", "wave1k"), ("num", "block2k")])
+    check(cfg, A, B, [("sym", "wave1k"), ("num", "wave512"), ("num", "block2k")])
+    A2 = fast_random_csr(300, 4000, 44, 3)
+    B2 = fast_random_csr(4000, 30000, 40, 4)
+    check(cfg, A2, B2, [("sym", "block4k"), ("num", "block2k")])
+    cfg.set_option("num_wave1k", 1)   # optional class: a wave per row for 342..682 nnz
+    try:
+        check(cfg, A, B, [("num", "wave512"), ("num", "wave1k")])
+        check(cfg, A2, B2, [("num", "wave1k"), ("num", "block2k")])
+    finally:
+        cfg.set_option("num_wave1k", 0)
 
 
 def test_empty_b_rows_and_long_a_rows(cfg):
