@@ -21,6 +21,21 @@ namespace speck {
 
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
+typedef u32 RowPtrPair __attribute__((ext_vector_type(2), aligned(4)));
+#ifdef SPECK_PHASE_CLOCKS
+static __device__ unsigned long long g_an_clk[1024 * 8];
+#define AN_BEGIN() long long an_t_ = clock64()
+#define AN_MARK(i_) \
+    do { \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        const long long an_n_ = clock64(); \
+        if (lane_id() == 0) atomicAdd(&g_an_clk[(blockIdx.x % 1024) * 8 + (i_)], (unsigned long long)(an_n_ - an_t_)); \
+        an_t_ = an_n_; \
+    } while (0)
+#else
+#define AN_BEGIN()
+#define AN_MARK(i_)
+#endif
 constexpr int kChunk = 256;  // rows per sub-chunk of the analysis / symbolic scatter
 
 // rows per block for the analysis / symbolic-scatter pair: contiguous, multiple of kChunk
@@ -33,36 +48,49 @@ static inline void row_chunking(u32 m, u32* rows_per_block, u32* blocks)
 }
 
 // --------------------------------------------------------------------------------
-// Analysis, nnz-parallel: a block walks its rows in sub-chunks of 256; inside a sub-chunk
-// the threads stride over the A ENTRIES (not the rows), so every thread has independent
-// 3-deep load chains (A.col -> B.rowptr pair -> first/last B.col) in flight and long rows
-// cost nothing extra.  Per-row results are combined with LDS atomics on distinct addresses.
+// Analysis, nnz-parallel and WAVE-granular: a block owns a contiguous row range, each of its
+// waves walks that range in sub-chunks of 64 rows, and inside a sub-chunk the lanes stride over
+// the A ENTRIES (not the rows), so every lane has independent 3-deep load chains
+// (A.col -> B.rowptr pair -> first/last B.col) in flight and long rows cost nothing extra.
+// Nothing but the final histogram crosses a wave: no workgroup barrier inside the loops (with
+// 256-row sub-chunks per workgroup, 75 % of the wave cycles of this kernel were barrier waits).
+// Per-row results are combined with LDS atomics in the wave's own staging area.
 // HBM traffic (algorithmic): 4(m+1) + 4 nnzA + 8 nnzA [B.rowptr pair] + 8 nnzA
-// [first/last col of the B row] + 17 m written.
+// [first/last col of the B row] + 17 m written (+ 8 nnzA for b_start / b_len).
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(kChunk) void analysis_kernel(
+constexpr int kAnThreads = 512;  // 8 waves x 32 rows = one kChunk of rows per pass of the block
+__global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     const u32* __restrict__ a_ro, const u32* __restrict__ a_col, const u32* __restrict__ b_ro,
     const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* __restrict__ row_ops,
     u32* __restrict__ row_max_ops, u32* __restrict__ row_col_min, u32* __restrict__ row_col_max,
     u8* __restrict__ sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
     ClassifyParams cp, u32* __restrict__ b_start, u32* __restrict__ b_len, DeviceStats* __restrict__ st)
 {
-    constexpr int NW = kChunk / 64;
-    constexpr int U = 4;
+    constexpr int NW = kAnThreads / 64;
+    constexpr int U = 4;   // entries per lane and tile: 256 entries cover most 32-row sub-chunks in ONE
+                           //   round of the dependent chain A.col -> B.rowptr -> B.col
+    constexpr u32 R = 32;  // rows per sub-chunk (one per lane when they are finalised): the kernel
+                           //   lasts as long as its slowest wave, so the waves are kept short and many
+    static_assert(NW * R == kChunk, "one pass of a block covers one kChunk of rows");
     // the statistics block of this call starts from zero (no memset node in the launch sequence;
     // nothing reads or writes it before the scatter kernel that follows)
     if (blockIdx.x == 0)
-        for (u32 i = threadIdx.x; i < sizeof(DeviceStats) / 4; i += kChunk) reinterpret_cast<u32*>(st)[i] = 0;
+        for (u32 i = threadIdx.x; i < sizeof(DeviceStats) / 4; i += kAnThreads) reinterpret_cast<u32*>(st)[i] = 0;
     const u32 e_base = a_ro[0];  // A may be a row-range view with absolute offsets
-    __shared__ u32 s_ro[kChunk + 1];
-    __shared__ u64 s_ops[kChunk];
-    __shared__ u32 s_mx[kChunk], s_cmin[kChunk], s_cmax[kChunk];
+    __shared__ u32 s_ro_all[NW][R + 1];
+    __shared__ u64 s_ops_all[NW][R];
+    __shared__ u32 s_mx_all[NW][R], s_cmin_all[NW][R], s_cmax_all[NW][R];
     __shared__ u64 s_products[NW];
     __shared__ u32 s_max[NW];
     __shared__ u32 s_hist[NW][kMaxClasses];
     __shared__ u64 s_bytes[kMaxClasses];
-    const u32 t = threadIdx.x;
+    const u32 t = threadIdx.x, lane = lane_id(), wid = t >> 6;
+    AN_BEGIN();
+    u32* s_ro = s_ro_all[wid];
+    u64* s_ops = s_ops_all[wid];
+    u32 *s_mx = s_mx_all[wid], *s_cmin = s_cmin_all[wid], *s_cmax = s_cmax_all[wid];
     if (t < kMaxClasses) s_bytes[t] = 0;
+    __syncthreads();
 
     const u32 row_begin = blockIdx.x * rows_per_block;
     const u32 row_end = min(m, row_begin + rows_per_block);
@@ -72,67 +100,88 @@ __global__ __launch_bounds__(kChunk) void analysis_kernel(
 #pragma unroll
     for (int c = 0; c < SYM_CLASSES; ++c) hist[c] = 0;
 
-    for (u32 row0 = row_begin; row0 < row_end; row0 += kChunk) {
-        const u32 nrows = min((u32)kChunk, row_end - row0);
-        __syncthreads();
-        if (t <= nrows) s_ro[t] = a_ro[row0 + t];
-        if (t == 0 && nrows == kChunk) s_ro[kChunk] = a_ro[row0 + kChunk];
-        s_ops[t] = 0;
-        s_mx[t] = 0;
-        s_cmin[t] = 0xFFFFFFFFu;
-        s_cmax[t] = 0;
-        __syncthreads();
+    for (u32 row0 = row_begin + wid * R; row0 < row_end; row0 += NW * R) {
+        const u32 nrows = min(R, row_end - row0);
+        wave_lds_fence();
+        if (lane <= nrows) s_ro[lane] = a_ro[row0 + lane];
+        if (lane == 0 && nrows == R) s_ro[R] = a_ro[row0 + R];
+        if (lane < R) {
+            s_ops[lane] = 0;
+            s_mx[lane] = 0;
+            s_cmin[lane] = 0xFFFFFFFFu;
+            s_cmax[lane] = 0;
+        }
+        wave_lds_fence();
+        AN_MARK(0);
         const u32 e_begin = s_ro[0], e_end = s_ro[nrows];
-        for (u32 e0 = e_begin + t; e0 < e_end; e0 += kChunk * U) {
+        for (u32 e0 = e_begin + lane; e0 < e_end; e0 += 64 * U) {
             u32 bs[U], be[U], first[U], last[U];
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const u32 e = e0 + u * kChunk;
+                const u32 e = e0 + u * 64;
                 ok[u] = e < e_end;
                 const u32 k = ok[u] ? a_col[e] : 0u;
-                bs[u] = ok[u] ? b_ro[k] : 0u;
-                be[u] = ok[u] ? b_ro[k + 1] : 0u;
+                // B.rowptr[k], B.rowptr[k+1] as ONE 8-byte gather (4-byte aligned): the random
+                // gathers of this kernel are bound by addresses per cycle, not by bytes
+                const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
+                bs[u] = ok[u] ? pr.x : 0u;
+                be[u] = ok[u] ? pr.y : 0u;
                 if (ok[u] && b_start) {  // hand the B-row bounds to the symbolic / numeric kernels
                     b_start[e - e_base] = bs[u];
                     b_len[e - e_base] = be[u] - bs[u];
                 }
             }
+            AN_MARK(1);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool has = ok[u] && be[u] > bs[u];
                 first[u] = has ? b_col[bs[u]] : 0xFFFFFFFFu;
                 last[u] = has ? b_col[be[u] - 1] : 0u;
             }
+            AN_MARK(2);
+            // local row of each entry: largest r with s_ro[r] <= e; the U searches advance in lock
+            // step (independent LDS reads)
+            u32 lo[U], hi[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (!ok[u]) continue;
-                const u32 e = e0 + u * kChunk;
-                // local row of entry e: largest r with s_ro[r] <= e
-                u32 lo = 0, hi = nrows;
-                while (hi - lo > 1) {
-                    const u32 mid = (lo + hi) >> 1;
-                    if (s_ro[mid] <= e) lo = mid; else hi = mid;
+                lo[u] = 0;
+                hi[u] = nrows;
+            }
+#pragma unroll
+            for (int step = 0; step < 5; ++step) {  // 2^5 = R
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const u32 mid = (lo[u] + hi[u]) >> 1;
+                    const bool act = hi[u] - lo[u] > 1;
+                    const bool le = s_ro[mid] <= e0 + u * 64;
+                    lo[u] = (act && le) ? mid : lo[u];
+                    hi[u] = (act && !le) ? mid : hi[u];
                 }
+            }
+            AN_MARK(3);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
                 const u32 len = be[u] - bs[u];
-                if (len) {
-                    atomicAdd(&s_ops[lo], (u64)len);
-                    atomicMax(&s_mx[lo], len);
-                    atomicMin(&s_cmin[lo], first[u]);
-                    atomicMax(&s_cmax[lo], last[u]);
+                if (ok[u] && len) {
+                    atomicAdd(&s_ops[lo[u]], (u64)len);
+                    atomicMax(&s_mx[lo[u]], len);
+                    atomicMin(&s_cmin[lo[u]], first[u]);
+                    atomicMax(&s_cmax[lo[u]], last[u]);
                 }
             }
         }
-        __syncthreads();
+        wave_lds_fence();
+        AN_MARK(4);
         u8 cls = SYM_NONE;
-        if (t < nrows) {
-            const u32 row = row0 + t;
-            const u64 ops = s_ops[t];
+        if (lane < nrows) {
+            const u32 row = row0 + lane;
+            const u64 ops = s_ops[lane];
             const u32 ops32 = ops > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)ops;
-            const u32 len_a = s_ro[t + 1] - s_ro[t];
-            const u32 cmin = s_cmin[t], cmax = s_cmax[t];
+            const u32 len_a = s_ro[lane + 1] - s_ro[lane];
+            const u32 cmin = s_cmin[lane], cmax = s_cmax[lane];
             if (row_ops) row_ops[row] = ops32;
-            if (row_max_ops) row_max_ops[row] = s_mx[t];
+            if (row_max_ops) row_max_ops[row] = s_mx[lane];
             if (row_col_min) row_col_min[row] = cmin;
             if (row_col_max) row_col_max[row] = cmax;
             my_products += ops;
@@ -153,11 +202,12 @@ __global__ __launch_bounds__(kChunk) void analysis_kernel(
             for (int c = 0; c < SYM_CLASSES; ++c) hist[c] += __popcll(__ballot(cls == c));
         }
     }
+    AN_MARK(5);
     my_products = wave_reduce_add(my_products);
     my_max = wave_reduce_max(my_max);
-    const u32 wid = t >> 6;
     __syncthreads();
-    if (lane_id() == 0) {
+    AN_MARK(6);
+    if (lane == 0) {
         s_products[wid] = my_products;
         s_max[wid] = my_max;
 #pragma unroll
@@ -568,7 +618,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
-    hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kChunk), 0, s, a_ro, a_col, b_ro, b_col, m,
+    hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kAnThreads), 0, s, a_ro, a_col, b_ro, b_col, m,
                        rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                        partials, cp, b_start, b_len, st);
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
@@ -600,3 +650,15 @@ void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const
 }
 
 }  // namespace speck
+#ifdef SPECK_PHASE_CLOCKS
+extern "C" int speck_debug_analysis_clocks(unsigned long long* out8)
+{
+    static unsigned long long all[1024 * 8];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(speck::g_an_clk), sizeof(all)) != hipSuccess) return 3;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int b = 0; b < 1024; ++b)
+        for (int i = 0; i < 8; ++i) out8[i] += all[b * 8 + i];
+    for (auto& x : all) x = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(speck::g_an_clk), all, sizeof(all)) == hipSuccess ? 0 : 3;
+}
+#endif
