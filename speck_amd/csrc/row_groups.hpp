@@ -4,13 +4,13 @@
 // Block<THREADS> (a workgroup).  All groups run the same three steps:
 //   1. stage the A row's metadata in LDS: for each entry a_ik the inclusive prefix of
 //      nnz(B_k), the B-row start rebased to that prefix, and a_ik itself;
-//   2. walk the FLATTENED product space p in [0, ops): lane -> p, the owning A entry is found
-//      by a (hinted) binary search in the LDS prefix; consecutive lanes read consecutive
-//      B entries (coalesced) and every lane has the same amount of work whatever the B-row
-//      length distribution is (the reference balances this with getThreadShiftNew,
-//      include/common.cuh:509-555, which assumes near-uniform B rows);
-//   3. the loads of product p+stride are issued before product p is accumulated, so the
-//      dependent chain LDS-search -> global load -> LDS atomic of successive products overlaps.
+//   2. walk the FLATTENED product space p in [0, ops): lane -> p; consecutive lanes read
+//      consecutive B entries (coalesced) and every lane has the same amount of work whatever the
+//      B-row length distribution is (the reference balances this with getThreadShiftNew,
+//      include/common.cuh:509-555, which assumes near-uniform B rows).  The A entry that owns a
+//      product is found per WINDOW of products from counts of where the entries' products end
+//      (window_owners below) -- one LDS read and one DPP scan per group-width of products;
+//   3. the kBatch gathers of a lane are all issued before the first of them is accumulated.
 #pragma once
 #include "device_common.hpp"
 
@@ -177,57 +177,6 @@ struct ProductSrc {
 // ---- product -> owning A entry ---------------------------------------------------------
 // Product p of a staged chunk belongs to the smallest entry s with incl[s] > p.
 //
-// Sub-wave groups (16 lanes): a per-lane binary search over <= 16 entries; the kBatch searches of
-// a lane advance in lock step so a round costs one LDS round trip.
-template <bool WITH_VALUES, typename T>
-__device__ __forceinline__ void fetch_batch(const ProductSrc<T>& src, const RowMeta<T>& m, u32 cnt, u32 p,
-                                            u32 step, u32 end, u32& s, u32 (&c)[kBatch],
-                                            T (&bv)[kBatch], T (&av)[kBatch])
-{
-    u32 lo[kBatch], hi[kBatch];
-    bool more = false;
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-        const u32 pu = p + u * step;
-        lo[u] = hi[u] = s;
-        if (pu < end) {
-            if (m.incl[s] <= pu) {
-                lo[u] = s + 1;
-                hi[u] = cnt - 1;
-            }
-        }
-        more |= lo[u] < hi[u];
-    }
-    while (more) {
-        more = false;
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const u32 mid = (lo[u] + hi[u]) >> 1;
-            const bool act = lo[u] < hi[u];
-            const bool gt = m.incl[mid] > p + u * step;
-            hi[u] = (act && gt) ? mid : hi[u];
-            lo[u] = (act && !gt) ? mid + 1 : lo[u];
-            more |= lo[u] < hi[u];
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-        const u32 pu = p + u * step;
-        c[u] = kEmptyKey;
-        bv[u] = T(0);
-        av[u] = T(0);
-        if (pu < end) {
-            const u32 ib = m.off[lo[u]] + pu;
-            c[u] = src.b_col[ib];
-            if (WITH_VALUES) {
-                bv[u] = src.b_val[ib];
-                av[u] = m.av[lo[u]];
-            }
-            s = lo[u];
-        }
-    }
-}
-
 // Wave and workgroup groups: a wave walks a contiguous slice of the product space in windows of
 // kBatch*64 products, lane l taking products base + 64u + l.  The owners of a whole window are
 // found cooperatively instead of by 256 binary searches (which made these kernels VALU- and
@@ -241,7 +190,7 @@ constexpr u32 kWinWords = kWinProducts / 2;  // LDS words per wave
 template <class G>
 constexpr u32 win_words()
 {
-    return G::SIZE >= 64 ? (G::SIZE / 64) * kWinWords : 0;
+    return G::SIZE >= 64 ? (G::SIZE / 64) * kWinWords : kBatch * 16 / 2;  // 16-lane groups: 64 positions
 }
 
 // owner(p), the same for all lanes of the wave (broadcast LDS reads, scalar control flow)
@@ -367,21 +316,49 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
                 base += kWinProducts;
             }
         } else {
-            u32 s = 0;
+            // 16-lane groups: the same end-count scheme on a window of kBatch*16 products.  The
+            // chunk has at most 16 entries and lane e holds incl[e] in a register, so the ends
+            // need no LDS read and the entries before the window are a ballot.
+            static_assert(G::SIZE == 16, "sub-wave groups are 16 lanes");
             PHASE_MARK(11);
-            while (p < end) {
+            u32* win = m.win;  // kBatch*16 16-bit counters of this group
+            const bool mine = g.lane < cnt;
+            for (u32 base = 0; base < total; base += kBatch * 16) {
+                reinterpret_cast<uint2*>(win)[g.lane] = make_uint2(0u, 0u);
+                wave_lds_fence();
+                const u32 before = (u32)__popcll(g.ballot(mine && incl <= base));
+                const u32 b = incl - base;  // position where my entry's products end
+                if (mine && incl > base && b < kBatch * 16)
+                    atomicAdd(&win[b >> 1], 1u << ((b & 1u) * 16u));
+                wave_lds_fence();
                 u32 c[kBatch];
-                T bv[kBatch], av_[kBatch];
-                fetch_batch<WITH_VALUES>(src, m, cnt, p, step, end, s, c, bv, av_);
-                u32 nvalid = 0;
-                T prod[kBatch];
+                T bv[kBatch], a[kBatch], prod[kBatch];
+                u32 nvalid = 0, carry = before;
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
-                    nvalid += (p + u * step < end) ? 1u : 0u;
-                    prod[u] = av_[u] * bv[u];
+                    const u32 pos = u * 16 + g.lane;
+                    const u32 x = (win[pos >> 1] >> ((pos & 1u) * 16u)) & 0xFFFFu;
+                    const u32 inc = row16_inclusive_scan(x);
+                    const u32 own = carry + inc;
+                    carry += (u32)__builtin_amdgcn_ds_swizzle((int)inc, 0x10 | (0x0F << 5));
+                    const u32 pu = base + pos;
+                    c[u] = kEmptyKey;
+                    bv[u] = T(0);
+                    a[u] = T(0);
+                    if (pu < total) {
+                        const u32 ib = m.off[own] + pu;
+                        c[u] = src.b_col[ib];
+                        if (WITH_VALUES) {
+                            bv[u] = src.b_val[ib];
+                            a[u] = m.av[own];
+                        }
+                        ++nvalid;
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) prod[u] = a[u] * bv[u];
                 f(c, prod, nvalid);
-                p += kBatch * step;
+                wave_lds_fence();
             }
         }
         PHASE_MARK(12);
