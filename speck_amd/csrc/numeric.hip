@@ -403,6 +403,28 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
         num_direct_body<T, 256>(src, w, c_col, c_val, b - cg.first[5], cg.first[6] - cg.first[5]);
 }
 
+// The three smallest classes alone: the merged kernel above takes the register count of its
+// hungriest body (5 waves per SIMD); these bodies need 70 VGPRs, and a launch of their own
+// reaches 7 waves per SIMD -- what rows that are one short chain of dependent loads need.
+template <typename T>
+__global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                       u32* __restrict__ c_col, T* __restrict__ c_val,
+                                                       ClassGrid cg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
+    const u32 b = blockIdx.x;
+    if (b < cg.first[4])
+        num_hash_body<SubWave<64>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[3], cg.first[4] - cg.first[3]);
+    else if (b < cg.first[5])
+        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
+    else
+        num_direct_body<T, 256>(src, w, c_col, c_val, b - cg.first[5], cg.first[6] - cg.first[5]);
+}
+
 // ------------------------------------------------------------------ NUM_G
 // Global-memory spill for heavy rows whose column range would need many dense windows
 // (role of the reference's global hash maps, include/HashMap.cuh:112-134 and
@@ -597,8 +619,12 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
     }
     if (cg.first[6] == 0) return;
     const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data};
-    hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[6]), dim3(256), lds, s, src, Av.row_offsets, w,
-                       c_col, c_val, cg);
+    if (cg.first[3] == 0)
+        hipLaunchKernelGGL((num_tiny_kernel<T>), dim3(cg.first[6]), dim3(256), lds, s, src, Av.row_offsets, w,
+                           c_col, c_val, cg);
+    else
+        hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[6]), dim3(256), lds, s, src, Av.row_offsets, w,
+                           c_col, c_val, cg);
 }
 
 template <typename T>

@@ -70,6 +70,7 @@ struct speck_config {
     hipEvent_t fork = nullptr;
     bool concurrent_classes = true;
     bool merge_light = true;  // all 256-thread classes of a phase in one launch
+    bool split_light = true;  // ... in two back-to-back launches, by LDS / register need
     u32 last_sym_counts[kMaxClasses] = {}, last_num_counts[kMaxClasses] = {};
 
     // captured launch sequence of the last repeated call
@@ -321,10 +322,19 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 4 : (int)SYM_CLASSES, sym_mask,
                          kSymLightMask, tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr,
                          [&](hipStream_t ks, int cls) {
-                             if (cls == kLightItem)
-                                 launch_symbolic_light(ks, hint, sym_mask & kSymLightMask, A->row_offsets, sc.b_start,
-                                                       sc.b_len, B->col_ids, w, c_ro, c->sm);
-                             else
+                             if (cls == kLightItem) {
+                                 // the launch's LDS size is the largest need among its classes and caps
+                                 // the waves per CU of all of them: the classes go in two back-to-back
+                                 // launches, big-LDS ones first (split_light)
+                                 const u32 big = c->split_light ? (1u << SYM_BM1) : 0u;
+                                 const u32 lm = sym_mask & kSymLightMask;
+                                 if (lm & big)
+                                     launch_symbolic_light(ks, hint, lm & big, A->row_offsets, sc.b_start, sc.b_len,
+                                                           B->col_ids, w, c_ro, c->sm);
+                                 if (lm & ~big)
+                                     launch_symbolic_light(ks, hint, lm & ~big, A->row_offsets, sc.b_start, sc.b_len,
+                                                           B->col_ids, w, c_ro, c->sm);
+                             } else
                                  launch_symbolic(ks, cls, hint[cls], A->row_offsets, sc.b_start, sc.b_len,
                                                  B->col_ids, w, c_ro, c->sm);
                          });
@@ -366,10 +376,14 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
                            // sequence (bench.py: the dominant kernel, timed live in the timed region)
                            const bool bracket = !tm && cls == c->time_num_class && c->tev0;
                            if (bracket) (void)hipEventRecord(c->tev0, ks);
-                           if (cls == kLightItem)
-                               launch_numeric_light<T>(ks, hint, num_mask & kNumLightMask, Av, Bv, w, c_col, c_val,
-                                                       c->sm);
-                           else
+                           if (cls == kLightItem) {
+                               const u32 big = c->split_light ? (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) : 0u;
+                               const u32 lm = num_mask & kNumLightMask;
+                               if (lm & big)
+                                   launch_numeric_light<T>(ks, hint, lm & big, Av, Bv, w, c_col, c_val, c->sm);
+                               if (lm & ~big)
+                                   launch_numeric_light<T>(ks, hint, lm & ~big, Av, Bv, w, c_col, c_val, c->sm);
+                           } else
                                launch_numeric<T>(ks, cls, hint[cls], Av, Bv, w, c_col, c_val, c->sm);
                            if (bracket) (void)hipEventRecord(c->tev1, ks);
                        });
@@ -780,6 +794,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "grid_rounds_sub") {
         set_grid_rounds(0, (u32)value);
+        drop_graph(c);
+    }
+    else if (n == "split_light") {
+        c->split_light = value != 0;
         drop_graph(c);
     }
     else if (n == "merge_light") {
