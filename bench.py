@@ -146,10 +146,15 @@ def main():
     st = cfg.last_stats()
     cfg.set_option("collect_bytes", 0)
     prof_steps = 5
-    # all 256-thread numeric classes run as ONE launch ("light"); the others launch separately
-    LIGHT = ("dense4k", "block2k", "wave512", "wave128", "g16", "direct")
+    # the 256-thread numeric classes run as TWO back-to-back launches: "light" (num_light_kernel: the
+    # big-LDS classes) and "tiny" (num_tiny_kernel); the other classes launch separately
+    LIGHT = ("dense4k", "block2k", "wave512")
+    TINY = ("wave128", "g16", "direct")
     merged = any(o.startswith("merge_light=0") for o in args.opt) is False
-    kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light"]}
+    split = any(o.startswith("split_light=0") for o in args.opt) is False
+    if not split:
+        LIGHT, TINY = LIGHT + TINY, ()
+    kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny"]}
     sym_ms = num_ms = 0.0
     for _ in range(prof_steps):
         step()
@@ -157,12 +162,15 @@ def main():
         for k in NUM_CLASS_NAMES:
             kernel_ms[k] += s["num_bin_ms"][k] / prof_steps
         kernel_ms["light"] += s["num_light_ms"] / prof_steps
-        sym_ms += (s["analysis_ms"] + s["scan_ms"] + max(max(s["sym_bin_ms"].values()), s["sym_light_ms"])) / prof_steps
-        num_ms += max(max(s["num_bin_ms"].values()), s["num_light_ms"]) / prof_steps
+        kernel_ms["tiny"] += s["num_tiny_ms"] / prof_steps
+        sym_ms += (s["analysis_ms"] + s["scan_ms"] +
+                   max(max(s["sym_bin_ms"].values()), s["sym_light_ms"] + s["sym_tiny_ms"])) / prof_steps
+        num_ms += max(max(s["num_bin_ms"].values()), s["num_light_ms"] + s["num_tiny_ms"]) / prof_steps
     P_local, nnzc_local = st["sum_products"], st["nnz_c"]
     kernel_bytes = dict(st["num_bin_bytes"])
     if merged:
         kernel_bytes["light"] = sum(kernel_bytes.pop(k) for k in LIGHT)
+        kernel_bytes["tiny"] = sum(kernel_bytes.pop(k) for k in TINY)
     # dominant kernel = the numeric launch that moves the most algorithmic bytes (under
     # concurrency a starved small launch can span the whole phase, so "longest" would mislead)
     dominant = max(kernel_bytes, key=lambda k: kernel_bytes[k])

@@ -64,7 +64,8 @@ typedef struct speck_stats {
     float num_bin_ms[SPECK_NUM_NUM_BINS];        /* HIP-event ms of each numeric kernel launch */
     float sym_bin_ms[SPECK_NUM_SYM_BINS];
     float analysis_ms, scan_ms;
-    float sym_light_ms, num_light_ms;            /* the merged launch of all 256-thread classes */
+    float sym_light_ms, num_light_ms;            /* merged launch of the 256-thread classes (big-LDS part) */
+    float sym_tiny_ms, num_tiny_ms;              /* ... and of the small classes, launched right behind it */
     int32_t kernel_events_valid;                 /* 1 if *_ms were recorded for the last call */
     int32_t numeric_reruns;                      /* replayed sequences rejected by the device-side checks */
     int32_t graph_replays;                       /* multiplies served by a replayed hipGraph (cumulative) */

@@ -31,6 +31,7 @@ class CStats(C.Structure):
                 ("num_bin_ms", C.c_float * NUM_NUM_BINS), ("sym_bin_ms", C.c_float * NUM_SYM_BINS),
                 ("analysis_ms", C.c_float), ("scan_ms", C.c_float),
                 ("sym_light_ms", C.c_float), ("num_light_ms", C.c_float),
+                ("sym_tiny_ms", C.c_float), ("num_tiny_ms", C.c_float),
                 ("kernel_events_valid", C.c_int32), ("numeric_reruns", C.c_int32),
                 ("graph_replays", C.c_int32), ("graph_captures", C.c_int32)]
 

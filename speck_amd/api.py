@@ -274,6 +274,7 @@ class spECKConfig:
             num_bin_ms=dict(zip(NUM_CLASS_NAMES, list(s.num_bin_ms))),
             analysis_ms=float(s.analysis_ms), scan_ms=float(s.scan_ms),
             sym_light_ms=float(s.sym_light_ms), num_light_ms=float(s.num_light_ms),
+            sym_tiny_ms=float(s.sym_tiny_ms), num_tiny_ms=float(s.num_tiny_ms),
             kernel_events_valid=bool(s.kernel_events_valid), numeric_reruns=int(s.numeric_reruns),
             graph_replays=int(s.graph_replays), graph_captures=int(s.graph_captures))
 

@@ -71,6 +71,8 @@ struct speck_config {
     bool concurrent_classes = true;
     bool merge_light = true;  // all 256-thread classes of a phase in one launch
     bool split_light = true;  // ... in two back-to-back launches, by LDS / register need
+    int light_parts[2] = {0, 0};          // symbolic / numeric: bit 0 = first launch ran, bit 1 = second
+    hipEvent_t mid_ev[2] = {nullptr, nullptr};  // between the two (kernel timing only)
     u32 last_sym_counts[kMaxClasses] = {}, last_num_counts[kMaxClasses] = {};
 
     // captured launch sequence of the last repeated call
@@ -224,6 +226,12 @@ hipEvent_t kernel_event(speck_config* c, size_t i)
 // latency-bound heavy-row kernels (few workgroups) overlap the throughput-bound small-row ones
 // (the reference does the same with its 6 streams, source/GPU/Multiply.cu:494-553, but relies on
 // legacy default-stream ordering; here the dependencies are explicit events).
+hipEvent_t mid_event(speck_config* c, int phase)
+{
+    if (!c->mid_ev[phase]) (void)hipEventCreate(&c->mid_ev[phase]);
+    return c->mid_ev[phase];
+}
+
 struct ClassTiming {
     int cls;
     size_t ev;
@@ -328,9 +336,11 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                                  // launches, big-LDS ones first (split_light)
                                  const u32 big = c->split_light ? (1u << SYM_BM1) : 0u;
                                  const u32 lm = sym_mask & kSymLightMask;
+                                 c->light_parts[0] = ((lm & big) ? 1 : 0) | ((lm & ~big) ? 2 : 0);
                                  if (lm & big)
                                      launch_symbolic_light(ks, hint, lm & big, A->row_offsets, sc.b_start, sc.b_len,
                                                            B->col_ids, w, c_ro, c->sm);
+                                 if (timed && c->light_parts[0] == 3) (void)hipEventRecord(mid_event(c, 0), ks);
                                  if (lm & ~big)
                                      launch_symbolic_light(ks, hint, lm & ~big, A->row_offsets, sc.b_start, sc.b_len,
                                                            B->col_ids, w, c_ro, c->sm);
@@ -379,8 +389,11 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
                            if (cls == kLightItem) {
                                const u32 big = c->split_light ? (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) : 0u;
                                const u32 lm = num_mask & kNumLightMask;
+                               c->light_parts[1] = ((lm & big) ? 1 : 0) | ((lm & ~big) ? 2 : 0);
                                if (lm & big)
                                    launch_numeric_light<T>(ks, hint, lm & big, Av, Bv, w, c_col, c_val, c->sm);
+                               if (tm && c->profile_kernels && c->light_parts[1] == 3)
+                                   (void)hipEventRecord(mid_event(c, 1), ks);
                                if (lm & ~big)
                                    launch_numeric_light<T>(ks, hint, lm & ~big, Av, Bv, w, c_col, c_val, c->sm);
                            } else
@@ -661,8 +674,24 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         };
         c->last.analysis_ms = ms(tm.ev_analysis);
         c->last.scan_ms = ms(tm.ev_scan);
-        for (const auto& ct : tm.sym) (ct.cls == kLightItem ? c->last.sym_light_ms : c->last.sym_bin_ms[ct.cls]) = ms(ct.ev);
-        for (const auto& ct : tm.num) (ct.cls == kLightItem ? c->last.num_light_ms : c->last.num_bin_ms[ct.cls]) = ms(ct.ev);
+        // the merged launches: [start, mid) = first (big-LDS classes), [mid, end) = second (small ones)
+        auto split = [&](const ClassTiming& ct, int phase, float* first, float* second) {
+            *first = *second = 0.f;
+            if (c->light_parts[phase] == 3) {
+                (void)hipEventElapsedTime(first, c->kev[ct.ev], c->mid_ev[phase]);
+                (void)hipEventElapsedTime(second, c->mid_ev[phase], c->kev[ct.ev + 1]);
+            } else {
+                *(c->light_parts[phase] == 2 && c->split_light ? second : first) = ms(ct.ev);
+            }
+        };
+        for (const auto& ct : tm.sym) {
+            if (ct.cls == kLightItem) split(ct, 0, &c->last.sym_light_ms, &c->last.sym_tiny_ms);
+            else c->last.sym_bin_ms[ct.cls] = ms(ct.ev);
+        }
+        for (const auto& ct : tm.num) {
+            if (ct.cls == kLightItem) split(ct, 1, &c->last.num_light_ms, &c->last.num_tiny_ms);
+            else c->last.num_bin_ms[ct.cls] = ms(ct.ev);
+        }
         c->last.kernel_events_valid = 1;
     }
     if (t->measureAll) {
@@ -745,6 +774,8 @@ int speck_config_destroy(speck_config* c)
     (void)hipEventDestroy(c->individualStart);
     (void)hipEventDestroy(c->individualEnd);
     for (auto e : c->kev) (void)hipEventDestroy(e);
+    for (auto e : c->mid_ev)
+        if (e) (void)hipEventDestroy(e);
     for (auto s : c->aux) (void)hipStreamDestroy(s);
     for (auto e : c->aux_done) (void)hipEventDestroy(e);
     if (c->fork) (void)hipEventDestroy(c->fork);
