@@ -70,10 +70,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # plumbing check of the N > 1 path on a box with fewer GPUs than ranks: every rank on GPU 0,
+    # gloo instead of RCCL (the exchange is staged through host memory) -- never a measurement
+    shared_gpu = os.environ.get("SPECK_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     n_gpus = world
@@ -130,7 +138,8 @@ def main():
         if gather:
             ro, col, val = shard_tensors(sC)
             if plan is None:
-                plan = GatherPlan(sC.rows, sC.nnz, col.dtype, val.dtype, dev, root=0, slots=len(slots))
+                plan = GatherPlan(sC.rows, sC.nnz, col.dtype, val.dtype, dev, root=0, slots=len(slots),
+                                  stage_on_host=shared_gpu)
             plan.start(slot, ro[1:] - ro[:-1], col, val)
 
     def drain():
@@ -232,7 +241,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": data_label,
+            "data": data_label if not shared_gpu else data_label + " (ranks share one GPU, gloo: plumbing check only)",
             "config": {
                 "workload": wl_name, "rows": A.rows, "nnzA": A.nnz, "products": P_total,
                 "nnzC": nnzc_total, "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",

@@ -94,13 +94,19 @@ class GatherPlan:
     it had when the plan was made (start() checks the local shard).
     """
 
-    def __init__(self, rows_local, nnz_local, col_dtype, val_dtype, device, root=0, group=None, slots=2):
+    def __init__(self, rows_local, nnz_local, col_dtype, val_dtype, device, root=0, group=None, slots=2,
+                 stage_on_host=False):
         self.group, self.root = group, root
+        # gloo cannot send device tensors point to point: the transfers then go through host copies
+        # (tests and the shared-GPU plumbing check of bench.py; RCCL sends device memory directly)
+        self.stage_on_host = stage_on_host
+        self.device = device
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.rows_local, self.nnz_local = int(rows_local), int(nnz_local)
-        sizes = torch.tensor([self.rows_local, self.nnz_local], dtype=torch.int64, device=device)
-        all_sizes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(self.world)]
+        meta_dev = "cpu" if stage_on_host else device
+        sizes = torch.tensor([self.rows_local, self.nnz_local], dtype=torch.int64, device=meta_dev)
+        all_sizes = [torch.zeros(2, dtype=torch.int64, device=meta_dev) for _ in range(self.world)]
         dist.all_gather(all_sizes, sizes, group=group)
         all_sizes = torch.stack(all_sizes).cpu().numpy()
         self.r_off = np.concatenate([[0], np.cumsum(all_sizes[:, 0])]).astype(np.int64)
@@ -109,15 +115,18 @@ class GatherPlan:
         self.out = [None] * slots
         if self.rank == root:
             rows, nnz = int(self.r_off[-1]), int(self.n_off[-1])
-            self.out = [(torch.empty(rows, dtype=torch.int32, device=device),
-                         torch.empty(nnz, dtype=col_dtype, device=device),
-                         torch.empty(nnz, dtype=val_dtype, device=device)) for _ in range(slots)]
+            out_dev = "cpu" if stage_on_host else device
+            self.out = [(torch.empty(rows, dtype=torch.int32, device=out_dev),
+                         torch.empty(nnz, dtype=col_dtype, device=out_dev),
+                         torch.empty(nnz, dtype=val_dtype, device=out_dev)) for _ in range(slots)]
 
     def start(self, slot, row_nnz, col_ids, data):
         assert self.pending[slot] is None, "slot still in flight: wait() first"
         if row_nnz.numel() != self.rows_local or col_ids.numel() != self.nnz_local:
             raise ValueError("shard size changed since the plan was made: build a new GatherPlan")
         row_nnz = row_nnz.to(torch.int32).contiguous()
+        if self.stage_on_host:
+            row_nnz, col_ids, data = row_nnz.cpu(), col_ids.cpu(), data.cpu()
         ops, keep = [], (row_nnz, col_ids, data)
         if self.rank != self.root:
             for t in keep:
@@ -155,6 +164,8 @@ class GatherPlan:
         if self.rank != self.root:
             return None
         cnt, col, val = self.out[slot]
+        if self.stage_on_host and torch.device(self.device).type != "cpu":
+            cnt, col, val = cnt.to(self.device), col.to(self.device), val.to(self.device)
         row_offsets = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=cnt.device)
         torch.cumsum(cnt.to(torch.int64), 0, out=row_offsets[1:])
         return row_offsets, col, val

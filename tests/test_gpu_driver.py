@@ -60,3 +60,23 @@ def test_driver_individual_times_table(tmp_path):
     rc, out = run(["gen:mac_econ:0.05:1", str(ini)], tmp_path)
     assert rc == 0, out
     assert "spECK      numeric kernel = " in out and "spECK     counting kernel = " in out
+
+
+def test_bench_two_ranks_share_the_gpu():
+    """Plumbing of bench.py's N > 1 path (row shards, two alternating output matrices, pipelined
+    gatherv) with both ranks on GPU 0 and gloo instead of RCCL -- not a measurement."""
+    import json
+    import sys
+    env = dict(os.environ, SPECK_BENCH_SHARED_GPU="1")
+    port = 29600 + os.getpid() % 300
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--scale", "0.25"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["gather"] and d["value"] > 0
+    assert d["graph_replays"] > 0 and d["config"]["parallelism"] == "rows2"
