@@ -48,22 +48,29 @@ __device__ __forceinline__ void num_direct_body(const ProductSrc<T>& src, const 
     }
 }
 
+// LDS accumulator cell.  fp32 rows accumulate in fp64 cells too: ds_add_f32 is ~10x slower than
+// ds_add_f64 on gfx950 (192 vs 20.6 cycles per wave instruction, scripts/ubench/lds_atomics.hip).
+// The product a*b is still rounded to T first (as the reference does); the sum is rounded to T
+// once, when the row is written.
+template <typename T>
+using Acc = double;
+
 // ------------------------------------------------------------------ sorting back-ends
 // Rank sort for tiny tables: every lane owns OWN = CAP/SIZE slots (registers).
 // `ckeys` may alias the table: all slots are in registers before the first write.
 // `cap_row` (a power of two, SIZE <= cap_row <= CAP) slots of the table are in use.
 template <class G, typename T, u32 CAP>
-__device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, const T* vals,
+__device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, const Acc<T>* vals,
                                                  u32* ckeys, u32 cap_row, u32 base,
                                                  u32* __restrict__ c_col, T* __restrict__ c_val)
 {
     constexpr u32 OWN = CAP / G::SIZE;
     u32 k[OWN];
-    T v[OWN];
+    Acc<T> v[OWN];
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j) {
         k[j] = kEmptyKey;
-        v[j] = T(0);
+        v[j] = 0;
         if (j * G::SIZE < cap_row) {
             k[j] = keys[j * G::SIZE + g.lane];
             v[j] = vals[j * G::SIZE + g.lane];
@@ -102,14 +109,14 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
     for (u32 j = 0; j < OWN; ++j)
         if (k[j] != kEmptyKey) {
             c_col[base + r[j]] = k[j];
-            c_val[base + r[j]] = v[j];
+            c_val[base + r[j]] = (T)v[j];
         }
 }
 
 // Two-level bitmap sort (see the header comment).  S: LDS scratch of max(2*W1, 2*NMAX) words;
 // it may alias the table (slots are loaded into registers first).
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX>
-__device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, const T* vals, u32* S,
+__device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, const Acc<T>* vals, u32* S,
                                                    u32* scan_scratch, u32 cap_row, u32 cmin, u32 cmax,
                                                    u32 base, u32* __restrict__ c_col,
                                                    T* __restrict__ c_val, int cls = 0)
@@ -118,13 +125,13 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
     constexpr u64 kWindowCols = u64(W1) * 1024;
     PHASE_BEGIN(cls);
     u32 k[OWN], brank[OWN];
-    T v[OWN];
+    Acc<T> v[OWN];
     // slots j*SIZE + lane: only the first cap_row / SIZE of them exist for this row (the guards
     // below are uniform for the group, whole iterations are skipped)
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j) {
         k[j] = kEmptyKey;
-        v[j] = T(0);
+        v[j] = 0;
         brank[j] = 0;
         if (j * G::SIZE < cap_row) {
             k[j] = keys[j * G::SIZE + g.lane];
@@ -184,7 +191,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
                 const u32 r = emitted + mpref[brank[j]] +
                               __popc(masks[brank[j]] & ((1u << (d & 31)) - 1u));
                 c_col[base + r] = k[j];
-                c_val[base + r] = v[j];
+                c_val[base + r] = (T)v[j];
             }
         }
         emitted += total;
@@ -206,7 +213,7 @@ template <class G, typename T, u32 CAP, int THREADS>
 constexpr u32 num_group_lds()
 {
     const u32 words = 2 * G::SIZE + scan_scratch_words<G, THREADS>() + win_words<G>();
-    return CAP * ((u32)sizeof(T) + 4u) + G::SIZE * (u32)sizeof(T) + (words + 3u) / 4u * 16u;
+    return CAP * ((u32)sizeof(Acc<T>) + 4u) + G::SIZE * (u32)sizeof(Acc<T>) + (words + 3u) / 4u * 16u;
 }
 
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
@@ -218,12 +225,12 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     constexpr u32 kGroupBytes = num_group_lds<G, T, CAP, THREADS>();
     // the sort scratch (rank: NMAX+8 words, bitmap: max(2*W1, 2*NMAX) words) fits in the table
     static_assert((MODE == SORT_RANK ? NMAX + 8 : (2 * W1 > 2 * NMAX ? 2 * W1 : 2 * NMAX)) * 4 <=
-                      CAP * (sizeof(T) + 4),
+                      CAP * (sizeof(Acc<T>) + 4),
                   "sort scratch must fit in the table it aliases");
     const G g;
     const u32 gid = G::kIsBlock ? 0u : threadIdx.x / G::SIZE;
     unsigned char* mine = smem + gid * kGroupBytes;
-    T* vals = reinterpret_cast<T*>(mine);
+    Acc<T>* vals = reinterpret_cast<Acc<T>*>(mine);
     u32* keys = reinterpret_cast<u32*>(vals + CAP);
     T* m_av = reinterpret_cast<T*>(keys + CAP);
     u32* m_incl = reinterpret_cast<u32*>(m_av + G::SIZE);
@@ -248,13 +255,16 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         const u32 cap_row = 1u << bits;
         for (u32 i = g.lane; i < cap_row; i += G::SIZE) {
             keys[i] = kEmptyKey;
-            vals[i] = T(0);
+            vals[i] = 0;
         }
         g.sync();
         PHASE_MARK(0);
         for_each_product<true>(g, src, rec.a0, rec.a1, meta, scan_scratch,
                                [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
-                                   table_accumulate_batch(keys, vals, bits, c, p, n);
+                                   Acc<T> pa[kBatch];
+#pragma unroll
+                                   for (int u = 0; u < kBatch; ++u) pa[u] = p[u];
+                                   table_accumulate_batch(keys, vals, bits, c, pa, n);
                                }, cls);
         PHASE_MARK(1);
         if constexpr (MODE == SORT_RANK) {
@@ -273,7 +283,7 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
 template <typename T, u32 WCOLS, int THREADS>
 constexpr u32 num_dense_lds()
 {
-    return (WCOLS + THREADS) * (u32)sizeof(T) +
+    return (WCOLS + THREADS) * (u32)sizeof(Acc<T>) +
            (2 * (WCOLS / 32) + 2 * THREADS + THREADS / 64 + 2 + win_words<Block<THREADS>>() + 3) / 4 * 16;
 }
 
@@ -285,8 +295,8 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
     constexpr u32 WORDS = WCOLS / 32;
     using G = Block<THREADS>;
     const G g;
-    T* vals = reinterpret_cast<T*>(smem);
-    T* m_av = vals + WCOLS;
+    Acc<T>* vals = reinterpret_cast<Acc<T>*>(smem);
+    T* m_av = reinterpret_cast<T*>(vals + WCOLS);
     u32* bm = reinterpret_cast<u32*>(m_av + THREADS);
     u32* pref = bm + WORDS;
     u32* scratch = pref + WORDS + 2 * THREADS;
@@ -304,7 +314,7 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
             const u32 ncols = left < WCOLS ? (u32)left : WCOLS;
             const u32 nwords = (ncols + 31) >> 5;
             const u32 wbase = (u32)w0;
-            for (u32 i = threadIdx.x; i < ncols; i += THREADS) vals[i] = T(0);
+            for (u32 i = threadIdx.x; i < ncols; i += THREADS) vals[i] = 0;
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             __syncthreads();
             for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch,
@@ -313,7 +323,7 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
                                        for (int u = 0; u < kBatch; ++u) {
                                            const u32 d = c[u] - wbase;
                                            if ((u32)u < n && d < ncols) {
-                                               atomicAdd(&vals[d], p[u]);
+                                               atomicAdd(&vals[d], (Acc<T>)p[u]);
                                                atomicOr(&bm[d >> 5], 1u << (d & 31));
                                            }
                                        }
@@ -324,7 +334,7 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
                 if (word & (1u << (d & 31))) {
                     const u32 r = emitted + pref[d >> 5] + __popc(word & ((1u << (d & 31)) - 1u));
                     c_col[rec.base + r] = wbase + d;
-                    c_val[rec.base + r] = vals[d];
+                    c_val[rec.base + r] = (T)vals[d];
                 }
             }
             emitted += total;
