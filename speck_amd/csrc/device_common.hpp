@@ -100,6 +100,9 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
     if (bitmap_ok && range <= u64(kSymBm1Words) * 32) return SYM_BM1;
     if (ops <= kSymW1KMaxOps) return SYM_W1K;
     if (ops <= kSymB4KMaxOps) return SYM_B4K;
+    // heavier rows: one bitmap window of the 256-thread class costs 32 words per thread to clear
+    // and count -- nothing against >= 3277 products -- and keeps the row in the merged launch
+    if (range <= u64(kSymBm1Words) * 32) return SYM_BM1;
     if (ops <= kSymB16KMaxOps) return SYM_B16K;
     if (bitmap_ok) return SYM_BM2;
     if (ops <= kSymB32KMaxOps) return SYM_B32K;
