@@ -1,6 +1,8 @@
-"""How the CPU oracle scales with threads on this host (bench.py picks the thread count)."""
+"""How the CPU oracle scales with threads on this host (bench.py picks the thread count).
+Lives under tests/: the oracle is test infrastructure, nothing outside tests/, smoke() and the
+cpu_baseline leg of bench.py may load it."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import speck_amd as sa
 from oracle import pyoracle as po
