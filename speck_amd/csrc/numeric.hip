@@ -28,23 +28,88 @@
 namespace speck {
 
 // ------------------------------------------------------------------ NUM_DIRECT
+// A row with one entry: C row = a * B row (already sorted).  These rows are short (a handful of
+// products) and there are many of them, so a workgroup takes a CHUNK of THREADS such rows and walks
+// the flattened product space of the chunk exactly like the products of one long row: product p
+// belongs to the row s with incl[s] > p (window_owners), lanes of a wave read consecutive B entries
+// and write consecutive C entries, and no lane idles on a short row.
 template <typename T, int THREADS>
-__device__ __forceinline__ void num_direct_body(const ProductSrc<T>& src, const RowWork& w,
+constexpr u32 num_direct_lds()
+{
+    // per row: incl | B source index rebased | C destination rebased | a   + scan scratch + windows
+    return THREADS * (12u + (u32)sizeof(T)) + (THREADS / 64 + 2 + win_words<Block<THREADS>>() + 3) / 4 * 16;
+}
+
+template <typename T, int THREADS>
+__device__ __forceinline__ void num_direct_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                                 u32* __restrict__ c_col, T* __restrict__ c_val, u32 bidx,
                                                 u32 nblk)
 {
-    constexpr u32 L = 16, NG = THREADS / L;
-    const u32 lane = threadIdx.x & (L - 1), gid = threadIdx.x / L;
+    using G = Block<THREADS>;
+    const G g;
+    T* m_av = reinterpret_cast<T*>(smem);
+    u32* m_incl = reinterpret_cast<u32*>(m_av + THREADS);
+    u32* m_src = m_incl + THREADS;
+    u32* m_dst = m_src + THREADS;
+    u32* scratch = m_dst + THREADS;
+    u32* win_all = scratch + THREADS / 64 + 2;
     const u32 count = w.st->num.count[NUM_DIRECT];
     const RowRec* recs = w.recs + w.st->num.offset[NUM_DIRECT];
-    for (u32 idx = bidx * NG + gid; idx < count; idx += nblk * NG) {
-        const RowRec rec = recs[idx];
-        const T av = src.a_val[rec.a0];
-        const u32 bs = src.b_start[rec.a0];
-        for (u32 j = lane; j < rec.nnz; j += L) {
-            c_col[rec.base + j] = src.b_col[bs + j];
-            c_val[rec.base + j] = av * src.b_val[bs + j];
+    const u32 l = lane_id();
+    u32* win = win_all + (threadIdx.x >> 6) * kWinWords;
+    for (u32 first = bidx * THREADS; first < count; first += nblk * THREADS) {
+        const u32 cnt = min((u32)THREADS, count - first);
+        u32 len = 0, bs = 0, base = 0;
+        T av = T(0);
+        if (threadIdx.x < cnt) {
+            const RowRec rec = recs[first + threadIdx.x];
+            len = rec.nnz;
+            base = rec.base;
+            av = src.a_val[rec.a0];
+            bs = src.b_start[rec.a0];
         }
+        u32 total;
+        const u32 incl = g.inclusive_scan(len, &total, scratch);
+        if (threadIdx.x < cnt) {
+            m_incl[threadIdx.x] = incl;
+            m_src[threadIdx.x] = bs - (incl - len);
+            m_dst[threadIdx.x] = base - (incl - len);
+            m_av[threadIdx.x] = av;
+        }
+        g.sync();
+        u32 p, step, end;
+        g.product_range(total, p, step, end);
+        u32 pbase = (u32)__builtin_amdgcn_readfirstlane((int)(p - l));
+        const u32 wend = (u32)__builtin_amdgcn_readfirstlane((int)end);
+        u32 s0 = 0;
+        if (pbase < wend) s0 = uniform_owner(m_incl, cnt, pbase);
+        while (pbase < wend) {
+            u32 own[kBatch];
+            window_owners(m_incl, win, cnt, pbase, s0, own);
+            u32 col[kBatch], dst[kBatch];
+            T bv[kBatch], a[kBatch];
+            bool ok[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const u32 pu = pbase + u * 64 + l;
+                ok[u] = pu < wend;
+                if (ok[u]) {
+                    const u32 ib = m_src[own[u]] + pu;
+                    dst[u] = m_dst[own[u]] + pu;
+                    a[u] = m_av[own[u]];
+                    col[u] = src.b_col[ib];
+                    bv[u] = src.b_val[ib];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)
+                if (ok[u]) {
+                    c_col[dst[u]] = col[u];
+                    c_val[dst[u]] = a[u] * bv[u];
+                }
+            pbase += kWinProducts;
+        }
+        g.sync();
     }
 }
 
@@ -356,7 +421,8 @@ __global__ __launch_bounds__(THREADS) void num_direct_kernel(ProductSrc<T> src, 
 {
     if (w.st->capacity_miss) return;
     src.rebase(a_ro);
-    num_direct_body<T, THREADS>(src, w, c_col, c_val, blockIdx.x, gridDim.x);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    num_direct_body<T, THREADS>(smem, src, w, c_col, c_val, blockIdx.x, gridDim.x);
 }
 
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
@@ -410,7 +476,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
         num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
             smem, src, w, c_col, c_val, NUM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
     else
-        num_direct_body<T, 256>(src, w, c_col, c_val, b - cg.first[5], cg.first[6] - cg.first[5]);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[5], cg.first[6] - cg.first[5]);
 }
 
 // The three smallest classes alone: the merged kernel above takes the register count of its
@@ -432,7 +498,7 @@ __global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const 
         num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
             smem, src, w, c_col, c_val, NUM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
     else
-        num_direct_body<T, 256>(src, w, c_col, c_val, b - cg.first[5], cg.first[6] - cg.first[5]);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[5], cg.first[6] - cg.first[5]);
 }
 
 // ------------------------------------------------------------------ NUM_G
@@ -575,7 +641,7 @@ template <typename T>
 u32 numeric_lds_bytes_t(int cls)
 {
     switch (cls) {
-        case NUM_DIRECT: return 0;
+        case NUM_DIRECT: return num_direct_lds<T, 256>();
         case NUM_G16: return 16 * num_group_lds<SubWave<16>, T, kNumG16Cap, 256>();
         case NUM_W128: return 4 * num_group_lds<SubWave<64>, T, kNumW128Cap, 256>();
         case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, 256>();
@@ -618,7 +684,7 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
                           const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
     static const int slots[6] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
-    static const u32 rows_per_block[6] = {1, 1, 4, 4, 16, 16};
+    static const u32 rows_per_block[6] = {1, 1, 4, 4, 16, 256};
     u32 lds = 0;
     for (int k = 0; k < 6; ++k)
         if (mask >> slots[k] & 1u) lds = lds > numeric_lds_bytes_t<T>(slots[k]) ? lds : numeric_lds_bytes_t<T>(slots[k]);
@@ -649,8 +715,8 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
     switch (cls) {
         case NUM_DIRECT: {
             constexpr int TH = 256;
-            hipLaunchKernelGGL((num_direct_kernel<T, TH>), dim3(grid_for(count, 0, TH, cu_count, TH / 16)),
-                               dim3(TH), 0, s, A, B, w, c_col, c_val);
+            hipLaunchKernelGGL((num_direct_kernel<T, TH>), dim3(grid_for(count, lds, TH, cu_count, TH)),
+                               dim3(TH), lds, s, A, B, w, c_col, c_val);
             break;
         }
         case NUM_G16:
