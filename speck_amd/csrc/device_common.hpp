@@ -158,6 +158,7 @@ struct DeviceStats {
     u32 capacity_miss;       // nnz(C) of this call does not fit the C buffers baked into the launch
     BinTable sym;
     BinTable num;
+    u64 g_products;          // products of the NUM_G rows (the host sizes the spill pool from it)
     u32 sym_queue[kMaxClasses];  // next unclaimed row of each workgroup-per-row class
     u32 num_queue[kMaxClasses];
 };
@@ -181,6 +182,7 @@ struct BlockPartial {
     u32 pad;
     u32 count[kMaxClasses];
     u64 bytes[kMaxClasses];
+    u64 g_ops;  // numeric phase: products of the block's NUM_G rows (sizes the spill pool)
 };
 
 #ifdef __HIPCC__

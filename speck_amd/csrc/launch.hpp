@@ -19,7 +19,24 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
-                 DeviceStats* host_mirror = nullptr);
+                 DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull);
+
+// Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
+// and two product pools (expanded by column bucket; reduced and sorted).
+struct GRowPlan {
+    u64 pbase;        // first pool slot of the row's products
+    u32 bbase, nb;    // first bucket, number of buckets
+    u32 shift, pad;   // bucket = (col - cmin) >> shift
+};
+struct SpillBuffers {
+    GRowPlan* plan;                    // one per NUM_G row, class-list order
+    u32 *bcount, *bcursor, *dcount;    // per bucket: products, scatter cursor, distinct columns
+                                       //   (contiguous, bucket_cap entries each: one memset)
+    u64* bstart;                       // per bucket: first pool slot
+    u32* pcol[2];
+    void* pval[2];
+    u32 bucket_cap;
+};
 
 // Everything a symbolic / numeric kernel needs besides the matrices.
 struct RowWork {
@@ -28,8 +45,7 @@ struct RowWork {
     u32* queue;             // per-class work-queue heads (device), zeroed per call
     const u32* b_start;     // per A entry (relative to the first entry of the A view):
     const u32* b_len;       //   start / length of the referenced B row, written by the analysis
-    u32* gkeys;             // global-memory spill pool of the NUM_G class: 2*nnz(C) keys ...
-    void* gvals;            //   ... and values (nullptr when no row needs it)
+    SpillBuffers spill;     // NUM_G class (all null when no row needs it)
 };
 
 // Block ranges of the classes inside a merged ("light") launch: class slot k owns the blocks

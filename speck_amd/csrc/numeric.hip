@@ -181,7 +181,7 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
 // Two-level bitmap sort (see the header comment).  S: LDS scratch of max(2*W1, 2*NMAX) words;
 // it may alias the table (slots are loaded into registers first).
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX>
-__device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, const Acc<T>* vals, u32* S,
+__device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, const u32* keys, const Acc<T>* vals, u32* S,
                                                    u32* scan_scratch, u32 cap_row, u32 cmin, u32 cmax,
                                                    u32 base, u32* __restrict__ c_col,
                                                    T* __restrict__ c_val, int cls = 0)
@@ -263,6 +263,7 @@ __device__ __forceinline__ void emit_bitmap_sorted(const G& g, const u32* keys, 
         g.sync();
         PHASE_MARK(9);
     }
+    return emitted;
 }
 
 // ------------------------------------------------------------------ hash kernels
@@ -502,140 +503,365 @@ __global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const 
 }
 
 // ------------------------------------------------------------------ NUM_G
-// Global-memory spill for heavy rows whose column range would need many dense windows
-// (role of the reference's global hash maps, include/HashMap.cuh:112-134 and
-// spECK_HashSpGEMM.cuh:25-36; the reference hard-disables the numeric one, Multiply.cu:699-700,
-// and falls back to multi-window dense rows instead).
-// The table of row i lives in a pool sized 2*nnz(C): slots [2*base_i, 2*base_i + 2*nnz_i), load
-// factor 1/2 from the EXACT nnz, so it can never fill.  One workgroup owns a row from
-// initialisation to emission, so no inter-workgroup protocol is needed: all table traffic during
-// accumulation is L2 atomics (global_atomic_cmpswap + global_atomic_add_f64), and the emission
-// reads it back with agent-scope loads that bypass this CU's L1.
-// Sorted output: the distinct keys are ranked with an LDS column bitmap (512 Ki columns per
-// window) -- prefix popcount, no comparisons.
-template <typename V>
-__device__ __forceinline__ V load_l2(const V* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// Spill path for heavy rows whose column range would need many dense windows (role of the
+// reference's global hash maps, include/HashMap.cuh:112-134 and spECK_HashSpGEMM.cuh:25-36; the
+// reference hard-disables the numeric one, Multiply.cu:699-700, and falls back to multi-window
+// dense rows instead).
+// A hash table in global memory costs two L2 atomics per product, and random global atomics top
+// out at ~20 G/s on this chip whatever the table size or scope (scripts/ubench/global_atomics.hip):
+// 2 ms for the 39 M atomics of the webbase-like input.  So the products of such a row are not
+// accumulated in global memory at all.  They are PARTITIONED by column into buckets of
+// ~2-4 k products with plain stores, and every bucket is then reduced in LDS like a NUM_B8K row:
+//   plan    : per row bucket width 2^shift (<= ops/2048 buckets), pool offsets (one workgroup)
+//   count   : products per bucket            -- column walk, LDS histogram, one global add per
+//                                               (workgroup, bucket)
+//   offsets : bucket starts (scan per row)
+//   scatter : (col, a*b) to the buckets      -- per staged chunk: LDS histogram, ONE global
+//                                               reservation per (chunk, bucket), LDS ranks
+//   reduce  : per bucket LDS hash accumulate + two-level bitmap sort (dense column windows for a
+//             bucket that outgrew the table), result to the second pool, distinct count
+//   copy    : the reduced buckets of a row, in bucket order, are its sorted C row
+// kGParts workgroups share the walk of one row; buckets are independent workgroups.
+struct GRowView {
+    RowRec rec;
+    GRowPlan plan;
+};
 
-template <typename T, int THREADS, u32 BMW>
-constexpr u32 num_global_lds()
-{
-    return THREADS * (u32)sizeof(T) +
-           (2 * BMW + 2 * THREADS + THREADS / 64 + 2 + win_words<Block<THREADS>>() + 3) / 4 * 16;
-}
+constexpr u32 kGParts = 16;         // workgroups sharing the product walk of one row
+constexpr u32 kGBucketTarget = 2048;  // products per bucket aimed at (<= kNumB8KMaxNnz after skew)
+constexpr u32 kGMaxBuckets = 4096;  // per row: the LDS histograms of count / scatter
+constexpr int kGWalkThreads = 256;
 
-template <typename T, int THREADS, u32 BMW>
-__global__ __launch_bounds__(THREADS) void num_global_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
-                                                             u32* __restrict__ c_col,
-                                                             T* __restrict__ c_val, int cls)
+__global__ __launch_bounds__(1024) void num_spill_plan_kernel(RowWork w, int cls)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using G = Block<THREADS>;
-    using Bits = typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned int>::type;
-    const G g;
-    T* m_av = reinterpret_cast<T*>(smem);
-    u32* bm = reinterpret_cast<u32*>(m_av + THREADS);
-    u32* pref = bm + BMW;
-    u32* scratch = pref + BMW + 2 * THREADS;
-    RowMeta<T> meta{pref + BMW, pref + BMW + THREADS, m_av, scratch + THREADS / 64 + 2};
+    __shared__ u32 s_scan[1024 / 64 + 2];
+    __shared__ u64 s_run_p;
+    __shared__ u32 s_run_b;
     if (w.st->capacity_miss) return;
-    src.rebase(a_ro);
-    u32* gkeys = w.gkeys;
-    T* gvals = static_cast<T*>(w.gvals);
-    constexpr u64 kWindowCols = u64(BMW) * 32;
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
-    RowRec next{};
-    if (blockIdx.x < count) next = recs[blockIdx.x];
-    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        PHASE_BEGIN(cls);
-        const RowRec rec = next;
-        if (idx + gridDim.x < count) next = recs[idx + gridDim.x];
-        const u32 cap = 2u * rec.nnz;
-        const size_t t0 = 2 * size_t(rec.base);
-        for (u32 i = threadIdx.x; i < cap; i += THREADS) {
-            gkeys[t0 + i] = kEmptyKey;
-            gvals[t0 + i] = T(0);
+    if (threadIdx.x == 0) {
+        s_run_p = 0;
+        s_run_b = 0;
+    }
+    __syncthreads();
+    for (u32 i0 = 0; i0 < count; i0 += 1024) {
+        const u32 i = i0 + threadIdx.x;
+        u32 ops = 0, nb = 0, shift = 0;
+        if (i < count) {
+            const RowRec rec = recs[i];
+            ops = rec.ops;
+            const u32 range_m1 = rec.cmax - rec.cmin;
+            u32 want = (ops + kGBucketTarget - 1) / kGBucketTarget;
+            want = want < 1u ? 1u : (want > kGMaxBuckets ? kGMaxBuckets : want);
+            while ((range_m1 >> shift) + 1u > want) ++shift;
+            nb = (range_m1 >> shift) + 1u;
         }
-        __syncthreads();  // the table is initialised (stores are acknowledged by L2) before any atomic
-        PHASE_MARK(0);
-        for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch,
-                               [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
-                                   u32 slot[kBatch], old[kBatch];
-#pragma unroll
-                                   for (int u = 0; u < kBatch; ++u) {  // kBatch L2 atomics in flight
-                                       slot[u] = __umulhi(c[u] * 0x9E3779B1u, cap);
-                                       old[u] = kEmptyKey;
-                                       if ((u32)u < n) old[u] = atomicCAS(&gkeys[t0 + slot[u]], kEmptyKey, c[u]);
-                                   }
-#pragma unroll
-                                   for (int u = 0; u < kBatch; ++u) {
-                                       if ((u32)u >= n) continue;
-                                       while (old[u] != kEmptyKey && old[u] != c[u]) {
-                                           slot[u] = slot[u] + 1 == cap ? 0u : slot[u] + 1;
-                                           old[u] = atomicCAS(&gkeys[t0 + slot[u]], kEmptyKey, c[u]);
-                                       }
-                                       unsafeAtomicAdd(&gvals[t0 + slot[u]], p[u]);
-                                   }
-                               }, cls);
+        u32 t_lo, t_hi, t_nb;
+        const u32 e_lo = block_exclusive_scan<1024>(ops & 0xFFFFu, s_scan, &t_lo);
+        const u32 e_hi = block_exclusive_scan<1024>(ops >> 16, s_scan, &t_hi);
+        const u32 e_nb = block_exclusive_scan<1024>(nb, s_scan, &t_nb);
+        if (i < count) {
+            GRowPlan p;
+            p.pbase = s_run_p + e_lo + (u64(e_hi) << 16);
+            p.bbase = s_run_b + e_nb;
+            p.nb = nb;
+            p.shift = shift;
+            p.pad = 0;
+            w.spill.plan[i] = p;
+        }
         __syncthreads();
-        PHASE_MARK(1);
-        u32 emitted = 0;
-        for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += kWindowCols) {
-            const u64 left = u64(rec.cmax) - w0 + 1;
-            const u32 ncols = left < kWindowCols ? (u32)left : (u32)kWindowCols;
-            const u32 nwords = (ncols + 31) >> 5;
-            const u32 wbase = (u32)w0;
-            for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
+        if (threadIdx.x == 0) {
+            s_run_p += t_lo + (u64(t_hi) << 16);
+            s_run_b += t_nb;
+        }
+        __syncthreads();
+    }
+}
+
+// LDS of the two walking kernels: A-row staging (+ values) | scan scratch | owner windows | histograms
+template <typename T, bool WITH_VALUES>
+constexpr u32 num_spill_walk_lds()
+{
+    using G = Block<kGWalkThreads>;
+    return kGWalkThreads * (WITH_VALUES ? (u32)sizeof(T) : 0u) +
+           (2 * kGWalkThreads + kGWalkThreads / 64 + 2 + win_words<G>() + (WITH_VALUES ? 2u : 1u) * kGMaxBuckets + 3) / 4 * 16;
+}
+
+// my slice of the A row: whole staging chunks, so that the slices of a short row collapse into
+// its first parts
+__device__ __forceinline__ bool spill_slice(const RowRec& rec, u32& lo, u32& hi)
+{
+    const u32 len = rec.a1 - rec.a0;
+    const u32 per = ((len + gridDim.y - 1) / gridDim.y + kGWalkThreads - 1) / kGWalkThreads * kGWalkThreads;
+    const u64 lo64 = u64(rec.a0) + u64(blockIdx.y) * per;
+    if (lo64 >= rec.a1) return false;
+    lo = (u32)lo64;
+    hi = (u32)min(u64(rec.a1), lo64 + per);
+    return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGWalkThreads) void num_spill_count_kernel(ProductSrc<T> src, const u32* a_ro,
+                                                                        RowWork w, int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = Block<kGWalkThreads>;
+    const G g;
+    u32* m_incl = reinterpret_cast<u32*>(smem);
+    u32* scratch = m_incl + 2 * kGWalkThreads;
+    u32* win = scratch + kGWalkThreads / 64 + 2;
+    u32* hist = win + win_words<G>();
+    RowMeta<T> meta{m_incl, m_incl + kGWalkThreads, nullptr, win};
+    if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
+    const u32 count = w.st->num.count[cls];
+    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const RowRec rec = recs[idx];
+        u32 lo, hi;
+        if (!spill_slice(rec, lo, hi)) continue;
+        const GRowPlan pl = w.spill.plan[idx];
+        for (u32 b = threadIdx.x; b < pl.nb; b += kGWalkThreads) hist[b] = 0;
+        __syncthreads();
+        for_each_product<false>(g, src, lo, hi, meta, scratch,
+                                [&](const u32(&c)[kBatch], const T(&)[kBatch], u32 n) {
+#pragma unroll
+                                    for (int u = 0; u < kBatch; ++u)
+                                        if ((u32)u < n) atomicAdd(&hist[(c[u] - rec.cmin) >> pl.shift], 1u);
+                                }, cls);
+        for (u32 b = threadIdx.x; b < pl.nb; b += kGWalkThreads)
+            if (hist[b]) atomicAdd(&w.spill.bcount[pl.bbase + b], hist[b]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void num_spill_offsets_kernel(RowWork w, int cls)
+{
+    __shared__ u32 s_scan[256 / 64 + 2];
+    if (w.st->capacity_miss) return;
+    const u32 count = w.st->num.count[cls];
+    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const GRowPlan pl = w.spill.plan[idx];
+        u64 run = pl.pbase;
+        for (u32 b0 = 0; b0 < pl.nb; b0 += 256) {
+            const u32 b = b0 + threadIdx.x;
+            const u32 v = b < pl.nb ? w.spill.bcount[pl.bbase + b] : 0u;
+            u32 total;
+            const u32 ex = block_exclusive_scan<256>(v, s_scan, &total);
+            if (b < pl.nb) w.spill.bstart[pl.bbase + b] = run + ex;
+            run += total;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(ProductSrc<T> src, const u32* a_ro,
+                                                                          RowWork w, int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = Block<kGWalkThreads>;
+    const G g;
+    T* m_av = reinterpret_cast<T*>(smem);
+    u32* m_incl = reinterpret_cast<u32*>(m_av + kGWalkThreads);
+    u32* scratch = m_incl + 2 * kGWalkThreads;
+    u32* win = scratch + kGWalkThreads / 64 + 2;
+    u32* hist = win + win_words<G>();
+    u32* lbase = hist + kGMaxBuckets;
+    RowMeta<T> meta{m_incl, m_incl + kGWalkThreads, m_av, win};
+    if (w.st->capacity_miss) return;
+    src.rebase(a_ro);
+    u32* pcol = w.spill.pcol[0];
+    T* pval = static_cast<T*>(w.spill.pval[0]);
+    const u32 count = w.st->num.count[cls];
+    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const RowRec rec = recs[idx];
+        u32 lo, hi;
+        if (!spill_slice(rec, lo, hi)) continue;
+        const GRowPlan pl = w.spill.plan[idx];
+        for (u32 c0 = lo; c0 < hi; c0 += kGWalkThreads) {
+            const u32 c1 = min(hi, c0 + (u32)kGWalkThreads);
+            for (u32 b = threadIdx.x; b < pl.nb; b += kGWalkThreads) hist[b] = 0;
             __syncthreads();
-            constexpr int kScan = 8;  // independent L2 loads in flight per thread
-            for (u32 i0 = threadIdx.x; i0 < cap; i0 += THREADS * kScan) {
-                u32 k[kScan];
+            // (a) products of this chunk per bucket
+            for_each_product<false>(g, src, c0, c1, meta, scratch,
+                                    [&](const u32(&c)[kBatch], const T(&)[kBatch], u32 n) {
 #pragma unroll
-                for (int u = 0; u < kScan; ++u) {
-                    const u32 i = i0 + u * THREADS;
-                    k[u] = i < cap ? load_l2(&gkeys[t0 + i]) : kEmptyKey;
-                }
-#pragma unroll
-                for (int u = 0; u < kScan; ++u) {
-                    const u32 d = k[u] - wbase;
-                    if (k[u] != kEmptyKey && d < ncols) atomicOr(&bm[d >> 5], 1u << (d & 31));
+                                        for (int u = 0; u < kBatch; ++u)
+                                            if ((u32)u < n) atomicAdd(&hist[(c[u] - rec.cmin) >> pl.shift], 1u);
+                                    }, cls);
+            // (b) one reservation per touched bucket; hist becomes the chunk-local fill count
+            for (u32 b = threadIdx.x; b < pl.nb; b += kGWalkThreads) {
+                const u32 cnt = hist[b];
+                if (cnt) {
+                    const u32 at = atomicAdd(&w.spill.bcursor[pl.bbase + b], cnt);
+                    lbase[b] = (u32)(w.spill.bstart[pl.bbase + b] - pl.pbase) + at;
+                    hist[b] = 0;
                 }
             }
             __syncthreads();
-            const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);
-            for (u32 i0 = threadIdx.x; i0 < cap; i0 += THREADS * kScan) {
-                u32 k[kScan];
-                Bits raw[kScan];
+            // (c) place (col, a*b)
+            for_each_product<true>(g, src, c0, c1, meta, scratch,
+                                   [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
 #pragma unroll
-                for (int u = 0; u < kScan; ++u) {
-                    const u32 i = i0 + u * THREADS;
-                    k[u] = i < cap ? load_l2(&gkeys[t0 + i]) : kEmptyKey;
-                    raw[u] = i < cap ? load_l2(reinterpret_cast<const Bits*>(&gvals[t0 + i])) : Bits(0);
+                                       for (int u = 0; u < kBatch; ++u)
+                                           if ((u32)u < n) {
+                                               const u32 b = (c[u] - rec.cmin) >> pl.shift;
+                                               const u64 pos = pl.pbase + lbase[b] + atomicAdd(&hist[b], 1u);
+                                               pcol[pos] = c[u];
+                                               pval[pos] = p[u];
+                                           }
+                                   }, cls);
+        }
+    }
+}
+
+// reduce: LDS of a NUM_B8K group (table | scan scratch); the dense fallback aliases the table
+constexpr int kGReduceThreads = 512;
+constexpr u32 kGDenseCols = 8192;
+template <typename T>
+constexpr u32 num_spill_reduce_lds()
+{
+    return kNumB8KCap * ((u32)sizeof(Acc<T>) + 4u) + (kGReduceThreads / 64 + 2 + 3) / 4 * 16;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGReduceThreads) void num_spill_reduce_kernel(RowWork w, int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = Block<kGReduceThreads>;
+    const G g;
+    Acc<T>* vals = reinterpret_cast<Acc<T>*>(smem);
+    u32* keys = reinterpret_cast<u32*>(vals + kNumB8KCap);
+    u32* scratch = keys + kNumB8KCap;
+    u32* S = reinterpret_cast<u32*>(smem);
+    static_assert(kGDenseCols * sizeof(Acc<T>) + 2 * (kGDenseCols / 32) * 4 <= kNumB8KCap * (sizeof(Acc<T>) + 4),
+                  "the dense fallback window aliases the table");
+    if (w.st->capacity_miss) return;
+    const u32* pcol = w.spill.pcol[0];
+    const T* pval = static_cast<const T*>(w.spill.pval[0]);
+    u32* ocol = w.spill.pcol[1];
+    T* oval = static_cast<T*>(w.spill.pval[1]);
+    const u32 count = w.st->num.count[cls];
+    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const RowRec rec = recs[idx];
+        const GRowPlan pl = w.spill.plan[idx];
+        for (u32 b = blockIdx.y; b < pl.nb; b += gridDim.y) {
+            const u32 n = w.spill.bcount[pl.bbase + b];
+            if (n == 0) {
+                if (threadIdx.x == 0) w.spill.dcount[pl.bbase + b] = 0;
+                continue;
+            }
+            const u64 s0 = w.spill.bstart[pl.bbase + b];
+            const u32 c_lo = rec.cmin + (b << pl.shift);
+            const u32 span_m1 = (1u << pl.shift) - 1u;
+            const u32 c_hi = (rec.cmax - c_lo) < span_m1 ? rec.cmax : c_lo + span_m1;
+            u32 distinct = 0;
+            if (n <= kNumB8KMaxNnz) {
+                u32 bits = 32u - (u32)__clz((int)max(n + (n >> 1), 2u) - 1);
+                bits = min(max(bits, (u32)__builtin_ctz(kGReduceThreads)), (u32)__builtin_ctz(kNumB8KCap));
+                bits = (u32)__builtin_amdgcn_readfirstlane((int)bits);
+                const u32 cap_row = 1u << bits;
+                for (u32 i = threadIdx.x; i < cap_row; i += kGReduceThreads) {
+                    keys[i] = kEmptyKey;
+                    vals[i] = 0;
                 }
+                __syncthreads();
+                for (u32 i0 = threadIdx.x; i0 < n; i0 += kBatch * kGReduceThreads) {
+                    u32 c[kBatch];
+                    Acc<T> p[kBatch];
+                    u32 nv = 0;
 #pragma unroll
-                for (int u = 0; u < kScan; ++u) {
-                    const u32 d = k[u] - wbase;
-                    if (k[u] != kEmptyKey && d < ncols) {
-                        const u32 r = emitted + pref[d >> 5] + __popc(bm[d >> 5] & ((1u << (d & 31)) - 1u));
-                        T val;
-                        __builtin_memcpy(&val, &raw[u], sizeof(T));
-                        c_col[rec.base + r] = k[u];
-                        c_val[rec.base + r] = val;
+                    for (int u = 0; u < kBatch; ++u) {
+                        const u32 i = i0 + u * kGReduceThreads;
+                        c[u] = kEmptyKey;
+                        p[u] = 0;
+                        if (i < n) {
+                            c[u] = pcol[s0 + i];
+                            p[u] = pval[s0 + i];
+                            ++nv;
+                        }
                     }
+                    table_accumulate_batch(keys, vals, bits, c, p, nv);
+                }
+                __syncthreads();
+                distinct = emit_bitmap_sorted<G, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz>(
+                    g, keys, vals, S, scratch, cap_row, c_lo, c_hi, 0u, ocol + s0, oval + s0, cls);
+            } else {
+                // the bucket outgrew the table (skewed columns): dense windows over its span, the
+                // products are re-read once per window
+                Acc<T>* dv = reinterpret_cast<Acc<T>*>(smem);
+                u32* bm = reinterpret_cast<u32*>(dv + kGDenseCols);
+                u32* pref = bm + kGDenseCols / 32;
+                for (u64 w0 = c_lo; w0 <= c_hi; w0 += kGDenseCols) {
+                    const u64 left = u64(c_hi) - w0 + 1;
+                    const u32 ncols = left < kGDenseCols ? (u32)left : kGDenseCols;
+                    const u32 nwords = (ncols + 31) >> 5;
+                    const u32 wbase = (u32)w0;
+                    for (u32 i = threadIdx.x; i < ncols; i += kGReduceThreads) dv[i] = 0;
+                    for (u32 i = threadIdx.x; i < nwords; i += kGReduceThreads) bm[i] = 0;
+                    __syncthreads();
+                    for (u32 i = threadIdx.x; i < n; i += kGReduceThreads) {
+                        const u32 d = pcol[s0 + i] - wbase;
+                        if (d < ncols) {
+                            atomicAdd(&dv[d], (Acc<T>)pval[s0 + i]);
+                            atomicOr(&bm[d >> 5], 1u << (d & 31));
+                        }
+                    }
+                    __syncthreads();
+                    const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);
+                    for (u32 d = threadIdx.x; d < ncols; d += kGReduceThreads) {
+                        const u32 word = bm[d >> 5];
+                        if (word & (1u << (d & 31))) {
+                            const u32 r = distinct + pref[d >> 5] + __popc(word & ((1u << (d & 31)) - 1u));
+                            ocol[s0 + r] = wbase + d;
+                            oval[s0 + r] = (T)dv[d];
+                        }
+                    }
+                    distinct += total;
+                    __syncthreads();
                 }
             }
-            emitted += total;
+            if (threadIdx.x == 0) w.spill.dcount[pl.bbase + b] = distinct;
             __syncthreads();
         }
-        PHASE_MARK(2);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void num_spill_copy_kernel(RowWork w, u32* __restrict__ c_col,
+                                                             T* __restrict__ c_val, int cls)
+{
+    __shared__ u32 s_red[256 / 64 + 2];
+    using G = Block<256>;
+    const G g;
+    if (w.st->capacity_miss) return;
+    const u32* ocol = w.spill.pcol[1];
+    const T* oval = static_cast<const T*>(w.spill.pval[1]);
+    const u32 count = w.st->num.count[cls];
+    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const RowRec rec = recs[idx];
+        const GRowPlan pl = w.spill.plan[idx];
+        for (u32 b = blockIdx.y; b < pl.nb; b += gridDim.y) {
+            const u32 n = w.spill.dcount[pl.bbase + b];
+            if (n == 0) continue;  // uniform for the workgroup
+            u32 before = 0;
+            for (u32 j = threadIdx.x; j < b; j += 256) before += w.spill.dcount[pl.bbase + j];
+            before = g.reduce_add(before, s_red);
+            const u64 s0 = w.spill.bstart[pl.bbase + b];
+            const size_t dst = size_t(rec.base) + before;
+            for (u32 i = threadIdx.x; i < n; i += 256) {
+                c_col[dst + i] = ocol[s0 + i];
+                c_val[dst + i] = oval[s0 + i];
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------ launchers
-constexpr u32 kNumGBmWords = 16384;  // 512 Ki columns per sort window of the global-spill class
 
 template <typename T>
 u32 numeric_lds_bytes_t(int cls)
@@ -650,7 +876,7 @@ u32 numeric_lds_bytes_t(int cls)
         case NUM_B8K: return num_group_lds<Block<512>, T, kNumB8KCap, 512>();
         case NUM_D1: return num_dense_lds<T, kNumD1Cols, 256>();
         case NUM_D2: return num_dense_lds<T, kNumD2Cols, 1024>();
-        case NUM_G: return num_global_lds<T, 1024, kNumGBmWords>();
+        case NUM_G: return num_spill_reduce_lds<T>();
     }
     return 0;
 }
@@ -758,10 +984,21 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             break;
         }
         case NUM_G: {
-            auto k = num_global_kernel<T, 1024, kNumGBmWords>;
-            set_dyn_lds(k, lds);
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,
-                               w, c_col, c_val, cls);
+            // same stream: the kernel boundaries are the grid-wide barriers between the steps
+            const u32 rows = count < 8192u ? (count ? count : 1u) : 8192u;
+            (void)hipMemsetAsync(w.spill.bcount, 0, size_t(w.spill.bucket_cap) * 3 * sizeof(u32), s);
+            hipLaunchKernelGGL(num_spill_plan_kernel, dim3(1), dim3(1024), 0, s, w, cls);
+            auto kc = num_spill_count_kernel<T>;
+            hipLaunchKernelGGL(kc, dim3(rows, kGParts), dim3(kGWalkThreads), (num_spill_walk_lds<T, false>()), s,
+                               A, B, w, cls);
+            hipLaunchKernelGGL(num_spill_offsets_kernel, dim3(rows), dim3(256), 0, s, w, cls);
+            auto ks = num_spill_scatter_kernel<T>;
+            hipLaunchKernelGGL(ks, dim3(rows, kGParts), dim3(kGWalkThreads), (num_spill_walk_lds<T, true>()), s,
+                               A, B, w, cls);
+            auto kr = num_spill_reduce_kernel<T>;
+            set_dyn_lds(kr, lds);
+            hipLaunchKernelGGL(kr, dim3(rows, 32), dim3(kGReduceThreads), lds, s, w, cls);
+            hipLaunchKernelGGL((num_spill_copy_kernel<T>), dim3(rows, 32), dim3(256), 0, s, w, c_col, c_val, cls);
             break;
         }
     }

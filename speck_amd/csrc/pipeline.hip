@@ -85,8 +85,10 @@ struct speck_config {
     GraphKey last_key;                         // ... and what it ran on
     bool last_key_valid = false;
     int graph_replays = 0, graph_captures = 0, graph_misses = 0;
-    void* gpool = nullptr;    // global-memory spill pool (NUM_G rows): keys then values
-    size_t gpool_bytes = 0, gpool_vals_off = 0;
+    void* gpool = nullptr;    // global-memory buffers of the NUM_G spill path, carved into `spill`
+    size_t gpool_bytes = 0;
+    SpillBuffers spill{};
+    u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
     int time_num_class = -1;  // numeric class bracketed by tev0/tev1 in replayed sequences
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
     speck_stats last{};
@@ -304,7 +306,7 @@ struct Timing {
 int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
                   const Scratch& sc, u32* c_ro, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
                   bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr,
-                  DeviceStats* host_mirror = nullptr)
+                  DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull)
 {
     const u32 m = (u32)A->rows;
     ClassifyParams cp = c->cp;
@@ -319,7 +321,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
                     c->d_stats, cp, sc.b_start, sc.b_len);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
-    RowWork w{sc.recs, c->d_stats, c->d_stats->sym_queue, sc.b_start, sc.b_len, nullptr, nullptr};
+    RowWork w{sc.recs, c->d_stats, c->d_stats->sym_queue, sc.b_start, sc.b_len, SpillBuffers{}};
     // heaviest classes first: they have the longest tails
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
@@ -355,7 +357,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     }
     launch_scan(s, c_ro, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                 classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
-                host_mirror);
+                host_mirror, expect_g);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -370,9 +372,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     CsrView<T> Av{A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
-    RowWork w{sc.recs, c->d_stats, c->d_stats->num_queue, sc.b_start, sc.b_len,
-              static_cast<u32*>(c->gpool),
-              c->gpool ? static_cast<void*>(static_cast<unsigned char*>(c->gpool) + c->gpool_vals_off) : nullptr};
+    RowWork w{sc.recs, c->d_stats, c->d_stats->num_queue, sc.b_start, sc.b_len, c->spill};
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;
     const u32* hint = counts ? counts : all_m;
@@ -452,7 +452,8 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     drop_graph(c);
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
-                           c->last_num_mask, true, nullptr, c->last_sym_counts, c->h_stats_dev);
+                           c->last_num_mask, true, nullptr, c->last_sym_counts, c->h_stats_dev,
+                           c->last_g_products);
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
                              c->last_num_mask, c->last_num_counts, nullptr);
@@ -626,9 +627,16 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // NUMERIC (Multiply.cu:835-1014) + in-kernel sort (Multiply.cu:1028-1043)
     const u32 num_mask = mask_of(c->h_stats->num.count, NUM_CLASSES);
     if (num_mask >> NUM_G & 1u) {
-        // global-memory spill pool of the heavy rows (role of the reference's global maps,
-        // Multiply.cu:357-427): 2*nnz(C) keys + values, grow-only
-        const size_t need = 2 * size_t(nnz_c) * (4 + sizeof(T)) + 256;
+        // global-memory spill buffers of the heavy rows (role of the reference's global maps,
+        // Multiply.cu:357-427), grow-only: per-row plan, per-bucket counters, and two product
+        // pools sized from the EXACT product count of the NUM_G rows (numeric.hip, NUM_G)
+        const u64 pg = c->h_stats->g_products;
+        const u32 rows_g = c->h_stats->num.count[NUM_G];
+        const u64 buckets = pg / 2048 + rows_g + 16;
+        if (buckets > 0xFFFFFFFFull) return fail(SPECK_ERR_OOM);
+        const size_t need = Carver::need(rows_g, sizeof(GRowPlan)) + 3 * Carver::need(buckets, 4) +
+                            Carver::need(buckets, 8) + 2 * Carver::need(pg, 4) + 2 * Carver::need(pg, sizeof(T)) +
+                            4096;
         if (need > c->gpool_bytes) {
             drop_graph(c);
             if (c->gpool) (void)hipFree(c->gpool);
@@ -636,12 +644,30 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             c->gpool_bytes = 0;
             if (hipMalloc(&c->gpool, need + need / 8) != hipSuccess) {
                 (void)hipGetLastError();
-                return SPECK_ERR_OOM;
+                return fail(SPECK_ERR_OOM);
             }
             c->gpool_bytes = need + need / 8;
         }
-        c->gpool_vals_off = (2 * size_t(nnz_c) * 4 + 255) & ~size_t(255);
+        Carver cv(c->gpool);
+        SpillBuffers sp{};
+        sp.plan = cv.take<GRowPlan>(rows_g);
+        // bcount | bcursor | dcount are cleared by ONE memset: keep them back to back
+        u32* counters = reinterpret_cast<u32*>(cv.take<unsigned char>(3 * size_t(buckets) * 4));
+        sp.bcount = counters;
+        sp.bcursor = counters + buckets;
+        sp.dcount = counters + 2 * buckets;
+        sp.bstart = cv.take<u64>(buckets);
+        sp.pcol[0] = cv.take<u32>(pg);
+        sp.pcol[1] = cv.take<u32>(pg);
+        sp.pval[0] = cv.take<T>(pg);
+        sp.pval[1] = cv.take<T>(pg);
+        sp.bucket_cap = (u32)buckets;
+        if (sp.plan != c->spill.plan || sp.pcol[0] != c->spill.pcol[0] || sp.pval[1] != c->spill.pval[1] ||
+            sp.bucket_cap != c->spill.bucket_cap)
+            drop_graph(c);  // a captured sequence holds the old layout
+        c->spill = sp;
     }
+    c->last_g_products = c->h_stats->g_products;
     t->globalMapsNumeric = st.lap();
     rc = enqueue_back<T>(c, s, A, B, sc, c_ro, c_col, static_cast<T*>(c_val), num_mask,
                          c->h_stats->num.count, &tm);

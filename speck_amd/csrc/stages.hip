@@ -223,6 +223,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
         }
         partials[blockIdx.x].products = p;
         partials[blockIdx.x].max_val = mxv;
+        partials[blockIdx.x].g_ops = 0;
     }
     if (t < kMaxClasses) {
         u32 h = 0;
@@ -244,6 +245,7 @@ struct Fold {
     u32 prefix[kMaxClasses];  // rows of each class in the blocks before mine
     u32 total[kMaxClasses];   // rows of each class in all blocks
     u64 sum_prefix, sum_total;  // products (analysis) / nnz (numeric) before mine / overall
+    u64 g_total;                // products of the NUM_G rows (numeric)
     u32 max_val;
 };
 
@@ -254,14 +256,15 @@ __device__ __forceinline__ void fold_partials(const BlockPartial* __restrict__ p
 {
     constexpr int NW = THREADS / 64;
     __shared__ u32 s_pre[NW][NCLS], s_tot[NW][NCLS], s_mx[NW];
-    __shared__ u64 s_sp[NW], s_st[NW], s_by[NW][NCLS];
+    __shared__ u64 s_sp[NW], s_st[NW], s_by[NW][NCLS], s_g[NW];
     u32 pre[NCLS], tot[NCLS];
     u64 by[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) pre[c] = tot[c] = 0, by[c] = 0;
-    u64 sp = 0, stt = 0;
+    u64 sp = 0, stt = 0, gs = 0;
     u32 mx = 0;
     for (u32 b = threadIdx.x; b < nb; b += THREADS) {
+        gs += parts[b].g_ops;
         const bool before = b < my_block;
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) {
@@ -289,10 +292,12 @@ __device__ __forceinline__ void fold_partials(const BlockPartial* __restrict__ p
     sp = wave_reduce_add(sp);
     stt = wave_reduce_add(stt);
     mx = wave_reduce_max(mx);
+    gs = wave_reduce_add(gs);
     if (lane == 0) {
         s_sp[wid] = sp;
         s_st[wid] = stt;
         s_mx[wid] = mx;
+        s_g[wid] = gs;
     }
     __syncthreads();
     if (threadIdx.x < kMaxClasses) {
@@ -309,15 +314,17 @@ __device__ __forceinline__ void fold_partials(const BlockPartial* __restrict__ p
         s_bytes[threadIdx.x] = y;
     }
     if (threadIdx.x == 0) {
-        u64 a = 0, t = 0;
+        u64 a = 0, t = 0, gt = 0;
         u32 m = 0;
         for (int w = 0; w < NW; ++w) {
             a += s_sp[w];
             t += s_st[w];
+            gt += s_g[w];
             m = max(m, s_mx[w]);
         }
         s_fold->sum_prefix = a;
         s_fold->sum_total = t;
+        s_fold->g_total = gt;
         s_fold->max_val = m;
     }
     __syncthreads();
@@ -443,10 +450,11 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
     __shared__ u32 s_hist[NW][kMaxClasses];
     __shared__ u64 s_bytes[kMaxClasses];
     __shared__ u32 s_max[NW];
+    __shared__ u64 s_gops[NW];
     if (threadIdx.x < kMaxClasses) s_bytes[threadIdx.x] = 0;
     __syncthreads();
     const u64 base = u64(blockIdx.x) * (kScanThreads * ITEMS) + u64(threadIdx.x) * ITEMS;
-    u64 tsum = 0, packed_lo = 0, packed_hi = 0;
+    u64 tsum = 0, packed_lo = 0, packed_hi = 0, g_ops = 0;
     u32 my_max = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -459,6 +467,7 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
                 const u32 len_a = a_ro[row + 1] - a_ro[row];
                 const u8 cls = classify_numeric(len_a, c, row_col_min[row], row_col_max[row], cp);
                 num_cls[row] = cls;
+                if (cls == NUM_G) g_ops += row_ops[row];
                 if (cls != NUM_NONE) {
                     packed_add(packed_lo, packed_hi, cls);
                     if (cp.want_bytes)
@@ -471,10 +480,12 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
     packed_lo = wave_reduce_add(packed_lo);
     packed_hi = wave_reduce_add(packed_hi);
     my_max = wave_reduce_max(my_max);
+    g_ops = wave_reduce_add(g_ops);
     const u32 wid = threadIdx.x >> 6;
     if (lane_id() == 0) {
         s_sum[wid] = tsum;
         s_max[wid] = my_max;
+        s_gops[wid] = g_ops;
 #pragma unroll
         for (int k = 0; k < kMaxClasses; ++k)
             s_hist[wid][k] = k < 10 ? packed_get(packed_lo, packed_hi, k) : 0u;
@@ -487,14 +498,16 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
         partials[blockIdx.x].bytes[threadIdx.x] = s_bytes[threadIdx.x];
     }
     if (threadIdx.x == 0) {
-        u64 s = 0;
+        u64 s = 0, gsum = 0;
         u32 mxv = 0;
         for (int w = 0; w < NW; ++w) {
             s += s_sum[w];
+            gsum += s_gops[w];
             mxv = max(mxv, s_max[w]);
         }
         partials[blockIdx.x].products = s;  // numeric phase: the tile's nnz sum
         partials[blockIdx.x].max_val = mxv;
+        partials[blockIdx.x].g_ops = gsum;
     }
 }
 
@@ -504,7 +517,8 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     const BlockPartial* __restrict__ parts, u32 nb, const u8* __restrict__ num_cls,
     const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
     const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
-    RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz, DeviceStats* __restrict__ host_mirror)
+    RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz, u64 expect_g,
+    DeviceStats* __restrict__ host_mirror)
 {
     constexpr int NW = kScanThreads / 64;
     __shared__ Fold s_fold;
@@ -520,6 +534,9 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
         if (nnz_c > 0xFFFFFFFFull) st->nnz_overflow = 1;
         // the C buffers of a replayed launch sequence were allocated for exactly `exact_nnz`
         if (exact_nnz != ~0ull && nnz_c != exact_nnz) st->capacity_miss = 1;
+        // ... and so was the spill pool of the NUM_G rows
+        st->g_products = s_fold.g_total;
+        if (expect_g != ~0ull && s_fold.g_total != expect_g) st->capacity_miss = 1;
         publish_bins(st->num, s_fold, s_bytes, num_cls ? cp.num_allowed : 0xFFFFFFFFu, st);
         // everything the host needs is final here: write it straight into pinned host memory
         // instead of a copy node at the end of the launch sequence
@@ -630,7 +647,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
-                 DeviceStats* host_mirror)
+                 DeviceStats* host_mirror, u64 expect_g)
 {
     const u32 tiles = scan_tiles(m);
     auto go = [&](auto items) {
@@ -640,7 +657,7 @@ void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const
                            partials, cp, vsize);
         hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts_inout, m, st,
                            (const BlockPartial*)partials, tiles, (const u8*)num_cls, a_ro, row_ops,
-                           row_col_min, row_col_max, recs, cp, exact_nnz, host_mirror);
+                           row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, host_mirror);
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;
