@@ -528,7 +528,6 @@ struct GRowView {
 };
 
 constexpr u32 kGParts = 16;         // workgroups sharing the product walk of one row
-constexpr u32 kGBucketTarget = 2048;  // products per bucket aimed at (<= kNumB8KMaxNnz after skew)
 constexpr u32 kGMaxBuckets = 4096;  // per row: the LDS histograms of count / scatter
 constexpr int kGWalkThreads = 256;
 
@@ -717,27 +716,33 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(Produc
     }
 }
 
-// reduce: LDS of a NUM_B8K group (table | scan scratch); the dense fallback aliases the table
-constexpr int kGReduceThreads = 512;
-constexpr u32 kGDenseCols = 8192;
-template <typename T>
+// reduce: two launches over all buckets.  The buckets aim at ~1 k products, so most of them fit
+// the table of a NUM_B2K group (256 threads, 6 workgroups per CU); skewed columns fill some
+// buckets beyond that: those take the NUM_B8K-sized launch, whose dense fallback handles anything.
+// LDS: table | scan scratch; the dense fallback window aliases the table.
+template <typename T, u32 CAP, int THREADS>
 constexpr u32 num_spill_reduce_lds()
 {
-    return kNumB8KCap * ((u32)sizeof(Acc<T>) + 4u) + (kGReduceThreads / 64 + 2 + 3) / 4 * 16;
+    return CAP * ((u32)sizeof(Acc<T>) + 4u) + (THREADS / 64 + 2 + 3) / 4 * 16;
 }
 
-template <typename T>
-__global__ __launch_bounds__(kGReduceThreads) void num_spill_reduce_kernel(RowWork w, int cls)
+// handles the buckets with N_LO < products <= N_HI by hashing (N_HI <= 2/3 CAP), and, if DENSE, the
+// larger ones by dense column windows
+template <typename T, u32 CAP, u32 W1, int THREADS, u32 N_LO, u32 N_HI, bool DENSE>
+__global__ __launch_bounds__(THREADS) void num_spill_reduce_kernel(RowWork w, int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using G = Block<kGReduceThreads>;
+    constexpr int kGReduceThreads = THREADS;
+    constexpr u32 kGDenseCols = CAP;
+    using G = Block<THREADS>;
     const G g;
     Acc<T>* vals = reinterpret_cast<Acc<T>*>(smem);
-    u32* keys = reinterpret_cast<u32*>(vals + kNumB8KCap);
-    u32* scratch = keys + kNumB8KCap;
+    u32* keys = reinterpret_cast<u32*>(vals + CAP);
+    u32* scratch = keys + CAP;
     u32* S = reinterpret_cast<u32*>(smem);
-    static_assert(kGDenseCols * sizeof(Acc<T>) + 2 * (kGDenseCols / 32) * 4 <= kNumB8KCap * (sizeof(Acc<T>) + 4),
+    static_assert(kGDenseCols * sizeof(Acc<T>) + 2 * (kGDenseCols / 32) * 4 <= CAP * (sizeof(Acc<T>) + 4),
                   "the dense fallback window aliases the table");
+    static_assert(N_HI + N_HI / 2 <= CAP, "load factor <= 2/3");
     if (w.st->capacity_miss) return;
     const u32* pcol = w.spill.pcol[0];
     const T* pval = static_cast<const T*>(w.spill.pval[0]);
@@ -750,18 +755,15 @@ __global__ __launch_bounds__(kGReduceThreads) void num_spill_reduce_kernel(RowWo
         const GRowPlan pl = w.spill.plan[idx];
         for (u32 b = blockIdx.y; b < pl.nb; b += gridDim.y) {
             const u32 n = w.spill.bcount[pl.bbase + b];
-            if (n == 0) {
-                if (threadIdx.x == 0) w.spill.dcount[pl.bbase + b] = 0;
-                continue;
-            }
+            if (n <= N_LO || (!DENSE && n > N_HI)) continue;  // empty (dcount stays 0) or the other launch's
             const u64 s0 = w.spill.bstart[pl.bbase + b];
             const u32 c_lo = rec.cmin + (b << pl.shift);
             const u32 span_m1 = (1u << pl.shift) - 1u;
             const u32 c_hi = (rec.cmax - c_lo) < span_m1 ? rec.cmax : c_lo + span_m1;
             u32 distinct = 0;
-            if (n <= kNumB8KMaxNnz) {
+            if (n <= N_HI) {
                 u32 bits = 32u - (u32)__clz((int)max(n + (n >> 1), 2u) - 1);
-                bits = min(max(bits, (u32)__builtin_ctz(kGReduceThreads)), (u32)__builtin_ctz(kNumB8KCap));
+                bits = min(max(bits, (u32)__builtin_ctz(kGReduceThreads)), (u32)__builtin_ctz(CAP));
                 bits = (u32)__builtin_amdgcn_readfirstlane((int)bits);
                 const u32 cap_row = 1u << bits;
                 for (u32 i = threadIdx.x; i < cap_row; i += kGReduceThreads) {
@@ -787,9 +789,9 @@ __global__ __launch_bounds__(kGReduceThreads) void num_spill_reduce_kernel(RowWo
                     table_accumulate_batch(keys, vals, bits, c, p, nv);
                 }
                 __syncthreads();
-                distinct = emit_bitmap_sorted<G, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz>(
-                    g, keys, vals, S, scratch, cap_row, c_lo, c_hi, 0u, ocol + s0, oval + s0, cls);
-            } else {
+                distinct = emit_bitmap_sorted<G, T, CAP, W1, N_HI>(g, keys, vals, S, scratch, cap_row, c_lo, c_hi,
+                                                                   0u, ocol + s0, oval + s0, cls);
+            } else if constexpr (DENSE) {
                 // the bucket outgrew the table (skewed columns): dense windows over its span, the
                 // products are re-read once per window
                 Acc<T>* dv = reinterpret_cast<Acc<T>*>(smem);
@@ -876,7 +878,7 @@ u32 numeric_lds_bytes_t(int cls)
         case NUM_B8K: return num_group_lds<Block<512>, T, kNumB8KCap, 512>();
         case NUM_D1: return num_dense_lds<T, kNumD1Cols, 256>();
         case NUM_D2: return num_dense_lds<T, kNumD2Cols, 1024>();
-        case NUM_G: return num_spill_reduce_lds<T>();
+        case NUM_G: return num_spill_reduce_lds<T, kNumB8KCap, 512>();
     }
     return 0;
 }
@@ -995,9 +997,12 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             auto ks = num_spill_scatter_kernel<T>;
             hipLaunchKernelGGL(ks, dim3(rows, kGParts), dim3(kGWalkThreads), (num_spill_walk_lds<T, true>()), s,
                                A, B, w, cls);
-            auto kr = num_spill_reduce_kernel<T>;
-            set_dyn_lds(kr, lds);
-            hipLaunchKernelGGL(kr, dim3(rows, 32), dim3(kGReduceThreads), lds, s, w, cls);
+            auto kr_small = num_spill_reduce_kernel<T, kNumB2KCap, kB2KW1, 256, 0, kNumB2KMaxNnz, false>;
+            hipLaunchKernelGGL(kr_small, dim3(rows, 32), dim3(256), (num_spill_reduce_lds<T, kNumB2KCap, 256>()), s, w,
+                               cls);
+            auto kr_big = num_spill_reduce_kernel<T, kNumB8KCap, kB8KW1, 512, kNumB2KMaxNnz, kNumB8KMaxNnz, true>;
+            set_dyn_lds(kr_big, lds);
+            hipLaunchKernelGGL(kr_big, dim3(rows, 32), dim3(512), lds, s, w, cls);
             hipLaunchKernelGGL((num_spill_copy_kernel<T>), dim3(rows, 32), dim3(256), 0, s, w, c_col, c_val, cls);
             break;
         }

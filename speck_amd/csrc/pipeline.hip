@@ -632,7 +632,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         // pools sized from the EXACT product count of the NUM_G rows (numeric.hip, NUM_G)
         const u64 pg = c->h_stats->g_products;
         const u32 rows_g = c->h_stats->num.count[NUM_G];
-        const u64 buckets = pg / 2048 + rows_g + 16;
+        const u64 buckets = pg / kGBucketTarget + rows_g + 16;
         if (buckets > 0xFFFFFFFFull) return fail(SPECK_ERR_OOM);
         const size_t need = Carver::need(rows_g, sizeof(GRowPlan)) + 3 * Carver::need(buckets, 4) +
                             Carver::need(buckets, 8) + 2 * Carver::need(pg, 4) + 2 * Carver::need(pg, sizeof(T)) +
