@@ -27,16 +27,21 @@ constexpr u32 kGBucketTarget = 1024;  // products per bucket aimed at (skewed co
 struct GRowPlan {
     u64 pbase;        // first pool slot of the row's products
     u32 bbase, nb;    // first bucket, number of buckets
-    u32 shift, pad;   // bucket = (col - cmin) >> shift
+    u32 fbase, nf;    // first cell of the fine column grid, number of cells
+    u32 shift, unit;  // cell = (col - cmin) >> shift; bucket of a cell = products before it / unit
 };
 struct SpillBuffers {
     GRowPlan* plan;                    // one per NUM_G row, class-list order
+    u32* fcount;                       // per cell: products   (fcount | bcount | bcursor | dcount are
     u32 *bcount, *bcursor, *dcount;    // per bucket: products, scatter cursor, distinct columns
-                                       //   (contiguous, bucket_cap entries each: one memset)
+    u32* big_count;                    //   length of big_list;  contiguous: one memset)
+    u64* big_list;                     // (row << 32 | bucket) of the buckets beyond the small table
+    u32* fmap;                         // per cell: its bucket
     u64* bstart;                       // per bucket: first pool slot
+    u32 *clo, *chi;                    // per bucket: column span
     u32* pcol[2];
     void* pval[2];
-    u32 bucket_cap;
+    u32 bucket_cap, cell_cap;
 };
 
 // Everything a symbolic / numeric kernel needs besides the matrices.

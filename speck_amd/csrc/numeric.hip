@@ -512,67 +512,72 @@ __global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const 
 // 2 ms for the 39 M atomics of the webbase-like input.  So the products of such a row are not
 // accumulated in global memory at all.  They are PARTITIONED by column into buckets of
 // ~2-4 k products with plain stores, and every bucket is then reduced in LDS like a NUM_B8K row:
-//   plan    : per row bucket width 2^shift (<= ops/2048 buckets), pool offsets (one workgroup)
-//   count   : products per bucket            -- column walk, LDS histogram, one global add per
-//                                               (workgroup, bucket)
-//   offsets : bucket starts (scan per row)
+//   plan    : per row a FINE column grid (width 2^shift, up to 8 cells per wanted bucket), pool
+//             offsets (one workgroup)
+//   count   : products per fine cell         -- column walk, LDS histogram, one global add per
+//                                               (workgroup, cell)
+//   offsets : cells are merged into buckets of ~kGBucketTarget products (bucket = products before
+//             the cell / unit: balanced whatever the column skew), bucket starts and column spans
 //   scatter : (col, a*b) to the buckets      -- per staged chunk: LDS histogram, ONE global
 //                                               reservation per (chunk, bucket), LDS ranks
 //   reduce  : per bucket LDS hash accumulate + two-level bitmap sort (dense column windows for a
 //             bucket that outgrew the table), result to the second pool, distinct count
 //   copy    : the reduced buckets of a row, in bucket order, are its sorted C row
 // kGParts workgroups share the walk of one row; buckets are independent workgroups.
-struct GRowView {
-    RowRec rec;
-    GRowPlan plan;
-};
-
 constexpr u32 kGParts = 16;         // workgroups sharing the product walk of one row
-constexpr u32 kGMaxBuckets = 4096;  // per row: the LDS histograms of count / scatter
+constexpr u32 kGMaxBuckets = 2048;  // per row: the LDS histograms of scatter
+constexpr u32 kGMaxCells = 4096;    // per row: the LDS histogram of count, the cell -> bucket map
 constexpr int kGWalkThreads = 256;
 
 __global__ __launch_bounds__(1024) void num_spill_plan_kernel(RowWork w, int cls)
 {
     __shared__ u32 s_scan[1024 / 64 + 2];
     __shared__ u64 s_run_p;
-    __shared__ u32 s_run_b;
+    __shared__ u32 s_run_b, s_run_f;
     if (w.st->capacity_miss) return;
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
     if (threadIdx.x == 0) {
         s_run_p = 0;
         s_run_b = 0;
+        s_run_f = 0;
     }
     __syncthreads();
     for (u32 i0 = 0; i0 < count; i0 += 1024) {
         const u32 i = i0 + threadIdx.x;
-        u32 ops = 0, nb = 0, shift = 0;
+        u32 ops = 0, nb = 0, nf = 0, shift = 0, unit = 1;
         if (i < count) {
             const RowRec rec = recs[i];
             ops = rec.ops;
             const u32 range_m1 = rec.cmax - rec.cmin;
-            u32 want = (ops + kGBucketTarget - 1) / kGBucketTarget;
-            want = want < 1u ? 1u : (want > kGMaxBuckets ? kGMaxBuckets : want);
-            while ((range_m1 >> shift) + 1u > want) ++shift;
-            nb = (range_m1 >> shift) + 1u;
+            nb = (ops + kGBucketTarget - 1) / kGBucketTarget;
+            nb = nb < 1u ? 1u : (nb > kGMaxBuckets ? kGMaxBuckets : nb);
+            unit = (ops + nb - 1) / nb;  // products per bucket (kGBucketTarget unless nb was clamped)
+            const u32 cells = min(kGMaxCells, 8u * nb);
+            while ((range_m1 >> shift) + 1u > cells) ++shift;
+            nf = (range_m1 >> shift) + 1u;
         }
-        u32 t_lo, t_hi, t_nb;
+        u32 t_lo, t_hi, t_nb, t_nf;
         const u32 e_lo = block_exclusive_scan<1024>(ops & 0xFFFFu, s_scan, &t_lo);
         const u32 e_hi = block_exclusive_scan<1024>(ops >> 16, s_scan, &t_hi);
         const u32 e_nb = block_exclusive_scan<1024>(nb, s_scan, &t_nb);
+        const u32 e_nf = block_exclusive_scan<1024>(nf, s_scan, &t_nf);
         if (i < count) {
             GRowPlan p;
             p.pbase = s_run_p + e_lo + (u64(e_hi) << 16);
             p.bbase = s_run_b + e_nb;
             p.nb = nb;
+            p.fbase = s_run_f + e_nf;
+            p.nf = nf;
             p.shift = shift;
-            p.pad = 0;
+            p.unit = unit;
             w.spill.plan[i] = p;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             s_run_p += t_lo + (u64(t_hi) << 16);
             s_run_b += t_nb;
+            s_run_f += t_nf;
         }
         __syncthreads();
     }
@@ -584,7 +589,8 @@ constexpr u32 num_spill_walk_lds()
 {
     using G = Block<kGWalkThreads>;
     return kGWalkThreads * (WITH_VALUES ? (u32)sizeof(T) : 0u) +
-           (2 * kGWalkThreads + kGWalkThreads / 64 + 2 + win_words<G>() + (WITH_VALUES ? 2u : 1u) * kGMaxBuckets + 3) / 4 * 16;
+           (2 * kGWalkThreads + kGWalkThreads / 64 + 2 + win_words<G>() +
+            (WITH_VALUES ? 2u * kGMaxBuckets + kGMaxCells / 2 : kGMaxCells) + 3) / 4 * 16;
 }
 
 // my slice of the A row: whole staging chunks, so that the slices of a short row collapse into
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_count_kernel(ProductS
         u32 lo, hi;
         if (!spill_slice(rec, lo, hi)) continue;
         const GRowPlan pl = w.spill.plan[idx];
-        for (u32 b = threadIdx.x; b < pl.nb; b += kGWalkThreads) hist[b] = 0;
+        for (u32 f = threadIdx.x; f < pl.nf; f += kGWalkThreads) hist[f] = 0;
         __syncthreads();
         for_each_product<false>(g, src, lo, hi, meta, scratch,
                                 [&](const u32(&c)[kBatch], const T(&)[kBatch], u32 n) {
@@ -629,8 +635,8 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_count_kernel(ProductS
                                     for (int u = 0; u < kBatch; ++u)
                                         if ((u32)u < n) atomicAdd(&hist[(c[u] - rec.cmin) >> pl.shift], 1u);
                                 }, cls);
-        for (u32 b = threadIdx.x; b < pl.nb; b += kGWalkThreads)
-            if (hist[b]) atomicAdd(&w.spill.bcount[pl.bbase + b], hist[b]);
+        for (u32 f = threadIdx.x; f < pl.nf; f += kGWalkThreads)
+            if (hist[f]) atomicAdd(&w.spill.fcount[pl.fbase + f], hist[f]);
         __syncthreads();
     }
 }
@@ -638,19 +644,62 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_count_kernel(ProductS
 __global__ __launch_bounds__(256) void num_spill_offsets_kernel(RowWork w, int cls)
 {
     __shared__ u32 s_scan[256 / 64 + 2];
+    __shared__ u32 s_map[256];
+    __shared__ u32 s_bc[kGMaxBuckets];  // products per bucket of the row (this workgroup owns them all)
     if (w.st->capacity_miss) return;
     const u32 count = w.st->num.count[cls];
+    const RowRec* recs = w.recs + w.st->num.offset[cls];
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
         const GRowPlan pl = w.spill.plan[idx];
-        u64 run = pl.pbase;
-        for (u32 b0 = 0; b0 < pl.nb; b0 += 256) {
-            const u32 b = b0 + threadIdx.x;
-            const u32 v = b < pl.nb ? w.spill.bcount[pl.bbase + b] : 0u;
+        const RowRec rec = recs[idx];
+        for (u32 b = threadIdx.x; b < pl.nb; b += 256) s_bc[b] = 0;
+        __syncthreads();
+        u32 run = 0;                 // products before the current chunk of cells
+        u32 prev_last = 0xFFFFFFFFu;  // bucket of the last cell of the previous chunk
+        for (u32 f0 = 0; f0 < pl.nf; f0 += 256) {
+            const u32 f = f0 + threadIdx.x;
+            const u32 v = f < pl.nf ? w.spill.fcount[pl.fbase + f] : 0u;
             u32 total;
-            const u32 ex = block_exclusive_scan<256>(v, s_scan, &total);
-            if (b < pl.nb) w.spill.bstart[pl.bbase + b] = run + ex;
+            const u32 ex = run + block_exclusive_scan<256>(v, s_scan, &total);
+            // bucket of a cell = products before it / unit: monotone in f, every bucket gets
+            // < unit + (its last cell) products
+            const u32 b = min(ex / pl.unit, pl.nb - 1u);
+            s_map[threadIdx.x] = b;
+            __syncthreads();
+            if (f < pl.nf) {
+                w.spill.fmap[pl.fbase + f] = b;
+                if (v) atomicAdd(&s_bc[b], v);
+                const u32 before = threadIdx.x ? s_map[threadIdx.x - 1] : prev_last;
+                if (before != b) {  // first cell of bucket b (and the end of the bucket before)
+                    w.spill.bstart[pl.bbase + b] = pl.pbase + ex;
+                    w.spill.clo[pl.bbase + b] = rec.cmin + (f << pl.shift);
+                    if (before != 0xFFFFFFFFu) w.spill.chi[pl.bbase + before] = rec.cmin + (f << pl.shift) - 1u;
+                }
+                if (f == pl.nf - 1) w.spill.chi[pl.bbase + b] = rec.cmax;
+            }
+            prev_last = s_map[255];
             run += total;
+            __syncthreads();
         }
+        // the buckets that outgrew the small table go on a work list: the launch with the big
+        // table runs over that list only (its workgroups own most of a CU's LDS; launching one per
+        // bucket just to find it small costs more than the reduction itself)
+        // (no device-scope fence anywhere here: on a multi-XCD part it writes the L2 back)
+        u32 mine = 0;
+        for (u32 b = threadIdx.x; b < pl.nb; b += 256) {
+            w.spill.bcount[pl.bbase + b] = s_bc[b];
+            mine += s_bc[b] > kNumB2KMaxNnz ? 1u : 0u;
+        }
+        u32 n_big;
+        u32 at = block_exclusive_scan<256>(mine, s_scan, &n_big);
+        if (n_big) {  // one reservation per row: same-address atomics serialise (~12 ns each)
+            if (threadIdx.x == 0) s_map[0] = atomicAdd(w.spill.big_count, n_big);
+            __syncthreads();
+            at += s_map[0];
+            for (u32 b = threadIdx.x; b < pl.nb; b += 256)
+                if (s_bc[b] > kNumB2KMaxNnz) w.spill.big_list[at++] = (u64(idx) << 32) | b;
+        }
+        __syncthreads();
     }
 }
 
@@ -667,6 +716,7 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(Produc
     u32* win = scratch + kGWalkThreads / 64 + 2;
     u32* hist = win + win_words<G>();
     u32* lbase = hist + kGMaxBuckets;
+    unsigned short* cell2b = reinterpret_cast<unsigned short*>(lbase + kGMaxBuckets);
     RowMeta<T> meta{m_incl, m_incl + kGWalkThreads, m_av, win};
     if (w.st->capacity_miss) return;
     src.rebase(a_ro);
@@ -679,6 +729,8 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(Produc
         u32 lo, hi;
         if (!spill_slice(rec, lo, hi)) continue;
         const GRowPlan pl = w.spill.plan[idx];
+        __syncthreads();
+        for (u32 f = threadIdx.x; f < pl.nf; f += kGWalkThreads) cell2b[f] = (unsigned short)w.spill.fmap[pl.fbase + f];
         for (u32 c0 = lo; c0 < hi; c0 += kGWalkThreads) {
             const u32 c1 = min(hi, c0 + (u32)kGWalkThreads);
             for (u32 b = threadIdx.x; b < pl.nb; b += kGWalkThreads) hist[b] = 0;
@@ -688,7 +740,7 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(Produc
                                     [&](const u32(&c)[kBatch], const T(&)[kBatch], u32 n) {
 #pragma unroll
                                         for (int u = 0; u < kBatch; ++u)
-                                            if ((u32)u < n) atomicAdd(&hist[(c[u] - rec.cmin) >> pl.shift], 1u);
+                                            if ((u32)u < n) atomicAdd(&hist[cell2b[(c[u] - rec.cmin) >> pl.shift]], 1u);
                                     }, cls);
             // (b) one reservation per touched bucket; hist becomes the chunk-local fill count
             for (u32 b = threadIdx.x; b < pl.nb; b += kGWalkThreads) {
@@ -706,7 +758,7 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(Produc
 #pragma unroll
                                        for (int u = 0; u < kBatch; ++u)
                                            if ((u32)u < n) {
-                                               const u32 b = (c[u] - rec.cmin) >> pl.shift;
+                                               const u32 b = cell2b[(c[u] - rec.cmin) >> pl.shift];
                                                const u64 pos = pl.pbase + lbase[b] + atomicAdd(&hist[b], 1u);
                                                pcol[pos] = c[u];
                                                pval[pos] = p[u];
@@ -749,17 +801,18 @@ __global__ __launch_bounds__(THREADS) void num_spill_reduce_kernel(RowWork w, in
     u32* ocol = w.spill.pcol[1];
     T* oval = static_cast<T*>(w.spill.pval[1]);
     const u32 count = w.st->num.count[cls];
-    const RowRec* recs = w.recs + w.st->num.offset[cls];
-    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const RowRec rec = recs[idx];
+    // the small launch walks (row, bucket) pairs; the big one the work list of oversized buckets
+    const u32 outer_n = DENSE ? *w.spill.big_count : count;
+    for (u32 it = blockIdx.x; it < outer_n; it += gridDim.x) {
+        const u32 idx = DENSE ? (u32)(w.spill.big_list[it] >> 32) : it;
         const GRowPlan pl = w.spill.plan[idx];
-        for (u32 b = blockIdx.y; b < pl.nb; b += gridDim.y) {
+        const u32 b_first = DENSE ? (u32)w.spill.big_list[it] : blockIdx.y;
+        const u32 b_step = DENSE ? 0xFFFFFFFFu - b_first : gridDim.y;  // big: exactly one bucket
+        for (u32 b = b_first; b < pl.nb; b += b_step) {
             const u32 n = w.spill.bcount[pl.bbase + b];
             if (n <= N_LO || (!DENSE && n > N_HI)) continue;  // empty (dcount stays 0) or the other launch's
             const u64 s0 = w.spill.bstart[pl.bbase + b];
-            const u32 c_lo = rec.cmin + (b << pl.shift);
-            const u32 span_m1 = (1u << pl.shift) - 1u;
-            const u32 c_hi = (rec.cmax - c_lo) < span_m1 ? rec.cmax : c_lo + span_m1;
+            const u32 c_lo = w.spill.clo[pl.bbase + b], c_hi = w.spill.chi[pl.bbase + b];
             u32 distinct = 0;
             if (n <= N_HI) {
                 u32 bits = 32u - (u32)__clz((int)max(n + (n >> 1), 2u) - 1);
@@ -988,7 +1041,8 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
         case NUM_G: {
             // same stream: the kernel boundaries are the grid-wide barriers between the steps
             const u32 rows = count < 8192u ? (count ? count : 1u) : 8192u;
-            (void)hipMemsetAsync(w.spill.bcount, 0, size_t(w.spill.bucket_cap) * 3 * sizeof(u32), s);
+            (void)hipMemsetAsync(w.spill.fcount, 0,
+                                 (size_t(w.spill.cell_cap) + 3 * size_t(w.spill.bucket_cap) + 4) * sizeof(u32), s);
             hipLaunchKernelGGL(num_spill_plan_kernel, dim3(1), dim3(1024), 0, s, w, cls);
             auto kc = num_spill_count_kernel<T>;
             hipLaunchKernelGGL(kc, dim3(rows, kGParts), dim3(kGWalkThreads), (num_spill_walk_lds<T, false>()), s,
@@ -1002,7 +1056,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                                cls);
             auto kr_big = num_spill_reduce_kernel<T, kNumB8KCap, kB8KW1, 512, kNumB2KMaxNnz, kNumB8KMaxNnz, true>;
             set_dyn_lds(kr_big, lds);
-            hipLaunchKernelGGL(kr_big, dim3(rows, 32), dim3(512), lds, s, w, cls);
+            hipLaunchKernelGGL(kr_big, dim3(2048), dim3(512), lds, s, w, cls);
             hipLaunchKernelGGL((num_spill_copy_kernel<T>), dim3(rows, 32), dim3(256), 0, s, w, c_col, c_val, cls);
             break;
         }

@@ -633,10 +633,12 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         const u64 pg = c->h_stats->g_products;
         const u32 rows_g = c->h_stats->num.count[NUM_G];
         const u64 buckets = pg / kGBucketTarget + rows_g + 16;
-        if (buckets > 0xFFFFFFFFull) return fail(SPECK_ERR_OOM);
-        const size_t need = Carver::need(rows_g, sizeof(GRowPlan)) + 3 * Carver::need(buckets, 4) +
-                            Carver::need(buckets, 8) + 2 * Carver::need(pg, 4) + 2 * Carver::need(pg, sizeof(T)) +
-                            4096;
+        const u64 cells = 8 * buckets;
+        if (cells > 0x7FFFFFFFull) return fail(SPECK_ERR_OOM);
+        const size_t need = Carver::need(rows_g, sizeof(GRowPlan)) + Carver::need(cells + 3 * buckets + 4, 4) +
+                            Carver::need(buckets, 8) +
+                            Carver::need(cells, 4) + Carver::need(buckets, 8) + 2 * Carver::need(buckets, 4) +
+                            2 * Carver::need(pg, 4) + 2 * Carver::need(pg, sizeof(T)) + 4096;
         if (need > c->gpool_bytes) {
             drop_graph(c);
             if (c->gpool) (void)hipFree(c->gpool);
@@ -651,17 +653,24 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         Carver cv(c->gpool);
         SpillBuffers sp{};
         sp.plan = cv.take<GRowPlan>(rows_g);
-        // bcount | bcursor | dcount are cleared by ONE memset: keep them back to back
-        u32* counters = reinterpret_cast<u32*>(cv.take<unsigned char>(3 * size_t(buckets) * 4));
-        sp.bcount = counters;
-        sp.bcursor = counters + buckets;
-        sp.dcount = counters + 2 * buckets;
+        // fcount | bcount | bcursor | dcount are cleared by ONE memset: keep them back to back
+        u32* counters = cv.take<u32>(cells + 3 * buckets + 4);
+        sp.fcount = counters;
+        sp.bcount = counters + cells;
+        sp.bcursor = sp.bcount + buckets;
+        sp.dcount = sp.bcursor + buckets;
+        sp.big_count = sp.dcount + buckets;
+        sp.big_list = cv.take<u64>(buckets);
+        sp.fmap = cv.take<u32>(cells);
         sp.bstart = cv.take<u64>(buckets);
+        sp.clo = cv.take<u32>(buckets);
+        sp.chi = cv.take<u32>(buckets);
         sp.pcol[0] = cv.take<u32>(pg);
         sp.pcol[1] = cv.take<u32>(pg);
         sp.pval[0] = cv.take<T>(pg);
         sp.pval[1] = cv.take<T>(pg);
         sp.bucket_cap = (u32)buckets;
+        sp.cell_cap = (u32)cells;
         if (sp.plan != c->spill.plan || sp.pcol[0] != c->spill.pcol[0] || sp.pval[1] != c->spill.pval[1] ||
             sp.bucket_cap != c->spill.bucket_cap)
             drop_graph(c);  // a captured sequence holds the old layout
