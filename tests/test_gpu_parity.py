@@ -417,3 +417,38 @@ def test_replay_detects_changed_inputs_under_the_same_pointers(cfg):
     for _ in range(3):
         sa.MultiplyspECK(dA, dA, dC, cfg)
     _assert_matches_oracle(dC, A2, A2)
+
+
+def _clustered_b(rows, cols, k, hot_cols, seed):
+    """B whose even rows live in the first `hot_cols` columns and whose odd rows are spread over all
+    of them: the products of a long A row pile up in one narrow column band (an oversized spill bucket
+    with many duplicates) on top of a thin wide background."""
+    rng = np.random.default_rng(seed)
+    c = rng.integers(0, cols, size=(rows, k), dtype=np.int64)
+    c[::2] = rng.integers(0, hot_cols, size=(len(c[::2]), k), dtype=np.int64)
+    c = np.sort(c, axis=1)
+    keep = np.ones((rows, k), dtype=bool)
+    keep[:, 1:] = c[:, 1:] != c[:, :-1]
+    ro = np.zeros(rows + 1, dtype=np.uint32)
+    ro[1:] = np.cumsum(keep.sum(axis=1))
+    v = (0.5 + rng.random(int(keep.sum()))) * rng.choice([-1.0, 1.0], size=int(keep.sum()))
+    return po.HostCSR(rows, cols, ro, c[keep].astype(np.uint32), v)
+
+
+def test_spill_path_skewed_columns_and_fp32(cfg):
+    """NUM_G: balanced buckets under column skew, the oversized-bucket list, the dense fallback of the
+    reduce step (a bucket with > 5461 products), fp32 values through the same kernels."""
+    B = _clustered_b(6000, 500000, 24, 3000, 81)
+    A = fast_random_csr(40, 6000, 1500, 82, jitter=False)     # ~36 k products per row, > 5461 distinct
+    check(cfg, A, B, [("num", "global")])
+    A32 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float32))
+    B32 = po.HostCSR(B.rows, B.cols, B.row_offsets, B.col_ids, B.data.astype(np.float32))
+    check(cfg, A32, B32, [("num", "global")], tol=TOL32)
+    # the same rows again through the replayed launch sequence (pool pointers baked into the graph)
+    dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR()
+    R, _ = po.spgemm(A, B)
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+        got = dC.to_host()
+        assert (got.row_offsets == R.row_offsets).all() and (got.col_ids == R.col_ids).all()
+    assert cfg.last_stats()["graph_replays"] > 0
