@@ -220,6 +220,27 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     gflops = 2.0 * P_total / (elapsed / args.steps) / 1e9
 
+    # N > 1, reported next to `value` (never instead of it): the same K steps without the exchange,
+    # i.e. what the row-sharded multiply alone sustains while C stays distributed like A
+    sharded_only = None
+    if gather:
+        def step_no_exchange():
+            nonlocal n_step
+            scfg, sC = slots[n_step % len(slots)]
+            n_step += 1
+            sa.MultiplyspECK(mine, dA, sC, scfg, timings)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_no_exchange()
+        barrier()
+        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+        e2 = float(e2.item())
+        sharded_only = {"value": round(2.0 * P_total / (e2 / args.steps) / 1e9, 3), "unit": "GFLOP/s",
+                        "ms_per_step": round(e2 * 1e3 / args.steps, 4),
+                        "note": "same steps without the gatherv (C left row-sharded); not the job metric"}
+
     if rank == 0:
         live = dom_live_n > 0 and dom_live_ms > 0
         dom_ms = dom_live_ms / dom_live_n if live else kernel_ms[dominant]
@@ -263,6 +284,8 @@ def main():
             "rows_per_class": {k: v for k, v in st["num_bin_rows"].items() if v},
             "graph_replays": replays,
         }
+        if sharded_only is not None:
+            out["multiply_only"] = sharded_only
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, P_total)
         print(json.dumps(out), flush=True)
