@@ -279,10 +279,13 @@ class spECKConfig:
             graph_replays=int(s.graph_replays), graph_captures=int(s.graph_captures))
 
 
+_NO_TIMINGS = CTimings()  # scratch for calls that do not ask for stage times
+
+
 def MultiplyspECK(A, B, matOut, config, timings=None):
     """spECK::MultiplyspECK<T,...>(A, B, matOut, config, timings), include/Multiply.h:15-16."""
     L = _lib.load()
-    t = timings._to_c() if timings is not None else CTimings()
+    t = timings._to_c() if timings is not None else _NO_TIMINGS
     if A.dtype != B.dtype:
         raise TypeError("A and B must share a value type")
     fn = L.speck_multiply_f64 if A.dtype == np.float64 else L.speck_multiply_f32
