@@ -1,0 +1,82 @@
+"""Randomised parity stress of the HIP path against the oracle (run by hand on a GPU box):
+power-law / uniform / clustered row lengths, empty rows and columns, rectangular shapes, fp32 and fp64,
+repeated calls (graph replay) with changing values.  usage: python tests/tools/stress_gpu.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402
+import speck_amd as sa  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+
+def rand_csr(rng, rows, cols, mean_len, kind, dtype):
+    if kind == "uniform":
+        ln = rng.integers(0, 2 * mean_len + 1, size=rows)
+    elif kind == "powerlaw":
+        ln = np.minimum((rng.pareto(1.2, size=rows) * mean_len * 0.5).astype(np.int64), cols)
+    elif kind == "sparse_empty":
+        ln = np.where(rng.random(rows) < 0.7, 0, rng.integers(1, 3 * mean_len + 2, size=rows))
+    else:  # "dense_band"
+        ln = rng.integers(mean_len, 2 * mean_len + 2, size=rows)
+    ln = np.minimum(ln, cols).astype(np.int64)
+    ro = np.zeros(rows + 1, dtype=np.int64)
+    ro[1:] = np.cumsum(ln)
+    col = np.empty(int(ro[-1]), dtype=np.uint32)
+    for r in range(rows):
+        n = int(ln[r])
+        if n == 0:
+            continue
+        if kind == "dense_band":
+            lo = int(rng.integers(0, max(1, cols - 4 * n)))
+            pool = np.arange(lo, min(cols, lo + 4 * n))
+            col[ro[r]:ro[r + 1]] = np.sort(rng.choice(pool, size=n, replace=False))
+        else:
+            col[ro[r]:ro[r + 1]] = np.sort(rng.choice(cols, size=n, replace=False))
+    val = ((0.5 + rng.random(col.size)) * rng.choice([-1.0, 1.0], size=col.size)).astype(dtype)
+    return po.HostCSR(rows, cols, ro.astype(np.uint32), col, val)
+
+
+def to_sa(h):
+    return sa.HostCSR(h.rows, h.cols, h.row_offsets, h.col_ids, h.data)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    cfg = sa.spECKConfig.initialize(0)
+    bad = 0
+    for it in range(cases):
+        dtype = np.float64 if rng.random() < 0.8 else np.float32
+        m = int(rng.integers(1, 3000))
+        k = int(rng.integers(1, 3000))
+        n = int(rng.choice([50, 1000, 20000, 300000, 3000000]))
+        ka = rng.choice(["uniform", "powerlaw", "sparse_empty", "dense_band"])
+        kb = rng.choice(["uniform", "powerlaw", "sparse_empty", "dense_band"])
+        A = rand_csr(rng, m, k, int(rng.choice([1, 3, 10, 40])), ka, dtype)
+        B = rand_csr(rng, k, n, int(rng.choice([1, 3, 10, 40, 150])), kb, dtype)
+        R, ab = po.spgemm(A, B)
+        dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR(dtype)
+        ok = True
+        for rep in range(3):  # the third call is a graph replay
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+            got = dC.to_host()
+            tol = 1e-12 if dtype == np.float64 else 2e-5
+            ok = ok and got.nnz == R.nnz and (got.row_offsets == R.row_offsets).all() and \
+                (got.col_ids == R.col_ids).all() and \
+                bool((np.abs(got.data.astype(np.float64) - R.data.astype(np.float64)) <= tol * ab + 1e-300).all())
+        st = cfg.last_stats()
+        cls = {k: v for k, v in st["num_bin_rows"].items() if v}
+        if not ok:
+            bad += 1
+        print(f"{it:4d} {'ok ' if ok else 'BAD'} {m}x{k}x{n} {ka}/{kb} {dtype.__name__} nnzC={R.nnz} {cls}", flush=True)
+    print("failures:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
