@@ -11,7 +11,6 @@ using u64 = uint64_t;
 using u8 = uint8_t;
 
 constexpr u32 kEmptyKey = 0xFFFFFFFFu;
-constexpr int kWave = 64;
 constexpr int kMaxClasses = 12;  // array extent of every per-class table
 
 // Trivially-copyable CSR view handed to kernels (reference: dCSRNoDealloc<T>,
@@ -159,8 +158,6 @@ struct DeviceStats {
     BinTable sym;
     BinTable num;
     u64 g_products;          // products of the NUM_G rows (the host sizes the spill pool from it)
-    u32 sym_queue[kMaxClasses];  // next unclaimed row of each workgroup-per-row class
-    u32 num_queue[kMaxClasses];
 };
 
 // One row of work as the class kernels see it: written in class order by the scatter kernels,

@@ -15,7 +15,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      u32* b_start, u32* b_len);
 
 // exclusive scan of the row counts (+ numeric classification, stats fold, ordered scatter of the
-// numeric row records when num_cls != nullptr).  tile_off: scan_tiles(m) u32 of scratch.
+// numeric row records when num_cls != nullptr).
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
@@ -48,7 +48,6 @@ struct SpillBuffers {
 struct RowWork {
     const RowRec* recs;     // row records grouped by class (device)
     const DeviceStats* st;  // offsets/counts live here (device)
-    u32* queue;             // per-class work-queue heads (device), zeroed per call
     const u32* b_start;     // per A entry (relative to the first entry of the A view):
     const u32* b_len;       //   start / length of the referenced B row, written by the analysis
     SpillBuffers spill;     // NUM_G class (all null when no row needs it)

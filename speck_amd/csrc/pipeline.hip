@@ -140,9 +140,7 @@ struct Scratch {
     u32 *row_ops, *row_max_ops, *row_col_min, *row_col_max;
     RowRec* recs;  // one 32-byte record per row, grouped by kernel class
     u8* cls;
-    u32* tile_off;
     BlockPartial* partials;
-    u32* blk_base;
     u32 *b_start, *b_len;  // per A entry: the referenced B row (written by the analysis)
 };
 
@@ -154,9 +152,7 @@ size_t scratch_bytes(u32 m, u64 nnz_a)
     b += 4 * Carver::need(m, 4);
     b += Carver::need(m, sizeof(RowRec));
     b += Carver::need(m, 1);
-    b += Carver::need(scan_tiles(m), 4);
     b += Carver::need(partial_blocks(m), sizeof(BlockPartial));
-    b += Carver::need(size_t(partial_blocks(m)) * kMaxClasses, 4);
     return b + 4096;
 }
 
@@ -172,9 +168,7 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
     s.row_col_min = cv.take<u32>(m);
     s.row_col_max = cv.take<u32>(m);
     s.cls = cv.take<u8>(m);
-    s.tile_off = cv.take<u32>(scan_tiles(m));
     s.partials = cv.take<BlockPartial>(partial_blocks(m));
-    s.blk_base = cv.take<u32>(size_t(partial_blocks(m)) * kMaxClasses);
     return s;
 }
 
@@ -321,7 +315,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
                     c->d_stats, cp, sc.b_start, sc.b_len);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
-    RowWork w{sc.recs, c->d_stats, c->d_stats->sym_queue, sc.b_start, sc.b_len, SpillBuffers{}};
+    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, SpillBuffers{}};
     // heaviest classes first: they have the longest tails
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
@@ -372,7 +366,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     CsrView<T> Av{A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
-    RowWork w{sc.recs, c->d_stats, c->d_stats->num_queue, sc.b_start, sc.b_len, c->spill};
+    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, c->spill};
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;
     const u32* hint = counts ? counts : all_m;
@@ -935,7 +929,7 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     }
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
-    Scratch sc = carve(c, m, A->nnz);  // partials / blk_base come from the arena, row arrays from the caller
+    Scratch sc = carve(c, m, A->nnz);  // partials come from the arena, row arrays from the caller
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DeviceStats), s));
     launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, d_row_ops,
                     d_row_max_ops, d_row_col_min, d_row_col_max, nullptr, nullptr, sc.partials, sc.recs,

@@ -125,17 +125,6 @@ struct Block {
     }
 };
 
-// Workgroup-per-row classes pull their next row from a device-side queue (rows of the heavy
-// classes differ a lot in cost; a static stride leaves CUs idle).  One returning device-scope
-// atomic per row (~0.3-1 us, MI355X_MICROARCH "dequeue") against >= 5 us of row time.
-__device__ __forceinline__ u32 next_queued_row(u32* queue_head, u32* lds_slot)
-{
-    __syncthreads();
-    if (threadIdx.x == 0) *lds_slot = atomicAdd(queue_head, 1u);
-    __syncthreads();
-    return *lds_slot;
-}
-
 // Per-group LDS staging area for one chunk of A entries (SIZE entries).
 template <typename T>
 struct RowMeta {
@@ -144,12 +133,6 @@ struct RowMeta {
     T* av;      // a_ik (unused by the symbolic kernels: pass nullptr)
     u32* win;   // win_words<G>() words of owner-window scratch (wave and workgroup groups)
 };
-
-template <int SIZE, typename T>
-constexpr u32 row_meta_bytes(bool with_values)
-{
-    return SIZE * (8 + (with_values ? (u32)sizeof(T) : 0));
-}
 
 constexpr int kBatch = 4;  // products per lane fetched before accumulating (memory-level parallelism)
 
