@@ -427,16 +427,29 @@ constexpr int kScanThreads = 256;
 // rows per thread: chosen by the host so that the tile count stays <= ~1024 (every block of
 // num_apply_kernel folds all tile partials) while small inputs still get >= ~300 blocks
 static inline int scan_items(u32 m) { return m <= (1u << 19) ? 2 : (m <= (1u << 21) ? 8 : 32); }
-constexpr int kFieldBits = 12;  // per-class counters packed 5 per u64 (<= 512 per wave)
-
-__device__ __forceinline__ void packed_add(u64& lo, u64& hi, u32 cls)
-{
-    if (cls < 5) lo += 1ull << (kFieldBits * cls); else hi += 1ull << (kFieldBits * (cls - 5));
-}
-__device__ __forceinline__ u32 packed_get(u64 lo, u64 hi, u32 cls)
-{
-    return (u32)((cls < 5 ? lo >> (kFieldBits * cls) : hi >> (kFieldBits * (cls - 5))) & 0xFFFu);
-}
+// One 16-bit counter per numeric class, four per u64: a count never exceeds the rows of a block
+// (256 threads x 32 items = 8192), and sums of whole structs are plain u64 additions.
+struct PackedCounts {
+    u64 a = 0, b = 0, c = 0;
+    __device__ __forceinline__ void add(u32 cls)
+    {
+        const u64 one = 1ull << (16 * (cls & 3u));
+        if (cls < 4) a += one; else if (cls < 8) b += one; else c += one;
+    }
+    __device__ __forceinline__ u32 get(u32 cls) const
+    {
+        const u64 w = cls < 4 ? a : (cls < 8 ? b : c);
+        return (u32)(w >> (16 * (cls & 3u))) & 0xFFFFu;
+    }
+    __device__ __forceinline__ PackedCounts& operator+=(const PackedCounts& o)
+    {
+        a += o.a;
+        b += o.b;
+        c += o.c;
+        return *this;
+    }
+};
+static_assert(kMaxClasses <= 12, "PackedCounts holds 12 classes");
 
 template <int ITEMS>
 __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
@@ -454,7 +467,8 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
     if (threadIdx.x < kMaxClasses) s_bytes[threadIdx.x] = 0;
     __syncthreads();
     const u64 base = u64(blockIdx.x) * (kScanThreads * ITEMS) + u64(threadIdx.x) * ITEMS;
-    u64 tsum = 0, packed_lo = 0, packed_hi = 0, g_ops = 0;
+    u64 tsum = 0, g_ops = 0;
+    PackedCounts packed;
     u32 my_max = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
                 num_cls[row] = cls;
                 if (cls == NUM_G) g_ops += row_ops[row];
                 if (cls != NUM_NONE) {
-                    packed_add(packed_lo, packed_hi, cls);
+                    packed.add(cls);
                     if (cp.want_bytes)
                         atomicAdd(&s_bytes[cls], numeric_row_bytes(len_a, row_ops[row], c, vsize));
                 }
@@ -477,8 +491,9 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
         }
     }
     tsum = wave_reduce_add(tsum);
-    packed_lo = wave_reduce_add(packed_lo);
-    packed_hi = wave_reduce_add(packed_hi);
+    packed.a = wave_reduce_add(packed.a);
+    packed.b = wave_reduce_add(packed.b);
+    packed.c = wave_reduce_add(packed.c);
     my_max = wave_reduce_max(my_max);
     g_ops = wave_reduce_add(g_ops);
     const u32 wid = threadIdx.x >> 6;
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
         s_gops[wid] = g_ops;
 #pragma unroll
         for (int k = 0; k < kMaxClasses; ++k)
-            s_hist[wid][k] = k < 10 ? packed_get(packed_lo, packed_hi, k) : 0u;
+            s_hist[wid][k] = packed.get(k);
     }
     __syncthreads();
     if (threadIdx.x < kMaxClasses) {
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     __shared__ Fold s_fold;
     __shared__ u64 s_bytes[kMaxClasses];
     __shared__ u32 s_scan[NW + 1];
-    __shared__ u64 s_wlo[NW], s_whi[NW];
+    __shared__ u64 s_wave[NW][3];
     const u32 lane = lane_id(), wid = threadIdx.x >> 6;
     fold_partials<kScanThreads, NUM_CLASSES>(parts, nb, blockIdx.x, &s_fold, s_bytes, cp.want_bytes != 0);
     const u64 nnz_c = s_fold.sum_total;
@@ -569,40 +584,45 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
 
     // class of my 8 rows, packed per-thread histogram, exclusive scan over the threads
     u8 cls[ITEMS];
-    u64 plo = 0, phi = 0;
+    PackedCounts mine;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         cls[i] = (base + i) < m ? num_cls[base + i] : (u8)NUM_NONE;
-        if (cls[i] != NUM_NONE) packed_add(plo, phi, cls[i]);
+        if (cls[i] != NUM_NONE) mine.add(cls[i]);
     }
-    u64 ilo = plo, ihi = phi;
+    PackedCounts incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const u64 tl = __shfl_up(ilo, o, 64), th = __shfl_up(ihi, o, 64);
+        const u64 ta = __shfl_up(incl.a, o, 64), tb = __shfl_up(incl.b, o, 64), tc = __shfl_up(incl.c, o, 64);
         if (lane >= (u32)o) {
-            ilo += tl;
-            ihi += th;
+            incl.a += ta;
+            incl.b += tb;
+            incl.c += tc;
         }
     }
     if (lane == 63) {
-        s_wlo[wid] = ilo;
-        s_whi[wid] = ihi;
+        s_wave[wid][0] = incl.a;
+        s_wave[wid][1] = incl.b;
+        s_wave[wid][2] = incl.c;
     }
     __syncthreads();
-    u64 blo = ilo - plo, bhi = ihi - phi;  // exclusive inside the wave
+    PackedCounts before;  // rows of each class in the threads before mine (exclusive)
+    before.a = incl.a - mine.a;
+    before.b = incl.b - mine.b;
+    before.c = incl.c - mine.c;
     for (u32 w = 0; w < wid; ++w) {
-        blo += s_wlo[w];
-        bhi += s_whi[w];
+        before.a += s_wave[w][0];
+        before.b += s_wave[w][1];
+        before.c += s_wave[w][2];
     }
-    u64 used_lo = 0, used_hi = 0;
+    PackedCounts used;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const u64 row = base + i;
         if (cls[i] == NUM_NONE) continue;
         const u32 k = cls[i];
-        const u32 pos = class_offset(s_fold, k) + s_fold.prefix[k] + packed_get(blo, bhi, k) +
-                        packed_get(used_lo, used_hi, k);
-        packed_add(used_lo, used_hi, k);
+        const u32 pos = class_offset(s_fold, k) + s_fold.prefix[k] + before.get(k) + used.get(k);
+        used.add(k);
         RowRec r;
         r.row = (u32)row;
         r.a0 = a_ro[row];

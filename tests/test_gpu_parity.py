@@ -452,3 +452,19 @@ def test_spill_path_skewed_columns_and_fp32(cfg):
         got = dC.to_host()
         assert (got.row_offsets == R.row_offsets).all() and (got.col_ids == R.col_ids).all()
     assert cfg.last_stats()["graph_replays"] > 0
+
+
+def test_more_than_two_million_rows_in_one_class(cfg):
+    """rows(A) > 2^21 switches the scan kernels to 32 rows per thread: 8192 rows per block, here all
+    of one numeric class (the per-class counters of a block once were 12 bits wide)."""
+    m = (1 << 21) + 70001
+    rng = np.random.default_rng(11)
+    c0 = rng.integers(0, m - 1, size=m, dtype=np.int64)
+    c1 = c0 + 1 + rng.integers(0, 3, size=m)
+    c1 = np.minimum(c1, m - 1)
+    c0 = np.minimum(c0, c1 - 1)
+    col = np.stack([c0, c1], axis=1).reshape(-1).astype(np.uint32)
+    ro = (np.arange(m + 1, dtype=np.int64) * 2).astype(np.uint32)
+    val = 0.5 + rng.random(2 * m)
+    A = po.HostCSR(m, m, ro, col, val)
+    check(cfg, A, A, [("num", "g16")])
