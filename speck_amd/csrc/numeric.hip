@@ -282,7 +282,9 @@ constexpr u32 num_group_lds()
     return CAP * ((u32)sizeof(Acc<T>) + 4u) + G::SIZE * (u32)sizeof(Acc<T>) + (words + 3u) / 4u * 16u;
 }
 
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
+// Rows of the class with nnz <= NLO or nnz > NMAX are skipped: a class may be served by two
+// launches with differently sized tables (NUM_B8K below).
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0>
 __device__ __forceinline__ void num_hash_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                               u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
                                               u32 bidx, u32 nblk)
@@ -313,6 +315,10 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         PHASE_BEGIN(cls);
         const RowRec rec = next;  // fetched while the previous row was being processed
         if (idx + stride < count) next = recs[idx + stride];
+        if (rec.nnz <= NLO || rec.nnz > NMAX) {  // the other launch's row (uniform for the group)
+            idx += stride;
+            continue;
+        }
         // table of this row: the smallest power of two >= 1.5 nnz (load <= 2/3), at least one slot
         // per lane; the class limit guarantees it fits (nnz <= 2/3 CAP)
         u32 bits = 32u - (u32)__clz((int)max(rec.nnz + (rec.nnz >> 1), 2u) - 1);
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(THREADS) void num_direct_kernel(ProductSrc<T> src, 
     num_direct_body<T, THREADS>(smem, src, w, c_col, c_val, blockIdx.x, gridDim.x);
 }
 
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0>
 __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                            u32* __restrict__ c_col,
                                                            T* __restrict__ c_val, int cls)
@@ -434,7 +440,8 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, co
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (w.st->capacity_miss) return;
     src.rebase(a_ro);
-    num_hash_body<G, T, CAP, W1, NMAX, MODE, THREADS>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
+    num_hash_body<G, T, CAP, W1, NMAX, MODE, THREADS, NLO>(smem, src, w, c_col, c_val, cls, blockIdx.x,
+                                                           gridDim.x);
 }
 
 template <typename T, u32 WCOLS, int THREADS>
@@ -949,12 +956,12 @@ static void set_dyn_lds(K kernel, u32 bytes)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS>
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0>
 static void launch_num_hash(hipStream_t s, int cls, u32 count, const ProductSrc<T>& A, const u32* B,
                             const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
-    auto k = num_hash_kernel<G, T, CAP, W1, NMAX, MODE, THREADS>;
-    const u32 lds = numeric_lds_bytes_t<T>(cls);
+    auto k = num_hash_kernel<G, T, CAP, W1, NMAX, MODE, THREADS, NLO>;
+    const u32 lds = (THREADS / G::SIZE) * num_group_lds<G, T, CAP, THREADS>();
     set_dyn_lds(k, lds);
     hipLaunchKernelGGL(k, dim3(grid_for(count, lds, THREADS, cu_count, THREADS / G::SIZE)),
                        dim3(THREADS), lds, s, A, B, w, c_col, c_val, cls);
@@ -1021,7 +1028,11 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_B8K:
-            launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512>(
+            // two launches over the class: the rows of the lower half fit a half-size table, whose
+            // workgroups run two per CU (the full table owns 106 of a CU's 160 KiB)
+            launch_num_hash<Block<512>, T, kNumB8KCap / 2, kB8KW1, kNumB8KMaxNnz / 2, SORT_BITMAP, 512>(
+                s, cls, count, A, B, w, c_col, c_val, cu_count);
+            launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KMaxNnz / 2>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_D1: {
