@@ -205,56 +205,57 @@ __device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, const u32* keys, c
     }
     g.sync();
     PHASE_MARK(3);
-    u32* l1 = S;
-    u32* l1pref = S + W1;
-    u32* masks = S;
-    u32* mpref = S + NMAX;
+    // both levels keep {bits, prefix} pairs: a rank lookup is one 8-byte LDS read
+    uint2* l1x = reinterpret_cast<uint2*>(S);
+    uint2* mx = reinterpret_cast<uint2*>(S);
     u32 emitted = 0;
     for (u64 w0 = cmin; w0 <= cmax; w0 += kWindowCols) {
         const u64 left = u64(cmax) - w0 + 1;
         const u32 ncols = left < kWindowCols ? (u32)left : (u32)kWindowCols;
         const u32 nw1 = (((ncols + 31) >> 5) + 31) >> 5;
         const u32 wbase = (u32)w0;
-        for (u32 i = g.lane; i < nw1; i += G::SIZE) l1[i] = 0;
+        for (u32 i = g.lane; i < nw1; i += G::SIZE) l1x[i].x = 0;
         g.sync();
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
             if (j * G::SIZE >= cap_row) continue;
             const u32 d = k[j] - wbase;
-            if (k[j] != kEmptyKey && d < ncols) atomicOr(&l1[d >> 10], 1u << ((d >> 5) & 31));
+            if (k[j] != kEmptyKey && d < ncols) atomicOr(&l1x[d >> 10].x, 1u << ((d >> 5) & 31));
         }
         g.sync();
         PHASE_MARK(4);
-        const u32 nocc = bitmap_prefix(g, l1, l1pref, nw1, scan_scratch);
+        const u32 nocc = bitmap_prefix<G, 2>(g, &l1x[0].x, &l1x[0].y, nw1, scan_scratch);
         PHASE_MARK(5);
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
             if (j * G::SIZE >= cap_row) continue;
             const u32 d = k[j] - wbase;
-            if (k[j] != kEmptyKey && d < ncols)
-                brank[j] = l1pref[d >> 10] + __popc(l1[d >> 10] & ((1u << ((d >> 5) & 31)) - 1u));
+            if (k[j] != kEmptyKey && d < ncols) {
+                const uint2 e = l1x[d >> 10];
+                brank[j] = e.y + __popc(e.x & ((1u << ((d >> 5) & 31)) - 1u));
+            }
         }
         g.sync();  // level-1 arrays are dead from here: the masks alias them
         PHASE_MARK(6);
-        for (u32 i = g.lane; i < nocc; i += G::SIZE) masks[i] = 0;
+        for (u32 i = g.lane; i < nocc; i += G::SIZE) mx[i].x = 0;
         g.sync();
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
             if (j * G::SIZE >= cap_row) continue;
             const u32 d = k[j] - wbase;
-            if (k[j] != kEmptyKey && d < ncols) atomicOr(&masks[brank[j]], 1u << (d & 31));
+            if (k[j] != kEmptyKey && d < ncols) atomicOr(&mx[brank[j]].x, 1u << (d & 31));
         }
         g.sync();
         PHASE_MARK(7);
-        const u32 total = bitmap_prefix(g, masks, mpref, nocc, scan_scratch);
+        const u32 total = bitmap_prefix<G, 2>(g, &mx[0].x, &mx[0].y, nocc, scan_scratch);
         PHASE_MARK(8);
 #pragma unroll
         for (u32 j = 0; j < OWN; ++j) {
             if (j * G::SIZE >= cap_row) continue;
             const u32 d = k[j] - wbase;
             if (k[j] != kEmptyKey && d < ncols) {
-                const u32 r = emitted + mpref[brank[j]] +
-                              __popc(masks[brank[j]] & ((1u << (d & 31)) - 1u));
+                const uint2 e = mx[brank[j]];
+                const u32 r = emitted + e.y + __popc(e.x & ((1u << (d & 31)) - 1u));
                 c_col[base + r] = k[j];
                 c_val[base + r] = (T)v[j];
             }

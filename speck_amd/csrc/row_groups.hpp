@@ -403,19 +403,21 @@ __device__ __forceinline__ void table_accumulate_batch(u32* keys, T* vals, u32 b
 
 // Exclusive prefix of popcounts over bm[0..nwords) into pref[]; returns the total.
 // Every lane owns a contiguous run of words.
-template <class G>
+// STRIDE 2: words and prefixes interleaved ({word, prefix} pairs: bm = base, pref = base + 1), so that a
+// later rank lookup is ONE 8-byte LDS read.
+template <class G, u32 STRIDE = 1>
 __device__ __forceinline__ u32 bitmap_prefix(const G& g, const u32* bm, u32* pref, u32 nwords,
                                              u32* scratch)
 {
     const u32 wpt = (nwords + G::SIZE - 1) / G::SIZE;
     const u32 w_begin = min(g.lane * wpt, nwords), w_end = min(w_begin + wpt, nwords);
     u32 local = 0;
-    for (u32 i = w_begin; i < w_end; ++i) local += __popc(bm[i]);
+    for (u32 i = w_begin; i < w_end; ++i) local += __popc(bm[i * STRIDE]);
     u32 total;
     u32 run = g.inclusive_scan(local, &total, scratch) - local;
     for (u32 i = w_begin; i < w_end; ++i) {
-        pref[i] = run;
-        run += __popc(bm[i]);
+        pref[i * STRIDE] = run;
+        run += __popc(bm[i * STRIDE]);
     }
     g.sync();
     return total;
