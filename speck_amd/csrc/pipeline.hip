@@ -89,8 +89,6 @@ struct speck_config {
     size_t gpool_bytes = 0;
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
-    int time_num_class = -1;  // numeric class bracketed by tev0/tev1 in replayed sequences
-    hipEvent_t tev0 = nullptr, tev1 = nullptr;
     speck_stats last{};
 };
 
@@ -376,10 +374,6 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 5 : (int)NUM_CLASSES, num_mask,
                        kNumLightMask, tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr,
                        [&](hipStream_t ks, int cls) {
-                           // one launch may be bracketed by timing events even inside a captured
-                           // sequence (bench.py: the dominant kernel, timed live in the timed region)
-                           const bool bracket = !tm && cls == c->time_num_class && c->tev0;
-                           if (bracket) (void)hipEventRecord(c->tev0, ks);
                            if (cls == kLightItem) {
                                const u32 big = c->split_light ? (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) : 0u;
                                const u32 lm = num_mask & kNumLightMask;
@@ -392,7 +386,6 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
                                    launch_numeric_light<T>(ks, hint, lm & ~big, Av, Bv, w, c_col, c_val, c->sm);
                            } else
                                launch_numeric<T>(ks, cls, hint[cls], Av, Bv, w, c_col, c_val, c->sm);
-                           if (bracket) (void)hipEventRecord(c->tev1, ks);
                        });
 }
 
@@ -526,15 +519,6 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             if (!c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 ++c->graph_replays;
                 publish_counts(c);
-                if (c->time_num_class >= 0 && c->time_num_class < SPECK_NUM_NUM_BINS && c->tev0) {
-                    float v = 0.f;
-                    if (hipEventElapsedTime(&v, c->tev0, c->tev1) == hipSuccess) {
-                        c->last.num_bin_ms[c->time_num_class] = v;
-                        c->last.kernel_events_valid = 2;
-                    } else {
-                        (void)hipGetLastError();
-                    }
-                }
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -863,14 +847,6 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "merge_light") {
         c->merge_light = value != 0;
         drop_graph(c);
-    }
-    else if (n == "time_num_class") {
-        if (!c->tev0) {
-            HIP_TRY(hipEventCreate(&c->tev0));
-            HIP_TRY(hipEventCreate(&c->tev1));
-        }
-        if (c->time_num_class != (int)value) drop_graph(c);
-        c->time_num_class = (int)value;
     }
     else return SPECK_ERR_INVALID;
     return SPECK_OK;
