@@ -192,7 +192,8 @@ __device__ __forceinline__ void window_owners(const u32* incl, u32* win, u32 cnt
                                               u32 (&own)[kBatch])
 {
     const u32 l = lane_id();
-    reinterpret_cast<uint2*>(win)[l] = make_uint2(0u, 0u);
+#pragma unroll
+    for (u32 i = 0; i < kWinWords / 128; ++i) reinterpret_cast<uint2*>(win)[i * 64 + l] = make_uint2(0u, 0u);
     wave_lds_fence();
     u32 sw = s0, at_end = 0;
     bool again;
@@ -307,7 +308,9 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
             u32* win = m.win;  // kBatch*16 16-bit counters of this group
             const bool mine = g.lane < cnt;
             for (u32 base = 0; base < total; base += kBatch * 16) {
-                reinterpret_cast<uint2*>(win)[g.lane] = make_uint2(0u, 0u);
+#pragma unroll
+                for (u32 i = 0; i < (u32)kBatch / 4; ++i)
+                    reinterpret_cast<uint2*>(win)[i * 16 + g.lane] = make_uint2(0u, 0u);
                 wave_lds_fence();
                 const u32 before = (u32)__popcll(g.ballot(mine && incl <= base));
                 const u32 b = incl - base;  // position where my entry's products end
