@@ -131,12 +131,19 @@ def symbolic(A, B, threads=0):
     return cnt, int(total)
 
 
-def spgemm(A, B, threads=0, with_abs=True):
-    """Full oracle SpGEMM. Returns (HostCSR C, abs_sum or None)."""
+def spgemm(A, B, threads=0, with_abs=True, out=None):
+    """Full oracle SpGEMM. Returns (HostCSR C, abs_sum or None).  `out` = a previous result of the
+    same product: its col_ids / data arrays are reused (the timed baseline must not measure the page
+    faults of fresh output arrays -- the GPU path reuses C as well)."""
     cnt, total = symbolic(A, B, threads)
     if total > 0xFFFFFFFF:
         raise OverflowError("nnz(C) exceeds the u32 row_offsets of the dCSR layout")
     lib().orc_exclusive_scan(cnt, A.rows)
+    if out is not None and out.col_ids.size == total and out.data.dtype == A.data.dtype and not with_abs:
+        lib_fn = lib().orc_numeric_f32 if A.data.dtype == np.float32 else lib().orc_numeric
+        lib_fn(A.rows, B.cols, A.row_offsets, A.col_ids, A.data, B.row_offsets, B.col_ids, B.data, cnt,
+               out.col_ids, out.data, None, threads)
+        return HostCSR(A.rows, B.cols, cnt, out.col_ids, out.data), None
     ci = np.zeros(total, dtype=np.uint32)
     if A.data.dtype == np.float32:
         da = np.zeros(total, dtype=np.float32)

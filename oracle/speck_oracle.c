@@ -167,6 +167,40 @@ static int pick_threads(int threads)
     return threads;
 }
 
+/* Per-thread workspace kept across calls (OpenMP reuses its threads): a call that timed the
+ * allocation and zeroing of cols-sized arrays per thread would measure the allocator, not the
+ * multiply, once there are dozens of threads.  stamp[] never needs clearing: every call uses a fresh
+ * range of stamp values (epoch). */
+typedef struct {
+    uint64_t *stamp;
+    double *acc, *aacc; /* also used as float arrays */
+    uint32_t *stmp;
+    uint64_t cols, epoch;
+} orc_workspace;
+static _Thread_local orc_workspace g_ws;
+
+static orc_workspace *workspace(uint64_t cols, uint64_t rows, uint64_t *epoch)
+{
+    orc_workspace *w = &g_ws;
+    if (cols == 0)
+        cols = 1;
+    if (w->cols < cols) {
+        free(w->stamp);
+        free(w->acc);
+        free(w->aacc);
+        free(w->stmp);
+        w->stamp = (uint64_t *)calloc(cols, sizeof(uint64_t));
+        w->acc = (double *)malloc(cols * sizeof(double));
+        w->aacc = (double *)malloc(cols * sizeof(double));
+        w->stmp = (uint32_t *)malloc(cols * sizeof(uint32_t));
+        w->cols = cols;
+        w->epoch = 0;
+    }
+    *epoch = w->epoch;
+    w->epoch += rows + 1;
+    return w;
+}
+
 uint64_t orc_symbolic(uint64_t a_rows, uint64_t b_cols, const uint32_t *a_row_offsets,
                       const uint32_t *a_col_ids, const uint32_t *b_row_offsets,
                       const uint32_t *b_col_ids, uint32_t *row_nnz, int threads)
@@ -175,17 +209,19 @@ uint64_t orc_symbolic(uint64_t a_rows, uint64_t b_cols, const uint32_t *a_row_of
     int nt = pick_threads(threads);
 #pragma omp parallel num_threads(nt) reduction(+ : total)
     {
-        /* stamp[c] == i+1  <=>  column c already seen in row i */
-        uint64_t *stamp = (uint64_t *)calloc(b_cols ? b_cols : 1, sizeof(uint64_t));
+        /* stamp[c] == epoch+i+1  <=>  column c already seen in row i */
+        uint64_t epoch;
+        uint64_t *stamp = workspace(b_cols, a_rows, &epoch)->stamp;
 #pragma omp for schedule(dynamic, 256)
         for (uint64_t i = 0; i < a_rows; ++i) {
             uint32_t cnt = 0;
+            const uint64_t mark = epoch + i + 1;
             for (uint32_t ia = a_row_offsets[i]; ia < a_row_offsets[i + 1]; ++ia) {
                 uint32_t k = a_col_ids[ia];
                 for (uint32_t ib = b_row_offsets[k]; ib < b_row_offsets[k + 1]; ++ib) {
                     uint32_t c = b_col_ids[ib];
-                    if (stamp[c] != i + 1) {
-                        stamp[c] = i + 1;
+                    if (stamp[c] != mark) {
+                        stamp[c] = mark;
                         ++cnt;
                     }
                 }
@@ -193,7 +229,6 @@ uint64_t orc_symbolic(uint64_t a_rows, uint64_t b_cols, const uint32_t *a_row_of
             row_nnz[i] = cnt;
             total += cnt;
         }
-        free(stamp);
     }
     return total;
 }
@@ -214,22 +249,25 @@ uint64_t orc_exclusive_scan(uint32_t *counts, uint64_t n)
     int nt = pick_threads(threads);                                                            \
     _Pragma("omp parallel num_threads(nt)")                                                    \
     {                                                                                          \
-        uint64_t *stamp = (uint64_t *)calloc(b_cols ? b_cols : 1, sizeof(uint64_t));          \
-        T *acc = (T *)malloc((b_cols ? b_cols : 1) * sizeof(T));                               \
-        T *aacc = (T *)malloc((b_cols ? b_cols : 1) * sizeof(T));                              \
-        uint32_t *stmp = (uint32_t *)malloc((b_cols ? b_cols : 1) * sizeof(uint32_t));         \
+        uint64_t epoch;                                                                        \
+        orc_workspace *ws = workspace(b_cols, a_rows, &epoch);                                 \
+        uint64_t *stamp = ws->stamp;                                                           \
+        T *acc = (T *)ws->acc;                                                                 \
+        T *aacc = (T *)ws->aacc;                                                               \
+        uint32_t *stmp = ws->stmp;                                                             \
         _Pragma("omp for schedule(dynamic, 256)")                                              \
         for (uint64_t i = 0; i < a_rows; ++i) {                                                \
             uint32_t base = c_row_offsets[i];                                                  \
             uint32_t cnt = 0;                                                                  \
+            const uint64_t mark = epoch + i + 1;                                               \
             for (uint32_t ia = a_row_offsets[i]; ia < a_row_offsets[i + 1]; ++ia) {            \
                 uint32_t k = a_col_ids[ia];                                                    \
                 T av = a_data[ia];                                                             \
                 for (uint32_t ib = b_row_offsets[k]; ib < b_row_offsets[k + 1]; ++ib) {        \
                     uint32_t c = b_col_ids[ib];                                                \
                     T p = av * b_data[ib];                                                     \
-                    if (stamp[c] != i + 1) {                                                   \
-                        stamp[c] = i + 1;                                                      \
+                    if (stamp[c] != mark) {                                                    \
+                        stamp[c] = mark;                                                       \
                         c_col_ids[base + cnt++] = c;                                           \
                         acc[c] = p;                                                            \
                         aacc[c] = ABSF(p);                                                     \
@@ -247,10 +285,6 @@ uint64_t orc_exclusive_scan(uint32_t *counts, uint64_t n)
                     c_abs[base + j] = aacc[c];                                                 \
             }                                                                                  \
         }                                                                                      \
-        free(stamp);                                                                           \
-        free(acc);                                                                             \
-        free(aacc);                                                                            \
-        free(stmp);                                                                            \
     }
 
 void orc_numeric(uint64_t a_rows, uint64_t b_cols, const uint32_t *a_row_offsets,

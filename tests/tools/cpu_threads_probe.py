@@ -11,9 +11,9 @@ A = sa.gen_matrix("scircuit", 1.0, 1)
 H = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data)
 P = po.analysis(H, H)["sum_products"]
 for th in (1, 2, 4, 8, 16, 32, 64, 128):
-    po.spgemm(H, H, threads=th, with_abs=False)
+    C, _ = po.spgemm(H, H, threads=th, with_abs=False)
     t = time.perf_counter(); n = 0
     while time.perf_counter() - t < 1.0:
-        po.spgemm(H, H, threads=th, with_abs=False); n += 1
+        po.spgemm(H, H, threads=th, with_abs=False, out=C); n += 1
     dt = (time.perf_counter() - t) / n
     print(th, "threads", round(dt * 1e3, 2), "ms", round(2 * P / dt / 1e9, 3), "GFLOP/s")
