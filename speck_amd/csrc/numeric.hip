@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
         num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
             smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2]);
     else if (b < cg.first[4])
-        num_hash_body<SubWave<64>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
+        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
             smem, src, w, c_col, c_val, NUM_W128, b - cg.first[3], cg.first[4] - cg.first[3]);
     else if (b < cg.first[5])
         num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const 
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
     if (b < cg.first[4])
-        num_hash_body<SubWave<64>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
+        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
             smem, src, w, c_col, c_val, NUM_W128, b - cg.first[3], cg.first[4] - cg.first[3]);
     else if (b < cg.first[5])
         num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
@@ -932,7 +932,7 @@ u32 numeric_lds_bytes_t(int cls)
     switch (cls) {
         case NUM_DIRECT: return num_direct_lds<T, 256>();
         case NUM_G16: return 16 * num_group_lds<SubWave<16>, T, kNumG16Cap, 256>();
-        case NUM_W128: return 4 * num_group_lds<SubWave<64>, T, kNumW128Cap, 256>();
+        case NUM_W128: return 8 * num_group_lds<SubWave<32>, T, kNumW128Cap, 256>();
         case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, 256>();
         case NUM_W1K: return 4 * num_group_lds<SubWave<64>, T, kNumW1KCap, 256>();
         case NUM_B2K: return num_group_lds<Block<256>, T, kNumB2KCap, 256>();
@@ -973,7 +973,7 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
                           const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
     static const int slots[6] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
-    static const u32 rows_per_block[6] = {1, 1, 4, 4, 16, 256};
+    static const u32 rows_per_block[6] = {1, 1, 4, 8, 16, 256};
     u32 lds = 0;
     for (int k = 0; k < 6; ++k)
         if (mask >> slots[k] & 1u) lds = lds > numeric_lds_bytes_t<T>(slots[k]) ? lds : numeric_lds_bytes_t<T>(slots[k]);
@@ -1013,7 +1013,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_W128:
-            launch_num_hash<SubWave<64>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
+            launch_num_hash<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_W512:

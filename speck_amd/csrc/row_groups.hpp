@@ -42,7 +42,7 @@ static __device__ unsigned long long g_phase_clk[kPhaseSlots * kMaxClasses * 16]
 // ---- group policies -------------------------------------------------------------
 template <int L>
 struct SubWave {
-    static_assert(L == 16 || L == 64, "sub-wave width");
+    static_assert(L == 16 || L == 32 || L == 64, "sub-wave width");
     static constexpr int SIZE = L;
     static constexpr bool kIsBlock = false;
     u32 lane;       // index inside the group
@@ -59,6 +59,11 @@ struct SubWave {
         if constexpr (L == 64) {
             v = wave_inclusive_scan(v);
             *total = (u32)__builtin_amdgcn_readlane((int)v, 63);
+        } else if constexpr (L == 32) {
+            v = row16_inclusive_scan(v);
+            v += dpp_move<kDppRowBcast15, 0xA>(0, v);  // rows 1 and 3 take the total of rows 0 and 2
+            // lane 31 of the own 32-lane half: ds_swizzle bit mode, lane' = (lane & 0) | 0x1F
+            *total = (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x1F << 5);
         } else {
             v = row16_inclusive_scan(v);
             // lane 15 of the own 16-lane row: ds_swizzle bit mode, lane' = (lane & 0x10) | 0x0F
@@ -173,7 +178,7 @@ constexpr u32 kWinWords = kWinProducts / 2;  // LDS words per wave
 template <class G>
 constexpr u32 win_words()
 {
-    return G::SIZE >= 64 ? (G::SIZE / 64) * kWinWords : kBatch * 16 / 2;  // 16-lane groups: 64 positions
+    return G::SIZE >= 64 ? (G::SIZE / 64) * kWinWords : kBatch * G::SIZE / 2;  // sub-wave groups: kBatch*SIZE positions
 }
 
 // owner(p), the same for all lanes of the wave (broadcast LDS reads, scalar control flow)
@@ -300,21 +305,22 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
                 base += kWinProducts;
             }
         } else {
-            // 16-lane groups: the same end-count scheme on a window of kBatch*16 products.  The
-            // chunk has at most 16 entries and lane e holds incl[e] in a register, so the ends
-            // need no LDS read and the entries before the window are a ballot.
-            static_assert(G::SIZE == 16, "sub-wave groups are 16 lanes");
+            // 16- and 32-lane groups: the same end-count scheme on a window of kBatch*SIZE products.
+            // The chunk has at most SIZE entries and lane e holds incl[e] in a register, so the
+            // ends need no LDS read and the entries before the window are a ballot.
+            constexpr u32 L = G::SIZE;
+            static_assert(L == 16 || L == 32, "sub-wave groups");
             PHASE_MARK(11);
-            u32* win = m.win;  // kBatch*16 16-bit counters of this group
+            u32* win = m.win;  // kBatch*L 16-bit counters of this group
             const bool mine = g.lane < cnt;
-            for (u32 base = 0; base < total; base += kBatch * 16) {
+            for (u32 base = 0; base < total; base += kBatch * L) {
 #pragma unroll
                 for (u32 i = 0; i < (u32)kBatch / 4; ++i)
-                    reinterpret_cast<uint2*>(win)[i * 16 + g.lane] = make_uint2(0u, 0u);
+                    reinterpret_cast<uint2*>(win)[i * L + g.lane] = make_uint2(0u, 0u);
                 wave_lds_fence();
                 const u32 before = (u32)__popcll(g.ballot(mine && incl <= base));
                 const u32 b = incl - base;  // position where my entry's products end
-                if (mine && incl > base && b < kBatch * 16)
+                if (mine && incl > base && b < kBatch * L)
                     atomicAdd(&win[b >> 1], 1u << ((b & 1u) * 16u));
                 wave_lds_fence();
                 u32 c[kBatch];
@@ -322,11 +328,12 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
                 u32 nvalid = 0, carry = before;
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
-                    const u32 pos = u * 16 + g.lane;
+                    const u32 pos = u * L + g.lane;
                     const u32 x = (win[pos >> 1] >> ((pos & 1u) * 16u)) & 0xFFFFu;
-                    const u32 inc = row16_inclusive_scan(x);
+                    u32 tot;
+                    const u32 inc = g.inclusive_scan(x, &tot, nullptr);
                     const u32 own = carry + inc;
-                    carry += (u32)__builtin_amdgcn_ds_swizzle((int)inc, 0x10 | (0x0F << 5));
+                    carry += tot;
                     const u32 pu = base + pos;
                     c[u] = kEmptyKey;
                     bv[u] = T(0);
