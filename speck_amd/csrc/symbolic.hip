@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     else if (b < cg.first[3])
         sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2]);
     else if (b < cg.first[4])
-        sym_hash_body<SubWave<64>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3]);
+        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3]);
     else
         sym_hash_body<SubWave<16>, kSymG16Cap, 256>(smem, src, w, counts, SYM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
 }
@@ -152,7 +152,7 @@ u32 symbolic_lds_bytes(int cls)
 {
     switch (cls) {
         case SYM_G16: return 16 * sym_group_lds<SubWave<16>, kSymG16Cap, 256>();
-        case SYM_W256: return 4 * sym_group_lds<SubWave<64>, kSymW256Cap, 256>();
+        case SYM_W256: return 8 * sym_group_lds<SubWave<32>, kSymW256Cap, 256>();
         case SYM_W1K: return 4 * sym_group_lds<SubWave<64>, kSymW1KCap, 256>();
         case SYM_B4K: return sym_group_lds<Block<256>, kSymB4KCap, 256>();
         case SYM_B16K: return sym_group_lds<Block<512>, kSymB16KCap, 512>();
@@ -214,7 +214,7 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
                            u32* counts, int cu_count)
 {
     static const int slots[5] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_G16};
-    static const u32 rows_per_block[5] = {1, 1, 4, 4, 16};
+    static const u32 rows_per_block[5] = {1, 1, 4, 8, 16};
     u32 lds = 0;
     for (int k = 0; k < 5; ++k)
         if (mask >> slots[k] & 1u) lds = lds > symbolic_lds_bytes(slots[k]) ? lds : symbolic_lds_bytes(slots[k]);
@@ -238,7 +238,7 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
         case SYM_G16: launch_sym_hash<SubWave<16>, kSymG16Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
-        case SYM_W256: launch_sym_hash<SubWave<64>, kSymW256Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
+        case SYM_W256: launch_sym_hash<SubWave<32>, kSymW256Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_W1K: launch_sym_hash<SubWave<64>, kSymW1KCap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_B4K: launch_sym_hash<Block<256>, kSymB4KCap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_B16K: launch_sym_hash<Block<512>, kSymB16KCap, 512>(s, cls, count, A, B, w, counts, cu_count); break;
