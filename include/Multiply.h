@@ -23,12 +23,14 @@ void MultiplyspECKImplementation(const dCSR<DataType>& A, const dCSR<DataType>& 
     speck_timings t = timings.to_c();
     const int rc = sizeof(DataType) == 8 ? speck_multiply_f64(config.handle, &a, &b, &c, &t)
                                          : speck_multiply_f32(config.handle, &a, &b, &c, &t);
+    // adopt on every path: on a guard failure `c` comes back unmodified; a failure after C was
+    // re-allocated leaves `c` owning the NEW buffers (the old ones are already freed)
+    matOut.adopt(c);
     if (rc != SPECK_OK) {
-        // the reference printf()s and returns, leaving matOut untouched (Multiply.cu:57-97)
+        // the reference printf()s and returns (Multiply.cu:57-97)
         std::printf("ERROR: %s\n", speck_status_string(rc));
         return;
     }
-    matOut.adopt(c);
     timings.from_c(t);
 }
 

@@ -1,5 +1,6 @@
 // Timings.h -- per-stage milliseconds of the reference (include/Timings.h:4-49); same field names,
-// same operators.  Layout-compatible with speck_timings of the C ABI.
+// same operators.  Converted to / from the C ABI's speck_timings by to_c() / from_c() (the flags are
+// `bool` here as upstream, int32_t there: the two structs are NOT layout-compatible).
 #pragma once
 #include "speck_c_api.h"
 

@@ -19,7 +19,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
-                 DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull);
+                 DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u);
 
 // Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
 // and two product pools (expanded by column bucket; reduced and sorted).

@@ -298,7 +298,7 @@ struct Timing {
 int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
                   const Scratch& sc, u32* c_ro, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
                   bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr,
-                  DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull)
+                  DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u)
 {
     const u32 m = (u32)A->rows;
     ClassifyParams cp = c->cp;
@@ -349,7 +349,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     }
     launch_scan(s, c_ro, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                 classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
-                host_mirror, expect_g);
+                host_mirror, expect_g, expect_g_rows);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -440,7 +440,7 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
                            c->last_num_mask, true, nullptr, c->last_sym_counts, c->h_stats_dev,
-                           c->last_g_products);
+                           c->last_g_products, c->last_num_counts[NUM_G]);
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
                              c->last_num_mask, c->last_num_counts, nullptr);
@@ -567,42 +567,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         return finish_complete();
     }
 
-    // ALLOC C: only when nnz changed (Multiply.cu:589-602)
-    void* c_val = C->data;
-    u32* c_col = C->col_ids;
-    if (C->nnz != nnz_c || !c_val || !c_col) {
-        void* nv = nullptr;
-        u32* nc = nullptr;
-        hipError_t e1 = hipMalloc(&nv, std::max<size_t>(nnz_c, 1) * sizeof(T));
-        hipError_t e2 = e1 == hipSuccess
-                            ? hipMalloc(reinterpret_cast<void**>(&nc), std::max<size_t>(nnz_c, 1) * 4)
-                            : e1;
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            if (nv) (void)hipFree(nv);
-            (void)hipGetLastError();
-            return fail(SPECK_ERR_OOM);
-        }
-        if (C->data) (void)hipFree(C->data);
-        if (C->col_ids) (void)hipFree(C->col_ids);
-        if (C->row_offsets && C->row_offsets != c_ro) (void)hipFree(C->row_offsets);
-        c_val = nv;
-        c_col = nc;
-    } else if (C->row_offsets && C->row_offsets != c_ro) {
-        (void)hipFree(C->row_offsets);
-    }
-    // publish (Multiply.cu:1116-1121); from here C owns c_ro
-    C->rows = A->rows;
-    C->cols = B->cols;
-    C->nnz = nnz_c;
-    C->data = c_val;
-    C->col_ids = c_col;
-    C->row_offsets = c_ro;
-    own_ro = false;
-    t->allocC = st.lap();
-    t->loadBalanceNumeric = 0.f;
-    t->globalMapsNumeric = 0.f;
-
-    // NUMERIC (Multiply.cu:835-1014) + in-kernel sort (Multiply.cu:1028-1043)
+    // Spill pool of the NUM_G rows FIRST: every failure up to here leaves C untouched (header contract).
     const u32 num_mask = mask_of(c->h_stats->num.count, NUM_CLASSES);
     if (num_mask >> NUM_G & 1u) {
         // global-memory spill buffers of the heavy rows (role of the reference's global maps,
@@ -654,8 +619,44 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             drop_graph(c);  // a captured sequence holds the old layout
         c->spill = sp;
     }
-    c->last_g_products = c->h_stats->g_products;
     t->globalMapsNumeric = st.lap();
+    // ALLOC C: only when nnz changed (Multiply.cu:589-602)
+    void* c_val = C->data;
+    u32* c_col = C->col_ids;
+    if (C->nnz != nnz_c || !c_val || !c_col) {
+        void* nv = nullptr;
+        u32* nc = nullptr;
+        hipError_t e1 = hipMalloc(&nv, std::max<size_t>(nnz_c, 1) * sizeof(T));
+        hipError_t e2 = e1 == hipSuccess
+                            ? hipMalloc(reinterpret_cast<void**>(&nc), std::max<size_t>(nnz_c, 1) * 4)
+                            : e1;
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            if (nv) (void)hipFree(nv);
+            (void)hipGetLastError();
+            return fail(SPECK_ERR_OOM);
+        }
+        if (C->data) (void)hipFree(C->data);
+        if (C->col_ids) (void)hipFree(C->col_ids);
+        if (C->row_offsets && C->row_offsets != c_ro) (void)hipFree(C->row_offsets);
+        c_val = nv;
+        c_col = nc;
+    } else if (C->row_offsets && C->row_offsets != c_ro) {
+        (void)hipFree(C->row_offsets);
+    }
+    // publish (Multiply.cu:1116-1121); from here C owns c_ro
+    C->rows = A->rows;
+    C->cols = B->cols;
+    C->nnz = nnz_c;
+    C->data = c_val;
+    C->col_ids = c_col;
+    C->row_offsets = c_ro;
+    own_ro = false;
+    t->allocC = st.lap();
+    t->loadBalanceNumeric = 0.f;
+
+
+    // NUMERIC (Multiply.cu:835-1014) + in-kernel sort (Multiply.cu:1028-1043)
+    c->last_g_products = c->h_stats->g_products;
     rc = enqueue_back<T>(c, s, A, B, sc, c_ro, c_col, static_cast<T*>(c_val), num_mask,
                          c->h_stats->num.count, &tm);
     if (rc != SPECK_OK) return rc;
@@ -956,6 +957,7 @@ int speck_partition_rows(speck_config* c, const speck_dcsr* A, const speck_dcsr*
     if (!c || !h_bounds || parts <= 0) return SPECK_ERR_INVALID;
     int rc = check_inputs(A, B);
     if (rc != SPECK_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
     const u32 m = (u32)A->rows;
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     const BlockPartial* __restrict__ parts, u32 nb, const u8* __restrict__ num_cls,
     const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
     const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
-    RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz, u64 expect_g,
+    RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz, u64 expect_g, u32 expect_g_rows,
     DeviceStats* __restrict__ host_mirror)
 {
     constexpr int NW = kScanThreads / 64;
@@ -552,6 +552,8 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
         // ... and so was the spill pool of the NUM_G rows
         st->g_products = s_fold.g_total;
         if (expect_g != ~0ull && s_fold.g_total != expect_g) st->capacity_miss = 1;
+        // ... and its per-row plan / bucket arrays for exactly that many NUM_G rows
+        if (expect_g_rows != ~0u && s_fold.total[NUM_G] != expect_g_rows) st->capacity_miss = 1;
         publish_bins(st->num, s_fold, s_bytes, num_cls ? cp.num_allowed : 0xFFFFFFFFu, st);
         // everything the host needs is final here: write it straight into pinned host memory
         // instead of a copy node at the end of the launch sequence
@@ -667,7 +669,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
-                 DeviceStats* host_mirror, u64 expect_g)
+                 DeviceStats* host_mirror, u64 expect_g, u32 expect_g_rows)
 {
     const u32 tiles = scan_tiles(m);
     auto go = [&](auto items) {
@@ -677,7 +679,7 @@ void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const
                            partials, cp, vsize);
         hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts_inout, m, st,
                            (const BlockPartial*)partials, tiles, (const u8*)num_cls, a_ro, row_ops,
-                           row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, host_mirror);
+                           row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, expect_g_rows, host_mirror);
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;

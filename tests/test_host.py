@@ -64,6 +64,48 @@ def test_standins_are_valid_sorted_csr(kind, scale):
     assert (np.abs(A.data) >= 0.5).all() and (np.abs(A.data) < 1.5).all() and (A.data < 0).any()
 
 
+# the SuiteSparse originals are not available offline, so the stand-ins
+# are fitted to their n, nnz(A), P and nnz(C) -- in particular to the compression P / nnz(C) that
+# decides how much a hash SpGEMM accumulates
+STANDIN_TARGETS = {
+    "scircuit": dict(n=170998, nnzA=958936, P=8.68e6, nnzC=5.22e6),
+    "webbase": dict(n=1000005, nnzA=3105536, P=69.5e6, nnzC=51.1e6),
+    "mac_econ": dict(n=206500, nnzA=1273389, P=7.56e6, nnzC=6.70e6),
+    "cant": dict(n=62451, nnzA=4007383, P=269.5e6, nnzC=17.4e6),
+}
+
+
+@pytest.mark.parametrize("kind", sorted(STANDIN_TARGETS))
+def test_standins_match_the_suitesparse_figures_within_5_percent(kind):
+    want = STANDIN_TARGETS[kind]
+    A = speck_amd.gen_matrix(kind, 1.0, 1, signed=True)     # bench.py's seed
+    H = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data)
+    P = po.analysis(H, H)["sum_products"]
+    _, nnzc = po.symbolic(H, H)
+    assert A.rows == want["n"]
+    assert abs(A.nnz / want["nnzA"] - 1) < 0.05
+    assert abs(P / want["P"] - 1) < 0.05
+    assert abs(nnzc / want["nnzC"] - 1) < 0.05
+    assert abs((P / nnzc) / (want["P"] / want["nnzC"]) - 1) < 0.05
+
+
+def test_corrupt_hicsr_is_rejected_not_thrown(tmp_path):
+    A = speck_amd.gen_matrix("mac_econ", 0.002, 3, signed=True)
+    good = str(tmp_path / "g.hicsr")
+    speck_amd.store_hicsr(A, good)
+    raw = bytearray(open(good, "rb").read())
+    cases = {}
+    b = bytearray(raw); b[72:80] = (1 << 60).to_bytes(8, "little"); cases["huge_nnz"] = b      # num_non_zeroes
+    cases["truncated"] = raw[:len(raw) - 8]
+    b = bytearray(raw); b[-4:] = (7).to_bytes(4, "little"); cases["bad_last_offset"] = b
+    b = bytearray(raw); off = 96 + A.nnz * 8; b[off:off + 4] = (0xFFFFFFF0).to_bytes(4, "little"); cases["col_oob"] = b
+    for name, data in cases.items():
+        path = str(tmp_path / (name + ".hicsr"))
+        open(path, "wb").write(bytes(data))
+        with pytest.raises(speck_amd.SpeckError):
+            speck_amd.load_hicsr(path)
+
+
 def test_mtx_reader_matches_reference_loader():
     meta = json.load(open(os.path.join(G, "formats.json")))
     for name, m in meta.items():
