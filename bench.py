@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- SpGEMM GFLOP/s (2 * intermediate products / s) for A*A, the metric of BASELINE.json.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload scircuit|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload scircuit|...] [--scaling weak|strong]
 
 One "step" = one complete MultiplyspECK call (analysis -> binning -> symbolic -> scan ->
 numeric, output matrix reused across steps exactly like the reference's benchmark loop,
-source/Executor.cpp:43-72) with A and B already resident in HBM.  For N > 1 (launched by
-torch.distributed.run, one rank per GPU) rows of A are sharded by the analysis pass'
-product counts, B is replicated, and every step has ONE exchange: the gatherv of the C shards
-to rank 0 over RCCL (speck_amd/sharding.py).  The exchange of step k is posted when its
-multiply ends and runs while step k+1 multiplies (two output matrices alternate; the timed
-region ends only when the last exchange has completed on every rank).  Weak scaling: the
-matrix has N x the rows of the 1-GPU workload, so per-GPU work stays fixed.
+source/Executor.cpp:43-72) with A and B already resident in HBM.
 
-SuiteSparse files are not available offline: the workload is the structure-matched
-synthetic stand-in of SURVEY.md 8d ("scircuit" = BASELINE.json configs[1]); a real .mtx is
-used instead when --mtx points at one.
+N > 1 (launched by torch.distributed.run, one rank per GPU): rows of A are sharded by the
+analysis pass' product counts, B is replicated, and every step has ONE exchange: the gatherv of
+the C shards to rank 0 over RCCL (speck_amd/sharding.py).  The exchange of step k is posted
+when its multiply ends and runs while step k+1 multiplies (two output matrices alternate; the
+timed region ends only when the last exchange has completed on every rank).
+  --scaling weak   (default) the matrix has N x the rows of the 1-GPU workload: per-GPU work fixed
+  --scaling strong the SAME matrix at every N (BASELINE.json configs[4]: nlpkkt160 at 1/2/4/8)
+`value` always includes the exchange; `multiply_only` is the same K steps with C left row-sharded.
+Unless --no-config5 is given the line also carries `config5`: a short strong-scaling measurement
+of the nlpkkt160 stand-in at this N (value with the exchange + multiply_only), so that the
+driver's `--gpus 1,2,4,8` sweep yields that curve without extra flags.
+
+Inputs: $SPECK_MTX_DIR/<name>.mtx (scircuit, webbase-1M, mac_econ_fwd500, cant, nlpkkt160) is used
+when present ("data": "suitesparse"); SuiteSparse files do not exist offline, so the default is the
+stand-in of SURVEY.md 8d fitted to the original's n / nnz / P / nnz(C) ("data": "synthetic").
 """
 import argparse
 import json
@@ -35,6 +41,11 @@ from speck_amd.api import NUM_CLASS_NAMES  # noqa: E402
 from speck_amd.sharding import GatherPlan  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SUITESPARSE_FILES = {"scircuit": "scircuit", "webbase": "webbase-1M", "mac_econ": "mac_econ_fwd500",
+                     "cant": "cant", "nlpkkt": "nlpkkt160"}
+# numeric launches as bench.py names them -> key in profiles/traffic.json (scripts/make_traffic.py)
+TRAFFIC_KEYS = {"light": "num_light", "tiny": "num_tiny", "block8k": "num_block8k", "dense16k": "num_dense16k",
+                "global": "num_global", "wave1k": "num_wave1k"}
 
 
 class _DevArray:
@@ -53,241 +64,329 @@ def shard_tensors(dC):
     return ro, col, val
 
 
+def find_suitesparse(workload):
+    """$SPECK_MTX_DIR/<name>.mtx or $SPECK_MTX_DIR/<name>/<name>.mtx (the layout of the collection's tarballs)."""
+    d, name = os.environ.get("SPECK_MTX_DIR"), SUITESPARSE_FILES.get(workload)
+    if not d or not name:
+        return None
+    for p in (os.path.join(d, name + ".mtx"), os.path.join(d, name, name + ".mtx")):
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def load_workload(workload, scale, seed, mtx=None):
+    path = mtx or find_suitesparse(workload)
+    if path:
+        return sa.load_matrix(path, write_cache=False), "suitesparse", os.path.basename(path)
+    A = sa.gen_matrix(workload, scale, seed, signed=True)
+    return A, "synthetic", f"{workload}-like A*A (SURVEY 8d stand-in, fitted to n/nnz/P/nnzC)"
+
+
+class Env:
+    """Process-wide state: ranks, device, options."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # plumbing check of the N > 1 path on a box with fewer GPUs than ranks: every rank on GPU 0,
+        # gloo instead of RCCL (the exchange is staged through host memory) -- never a measurement
+        self.shared_gpu = os.environ.get("SPECK_BENCH_SHARED_GPU") == "1"
+        if self.shared_gpu:
+            self.local_rank = 0
+        if self.world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(self.local_rank)
+            if self.shared_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+        else:
+            torch.cuda.set_device(0)
+        assert self.world == args.gpus or self.world == 1, "launch with torch.distributed.run for --gpus > 1"
+        self.dev = torch.device("cuda", self.local_rank)
+        self.opts = [o.split("=") for o in args.opt]
+
+    def new_config(self):
+        cfg = sa.spECKConfig.initialize(self.local_rank)
+        for name, value in self.opts:
+            cfg.set_option(name, int(value))
+        return cfg
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, *ints):
+        if self.world == 1:
+            return ints
+        t = torch.tensor(list(ints), dtype=torch.int64, device=self.dev)
+        dist.all_reduce(t)
+        return tuple(int(x) for x in t.tolist())
+
+
+class Job:
+    """A (resident in HBM) x A on this rank's row shard, with the optional pipelined gatherv."""
+
+    def __init__(self, env, A, gather):
+        self.env, self.A = env, A
+        dev = env.dev
+        self.t_ro = torch.from_numpy(A.row_offsets.view(np.int32)).to(dev)
+        self.t_col = torch.from_numpy(A.col_ids.view(np.int32)).to(dev)
+        self.t_val = torch.from_numpy(A.data).to(dev)
+        self.dA = sa.dCSR.from_device(A.rows, A.cols, A.nnz, self.t_ro.data_ptr(), self.t_col.data_ptr(),
+                                      self.t_val.data_ptr(), keep=(self.t_ro, self.t_col, self.t_val),
+                                      host_row_offsets=A.row_offsets)
+        self.cfg = env.new_config()
+        if env.world > 1:
+            bounds = sa.partition_rows(self.dA, self.dA, self.cfg, env.world)
+            self.mine = self.dA.row_view(bounds[env.rank], bounds[env.rank + 1])
+        else:
+            self.mine = self.dA
+        self.gather = gather and env.world > 1
+        # N > 1: two output matrices (each with its own config: a captured launch sequence is tied to
+        # the buffers it writes) alternate, so that a shard can be sent while the next one is computed
+        self.slots = [(self.cfg, sa.dCSR())]
+        if self.gather:
+            self.slots.append((env.new_config(), sa.dCSR()))
+        self.plan = None
+        self.n_step = 0
+
+    def step(self, exchange=True):
+        slot = self.n_step % len(self.slots)
+        self.n_step += 1
+        scfg, sC = self.slots[slot]
+        if self.plan is not None:
+            self.plan.wait(slot)  # the exchange that still reads this slot's output matrix
+        sa.MultiplyspECK(self.mine, self.dA, sC, scfg)  # returns with C complete in HBM
+        if self.gather and exchange:
+            ro, col, val = shard_tensors(sC)
+            if self.plan is None:
+                self.plan = GatherPlan(sC.rows, sC.nnz, col.dtype, val.dtype, self.env.dev, root=0,
+                                       slots=len(self.slots), stage_on_host=self.env.shared_gpu)
+            self.plan.start(slot, ro[1:] - ro[:-1], col, val)
+
+    def drain(self):
+        if self.plan is not None:
+            self.plan.wait_all()
+
+    def barrier(self):
+        self.drain()
+        self.env.barrier()
+
+    def timed(self, steps, exchange=True):
+        """K steps between barriers; MAX over ranks, seconds."""
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(exchange)
+        self.barrier()
+        return self.env.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        self.drain()
+        for scfg, _ in self.slots:
+            scfg.cleanup()
+
+
+def profile_prepass(job, split, merged, prof_steps=5):
+    """Untimed eager steps with HIP events around every launch, each recorded on the stream the
+    launch runs on: algorithmic bytes per class, per-launch / per-phase ms."""
+    cfg = job.cfg
+    cfg.profile_kernels(1)
+    cfg.set_option("collect_bytes", 1)   # per-class algorithmic bytes: one call is enough
+    job.step()
+    torch.cuda.synchronize()
+    st = cfg.last_stats()
+    cfg.set_option("collect_bytes", 0)
+    # the 256-thread numeric classes run as TWO launches: "light" (num_light_kernel: the big-LDS
+    # classes) and "tiny" (num_tiny_kernel); the other classes launch separately
+    LIGHT, TINY = ("dense4k", "block2k", "wave512"), ("wave128", "g16", "direct")
+    if not split:
+        LIGHT, TINY = LIGHT + TINY, ()
+    kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny"]}
+    sym_ms = num_ms = 0.0
+    for _ in range(prof_steps):
+        job.step()
+        s = cfg.last_stats()
+        for k in NUM_CLASS_NAMES:
+            kernel_ms[k] += s["num_bin_ms"][k] / prof_steps
+        kernel_ms["light"] += s["num_light_ms"] / prof_steps
+        kernel_ms["tiny"] += s["num_tiny_ms"] / prof_steps
+        sym_ms += (s["analysis_ms"] + s["scan_ms"] + s["sym_phase_ms"]) / prof_steps
+        num_ms += s["num_phase_ms"] / prof_steps
+    kernel_bytes = dict(st["num_bin_bytes"])
+    if merged:
+        kernel_bytes["light"] = sum(kernel_bytes.pop(k) for k in LIGHT)
+        kernel_bytes["tiny"] = sum(kernel_bytes.pop(k) for k in TINY)
+    cfg.profile_kernels(0)
+    st["num_bin_bytes"] = kernel_bytes
+    return st, kernel_ms, sym_ms, num_ms
+
+
+def roofline_block(workload, st, kernel_ms, num_ms):
+    """Every numeric launch with its algorithmic bytes, duration and fraction of the HBM peak; the
+    headline `kernel` is the launch with the LONGEST duration (it bounds the phase), `largest` the one
+    that moves the most algorithmic bytes."""
+    launches = []
+    for name, b in st["num_bin_bytes"].items():
+        ms = kernel_ms.get(name, 0.0)
+        if b <= 0 or ms <= 0:
+            continue
+        gbs = b / (ms * 1e-3) / 1e9
+        launches.append({"name": name, "bytes": int(b), "ms": round(ms, 5), "GBps": round(gbs, 1),
+                         "frac": round(gbs / HBM_PEAK_GBS, 4)})
+    launches.sort(key=lambda x: -x["ms"])
+    if not launches:
+        return None
+    traffic_tab, tsrc = {}, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic_tab = json.load(open(tpath))
+        tsrc = traffic_tab.get("_source")
+    dom, big = launches[0], max(launches, key=lambda x: x["bytes"])
+    traffic = traffic_tab.get(f"{workload}:{TRAFFIC_KEYS.get(dom['name'], 'num_' + dom['name'])}")
+    total_bytes = sum(x["bytes"] for x in launches)
+    return {
+        "bound": "hbm", "kernel": f"numeric:{dom['name']}", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
+        "traffic_source": (tsrc or "profiles/traffic.json") + " (separate rocprofv3 --pmc passes of the same "
+                          "command, (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch; not measured in this run)"
+        if traffic is not None else None,
+        "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": dom["ms"],
+        "selected_by": "longest numeric launch (HIP events on the launch's own stream)",
+        "timed_with": "HIP events, profiled pre-pass (eager) of the same process",
+        "largest": {"kernel": f"numeric:{big['name']}", "bytes": big["bytes"], "ms": big["ms"], "frac": big["frac"]},
+        "numeric_phase_frac": round(total_bytes / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+        "launches": launches,
+    }
+
+
+def measure(env, A, steps, warmup, gather, profile):
+    """Returns (result dict on every rank)."""
+    job = Job(env, A, gather)
+    out = {}
+    if profile:
+        merged = not any(n == "merge_light" and v == "0" for n, v in env.opts)
+        split = not any(n == "split_light" and v == "0" for n, v in env.opts)
+        st, kernel_ms, sym_ms, num_ms = profile_prepass(job, split, merged)
+        out.update(st=st, kernel_ms=kernel_ms, sym_ms=sym_ms, num_ms=num_ms)
+    else:
+        job.step()
+        out["st"] = job.cfg.last_stats()
+    P_local, nnzc_local = out["st"]["sum_products"], out["st"]["nnz_c"]
+    for _ in range(max(warmup, 2 * len(job.slots) + 2)):  # every slot reaches its replayed sequence
+        job.step()
+    elapsed = job.timed(steps)
+    out["replays"] = job.cfg.last_stats()["graph_replays"]
+    out["P"], out["nnzC"] = env.sum_over_ranks(P_local, nnzc_local)
+    out["elapsed"] = elapsed
+    out["ms_per_step"] = elapsed * 1e3 / steps
+    out["gflops"] = 2.0 * out["P"] / (elapsed / steps) / 1e9
+    # N > 1, reported next to `value` (never instead of it): the same K steps without the exchange,
+    # i.e. what the row-sharded multiply alone sustains while C stays distributed like A
+    out["multiply_only"] = None
+    if job.gather:
+        e2 = job.timed(steps, exchange=False)
+        out["multiply_only"] = {"value": round(2.0 * out["P"] / (e2 / steps) / 1e9, 3), "unit": "GFLOP/s",
+                                "ms_per_step": round(e2 * 1e3 / steps, 4),
+                                "note": "same steps without the gatherv (C left row-sharded); not the job metric"}
+    job.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="scircuit")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mtx", default=None, help="real MatrixMarket file instead of the stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gatherv exchange")
+    ap.add_argument("--no-config5", action="store_true", help="skip the nlpkkt160 strong-scaling leg")
+    ap.add_argument("--config5-scale", type=float, default=1.0)
+    ap.add_argument("--config5-steps", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (tuning)")
     args = ap.parse_args()
+    env = Env(args)
+    n_gpus, rank = env.world, env.rank
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # plumbing check of the N > 1 path on a box with fewer GPUs than ranks: every rank on GPU 0,
-    # gloo instead of RCCL (the exchange is staged through host memory) -- never a measurement
-    shared_gpu = os.environ.get("SPECK_BENCH_SHARED_GPU") == "1"
-    if shared_gpu:
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        if shared_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    n_gpus = world
-    assert n_gpus == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-
-    # ---- workload (same on every rank: deterministic generator, B replicated)
-    if args.mtx:
-        A = sa.load_matrix(args.mtx, write_cache=False)
-        data_label, wl_name = "suitesparse", os.path.basename(args.mtx)
-    else:
-        A = sa.gen_matrix(args.workload, args.scale * n_gpus, args.seed, signed=True)
-        data_label, wl_name = "synthetic", f"{args.workload}-like A*A (SURVEY 8d stand-in)"
+    # ---- workload (same on every rank: deterministic generator / same file, B replicated)
+    scale = args.scale * (n_gpus if args.scaling == "weak" else 1)
+    A, data_label, wl_name = load_workload(args.workload, scale, args.seed, args.mtx)
+    if data_label == "suitesparse" and args.scaling == "weak" and n_gpus > 1:
+        args.scaling = "strong"  # a file has one size
     assert A.rows == A.cols, "A*A needs a square matrix (use the transpose for rectangular inputs)"
-    dev = torch.device("cuda", local_rank)
-    t_ro = torch.from_numpy(A.row_offsets.view(np.int32)).to(dev)
-    t_col = torch.from_numpy(A.col_ids.view(np.int32)).to(dev)
-    t_val = torch.from_numpy(A.data).to(dev)
-    dA = sa.dCSR.from_device(A.rows, A.cols, A.nnz, t_ro.data_ptr(), t_col.data_ptr(), t_val.data_ptr(),
-                             keep=(t_ro, t_col, t_val), host_row_offsets=A.row_offsets)
-    cfg = sa.spECKConfig.initialize(local_rank)
-    for o in args.opt:
-        name, value = o.split("=")
-        cfg.set_option(name, int(value))
+    res = measure(env, A, args.steps, args.warmup, gather=not args.no_gather, profile=True)
 
-    if n_gpus > 1:
-        bounds = sa.partition_rows(dA, dA, cfg, n_gpus)
-        mine = dA.row_view(bounds[rank], bounds[rank + 1])
-    else:
-        bounds = [0, A.rows]
-        mine = dA
-    dC = sa.dCSR()
-    gather = n_gpus > 1 and not args.no_gather
-    # N > 1: two output matrices (each with its own config: a captured launch sequence is tied to
-    # the buffers it writes) alternate, so that a shard can be sent while the next one is computed
-    slots = [(cfg, dC)]
-    if gather:
-        cfg2 = sa.spECKConfig.initialize(local_rank)
-        for o in args.opt:
-            name, value = o.split("=")
-            cfg2.set_option(name, int(value))
-        slots.append((cfg2, sa.dCSR()))
-    plan = None
-    n_step = 0
-
-    def step():
-        nonlocal plan, n_step
-        slot = n_step % len(slots)
-        n_step += 1
-        scfg, sC = slots[slot]
-        if plan is not None:
-            plan.wait(slot)  # the exchange that still reads this slot's output matrix
-        sa.MultiplyspECK(mine, dA, sC, scfg)  # returns with C complete in HBM
-        if gather:
-            ro, col, val = shard_tensors(sC)
-            if plan is None:
-                plan = GatherPlan(sC.rows, sC.nnz, col.dtype, val.dtype, dev, root=0, slots=len(slots),
-                                  stage_on_host=shared_gpu)
-            plan.start(slot, ro[1:] - ro[:-1], col, val)
-
-    def drain():
-        if plan is not None:
-            plan.wait_all()
-
-    # ---- pre-pass (untimed, eager path with per-kernel HIP events on each kernel's own stream):
-    #      algorithmic bytes per class, per-class / per-phase ms, the dominant numeric kernel
-    cfg.profile_kernels(1)
-    cfg.set_option("collect_bytes", 1)   # per-class algorithmic bytes: one call is enough
-    step()
-    torch.cuda.synchronize()
-    st = cfg.last_stats()
-    cfg.set_option("collect_bytes", 0)
-    prof_steps = 5
-    # the 256-thread numeric classes run as TWO back-to-back launches: "light" (num_light_kernel: the
-    # big-LDS classes) and "tiny" (num_tiny_kernel); the other classes launch separately
-    LIGHT = ("dense4k", "block2k", "wave512")
-    TINY = ("wave128", "g16", "direct")
-    merged = any(o.startswith("merge_light=0") for o in args.opt) is False
-    split = any(o.startswith("split_light=0") for o in args.opt) is False
-    if not split:
-        LIGHT, TINY = LIGHT + TINY, ()
-    kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny"]}
-    sym_ms = num_ms = 0.0
-    for _ in range(prof_steps):
-        step()
-        s = cfg.last_stats()
-        for k in NUM_CLASS_NAMES:
-            kernel_ms[k] += s["num_bin_ms"][k] / prof_steps
-        kernel_ms["light"] += s["num_light_ms"] / prof_steps
-        kernel_ms["tiny"] += s["num_tiny_ms"] / prof_steps
-        sym_ms += (s["analysis_ms"] + s["scan_ms"] +
-                   max(max(s["sym_bin_ms"].values()), s["sym_light_ms"] + s["sym_tiny_ms"])) / prof_steps
-        num_ms += max(max(s["num_bin_ms"].values()), s["num_light_ms"] + s["num_tiny_ms"]) / prof_steps
-    P_local, nnzc_local = st["sum_products"], st["nnz_c"]
-    kernel_bytes = dict(st["num_bin_bytes"])
-    if merged:
-        kernel_bytes["light"] = sum(kernel_bytes.pop(k) for k in LIGHT)
-        kernel_bytes["tiny"] = sum(kernel_bytes.pop(k) for k in TINY)
-    # dominant kernel = the numeric launch that moves the most algorithmic bytes (under
-    # concurrency a starved small launch can span the whole phase, so "longest" would mislead)
-    dominant = max(kernel_bytes, key=lambda k: kernel_bytes[k])
-    st["num_bin_bytes"] = kernel_bytes
-    cfg.profile_kernels(0)
-    for _ in range(max(args.warmup, 2 * len(slots) + 2)):  # every slot reaches its replayed sequence
-        step()
-    drain()
-    torch.cuda.synchronize()
-
-    def barrier():
-        drain()
-        if n_gpus > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- timed region: exactly K steps
-    # (event-record nodes captured inside the replayed graph do not deliver times on this ROCm,
-    #  so the dominant kernel's duration comes from the profiled pre-pass above)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    replays = cfg.last_stats()["graph_replays"]
-    if n_gpus > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        pp = torch.tensor([P_local, nnzc_local], dtype=torch.int64, device=dev)
-        dist.all_reduce(pp)
-        P_total, nnzc_total = int(pp[0].item()), int(pp[1].item())
-    else:
-        P_total, nnzc_total = P_local, nnzc_local
-
-    ms_per_step = elapsed * 1e3 / args.steps
-    gflops = 2.0 * P_total / (elapsed / args.steps) / 1e9
-
-    # N > 1, reported next to `value` (never instead of it): the same K steps without the exchange,
-    # i.e. what the row-sharded multiply alone sustains while C stays distributed like A
-    sharded_only = None
-    if gather:
-        def step_no_exchange():
-            nonlocal n_step
-            scfg, sC = slots[n_step % len(slots)]
-            n_step += 1
-            sa.MultiplyspECK(mine, dA, sC, scfg)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step_no_exchange()
-        barrier()
-        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        dist.all_reduce(e2, op=dist.ReduceOp.MAX)
-        e2 = float(e2.item())
-        sharded_only = {"value": round(2.0 * P_total / (e2 / args.steps) / 1e9, 3), "unit": "GFLOP/s",
-                        "ms_per_step": round(e2 * 1e3 / args.steps, 4),
-                        "note": "same steps without the gatherv (C left row-sharded); not the job metric"}
-
+    out = None
     if rank == 0:
-        dom_ms = kernel_ms[dominant]
-        dom_bytes = st["num_bin_bytes"][dominant]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"{args.workload}:num_{dominant}")
+        st = res["st"]
         out = {
             "metric": "SpGEMM GFLOP/s (2*flops_intermediate/s), A*A",
-            "value": round(gflops, 3),
+            "value": round(res["gflops"], 3),
             "unit": "GFLOP/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step": round(res["ms_per_step"], 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": data_label if not shared_gpu else data_label + " (ranks share one GPU, gloo: plumbing check only)",
+            "data": data_label if not env.shared_gpu else data_label + " (ranks share one GPU, gloo: plumbing check only)",
             "config": {
-                "workload": wl_name, "rows": A.rows, "nnzA": A.nnz, "products": P_total,
-                "nnzC": nnzc_total, "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",
-                "gather": bool(gather), "exchange": "pipelined gatherv to rank 0" if gather else None,
+                "workload": wl_name, "rows": A.rows, "nnzA": A.nnz, "products": res["P"],
+                "nnzC": res["nnzC"], "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",
+                "gather": bool(n_gpus > 1 and not args.no_gather),
+                "exchange": "pipelined gatherv to rank 0" if n_gpus > 1 and not args.no_gather else None,
             },
-            "phases_ms": {"symbolic": round(sym_ms, 4), "numeric": round(num_ms, 4),
-                          "note": "untimed profiled pre-pass; classes run concurrently (max over classes)"},
-            "roofline": {
-                "bound": "hbm", "kernel": f"numeric:{dominant}",
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
-                "timed_with": "HIP events, profiled pre-pass (eager) of the same process",
-                "numeric_phase_frac": round(
-                    sum(st["num_bin_bytes"].values()) / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
-            },
-            "kernels_ms": {k: round(v, 5) for k, v in kernel_ms.items() if v > 0},
+            "parity": "oracle- and rocSPARSE-pinned (reference ships no golden vectors): indices bit-exact, "
+                      "|c - c_ref| <= 1e-12 * sum|a*b| per entry",
+            "phases_ms": {"symbolic": round(res["sym_ms"], 4), "numeric": round(res["num_ms"], 4),
+                          "note": "untimed profiled pre-pass; symbolic = analysis + binning + symbolic launches "
+                                  "+ scan, numeric = fork to join of the numeric launches"},
+            "roofline": roofline_block(args.workload, st, res["kernel_ms"], res["num_ms"]),
+            "kernels_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items() if v > 0},
             "rows_per_class": {k: v for k, v in st["num_bin_rows"].items() if v},
-            "graph_replays": replays,
+            "graph_replays": res["replays"],
         }
-        if sharded_only is not None:
-            out["multiply_only"] = sharded_only
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(A, P_total)
-        print(json.dumps(out), flush=True)
+        if res["multiply_only"] is not None:
+            out["multiply_only"] = res["multiply_only"]
+    del res
 
-    for scfg, _ in slots:
-        scfg.cleanup()
+    # ---- BASELINE.json configs[4]: the nlpkkt160 stand-in, STRONG scaling, at this N
+    if not args.no_config5 and not (args.workload == "nlpkkt" and args.scaling == "strong"):
+        A5, label5, name5 = load_workload("nlpkkt", args.config5_scale, args.seed)
+        r5 = measure(env, A5, args.config5_steps, 2, gather=not args.no_gather, profile=False)
+        if rank == 0:
+            out["config5"] = {
+                "workload": name5, "data": label5, "scaling": "strong", "n_gpus": n_gpus, "rows": A5.rows,
+                "nnzA": A5.nnz, "products": r5["P"], "nnzC": r5["nnzC"], "steps": args.config5_steps,
+                "value": round(r5["gflops"], 3), "unit": "GFLOP/s", "ms_per_step": round(r5["ms_per_step"], 4),
+                "multiply_only": r5["multiply_only"] if r5["multiply_only"] is not None else
+                {"value": round(r5["gflops"], 3), "unit": "GFLOP/s", "ms_per_step": round(r5["ms_per_step"], 4),
+                 "note": "N = 1: nothing to exchange"},
+            }
+        del A5, r5
+
+    if rank == 0:
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, out["config"]["products"])
+        print(json.dumps(out), flush=True)
     if n_gpus > 1:
         dist.destroy_process_group()
 

@@ -70,6 +70,7 @@ typedef struct speck_stats {
     int32_t numeric_reruns;                      /* replayed sequences rejected by the device-side checks */
     int32_t graph_replays;                       /* multiplies served by a replayed hipGraph (cumulative) */
     int32_t graph_captures;
+    float sym_phase_ms, num_phase_ms;            /* fork-to-join span of the symbolic / numeric launches (pipeline stream) */
 } speck_stats;
 
 typedef struct speck_config speck_config; /* opaque; reference: spECKConfig, include/spECKConfig.h:8-53 */

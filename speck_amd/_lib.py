@@ -33,7 +33,8 @@ class CStats(C.Structure):
                 ("sym_light_ms", C.c_float), ("num_light_ms", C.c_float),
                 ("sym_tiny_ms", C.c_float), ("num_tiny_ms", C.c_float),
                 ("kernel_events_valid", C.c_int32), ("numeric_reruns", C.c_int32),
-                ("graph_replays", C.c_int32), ("graph_captures", C.c_int32)]
+                ("graph_replays", C.c_int32), ("graph_captures", C.c_int32),
+                ("sym_phase_ms", C.c_float), ("num_phase_ms", C.c_float)]
 
 
 # every symbol include/speck_c_api.h declares, with its ctypes signature

@@ -276,7 +276,8 @@ class spECKConfig:
             sym_light_ms=float(s.sym_light_ms), num_light_ms=float(s.num_light_ms),
             sym_tiny_ms=float(s.sym_tiny_ms), num_tiny_ms=float(s.num_tiny_ms),
             kernel_events_valid=bool(s.kernel_events_valid), numeric_reruns=int(s.numeric_reruns),
-            graph_replays=int(s.graph_replays), graph_captures=int(s.graph_captures))
+            graph_replays=int(s.graph_replays), graph_captures=int(s.graph_captures),
+            sym_phase_ms=float(s.sym_phase_ms), num_phase_ms=float(s.num_phase_ms))
 
 
 _NO_TIMINGS = CTimings()  # scratch for calls that do not ask for stage times

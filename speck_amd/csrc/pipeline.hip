@@ -289,7 +289,7 @@ u32 mask_of(const u32* counts, int n)
 }
 
 struct Timing {
-    size_t ev = 0, ev_analysis = 0, ev_scan = 0;
+    size_t ev = 0, ev_analysis = 0, ev_scan = 0, ev_num = 0;
     std::vector<ClassTiming> sym, num;
 };
 
@@ -657,9 +657,15 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     // NUMERIC (Multiply.cu:835-1014) + in-kernel sort (Multiply.cu:1028-1043)
     c->last_g_products = c->h_stats->g_products;
+    if (c->profile_kernels) {
+        tm.ev_num = tm.ev;
+        (void)hipEventRecord(kernel_event(c, tm.ev++), s);
+    }
     rc = enqueue_back<T>(c, s, A, B, sc, c_ro, c_col, static_cast<T*>(c_val), num_mask,
                          c->h_stats->num.count, &tm);
     if (rc != SPECK_OK) return rc;
+    const size_t ev_num_end = tm.ev;
+    if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, tm.ev++), s);
     // The reference may return before its kernels finish when measureCompleteTime is off
     // (Multiply.cu:1082-1085) and relies on blocking streams to order later copies.  The
     // pipeline streams here are non-blocking, so the call always returns with C complete.
@@ -688,6 +694,10 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         };
         c->last.analysis_ms = ms(tm.ev_analysis);
         c->last.scan_ms = ms(tm.ev_scan);
+        // phases: end of the analysis launches -> start of the scan (all symbolic branches joined);
+        // before the first numeric launch -> after the last join
+        (void)hipEventElapsedTime(&c->last.sym_phase_ms, c->kev[tm.ev_analysis + 1], c->kev[tm.ev_scan]);
+        (void)hipEventElapsedTime(&c->last.num_phase_ms, c->kev[tm.ev_num], c->kev[ev_num_end]);
         // the merged launches: [start, mid) = first (big-LDS classes), [mid, end) = second (small ones)
         auto split = [&](const ClassTiming& ct, int phase, float* first, float* second) {
             *first = *second = 0.f;
