@@ -51,6 +51,7 @@ struct RowWork {
     const u32* b_start;     // per A entry (relative to the first entry of the A view):
     const u32* b_len;       //   start / length of the referenced B row, written by the analysis
     SpillBuffers spill;     // NUM_G class (all null when no row needs it)
+    u32 xcd_aware;          // class lists are walked in per-XCD contiguous slices (row_groups.hpp)
 };
 
 // Block ranges of the classes inside a merged ("light") launch: class slot k owns the blocks

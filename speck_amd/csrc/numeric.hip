@@ -57,8 +57,9 @@ __device__ __forceinline__ void num_direct_body(unsigned char* smem, const Produ
     const RowRec* recs = w.recs + w.st->num.offset[NUM_DIRECT];
     const u32 l = lane_id();
     u32* win = win_all + (threadIdx.x >> 6) * kWinWords;
-    for (u32 first = bidx * THREADS; first < count; first += nblk * THREADS) {
-        const u32 cnt = min((u32)THREADS, count - first);
+    const RowSlice rs = row_slice(count, bidx, nblk, THREADS, 0u, (w.xcd_aware & 1u) != 0);
+    for (u32 first = rs.idx; first < rs.end; first += rs.stride) {
+        const u32 cnt = min((u32)THREADS, rs.end - first);
         u32 len = 0, bs = 0, base = 0;
         T av = T(0);
         if (threadIdx.x < cnt) {
@@ -306,10 +307,10 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     u32* scan_scratch = m_incl + 2 * G::SIZE;
     RowMeta<T> meta{m_incl, m_incl + G::SIZE, m_av, scan_scratch + scan_scratch_words<G, THREADS>()};
     u32* S = reinterpret_cast<u32*>(mine);
-    const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
-    u32 idx = bidx * NG + gid;
-    const u32 stride = nblk * NG;
+    const RowSlice rs = row_slice(w.st->num.count[cls], bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
+    u32 idx = rs.idx;
+    const u32 stride = rs.stride, count = rs.end;
     RowRec next{};
     if (idx < count) next = recs[idx];
     while (idx < count) {
@@ -374,13 +375,13 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
     u32* pref = bm + WORDS;
     u32* scratch = pref + WORDS + 2 * THREADS;
     RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av, scratch + THREADS / 64 + 2};
-    const u32 count = w.st->num.count[cls];
+    const RowSlice rs = row_slice(w.st->num.count[cls], bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
     const RowRec* recs = w.recs + w.st->num.offset[cls];
     RowRec next{};
-    if (bidx < count) next = recs[bidx];
-    for (u32 idx = bidx; idx < count; idx += nblk) {
+    if (rs.idx < rs.end) next = recs[rs.idx];
+    for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
         const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + nblk < count) next = recs[idx + nblk];
+        if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
         u32 emitted = 0;
         for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += WCOLS) {
             const u64 left = u64(rec.cmax) - w0 + 1;

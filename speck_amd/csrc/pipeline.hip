@@ -71,8 +71,9 @@ struct speck_config {
     bool concurrent_classes = true;
     bool merge_light = true;  // all 256-thread classes of a phase in one launch
     bool split_light = true;  // ... in two back-to-back launches, by LDS / register need
-    int light_parts[2] = {0, 0};          // symbolic / numeric: bit 0 = first launch ran, bit 1 = second
-    hipEvent_t mid_ev[2] = {nullptr, nullptr};  // between the two (kernel timing only)
+    u32 xcd_aware = 2;        // class lists walked in per-XCD contiguous slices: bit 0 sub-wave classes,
+                              //   bit 1 dense-window / bitmap classes, bit 2 workgroup hash classes (measured:
+                              //   +3.5 % on the cant stand-in for bit 1; bits 0 and 2 lose to load imbalance)
     u32 last_sym_counts[kMaxClasses] = {}, last_num_counts[kMaxClasses] = {};
 
     // captured launch sequence of the last repeated call
@@ -220,26 +221,25 @@ hipEvent_t kernel_event(speck_config* c, size_t i)
 // latency-bound heavy-row kernels (few workgroups) overlap the throughput-bound small-row ones
 // (the reference does the same with its 6 streams, source/GPU/Multiply.cu:494-553, but relies on
 // legacy default-stream ordering; here the dependencies are explicit events).
-hipEvent_t mid_event(speck_config* c, int phase)
-{
-    if (!c->mid_ev[phase]) (void)hipEventCreate(&c->mid_ev[phase]);
-    return c->mid_ev[phase];
-}
-
 struct ClassTiming {
     int cls;
     size_t ev;
 };
 
-constexpr int kLightItem = -1;  // pseudo class: the merged launch of all 256-thread classes
+// pseudo classes: the merged launches of the 256-thread classes -- the big-LDS ones and the small ones
+constexpr int kLightBig = -1, kLightTiny = -2;
 
 template <typename LaunchFn>
-int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u32 mask, u32 light_mask,
-                size_t* ev_idx, std::vector<ClassTiming>* timing, LaunchFn&& launch)
+int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u32 mask, u32 big_mask,
+                u32 tiny_mask, size_t* ev_idx, std::vector<ClassTiming>* timing, LaunchFn&& launch)
 {
     bool forked = false;
     size_t used = 0;
-    auto active = [&](int cls) { return cls == kLightItem ? (mask & light_mask) != 0 : (mask >> cls & 1u) != 0; };
+    auto active = [&](int cls) {
+        if (cls == kLightBig) return (mask & big_mask) != 0;
+        if (cls == kLightTiny) return (mask & tiny_mask) != 0;
+        return (mask >> cls & 1u) != 0;
+    };
     // The last active item stays on the pipeline stream: a fork costs its branch 10-20 us of
     // cross-queue latency, a join on an already finished branch almost nothing -- so a phase with
     // one kernel pays no event at all, and the merged light launch (usually the longest) starts
@@ -313,31 +313,25 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
                     c->d_stats, cp, sc.b_start, sc.b_len);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
-    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, SpillBuffers{}};
+    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, SpillBuffers{}, c->xcd_aware};
     // heaviest classes first: they have the longest tails
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
     const u32* hint = sym_hint ? sym_hint : all_m;
-    static const int merged[4] = {SYM_BM2, SYM_B32K, SYM_B16K, kLightItem};
+    static const int merged[5] = {SYM_BM2, SYM_B32K, SYM_B16K, kLightBig, kLightTiny};
     static const int separate[SYM_CLASSES] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_B4K,
                                               SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
-    int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 4 : (int)SYM_CLASSES, sym_mask,
-                         kSymLightMask, tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr,
-                         [&](hipStream_t ks, int cls) {
-                             if (cls == kLightItem) {
-                                 // the launch's LDS size is the largest need among its classes and caps
-                                 // the waves per CU of all of them: the classes go in two back-to-back
-                                 // launches, big-LDS ones first (split_light)
-                                 const u32 big = c->split_light ? (1u << SYM_BM1) : 0u;
-                                 const u32 lm = sym_mask & kSymLightMask;
-                                 c->light_parts[0] = ((lm & big) ? 1 : 0) | ((lm & ~big) ? 2 : 0);
-                                 if (lm & big)
-                                     launch_symbolic_light(ks, hint, lm & big, A->row_offsets, sc.b_start, sc.b_len,
-                                                           B->col_ids, w, c_ro, c->sm);
-                                 if (timed && c->light_parts[0] == 3) (void)hipEventRecord(mid_event(c, 0), ks);
-                                 if (lm & ~big)
-                                     launch_symbolic_light(ks, hint, lm & ~big, A->row_offsets, sc.b_start, sc.b_len,
-                                                           B->col_ids, w, c_ro, c->sm);
+    // the launch's LDS size is the largest need among its classes and caps the waves per CU of all of
+    // them: the 256-thread classes go in two launches, the big-LDS ones apart (split_light); the
+    // first runs on a side stream next to the second
+    const u32 sym_big = c->split_light ? (1u << SYM_BM1) : kSymLightMask;
+    int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 5 : (int)SYM_CLASSES, sym_mask,
+                         kSymLightMask & sym_big, kSymLightMask & ~sym_big, tm ? &tm->ev : nullptr,
+                         tm ? &tm->sym : nullptr, [&](hipStream_t ks, int cls) {
+                             if (cls == kLightBig || cls == kLightTiny) {
+                                 const u32 part = cls == kLightBig ? sym_big : ~sym_big;
+                                 launch_symbolic_light(ks, hint, sym_mask & kSymLightMask & part, A->row_offsets,
+                                                       sc.b_start, sc.b_len, B->col_ids, w, c_ro, c->sm);
                              } else
                                  launch_symbolic(ks, cls, hint[cls], A->row_offsets, sc.b_start, sc.b_len,
                                                  B->col_ids, w, c_ro, c->sm);
@@ -364,26 +358,21 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     CsrView<T> Av{A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
-    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, c->spill};
+    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, c->spill, c->xcd_aware};
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;
     const u32* hint = counts ? counts : all_m;
-    static const int merged[5] = {NUM_G, NUM_D2, NUM_B8K, NUM_W1K, kLightItem};
+    static const int merged[6] = {NUM_G, NUM_D2, NUM_B8K, NUM_W1K, kLightBig, kLightTiny};
     static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K,  NUM_B2K, NUM_W1K,
                                               NUM_D1, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
-    return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 5 : (int)NUM_CLASSES, num_mask,
-                       kNumLightMask, tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr,
-                       [&](hipStream_t ks, int cls) {
-                           if (cls == kLightItem) {
-                               const u32 big = c->split_light ? (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) : 0u;
-                               const u32 lm = num_mask & kNumLightMask;
-                               c->light_parts[1] = ((lm & big) ? 1 : 0) | ((lm & ~big) ? 2 : 0);
-                               if (lm & big)
-                                   launch_numeric_light<T>(ks, hint, lm & big, Av, Bv, w, c_col, c_val, c->sm);
-                               if (tm && c->profile_kernels && c->light_parts[1] == 3)
-                                   (void)hipEventRecord(mid_event(c, 1), ks);
-                               if (lm & ~big)
-                                   launch_numeric_light<T>(ks, hint, lm & ~big, Av, Bv, w, c_col, c_val, c->sm);
+    const u32 num_big = c->split_light ? (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) : kNumLightMask;
+    return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 6 : (int)NUM_CLASSES, num_mask,
+                       kNumLightMask & num_big, kNumLightMask & ~num_big, tm ? &tm->ev : nullptr,
+                       tm ? &tm->num : nullptr, [&](hipStream_t ks, int cls) {
+                           if (cls == kLightBig || cls == kLightTiny) {
+                               const u32 part = cls == kLightBig ? num_big : ~num_big;
+                               launch_numeric_light<T>(ks, hint, num_mask & kNumLightMask & part, Av, Bv, w, c_col,
+                                                       c_val, c->sm);
                            } else
                                launch_numeric<T>(ks, cls, hint[cls], Av, Bv, w, c_col, c_val, c->sm);
                        });
@@ -698,22 +687,14 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         // before the first numeric launch -> after the last join
         (void)hipEventElapsedTime(&c->last.sym_phase_ms, c->kev[tm.ev_analysis + 1], c->kev[tm.ev_scan]);
         (void)hipEventElapsedTime(&c->last.num_phase_ms, c->kev[tm.ev_num], c->kev[ev_num_end]);
-        // the merged launches: [start, mid) = first (big-LDS classes), [mid, end) = second (small ones)
-        auto split = [&](const ClassTiming& ct, int phase, float* first, float* second) {
-            *first = *second = 0.f;
-            if (c->light_parts[phase] == 3) {
-                (void)hipEventElapsedTime(first, c->kev[ct.ev], c->mid_ev[phase]);
-                (void)hipEventElapsedTime(second, c->mid_ev[phase], c->kev[ct.ev + 1]);
-            } else {
-                *(c->light_parts[phase] == 2 && c->split_light ? second : first) = ms(ct.ev);
-            }
-        };
         for (const auto& ct : tm.sym) {
-            if (ct.cls == kLightItem) split(ct, 0, &c->last.sym_light_ms, &c->last.sym_tiny_ms);
+            if (ct.cls == kLightBig) c->last.sym_light_ms = ms(ct.ev);
+            else if (ct.cls == kLightTiny) c->last.sym_tiny_ms = ms(ct.ev);
             else c->last.sym_bin_ms[ct.cls] = ms(ct.ev);
         }
         for (const auto& ct : tm.num) {
-            if (ct.cls == kLightItem) split(ct, 1, &c->last.num_light_ms, &c->last.num_tiny_ms);
+            if (ct.cls == kLightBig) c->last.num_light_ms = ms(ct.ev);
+            else if (ct.cls == kLightTiny) c->last.num_tiny_ms = ms(ct.ev);
             else c->last.num_bin_ms[ct.cls] = ms(ct.ev);
         }
         c->last.kernel_events_valid = 1;
@@ -798,8 +779,6 @@ int speck_config_destroy(speck_config* c)
     (void)hipEventDestroy(c->individualStart);
     (void)hipEventDestroy(c->individualEnd);
     for (auto e : c->kev) (void)hipEventDestroy(e);
-    for (auto e : c->mid_ev)
-        if (e) (void)hipEventDestroy(e);
     for (auto s : c->aux) (void)hipStreamDestroy(s);
     for (auto e : c->aux_done) (void)hipEventDestroy(e);
     if (c->fork) (void)hipEventDestroy(c->fork);
@@ -853,6 +832,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "split_light") {
         c->split_light = value != 0;
+        drop_graph(c);
+    }
+    else if (n == "xcd_aware") {
+        c->xcd_aware = (u32)value;
         drop_graph(c);
     }
     else if (n == "merge_light") {

@@ -130,6 +130,27 @@ struct Block {
     }
 };
 
+// ---- which rows of a class list a group walks ---------------------------------------------
+// The lists are in ascending row order and neighbouring rows of A reference neighbouring rows of B
+// (bands, communities, meshes).  Workgroup b of a launch runs on XCD b % 8 and every XCD has its own
+// L2: with the plain mapping (row = block * groups + group, stride = all blocks) the eight L2s each
+// fetch every B row.  XCD-aware mapping: the workgroups of one XCD walk a CONTIGUOUS eighth of the
+// list, so a B row is fetched by (mostly) one L2.  Placement is only a speed assumption.
+struct RowSlice {
+    u32 idx, end, stride;
+};
+__device__ __forceinline__ RowSlice row_slice(u32 count, u32 bidx, u32 nblk, u32 groups, u32 gid, bool xcd_aware)
+{
+    if (!xcd_aware || nblk < 16u) return RowSlice{bidx * groups + gid, count, nblk * groups};
+    const u32 first = blockIdx.x - bidx;            // first physical block of this class' range
+    const u32 x = blockIdx.x & 7u;
+    const u32 i0 = (x + 8u - (first & 7u)) & 7u;    // first block of the range with my residue
+    const u32 nb_x = (nblk - i0 + 7u) >> 3;         // >= 1: nblk >= 16
+    const u32 j = (bidx - i0) >> 3;
+    const u32 lo = (u32)(u64(count) * x >> 3), hi = (u32)(u64(count) * (x + 1u) >> 3);
+    return RowSlice{lo + j * groups + gid, hi, nb_x * groups};
+}
+
 // Per-group LDS staging area for one chunk of A entries (SIZE entries).
 template <typename T>
 struct RowMeta {

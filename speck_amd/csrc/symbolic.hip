@@ -41,10 +41,10 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
     u32* tab = reinterpret_cast<u32*>(smem + gid * kGroupBytes);
     u32* scratch = tab + CAP + 2 * G::SIZE;
     RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr, scratch + sym_scratch_words<G, THREADS>()};
-    const u32 count = w.st->sym.count[cls];
+    const RowSlice rs = row_slice(w.st->sym.count[cls], bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
     const RowRec* recs = w.recs + w.st->sym.offset[cls];
-    u32 idx = bidx * NG + gid;
-    const u32 stride = nblk * NG;
+    u32 idx = rs.idx;
+    const u32 stride = rs.stride, count = rs.end;
     RowRec next{};
     if (idx < count) next = recs[idx];
     while (idx < count) {
@@ -75,13 +75,13 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
     u32* scratch = bm + WORDS + 2 * THREADS;
     RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr, scratch + THREADS / 64 + 2};
     constexpr u64 kWindowCols = u64(WORDS) * 32;
-    const u32 count = w.st->sym.count[cls];
+    const RowSlice rs = row_slice(w.st->sym.count[cls], bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
     const RowRec* recs = w.recs + w.st->sym.offset[cls];
     RowRec next{};
-    if (bidx < count) next = recs[bidx];
-    for (u32 idx = bidx; idx < count; idx += nblk) {
+    if (rs.idx < rs.end) next = recs[rs.idx];
+    for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
         const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + nblk < count) next = recs[idx + nblk];
+        if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
         u32 total = 0;
         for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += kWindowCols) {
             const u64 left = u64(rec.cmax) - w0 + 1;
