@@ -163,14 +163,13 @@ struct DeviceStats {
 // One row of work as the class kernels see it: written in class order by the scatter kernels,
 // read with a single 32-byte load (the next row's record is fetched while the current one runs).
 struct __attribute__((aligned(32))) RowRec {
-    u32 row;         // row of A / C
     u32 a0, a1;      // bounds of the A row (absolute offsets into A.col_ids / A.data)
     u32 base;        // first entry of the C row (numeric phase)
+    u32 nnz;         // nnz of the C row (numeric phase)
     u32 cmin, cmax;  // column range reachable by the row (analysis)
     u32 ops;         // intermediate products of the row
-    u32 nnz;         // nnz of the C row (numeric phase)
+    u32 row;         // row of A / C
 };
-
 // What every analysis / scan-apply block leaves behind for the single-block stats kernel
 // (plain stores: ~12 ns per same-line global atomic would otherwise dominate these kernels).
 struct BlockPartial {

@@ -1032,6 +1032,12 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
         case NUM_B8K:
             // two launches over the class: the rows of the lower half fit a half-size table, whose
             // workgroups run two per CU (the full table owns 106 of a CU's 160 KiB)
+            // (a handful of rows cannot fill the CUs anyway: one launch, one row's latency less)
+            if (count * 2 < (u32)cu_count) {
+                launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512>(
+                    s, cls, count, A, B, w, c_col, c_val, cu_count);
+                break;
+            }
             launch_num_hash<Block<512>, T, kNumB8KCap / 2, kB8KW1, kNumB8KMaxNnz / 2, SORT_BITMAP, 512>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KMaxNnz / 2>(

@@ -69,6 +69,8 @@ struct speck_config {
     std::vector<hipEvent_t> aux_done;
     hipEvent_t fork = nullptr;
     bool concurrent_classes = true;
+    u32 max_side_streams = 12;
+    float fork_min_us = 60.f;  // estimated duration from which a class launch gets its own stream
     bool merge_light = true;  // all 256-thread classes of a phase in one launch
     bool split_light = true;  // ... in two back-to-back launches, by LDS / register need
     u32 xcd_aware = 2;        // class lists walked in per-XCD contiguous slices: bit 0 sub-wave classes,
@@ -231,7 +233,8 @@ constexpr int kLightBig = -1, kLightTiny = -2;
 
 template <typename LaunchFn>
 int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u32 mask, u32 big_mask,
-                u32 tiny_mask, size_t* ev_idx, std::vector<ClassTiming>* timing, LaunchFn&& launch)
+                u32 tiny_mask, const u32* counts, const float* ns_per_row, size_t* ev_idx,
+                std::vector<ClassTiming>* timing, LaunchFn&& launch)
 {
     bool forked = false;
     size_t used = 0;
@@ -240,6 +243,21 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
         if (cls == kLightTiny) return (mask & tiny_mask) != 0;
         return (mask >> cls & 1u) != 0;
     };
+    // Estimated duration of an item from the host-known row counts of the previous identical call
+    // (isolated per-row costs, scripts/class_times.py).  An item earns a side stream only when it is
+    // long enough to pay for the cross-queue dependency (~10-15 us per branch of a replayed graph):
+    // the scircuit / mac_econ stand-ins run fastest on ONE stream, the webbase one with four.
+    auto est_us = [&](int cls) -> float {
+        if (!counts) return 1e9f;  // eager first call: counts unknown, keep every class apart
+        u32 m = cls == kLightBig ? (mask & big_mask) : cls == kLightTiny ? (mask & tiny_mask) : (1u << cls);
+        float us = 0.f;
+        for (int k = 0; k < kMaxClasses; ++k)
+            if (m >> k & 1u) us += counts[k] * ns_per_row[k] * 1e-3f;
+        return us;
+    };
+    int n_big = 0;
+    for (int i = 0; i < n_order; ++i)
+        if (active(order[i]) && est_us(order[i]) >= c->fork_min_us) ++n_big;
     // The last active item stays on the pipeline stream: a fork costs its branch 10-20 us of
     // cross-queue latency, a join on an already finished branch almost nothing -- so a phase with
     // one kernel pays no event at all, and the merged light launch (usually the longest) starts
@@ -247,17 +265,31 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
     int last_active = -1;
     for (int i = 0; i < n_order; ++i)
         if (active(order[i])) last_active = i;
+    // ... and the last LONG one if there are several (the short ones queue on the pipeline stream too)
+    if (n_big >= 2)
+        for (int i = 0; i < n_order; ++i)
+            if (active(order[i]) && est_us(order[i]) >= c->fork_min_us) last_active = i;
+    // at most `max_side_streams` branches: every cross-queue dependency of a replayed graph costs
+    // ~10 us, so further side items queue behind each other on the last side stream
+    const size_t max_side = std::min<size_t>(c->aux.size(), c->max_side_streams);
+    size_t touched = 0;  // side streams that carry work
     for (int i = 0; i < n_order; ++i) {
         const int cls = order[i];
         if (!active(cls)) continue;
         hipStream_t ks = s;
-        if (c->concurrent_classes && used < c->aux.size() && i != last_active) {
+        if (c->concurrent_classes && max_side > 0 && i != last_active && n_big >= 2 &&
+            est_us(cls) >= c->fork_min_us) {
             if (!forked) {
                 HIP_TRY(hipEventRecord(c->fork, s));
                 forked = true;
             }
-            ks = c->aux[used];
-            HIP_TRY(hipStreamWaitEvent(ks, c->fork, 0));
+            const size_t slot = std::min(used, max_side - 1);
+            ks = c->aux[slot];
+            if (slot >= touched) {
+                HIP_TRY(hipStreamWaitEvent(ks, c->fork, 0));
+                touched = slot + 1;
+            }
+            ++used;
         }
         const bool timed = c->profile_kernels && timing;
         if (timed) (void)hipEventRecord(kernel_event(c, *ev_idx), ks);
@@ -267,16 +299,18 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
             timing->push_back({cls, *ev_idx});
             *ev_idx += 2;
         }
-        if (ks != s) {
-            HIP_TRY(hipEventRecord(c->aux_done[used], ks));
-            ++used;
-        }
     }
-    for (size_t k = 0; k < used; ++k) HIP_TRY(hipStreamWaitEvent(s, c->aux_done[k], 0));
+    for (size_t k = 0; k < touched; ++k) {
+        HIP_TRY(hipEventRecord(c->aux_done[k], c->aux[k]));
+        HIP_TRY(hipStreamWaitEvent(s, c->aux_done[k], 0));
+    }
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
 }
 
+// isolated cost per row of every class (ns, MI355X, scripts/class_times.py on the four stand-ins)
+constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 0, 0, 0, 0};
+constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 6.f, 0, 0};
 constexpr u32 kAllSym = (1u << SYM_CLASSES) - 1u;
 constexpr u32 kAllNum = (1u << NUM_CLASSES) - 1u;
 
@@ -326,8 +360,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     // first runs on a side stream next to the second
     const u32 sym_big = c->split_light ? (1u << SYM_BM1) : kSymLightMask;
     int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 5 : (int)SYM_CLASSES, sym_mask,
-                         kSymLightMask & sym_big, kSymLightMask & ~sym_big, tm ? &tm->ev : nullptr,
-                         tm ? &tm->sym : nullptr, [&](hipStream_t ks, int cls) {
+                         kSymLightMask & sym_big, kSymLightMask & ~sym_big, sym_hint, kSymNsPerRow,
+                         tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr, [&](hipStream_t ks, int cls) {
                              if (cls == kLightBig || cls == kLightTiny) {
                                  const u32 part = cls == kLightBig ? sym_big : ~sym_big;
                                  launch_symbolic_light(ks, hint, sym_mask & kSymLightMask & part, A->row_offsets,
@@ -367,8 +401,8 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
                                               NUM_D1, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
     const u32 num_big = c->split_light ? (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) : kNumLightMask;
     return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 6 : (int)NUM_CLASSES, num_mask,
-                       kNumLightMask & num_big, kNumLightMask & ~num_big, tm ? &tm->ev : nullptr,
-                       tm ? &tm->num : nullptr, [&](hipStream_t ks, int cls) {
+                       kNumLightMask & num_big, kNumLightMask & ~num_big, counts, kNumNsPerRow,
+                       tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr, [&](hipStream_t ks, int cls) {
                            if (cls == kLightBig || cls == kLightTiny) {
                                const u32 part = cls == kLightBig ? num_big : ~num_big;
                                launch_numeric_light<T>(ks, hint, num_mask & kNumLightMask & part, Av, Bv, w, c_col,
@@ -821,6 +855,14 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
+    else if (n == "fork_min_us") {
+        c->fork_min_us = (float)value;
+        drop_graph(c);
+    }
+    else if (n == "max_side_streams") {
+        c->max_side_streams = (u32)value;
+        drop_graph(c);
+    }
     else if (n == "use_graph") c->use_graph = value != 0;
     else if (n == "grid_rounds_block") {
         set_grid_rounds((u32)value, 0);
