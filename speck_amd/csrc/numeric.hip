@@ -122,25 +122,26 @@ template <typename T>
 using Acc = double;
 
 // ------------------------------------------------------------------ sorting back-ends
-// Rank sort for tiny tables: every lane owns OWN = CAP/SIZE slots (registers).
-// `ckeys` may alias the table: all slots are in registers before the first write.
+// Rank sort for tiny tables.  The occupied slots are first COMPACTED (ballots) into `ckeys` with their
+// slot numbers in `cslot`, then every lane ranks ceil(nnz / SIZE) <= EMAX compacted keys against all of
+// them -- not its CAP / SIZE table slots, a third to a half of which are empty at a load <= 2/3: these
+// kernels are bound by VALU issue (80 % busy, profiles/r02_pmc_mac_econ_tiny.csv), and the compare
+// loop is their largest single part.  `ckeys` may alias the keys of the table (all slots are in
+// registers before the first write); the values stay where they are and are fetched by slot number.
 // `cap_row` (a power of two, SIZE <= cap_row <= CAP) slots of the table are in use.
-template <class G, typename T, u32 CAP>
+template <class G, typename T, u32 CAP, u32 NMAX>
 __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, const Acc<T>* vals,
-                                                 u32* ckeys, u32 cap_row, u32 base,
+                                                 u32* ckeys, u32* cslot, u32 cap_row, u32 base,
                                                  u32* __restrict__ c_col, T* __restrict__ c_val)
 {
     constexpr u32 OWN = CAP / G::SIZE;
+    constexpr u32 EMAX = (NMAX + G::SIZE - 1) / G::SIZE;
+    static_assert(NMAX + 4 <= CAP, "the compacted keys (padded to a uint4) alias the table's keys");
     u32 k[OWN];
-    Acc<T> v[OWN];
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j) {
         k[j] = kEmptyKey;
-        v[j] = 0;
-        if (j * G::SIZE < cap_row) {
-            k[j] = keys[j * G::SIZE + g.lane];
-            v[j] = vals[j * G::SIZE + g.lane];
-        }
+        if (j * G::SIZE < cap_row) k[j] = keys[j * G::SIZE + g.lane];
     }
     g.sync();
     u32 run = 0;
@@ -148,34 +149,54 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j) {
         const u64 mask = g.ballot(k[j] != kEmptyKey);
-        if (k[j] != kEmptyKey) ckeys[run + __popcll(mask & lt)] = k[j];
+        if (k[j] != kEmptyKey) {
+            const u32 pos = run + __popcll(mask & lt);
+            ckeys[pos] = k[j];
+            cslot[pos] = j * G::SIZE + g.lane;
+        }
         run += __popcll(mask);
     }
     if (g.lane < 4) ckeys[run + g.lane] = kEmptyKey;  // pad the last uint4
     g.sync();
-    u32 r[OWN];
+    u32 mk[EMAX], ms[EMAX], r[EMAX];
 #pragma unroll
-    for (u32 j = 0; j < OWN; ++j) r[j] = 0;
+    for (u32 e = 0; e < EMAX; ++e) {
+        const u32 idx = e * G::SIZE + g.lane;
+        mk[e] = kEmptyKey;
+        ms[e] = 0;
+        r[e] = 0;
+        if (idx < run) {
+            mk[e] = ckeys[idx];
+            ms[e] = cslot[idx];
+        }
+    }
     const uint4* ck4 = reinterpret_cast<const uint4*>(ckeys);
-    // most rows of these classes are far smaller than the class limit: when every group of the
-    // wave uses a single slot per lane, only that slot is ranked
-    if (__ballot(cap_row > (u32)G::SIZE) == 0) {
+    // how many keys per lane the groups of this wave hold at most (uniform for the wave)
+    const u32 depth = __ballot(run > 2u * G::SIZE) ? 3u : (__ballot(run > (u32)G::SIZE) ? 2u : 1u);
+    if (depth == 1) {
         for (u32 q = 0; q < (run + 3) / 4; ++q) {
             const uint4 x = ck4[q];  // same address for the whole group: LDS broadcast
-            r[0] += (x.x < k[0]) + (x.y < k[0]) + (x.z < k[0]) + (x.w < k[0]);
+            r[0] += (x.x < mk[0]) + (x.y < mk[0]) + (x.z < mk[0]) + (x.w < mk[0]);
+        }
+    } else if (depth == 2 || EMAX < 3) {
+        for (u32 q = 0; q < (run + 3) / 4; ++q) {
+            const uint4 x = ck4[q];
+#pragma unroll
+            for (u32 e = 0; e < (EMAX < 2 ? EMAX : 2u); ++e)
+                r[e] += (x.x < mk[e]) + (x.y < mk[e]) + (x.z < mk[e]) + (x.w < mk[e]);
         }
     } else {
         for (u32 q = 0; q < (run + 3) / 4; ++q) {
             const uint4 x = ck4[q];
 #pragma unroll
-            for (u32 j = 0; j < OWN; ++j) r[j] += (x.x < k[j]) + (x.y < k[j]) + (x.z < k[j]) + (x.w < k[j]);
+            for (u32 e = 0; e < EMAX; ++e) r[e] += (x.x < mk[e]) + (x.y < mk[e]) + (x.z < mk[e]) + (x.w < mk[e]);
         }
     }
 #pragma unroll
-    for (u32 j = 0; j < OWN; ++j)
-        if (k[j] != kEmptyKey) {
-            c_col[base + r[j]] = k[j];
-            c_val[base + r[j]] = (T)v[j];
+    for (u32 e = 0; e < EMAX; ++e)
+        if (mk[e] != kEmptyKey) {
+            c_col[base + r[e]] = mk[e];
+            c_val[base + r[e]] = (T)vals[ms[e]];
         }
 }
 
@@ -297,6 +318,8 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     static_assert((MODE == SORT_RANK ? NMAX + 8 : (2 * W1 > 2 * NMAX ? 2 * W1 : 2 * NMAX)) * 4 <=
                       CAP * (sizeof(Acc<T>) + 4),
                   "sort scratch must fit in the table it aliases");
+    static_assert(MODE != SORT_RANK || NMAX * 4 <= G::SIZE * (sizeof(T) + 8),
+                  "rank sort: the slot numbers of the compacted keys fit in the A-row staging area");
     const G g;
     const u32 gid = G::kIsBlock ? 0u : threadIdx.x / G::SIZE;
     unsigned char* mine = smem + gid * kGroupBytes;
@@ -342,7 +365,9 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
                                }, cls);
         PHASE_MARK(1);
         if constexpr (MODE == SORT_RANK) {
-            emit_rank_sorted<G, T, CAP>(g, keys, vals, S, cap_row, rec.base, c_col, c_val);
+            // scratch: the compacted keys over the table's keys, their slot numbers over the A-row staging
+            emit_rank_sorted<G, T, CAP, NMAX>(g, keys, vals, keys, reinterpret_cast<u32*>(m_av), cap_row, rec.base,
+                                              c_col, c_val);
         } else {
             emit_bitmap_sorted<G, T, CAP, W1, NMAX>(g, keys, vals, S, scan_scratch, cap_row, rec.cmin,
                                                     rec.cmax, rec.base, c_col, c_val, cls);
