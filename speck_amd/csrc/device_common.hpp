@@ -170,8 +170,11 @@ struct __attribute__((aligned(32))) RowRec {
     u32 ops;         // intermediate products of the row
     u32 row;         // row of A / C
 };
-// What every analysis / scan-apply block leaves behind for the single-block stats kernel
+// What every analysis / scan block leaves behind for the blocks of the scatter kernel that follows
 // (plain stores: ~12 ns per same-line global atomic would otherwise dominate these kernels).
+// Stored as a structure of arrays over the blocks -- every scatter block folds ALL partials, and with
+// one record per block that was ~130 KB of strided reads per workgroup (the fold was most of the
+// 16-22 us these kernels took on the 200 k-row stand-ins).  BlockPartial only sizes the allocation.
 struct BlockPartial {
     u64 products;
     u32 max_val;
@@ -179,7 +182,26 @@ struct BlockPartial {
     u32 count[kMaxClasses];
     u64 bytes[kMaxClasses];
     u64 g_ops;  // numeric phase: products of the block's NUM_G rows (sizes the spill pool)
+    u64 pad2[2];
 };
+struct PartialArrays {
+    u64* products;  // [cap]   analysis: products of the block's rows; scan: nnz of the tile
+    u64* g_ops;     // [cap]
+    u64* bytes;     // [kMaxClasses][cap]  (only with ClassifyParams::want_bytes)
+    u32* count;     // [kMaxClasses][cap]  rows per class
+    u32* max_val;   // [cap]
+    u32 cap;
+    __host__ __device__ PartialArrays(BlockPartial* base, u32 blocks)
+    {
+        cap = (blocks + 1u) & ~1u;
+        products = reinterpret_cast<u64*>(base);
+        g_ops = products + cap;
+        bytes = g_ops + cap;
+        count = reinterpret_cast<u32*>(bytes + size_t(kMaxClasses) * cap);
+        max_val = count + size_t(kMaxClasses) * cap;
+    }
+};
+static_assert(sizeof(BlockPartial) >= 8 + 8 + 8 * kMaxClasses + 4 * kMaxClasses + 4 + 8, "PartialArrays fits");
 
 #ifdef __HIPCC__
 // ---- wave64 primitives ---------------------------------------------------------

@@ -145,7 +145,7 @@ struct Scratch {
     u32 *b_start, *b_len;  // per A entry: the referenced B row (written by the analysis)
 };
 
-u32 partial_blocks(u32 m) { return std::max(analysis_blocks(m), scan_tiles(m)); }
+u32 partial_blocks(u32 m) { return std::max(analysis_blocks(m), scan_tiles(m)) + 2; }  // + PartialArrays padding
 
 size_t scratch_bytes(u32 m, u64 nnz_a)
 {

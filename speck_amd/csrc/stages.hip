@@ -214,6 +214,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
         for (int c = 0; c < SYM_CLASSES; ++c) s_hist[wid][c] = hist[c];
     }
     __syncthreads();
+    const PartialArrays pa(partials, gridDim.x);
     if (t == 0) {
         u64 p = 0;
         u32 mxv = 0;
@@ -221,16 +222,16 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
             p += s_products[w];
             mxv = max(mxv, s_max[w]);
         }
-        partials[blockIdx.x].products = p;
-        partials[blockIdx.x].max_val = mxv;
-        partials[blockIdx.x].g_ops = 0;
+        pa.products[blockIdx.x] = p;
+        pa.max_val[blockIdx.x] = mxv;
+        pa.g_ops[blockIdx.x] = 0;
     }
     if (t < kMaxClasses) {
         u32 h = 0;
         if (t < SYM_CLASSES)
             for (int w = 0; w < NW; ++w) h += s_hist[w][t];
-        partials[blockIdx.x].count[t] = h;
-        partials[blockIdx.x].bytes[t] = s_bytes[t];
+        pa.count[t * pa.cap + blockIdx.x] = h;
+        if (cp.want_bytes) pa.bytes[t * pa.cap + blockIdx.x] = s_bytes[t];
     }
 }
 
@@ -250,33 +251,34 @@ struct Fold {
 };
 
 template <int THREADS, int NCLS>
-__device__ __forceinline__ void fold_partials(const BlockPartial* __restrict__ parts, u32 nb,
+__device__ __forceinline__ void fold_partials(BlockPartial* parts, u32 nb,
                                               u32 my_block, Fold* s_fold /*LDS*/, u64* s_bytes /*LDS*/,
                                               bool want_bytes)
 {
     constexpr int NW = THREADS / 64;
     __shared__ u32 s_pre[NW][NCLS], s_tot[NW][NCLS], s_mx[NW];
     __shared__ u64 s_sp[NW], s_st[NW], s_by[NW][NCLS], s_g[NW];
+    const PartialArrays pa(parts, nb);
     u32 pre[NCLS], tot[NCLS];
     u64 by[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) pre[c] = tot[c] = 0, by[c] = 0;
     u64 sp = 0, stt = 0, gs = 0;
     u32 mx = 0;
-    for (u32 b = threadIdx.x; b < nb; b += THREADS) {
-        gs += parts[b].g_ops;
+    for (u32 b = threadIdx.x; b < nb; b += THREADS) {  // consecutive threads, consecutive blocks: coalesced
+        gs += pa.g_ops[b];
         const bool before = b < my_block;
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) {
-            const u32 v = parts[b].count[c];
+            const u32 v = pa.count[c * pa.cap + b];
             tot[c] += v;
             if (before) pre[c] += v;
-            if (want_bytes) by[c] += parts[b].bytes[c];
+            if (want_bytes) by[c] += pa.bytes[c * pa.cap + b];
         }
-        const u64 p = parts[b].products;
+        const u64 p = pa.products[b];
         stt += p;
         if (before) sp += p;
-        mx = max(mx, parts[b].max_val);
+        mx = max(mx, pa.max_val[b]);
     }
     const u32 wid = threadIdx.x >> 6, lane = lane_id();
 #pragma unroll
@@ -357,7 +359,7 @@ __device__ __forceinline__ void publish_bins(BinTable& t, const Fold& f, const u
 // each row's record at class_offset + rows-before-my-block + rank (ballots, ascending rows).
 __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
     const u8* __restrict__ cls, u32 m, u32 rows_per_block, DeviceStats* __restrict__ st,
-    const BlockPartial* __restrict__ parts, u32 nb, const u32* __restrict__ a_ro,
+    BlockPartial* __restrict__ parts, u32 nb, const u32* __restrict__ a_ro,
     const u32* __restrict__ row_ops, const u32* __restrict__ row_col_min,
     const u32* __restrict__ row_col_max, RowRec* __restrict__ recs, ClassifyParams cp)
 {
@@ -506,11 +508,12 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
             s_hist[wid][k] = packed.get(k);
     }
     __syncthreads();
+    const PartialArrays pa(partials, gridDim.x);
     if (threadIdx.x < kMaxClasses) {
         u32 h = 0;
         for (int w = 0; w < NW; ++w) h += s_hist[w][threadIdx.x];
-        partials[blockIdx.x].count[threadIdx.x] = h;
-        partials[blockIdx.x].bytes[threadIdx.x] = s_bytes[threadIdx.x];
+        pa.count[threadIdx.x * pa.cap + blockIdx.x] = h;
+        if (cp.want_bytes) pa.bytes[threadIdx.x * pa.cap + blockIdx.x] = s_bytes[threadIdx.x];
     }
     if (threadIdx.x == 0) {
         u64 s = 0, gsum = 0;
@@ -520,16 +523,16 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
             gsum += s_gops[w];
             mxv = max(mxv, s_max[w]);
         }
-        partials[blockIdx.x].products = s;  // numeric phase: the tile's nnz sum
-        partials[blockIdx.x].max_val = mxv;
-        partials[blockIdx.x].g_ops = gsum;
+        pa.products[blockIdx.x] = s;  // numeric phase: the tile's nnz sum
+        pa.max_val[blockIdx.x] = mxv;
+        pa.g_ops[blockIdx.x] = gsum;
     }
 }
 
 template <int ITEMS>
 __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     u32* __restrict__ counts_inout, u32 m, DeviceStats* __restrict__ st,
-    const BlockPartial* __restrict__ parts, u32 nb, const u8* __restrict__ num_cls,
+    BlockPartial* __restrict__ parts, u32 nb, const u8* __restrict__ num_cls,
     const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
     const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
     RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz, u64 expect_g, u32 expect_g_rows,
@@ -662,7 +665,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                        partials, cp, b_start, b_len, st);
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,
-                       (const u8*)sym_cls, m, rows_per_block, st, (const BlockPartial*)partials, blocks, a_ro,
+                       (const u8*)sym_cls, m, rows_per_block, st, partials, blocks, a_ro,
                        (const u32*)row_ops, (const u32*)row_col_min, (const u32*)row_col_max, recs, cp);
 }
 
@@ -678,7 +681,7 @@ void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const
                            (const u32*)counts_inout, m, a_ro, row_ops, row_col_min, row_col_max, num_cls,
                            partials, cp, vsize);
         hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts_inout, m, st,
-                           (const BlockPartial*)partials, tiles, (const u8*)num_cls, a_ro, row_ops,
+                           partials, tiles, (const u8*)num_cls, a_ro, row_ops,
                            row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, expect_g_rows, host_mirror);
     };
     switch (scan_items(m)) {
