@@ -210,7 +210,7 @@ int main(int argc, char* argv[])
     try {
         CSR<double> cpuA = load_input(filePath);
         std::cout << "Matrix: " << cpuA.rows << "x" << cpuA.cols << ": " << cpuA.nnz << " nonzeros\n";
-        dCSR<double> gpuA, gpuB, dCsrHiRes, dCsrReference;
+        dCSR<double> gpuA, gpuB, dCsrHiRes, dCsrReference, dCsrAbs;
         convert(gpuA, cpuA, 0);
         if (gpuA.rows != gpuA.cols)
             spECK::Transpose(gpuA, gpuB);  // DataLoader.cpp:65-69
@@ -218,9 +218,21 @@ int main(int argc, char* argv[])
             convert(gpuB, cpuA, 0);
 
         auto config = spECK::spECKConfig::initialize(0);
-        if (compareResult && !rocsparse_reference(gpuA, gpuB, dCsrReference)) {
-            std::printf("Error: rocSPARSE reference failed\n");
-            return 2;
+        if (compareResult) {
+            // reference product and, for the value bound, |A| * |B| = sum |a*b| per entry (rocSPARSE both)
+            dCSR<double> absA, absB;
+            CSR<double> cpuAbs;
+            convert(cpuAbs, cpuA, 0);
+            for (size_t i = 0; i < cpuAbs.nnz; ++i) cpuAbs.data[i] = std::fabs(cpuAbs.data[i]);
+            convert(absA, cpuAbs, 0);
+            if (gpuA.rows != gpuA.cols)
+                spECK::Transpose(absA, absB);
+            else
+                convert(absB, cpuAbs, 0);
+            if (!rocsparse_reference(gpuA, gpuB, dCsrReference) || !rocsparse_reference(absA, absB, dCsrAbs)) {
+                std::printf("Error: rocSPARSE reference failed\n");
+                return 2;
+            }
         }
         Timings timings, warmupTimings, benchTimings;
         int errors = 0;
@@ -232,17 +244,17 @@ int main(int argc, char* argv[])
                 gpuA, gpuB, dCsrHiRes, config, timings);
             acc += timings;
             if (compareResult && dCsrHiRes.data != nullptr && dCsrHiRes.col_ids != nullptr) {
-                speck_dcsr a = dCsrReference.raw(), b = dCsrHiRes.raw();
-                uint64_t bad = 1;
-                speck_compare_f64(nullptr, &a, &b, 0, 0.0, &bad);
-                uint64_t badv = 1;
-                speck_compare_f64(nullptr, &a, &b, 1, 1e-10, &badv);
+                // structure bit-exact AND values within 1e-12 * sum|a*b| per entry: either one fails the run
+                speck_dcsr a = dCsrReference.raw(), b = dCsrHiRes.raw(), sc = dCsrAbs.raw();
+                uint64_t bad = 1, badv = 1;
+                speck_compare_bounded_f64(nullptr, &a, &b, &sc, 1e-12, &bad, &badv);
                 if (bad != 0) {
                     std::printf("Error: Matrix incorrect\n");
                     ++errors;
                 } else if (badv != 0) {
-                    std::printf("Note: %llu rows differ from rocSPARSE by more than 1e-10 relative (values only)\n",
+                    std::printf("Error: %llu rows differ from rocSPARSE by more than 1e-12 * sum|a*b|\n",
                                 (unsigned long long)badv);
+                    ++errors;
                 }
             }
         };

@@ -1,4 +1,5 @@
-// Transpose.h -- spECK::Transpose of the reference (include/Transpose.h, source/GPU/Transpose.cu:10-117).
+// Transpose.h -- spECK::Transpose of the reference (include/Transpose.h, source/GPU/Transpose.cu:10-117;
+// instantiated for float and double, :116-117).
 #pragma once
 #include "dCSR.h"
 
@@ -6,9 +7,9 @@ namespace spECK {
 template <typename DataType>
 void Transpose(const dCSR<DataType>& matIn, dCSR<DataType>& matTransposeOut)
 {
-    static_assert(sizeof(DataType) == 8, "Transpose is provided for double (the reference driver's type)");
     speck_dcsr a = matIn.raw(), t = matTransposeOut.raw();
-    speck_transpose_f64(nullptr, &a, &t);
+    if (sizeof(DataType) == 8) speck_transpose_f64(nullptr, &a, &t);
+    else speck_transpose_f32(nullptr, &a, &t);
     matTransposeOut.adopt(t);
 }
 }  // namespace spECK

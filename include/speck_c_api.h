@@ -26,7 +26,9 @@ enum {
     SPECK_ERR_OOM = 4,            /* device allocation failed, source/GPU/Multiply.cu:594-599 */
     SPECK_ERR_NNZ_OVERFLOW = 5,   /* nnz(C) does not fit the u32 row_offsets of dCSR */
     SPECK_ERR_NO_DEVICE = 6,
-    SPECK_ERR_IO = 7
+    SPECK_ERR_IO = 7,
+    SPECK_ERR_UNSORTED = 8        /* a row of B is not strictly ascending / column >= cols: the reference's
+                                   * undocumented precondition (its loader sorts, source/CSR.cpp:173-212) */
 };
 
 /* ---- device CSR: field-for-field the reference's dCSR<T> / dCSRNoDealloc<T>
@@ -138,8 +140,20 @@ int speck_dcsr_update(speck_dcsr *dst, const uint32_t *h_row_offsets, const uint
  * *h_mismatches = number of differing rows (0 = equal). */
 int speck_compare_f64(speck_config *cfg, const speck_dcsr *ref, const speck_dcsr *cmp,
                       int compare_data, double rel_tol, uint64_t *h_mismatches);
+/* ... and its float instantiation (source/GPU/Compare.cu:84) */
+int speck_compare_f32(speck_config *cfg, const speck_dcsr *ref, const speck_dcsr *cmp,
+                      int compare_data, double rel_tol, uint64_t *h_mismatches);
+/* The value check a SpGEMM result admits whatever its summation order: |ref - cmp| <= tol * S per
+ * entry, S = sum |a*b| of the entry, handed over as `abs_products` = |A|*|B| (same pattern as ref).
+ * Role of the reference's compare against cuSPARSE (source/Executor.cpp:29-40), made to FAIL on
+ * values: *h_structure_rows / *h_value_rows = rows that differ in pattern / beyond the bound. */
+int speck_compare_bounded_f64(speck_config *cfg, const speck_dcsr *ref, const speck_dcsr *cmp,
+                              const speck_dcsr *abs_products, double tol, uint64_t *h_structure_rows,
+                              uint64_t *h_value_rows);
 /* Order-preserving transpose (source/GPU/Transpose.cu:10-117; DataLoader.cpp:65-69 for rows!=cols). */
 int speck_transpose_f64(speck_config *cfg, const speck_dcsr *A, speck_dcsr *At);
+/* ... and its float instantiation (source/GPU/Transpose.cu:116) */
+int speck_transpose_f32(speck_config *cfg, const speck_dcsr *A, speck_dcsr *At);
 
 /* ---- host-side synthetic inputs and on-disk formats ---- */
 typedef struct speck_host_csr speck_host_csr; /* opaque host CSR<double>, include/CSR.h */

@@ -61,6 +61,10 @@ _SIGS = {
     "speck_dcsr_update": (C.c_int, [_P(DCsr), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "speck_compare_f64": (C.c_int, [C.c_void_p, _P(DCsr), _P(DCsr), C.c_int, C.c_double, _P(C.c_uint64)]),
     "speck_transpose_f64": (C.c_int, [C.c_void_p, _P(DCsr), _P(DCsr)]),
+    "speck_transpose_f32": (C.c_int, [C.c_void_p, _P(DCsr), _P(DCsr)]),
+    "speck_compare_f32": (C.c_int, [C.c_void_p, _P(DCsr), _P(DCsr), C.c_int, C.c_double, _P(C.c_uint64)]),
+    "speck_compare_bounded_f64": (C.c_int, [C.c_void_p, _P(DCsr), _P(DCsr), _P(DCsr), C.c_double, _P(C.c_uint64),
+                                            _P(C.c_uint64)]),
     "speck_gen_matrix": (C.c_int, [C.c_char_p, C.c_double, C.c_uint64, C.c_int, _P(C.c_void_p)]),
     "speck_load_mtx": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),
     "speck_load_hicsr": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),

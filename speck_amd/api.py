@@ -347,12 +347,23 @@ def partition_rows(A, B, config, parts):
 def compare(ref, cmp, config, compare_data=False, rel_tol=1e-12):
     """spECK::Compare(reference_mat, compare_mat, compare_data) -> bool, include/Compare.h:5-6."""
     n = C.c_uint64()
-    _check(_lib.load().speck_compare_f64(config._h, C.byref(ref._c), C.byref(cmp._c), int(compare_data),
-                                         float(rel_tol), C.byref(n)), "Compare")
+    fn = _lib.load().speck_compare_f32 if ref.dtype == np.float32 else _lib.load().speck_compare_f64
+    _check(fn(config._h, C.byref(ref._c), C.byref(cmp._c), int(compare_data), float(rel_tol), C.byref(n)), "Compare")
     return n.value == 0
 
 
+def compare_bounded(ref, cmp, abs_products, config, tol=1e-12):
+    """(rows differing in structure, rows with |ref - cmp| > tol * sum|a*b|); abs_products = |A|*|B|."""
+    ns, nv = C.c_uint64(), C.c_uint64()
+    _check(_lib.load().speck_compare_bounded_f64(config._h, C.byref(ref._c), C.byref(cmp._c),
+                                                 C.byref(abs_products._c), float(tol), C.byref(ns), C.byref(nv)),
+           "compare_bounded")
+    return int(ns.value), int(nv.value)
+
+
 def transpose(A, config):
+    """spECK::Transpose(matIn, matTransposeOut), include/Transpose.h (float and double)."""
     At = dCSR(A.dtype)
-    _check(_lib.load().speck_transpose_f64(config._h, C.byref(A._c), C.byref(At._c)), "Transpose")
+    fn = _lib.load().speck_transpose_f32 if A.dtype == np.float32 else _lib.load().speck_transpose_f64
+    _check(fn(config._h, C.byref(A._c), C.byref(At._c)), "Transpose")
     return At

@@ -158,6 +158,8 @@ struct DeviceStats {
     BinTable sym;
     BinTable num;
     u64 g_products;          // products of the NUM_G rows (the host sizes the spill pool from it)
+    u32 b_invalid;           // a row of B is not strictly ascending / holds a column >= cols (eager path)
+    u32 pad_;
 };
 
 // One row of work as the class kernels see it: written in class order by the scatter kernels,

@@ -32,30 +32,39 @@ using namespace speck;
 
 namespace {
 
+// one wave per row.  Structure: offsets and column ids bit-exact.  Values (compare_data): relative to
+// max(|x|, |y|), or -- when `scale` is given -- |x - y| <= rel_tol * scale[j] with scale = sum |a*b| of
+// the entry (the bound any summation order satisfies; `scale` has the pattern of `ref`).
+template <typename T>
 __global__ void compare_kernel(const u32* __restrict__ ro_a, const u32* __restrict__ col_a,
-                               const double* __restrict__ val_a, const u32* __restrict__ ro_b,
-                               const u32* __restrict__ col_b, const double* __restrict__ val_b,
+                               const T* __restrict__ val_a, const u32* __restrict__ ro_b,
+                               const u32* __restrict__ col_b, const T* __restrict__ val_b,
+                               const u32* __restrict__ ro_s, const T* __restrict__ val_s,
                                u32 rows, int compare_data, double rel_tol,
-                               unsigned long long* __restrict__ mismatches)
+                               unsigned long long* __restrict__ mismatches /*[2]: structure, values*/)
 {
-    // one wave per row
     const u32 lane = lane_id();
     const u64 wave = (u64(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const u64 nwaves = (u64(gridDim.x) * blockDim.x) >> 6;
     for (u64 row = wave; row < rows; row += nwaves) {
+        // offsets relative to the first one: row-range views compare equal to their copies
         const u32 a0 = ro_a[row], a1 = ro_a[row + 1], b0 = ro_b[row], b1 = ro_b[row + 1];
-        bool bad = (a1 - a0) != (b1 - b0) || a0 != b0;
+        bool bad = (a1 - a0) != (b1 - b0) || (a0 - ro_a[0]) != (b0 - ro_b[0]);
+        bool badv = false;
         if (!bad) {
-            for (u32 j = lane; j < a1 - a0; j += 64) {
+            const u32 s0 = ro_s ? ro_s[row] : 0u;
+            if (ro_s && ro_s[row + 1] - s0 != a1 - a0) bad = true;
+            for (u32 j = lane; j < a1 - a0 && !bad; j += 64) {
                 if (col_a[a0 + j] != col_b[b0 + j]) bad = true;
                 if (compare_data) {
-                    const double x = val_a[a0 + j], y = val_b[b0 + j];
-                    const double scale = fmax(fabs(x), fabs(y));
-                    if (!(fabs(x - y) <= rel_tol * scale)) bad = true;
+                    const double x = (double)val_a[a0 + j], y = (double)val_b[b0 + j];
+                    const double scale = val_s ? fabs((double)val_s[s0 + j]) : fmax(fabs(x), fabs(y));
+                    if (!(fabs(x - y) <= rel_tol * scale + 1e-300)) badv = true;
                 }
             }
         }
-        if (__ballot(bad) != 0 && lane == 0) atomicAdd(mismatches, 1ull);
+        if (__ballot(bad) != 0 && lane == 0) atomicAdd(&mismatches[0], 1ull);
+        if (__ballot(badv) != 0 && lane == 0) atomicAdd(&mismatches[1], 1ull);
     }
 }
 
@@ -77,9 +86,10 @@ __global__ void iota_kernel(u32* p, u32 n)
         p[i] = (u32)i;
 }
 
+template <typename T>
 __global__ void transpose_gather_kernel(const u32* __restrict__ perm, const u32* __restrict__ row_of,
-                                        const double* __restrict__ val, u32 nnz,
-                                        u32* __restrict__ t_col, double* __restrict__ t_val)
+                                        const T* __restrict__ val, u32 nnz,
+                                        u32* __restrict__ t_col, T* __restrict__ t_val)
 {
     for (u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; i < nnz; i += u64(gridDim.x) * blockDim.x) {
         const u32 src = perm[i];
@@ -102,43 +112,46 @@ __global__ void offsets_from_sorted_kernel(const u32* __restrict__ keys, u32 nnz
     }
 }
 
-}  // namespace
-
-extern "C" {
-
-int speck_compare_f64(speck_config* /*cfg*/, const speck_dcsr* ref, const speck_dcsr* cmp,
-                      int compare_data, double rel_tol, uint64_t* h_mismatches)
+template <typename T>
+int compare_impl(const speck_dcsr* ref, const speck_dcsr* cmp, const speck_dcsr* scale, int compare_data,
+                 double rel_tol, uint64_t* h_structure, uint64_t* h_values)
 {
-    if (!ref || !cmp || !h_mismatches) return SPECK_ERR_INVALID;
-    if (ref->rows != cmp->rows || ref->cols != cmp->cols || ref->nnz != cmp->nnz) {
-        *h_mismatches = ref->rows ? ref->rows : 1;
+    if (!ref || !cmp || !h_structure) return SPECK_ERR_INVALID;
+    if (h_values) *h_values = 0;
+    if (ref->rows != cmp->rows || ref->cols != cmp->cols || ref->nnz != cmp->nnz ||
+        (scale && (scale->rows != ref->rows || scale->nnz != ref->nnz))) {
+        *h_structure = ref->rows ? ref->rows : 1;
         return SPECK_OK;
     }
     if (ref->rows == 0) {
-        *h_mismatches = 0;
+        *h_structure = 0;
         return SPECK_OK;
     }
     unsigned long long* d = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), 8));
-    HIP_TRY(hipMemset(d, 0, 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), 16));
+    HIP_TRY(hipMemset(d, 0, 16));
     const u32 rows = (u32)ref->rows;
     u32 blocks = (rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(compare_kernel, dim3(blocks), dim3(256), 0, 0, ref->row_offsets, ref->col_ids,
-                       static_cast<const double*>(ref->data), cmp->row_offsets, cmp->col_ids,
-                       static_cast<const double*>(cmp->data), rows, compare_data, rel_tol, d);
-    unsigned long long h = 0;
-    HIP_TRY(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(compare_kernel<T>, dim3(blocks), dim3(256), 0, 0, ref->row_offsets, ref->col_ids,
+                       static_cast<const T*>(ref->data), cmp->row_offsets, cmp->col_ids,
+                       static_cast<const T*>(cmp->data), scale ? scale->row_offsets : nullptr,
+                       scale ? static_cast<const T*>(scale->data) : nullptr, rows, compare_data, rel_tol, d);
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
     (void)hipFree(d);
-    *h_mismatches = h;
+    *h_structure = h[0];
+    if (h_values) *h_values = h[1];
+    else *h_structure += h[1];
     return SPECK_OK;
 }
 
-int speck_transpose_f64(speck_config* /*cfg*/, const speck_dcsr* A, speck_dcsr* At)
+template <typename T>
+int transpose_impl(const speck_dcsr* A, speck_dcsr* At)
 {
     if (!A || !At) return SPECK_ERR_INVALID;
     const u32 nnz = (u32)A->nnz, rows = (u32)A->rows, cols = (u32)A->cols;
-    int rc = speck_dcsr_alloc(At, cols, rows, nnz, 1, sizeof(double));
+    int rc = speck_dcsr_alloc(At, cols, rows, nnz, 1, sizeof(T));
     if (rc != SPECK_OK) return rc;
     if (nnz == 0) {
         HIP_TRY(hipMemset(At->row_offsets, 0, (size_t(cols) + 1) * 4));
@@ -166,9 +179,8 @@ int speck_transpose_f64(speck_config* /*cfg*/, const speck_dcsr* A, speck_dcsr* 
     HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
     HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, perm_in, perm_out, nnz, 0,
                                       end_bit, (hipStream_t)0));
-    hipLaunchKernelGGL(transpose_gather_kernel, dim3(2048), dim3(256), 0, 0, perm_out, row_of,
-                       static_cast<const double*>(A->data) + base, nnz, At->col_ids,
-                       static_cast<double*>(At->data));
+    hipLaunchKernelGGL(transpose_gather_kernel<T>, dim3(2048), dim3(256), 0, 0, perm_out, row_of,
+                       static_cast<const T*>(A->data) + base, nnz, At->col_ids, static_cast<T*>(At->data));
     hipLaunchKernelGGL(offsets_from_sorted_kernel, dim3(2048), dim3(256), 0, 0, keys_out, nnz, cols,
                        At->row_offsets);
     HIP_TRY(hipDeviceSynchronize());
@@ -178,6 +190,40 @@ int speck_transpose_f64(speck_config* /*cfg*/, const speck_dcsr* A, speck_dcsr* 
     (void)hipFree(perm_out);
     (void)hipFree(keys_out);
     return SPECK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int speck_compare_f64(speck_config* /*cfg*/, const speck_dcsr* ref, const speck_dcsr* cmp,
+                      int compare_data, double rel_tol, uint64_t* h_mismatches)
+{
+    return compare_impl<double>(ref, cmp, nullptr, compare_data, rel_tol, h_mismatches, nullptr);
+}
+
+int speck_compare_f32(speck_config* /*cfg*/, const speck_dcsr* ref, const speck_dcsr* cmp,
+                      int compare_data, double rel_tol, uint64_t* h_mismatches)
+{
+    return compare_impl<float>(ref, cmp, nullptr, compare_data, rel_tol, h_mismatches, nullptr);
+}
+
+int speck_compare_bounded_f64(speck_config* /*cfg*/, const speck_dcsr* ref, const speck_dcsr* cmp,
+                              const speck_dcsr* abs_products, double tol, uint64_t* h_structure_rows,
+                              uint64_t* h_value_rows)
+{
+    if (!abs_products || !h_value_rows) return SPECK_ERR_INVALID;
+    return compare_impl<double>(ref, cmp, abs_products, 1, tol, h_structure_rows, h_value_rows);
+}
+
+int speck_transpose_f64(speck_config* /*cfg*/, const speck_dcsr* A, speck_dcsr* At)
+{
+    return transpose_impl<double>(A, At);
+}
+
+int speck_transpose_f32(speck_config* /*cfg*/, const speck_dcsr* A, speck_dcsr* At)
+{
+    return transpose_impl<float>(A, At);
 }
 
 }  // extern "C"

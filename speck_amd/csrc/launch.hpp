@@ -14,6 +14,9 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
                      u32* b_start, u32* b_len);
 
+// strictly ascending, in-range column ids in every row of B (sets DeviceStats::b_invalid)
+void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st);
+
 // exclusive scan of the row counts (+ numeric classification, stats fold, ordered scatter of the
 // numeric row records when num_cls != nullptr).
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,

@@ -68,6 +68,7 @@ struct speck_config {
     std::vector<hipStream_t> aux;  // one stream per kernel class: classes run concurrently
     std::vector<hipEvent_t> aux_done;
     hipEvent_t fork = nullptr;
+    bool validate_inputs = true;  // eager path: B's rows strictly ascending and in range
     bool concurrent_classes = true;
     u32 max_side_streams = 12;
     float fork_min_us = 60.f;  // estimated duration from which a class launch gets its own stream
@@ -569,8 +570,10 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     Timing tm;
     rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm);
     if (rc != SPECK_OK) return fail(rc);
+    if (c->validate_inputs) launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats);
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return fail(rc);
+    if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
     t->countProducts = 0.f;
     t->loadBalanceCounting = 0.f;
     t->globalMapsCounting = 0.f;
@@ -855,6 +858,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
+    else if (n == "validate_inputs") c->validate_inputs = value != 0;
     else if (n == "fork_min_us") {
         c->fork_min_us = (float)value;
         drop_graph(c);
@@ -1094,6 +1098,7 @@ const char* speck_status_string(int status)
         case SPECK_ERR_NNZ_OVERFLOW: return "nnz(C) exceeds 2^32-1 (u32 row_offsets)";
         case SPECK_ERR_NO_DEVICE: return "no such HIP device";
         case SPECK_ERR_IO: return "I/O error";
+        case SPECK_ERR_UNSORTED: return "a row of B is not strictly ascending (or holds a column >= cols)";
     }
     return "unknown";
 }

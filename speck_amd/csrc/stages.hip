@@ -369,6 +369,20 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
     __shared__ u32 s_wcnt[SYM_CLASSES][NW];
     __shared__ u32 s_run[SYM_CLASSES];
     const u32 lane = lane_id(), wid = threadIdx.x >> 6;
+    const u32 row_begin = blockIdx.x * rows_per_block;
+    const u32 row_end = min(m, row_begin + rows_per_block);
+    // what the first chunk of rows needs is requested BEFORE the fold (a chain of dependent loads and
+    // barriers): the two latencies overlap
+    u32 p_c = 0xFFu, p_a0 = 0, p_a1 = 0, p_min = 0, p_max = 0, p_ops = 0;
+    if (cls && row_begin + threadIdx.x < row_end) {
+        const u32 row = row_begin + threadIdx.x;
+        p_c = cls[row];
+        p_a0 = a_ro[row];
+        p_a1 = a_ro[row + 1];
+        p_min = row_col_min[row];
+        p_max = row_col_max[row];
+        p_ops = row_ops[row];
+    }
     fold_partials<kChunk, SYM_CLASSES>(parts, nb, blockIdx.x, &s_fold, s_bytes, cp.want_bytes != 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->sum_products = s_fold.sum_total;
@@ -378,11 +392,10 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
     if (!cls) return;
     if (threadIdx.x < SYM_CLASSES) s_run[threadIdx.x] = class_offset(s_fold, threadIdx.x) + s_fold.prefix[threadIdx.x];
     __syncthreads();
-    const u32 row_begin = blockIdx.x * rows_per_block;
-    const u32 row_end = min(m, row_begin + rows_per_block);
     for (u32 row0 = row_begin; row0 < row_end; row0 += kChunk) {
         const u32 row = row0 + threadIdx.x;
-        const u32 c = row < row_end ? cls[row] : 0xFFu;
+        const bool first = row0 == row_begin;
+        const u32 c = first ? p_c : (row < row_end ? cls[row] : 0xFFu);
         u32 my_rank = 0;
 #pragma unroll
         for (u32 b = 0; b < SYM_CLASSES; ++b) {
@@ -396,12 +409,12 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
             for (u32 w = 0; w < wid; ++w) pos += s_wcnt[c][w];
             RowRec r;
             r.row = row;
-            r.a0 = a_ro[row];
-            r.a1 = a_ro[row + 1];
+            r.a0 = first ? p_a0 : a_ro[row];
+            r.a1 = first ? p_a1 : a_ro[row + 1];
             r.base = 0;
-            r.cmin = row_col_min[row];
-            r.cmax = row_col_max[row];
-            r.ops = row_ops[row];
+            r.cmin = first ? p_min : row_col_min[row];
+            r.cmax = first ? p_max : row_col_max[row];
+            r.ops = first ? p_ops : row_ops[row];
             r.nnz = 0;
             recs[pos] = r;
         }
@@ -544,6 +557,16 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     __shared__ u32 s_scan[NW + 1];
     __shared__ u64 s_wave[NW][3];
     const u32 lane = lane_id(), wid = threadIdx.x >> 6;
+    // my rows' counts and classes are requested BEFORE the fold (dependent loads + barriers)
+    const u64 base = u64(blockIdx.x) * (kScanThreads * ITEMS) + u64(threadIdx.x) * ITEMS;
+    u32 c[ITEMS];
+    u8 cls[ITEMS];
+    u32 tsum = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        c[i] = (base + i) < m ? counts_inout[base + i] : 0;
+        cls[i] = (num_cls && (base + i) < m) ? num_cls[base + i] : (u8)NUM_NONE;
+    }
     fold_partials<kScanThreads, NUM_CLASSES>(parts, nb, blockIdx.x, &s_fold, s_bytes, cp.want_bytes != 0);
     const u64 nnz_c = s_fold.sum_total;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -566,14 +589,8 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
             for (u32 i = 0; i < sizeof(DeviceStats) / 8; ++i) dst[i] = src[i];
         }
     }
-    const u64 base = u64(blockIdx.x) * (kScanThreads * ITEMS) + u64(threadIdx.x) * ITEMS;
-    u32 c[ITEMS];
-    u32 tsum = 0;
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        c[i] = (base + i) < m ? counts_inout[base + i] : 0;
-        tsum += c[i];
-    }
+    for (int i = 0; i < ITEMS; ++i) tsum += c[i];
     u32 total;
     const u32 excl = block_exclusive_scan<kScanThreads>(tsum, s_scan, &total);
     u32 run = (u32)s_fold.sum_prefix + excl;
@@ -587,14 +604,11 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts_inout[m] = (u32)nnz_c;
     if (!num_cls) return;
 
-    // class of my 8 rows, packed per-thread histogram, exclusive scan over the threads
-    u8 cls[ITEMS];
+    // class of my rows, packed per-thread histogram, exclusive scan over the threads
     PackedCounts mine;
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        cls[i] = (base + i) < m ? num_cls[base + i] : (u8)NUM_NONE;
+    for (int i = 0; i < ITEMS; ++i)
         if (cls[i] != NUM_NONE) mine.add(cls[i]);
-    }
     PackedCounts incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -639,6 +653,55 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
         r.nnz = c[i];
         recs[pos] = r;
     }
+}
+
+// --------------------------------------------------------------------------------
+// Input precondition (undocumented upstream): the column ids of every row of B are
+// strictly ascending (the min/max column range of the analysis, the scaled-copy rows and the bitmap
+// sorts rely on it; the reference's loader guarantees it and silently computes garbage otherwise).
+// One coalesced pass over B.col_ids, eager path only (a replayed sequence runs on unchanged inputs).
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__ b_ro, const u32* __restrict__ b_col,
+                                                         u32 b_rows, u32 b_cols, DeviceStats* __restrict__ st)
+{
+    __shared__ u32 s_ro_all[4][66];
+    const u32 lane = lane_id();
+    u32* s_ro = s_ro_all[threadIdx.x >> 6];
+    const u64 wave = (u64(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const u64 nwaves = (u64(gridDim.x) * blockDim.x) >> 6;
+    bool bad = false;
+    // a wave walks the entries of 64 consecutive rows as one range: entry e is checked against e + 1
+    // unless e + 1 starts a row (a search in the wave's 65 row offsets, staged in LDS)
+    for (u64 r0 = wave * 64; r0 < b_rows; r0 += nwaves * 64) {
+        const u32 nr = (u32)min((u64)64, b_rows - r0);
+        wave_lds_fence();
+        if (lane <= nr) s_ro[lane] = b_ro[r0 + lane];
+        if (lane == 0 && nr == 64) s_ro[64] = b_ro[r0 + 64];
+        wave_lds_fence();
+        const u32 e0 = s_ro[0], e1 = s_ro[nr];
+        if (e1 < e0) bad = true;
+        for (u32 e = e0 + lane; e < e1; e += 64) {
+            const u32 c = b_col[e];
+            if (c >= b_cols) bad = true;
+            if (e + 1 < e1 && b_col[e + 1] <= c) {
+                u32 lo = 0, hi = nr;  // first offset >= e + 1
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (s_ro[mid] < e + 1) lo = mid + 1; else hi = mid;
+                }
+                if (s_ro[lo] != e + 1) bad = true;
+            }
+        }
+    }
+    if (__ballot(bad) != 0 && lane == 0) st->b_invalid = 1;  // plain store: every writer stores the same value
+}
+
+void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st)
+{
+    if (b_rows == 0) return;
+    u32 blocks = cdiv(b_rows, 64 * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(validate_b_kernel, dim3(blocks), dim3(256), 0, s, b_ro, b_col, b_rows, b_cols, st);
 }
 
 // --------------------------------------------------------------------------------

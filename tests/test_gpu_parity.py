@@ -52,12 +52,12 @@ def fast_random_csr(rows, cols, k, seed, signed=True, jitter=True):
     return po.HostCSR(rows, cols, ro, ci, v)
 
 
-def check(cfg, A, B, expect_classes=None, tol=TOL64, C_reuse=None):
+def check(cfg, A, B, expect_classes=None, tol=TOL64, C_reuse=None, threads=0):
     dA, dB = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B))
     dC = C_reuse if C_reuse is not None else sa.dCSR(A.data.dtype)
     sa.MultiplyspECK(dA, dB, dC, cfg)
     st = cfg.last_stats()
-    R, ab = po.spgemm(A, B)
+    R, ab = po.spgemm(A, B, threads=threads)
     got = dC.to_host()
     assert got.rows == R.rows and got.cols == R.cols and got.nnz == R.nnz
     assert (got.row_offsets == R.row_offsets).all(), "row_offsets differ"
@@ -346,13 +346,39 @@ def test_compare_and_transpose(cfg):
     sa.MultiplyspECK(sa.dCSR.from_host(to_sa(A2)), dT, dC3, cfg)
     assert not sa.compare(dC1, dC3, cfg)
     check(cfg, A, R)
+    # float instantiations (reference source/GPU/Transpose.cu:116, Compare.cu:84)
+    A32 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float32))
+    dA32 = sa.dCSR.from_host(to_sa(A32))
+    dT32 = sa.transpose(dA32, cfg)
+    T32 = dT32.to_host()
+    assert T32.data.dtype == np.float32
+    assert (T32.row_offsets == R.row_offsets).all() and (T32.col_ids == R.col_ids).all()
+    assert (T32.data == R.data.astype(np.float32)).all()
+    dF1, dF2 = sa.dCSR(np.float32), sa.dCSR(np.float32)
+    sa.MultiplyspECK(dA32, dT32, dF1, cfg)
+    sa.MultiplyspECK(dA32, dT32, dF2, cfg)
+    assert sa.compare(dF1, dF2, cfg, compare_data=True, rel_tol=1e-4)
+    # the bounded compare: |ref - cmp| <= tol * sum|a*b| with the sums from |A| * |A^T|
+    Aabs = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, np.abs(A.data))
+    dAabs = sa.dCSR.from_host(to_sa(Aabs))
+    dS = sa.dCSR()
+    sa.MultiplyspECK(dAabs, sa.transpose(dAabs, cfg), dS, cfg)
+    assert sa.compare_bounded(dC1, dC2, dS, cfg, tol=1e-12) == (0, 0)
+    bad_structure, bad_values = sa.compare_bounded(dC1, dC3, dS, cfg, tol=1e-12)
+    assert bad_structure > 0
 
 
-@pytest.mark.parametrize("kind,scale", [("scircuit", 1.0), ("mac_econ", 1.0), ("cant", 0.25),
-                                        ("webbase", 0.1), ("nlpkkt", 0.002)])
-def test_suitesparse_standins_full_parity(cfg, kind, scale):
+# BASELINE.json configs[1..3] at FULL size (the stand-ins fitted to the SuiteSparse figures), the
+# nlpkkt one at a size the oracle finishes in seconds (its full size runs in bench.py's config5 leg)
+@pytest.mark.parametrize("kind,scale,expect", [
+    ("scircuit", 1.0, [("num", "g16"), ("num", "wave512"), ("num", "block2k")]),
+    ("mac_econ", 1.0, [("num", "g16"), ("num", "wave128")]),
+    ("cant", 1.0, [("sym", "bitmap256k"), ("num", "dense4k")]),
+    ("webbase", 1.0, [("num", "global"), ("num", "block8k"), ("num", "direct"), ("sym", "block16k")]),
+    ("nlpkkt", 0.002, None)])
+def test_suitesparse_standins_full_parity(cfg, kind, scale, expect):
     A = to_po(sa.gen_matrix(kind, scale, 1, signed=True))
-    dC, st, R = check(cfg, A, A)
+    dC, st, R = check(cfg, A, A, expect)
     # size-independent properties: sorted rows, row-sum identity (C*1 == A*(A*1))
     ones = np.ones(A.cols)
     S = A.to_scipy()
@@ -468,3 +494,81 @@ def test_more_than_two_million_rows_in_one_class(cfg):
     val = 0.5 + rng.random(2 * m)
     A = po.HostCSR(m, m, ro, col, val)
     check(cfg, A, A, [("num", "g16")])
+
+
+def test_unsorted_or_out_of_range_b_is_rejected(cfg):
+    """The reference's undocumented precondition: rows of B strictly ascending.  A status
+    code instead of silently wrong column ranges; C stays untouched."""
+    A = random_csr(60, 40, 4, 1)
+    B = random_csr(40, 70, 6, 2)
+    ln = np.diff(B.row_offsets.astype(np.int64))
+    r = int(np.argmax(ln >= 2))
+    s0 = int(B.row_offsets[r])
+    dA = sa.dCSR.from_host(to_sa(A))
+    cases = []
+    sw = B.col_ids.copy(); sw[s0], sw[s0 + 1] = sw[s0 + 1], sw[s0]; cases.append((sw, B.cols))       # descending pair
+    du = B.col_ids.copy(); du[s0 + 1] = du[s0]; cases.append((du, B.cols))                            # duplicate column
+    cases.append((B.col_ids.copy(), int(B.col_ids.max())))                                            # column == cols
+    for cols_arr, ncols in cases:
+        Bx = po.HostCSR(B.rows, ncols, B.row_offsets, cols_arr, B.data)
+        dC = sa.dCSR()
+        with pytest.raises(sa.SpeckError) as e:
+            sa.MultiplyspECK(dA, sa.dCSR.from_host(to_sa(Bx)), dC, cfg)
+        assert e.value.status == 8
+        assert dC.nnz == 0 and not dC._c.data and not dC._c.col_ids
+    check(cfg, A, B)          # the untouched B is fine
+
+
+def test_products_beyond_2_32_use_the_u64_path(cfg):
+    """P = 4096 * 1100 * 1100 = 4.96e9 > 2^32 (the reference's u32 sumProducts wraps, Multiply.cu:237)."""
+    rng = np.random.default_rng(5)
+    m, k = 4096, 1100
+    cols = np.sort(np.argsort(rng.random((m, m)), axis=1)[:, :k], axis=1).astype(np.uint32).reshape(-1)
+    ro = (np.arange(m + 1, dtype=np.int64) * k).astype(np.uint32)
+    val = (0.5 + rng.random(m * k)) * rng.choice([-1.0, 1.0], size=m * k)
+    A = po.HostCSR(m, m, ro, cols, val)
+    dC, st, R = check(cfg, A, A)
+    assert st["sum_products"] == m * k * k and st["sum_products"] > 2 ** 32
+    assert st["max_row_ops"] == k * k
+
+
+def test_nnz_of_c_beyond_u32_is_reported_not_wrapped(cfg):
+    """nnz(C) = 66000^2 > 2^32 - 1 does not fit dCSR's u32 row_offsets: SPECK_ERR_NNZ_OVERFLOW, C untouched."""
+    m = 66000
+    A = po.HostCSR(m, 1, np.arange(m + 1, dtype=np.uint32), np.zeros(m, np.uint32), np.ones(m))
+    B = po.HostCSR(1, m, np.array([0, m], np.uint32), np.arange(m, dtype=np.uint32), np.ones(m))
+    dC = sa.dCSR()
+    with pytest.raises(sa.SpeckError) as e:
+        sa.MultiplyspECK(sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), dC, cfg)
+    assert e.value.status == 5
+    assert dC.nnz == 0 and not dC._c.data
+    ro, nnz = None, None
+    with pytest.raises(sa.SpeckError) as e:
+        sa.symbolic(sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), cfg)
+    assert e.value.status == 5
+
+
+def test_dimensions_exactly_at_the_2_27_limit(cfg):
+    """rows(A) = cols(B) = 2^27, the largest sizes the reference accepts (Multiply.cu:57-66); four rows
+    reach columns over the WHOLE range: 128 one-Mi-column bitmap windows in the symbolic phase, the
+    global spill in the numeric one; the last row of A is non-empty too."""
+    n = 1 << 27
+    rng = np.random.default_rng(9)
+    kb, lb = 300, 200
+    bc = np.sort(rng.integers(0, n, size=(kb, lb), dtype=np.int64), axis=1)
+    bc[:, 0], bc[:, -1] = np.minimum(bc[:, 0], 5), n - 1          # every row spans [<=5, 2^27 - 1]
+    keep = np.ones((kb, lb), dtype=bool)
+    keep[:, 1:] = bc[:, 1:] != bc[:, :-1]
+    bro = np.zeros(kb + 1, dtype=np.uint32)
+    bro[1:] = np.cumsum(keep.sum(axis=1))
+    B = po.HostCSR(kb, n, bro, bc[keep].astype(np.uint32), 0.5 + rng.random(int(keep.sum())))
+    heavy = 4
+    aro = np.zeros(n + 1, dtype=np.uint32)
+    aro[1:heavy + 1] = kb * np.arange(1, heavy + 1)
+    aro[heavy + 1:n] = kb * heavy
+    aro[n] = kb * heavy + 3
+    acol = np.concatenate([np.tile(np.arange(kb, dtype=np.uint32), heavy), np.array([1, 7, 250], np.uint32)])
+    A = po.HostCSR(n, kb, aro, acol, 0.5 + rng.random(acol.size))
+    dC, st, R = check(cfg, A, B, [("sym", "bitmap1m"), ("num", "global")], threads=2)
+    assert dC.rows == n and dC.cols == n
+    assert st["max_row_ops"] == int(np.diff(bro.astype(np.int64)).sum())
