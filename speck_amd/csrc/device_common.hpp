@@ -266,6 +266,10 @@ __device__ __forceinline__ u32 wave_reduce_max(u32 v)
     v = max(v, dpp_move<kDppRowBcast31, 0xC>(0, v));
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ u32 wave_reduce_min(u32 v)
+{
+    return ~wave_reduce_max(~v);
+}
 __device__ __forceinline__ u64 lanemask_lt()
 {
     return (1ull << lane_id()) - 1ull;

@@ -54,6 +54,8 @@ struct RowWork {
     const u32* b_start;     // per A entry (relative to the first entry of the A view):
     const u32* b_len;       //   start / length of the referenced B row, written by the analysis
     SpillBuffers spill;     // NUM_G class (all null when no row needs it)
+    u32* w_start;           // per A entry: start / length of its B row INSIDE the current column window
+    u32* w_len;             //   (multi-window rows, row_groups.hpp WindowCursors); a row's entries belong to its workgroup
     u32 xcd_aware;          // class lists are walked in per-XCD contiguous slices (row_groups.hpp)
 };
 

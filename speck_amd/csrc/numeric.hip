@@ -404,19 +404,34 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
     const RowRec* recs = w.recs + w.st->num.offset[cls];
     RowRec next{};
     if (rs.idx < rs.end) next = recs[rs.idx];
+    for (u32 i = threadIdx.x; i < WCOLS; i += THREADS) vals[i] = 0;
+    for (u32 i = threadIdx.x; i < WORDS; i += THREADS) bm[i] = 0;
+    __syncthreads();
     for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
         const RowRec rec = next;  // fetched while the previous row was being processed
         if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
         u32 emitted = 0;
-        for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += WCOLS) {
-            const u64 left = u64(rec.cmax) - w0 + 1;
+        // a row wider than one window: per-entry cursors, every B entry is read once (WindowCursors)
+        const bool multi = u64(rec.cmax) - rec.cmin + 1 > WCOLS;
+        const WindowCursors<THREADS> cur{src.b_start, src.b_len, src.b_col, src.w_start, src.w_len, rec.a0, rec.a1};
+        ProductSrc<T> wsrc = src;
+        if (multi) {
+            wsrc.b_start = src.w_start;
+            wsrc.b_len = src.w_len;
+            cur.reset();
+        }
+        u32 wbase = rec.cmin;
+        while (true) {
+            if (multi) {
+                wbase = cur.next_window(WCOLS, scratch);
+                if (wbase == 0xFFFFFFFFu) break;
+            }
+            const u64 left = u64(rec.cmax) - wbase + 1;
             const u32 ncols = left < WCOLS ? (u32)left : WCOLS;
             const u32 nwords = (ncols + 31) >> 5;
-            const u32 wbase = (u32)w0;
-            for (u32 i = threadIdx.x; i < ncols; i += THREADS) vals[i] = 0;
-            for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
-            __syncthreads();
-            for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch,
+            // (the accumulators and the bitmap are clean here: cleared once per workgroup below, and every
+            //  emit zeroes exactly the cells it read -- a window costs its entries, not its width)
+            for_each_product<true>(g, wsrc, rec.a0, rec.a1, meta, scratch,
                                    [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
 #pragma unroll
                                        for (int u = 0; u < kBatch; ++u) {
@@ -428,16 +443,36 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
                                        }
                                    });
             const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);
-            for (u32 d = threadIdx.x; d < ncols; d += THREADS) {
-                const u32 word = bm[d >> 5];
-                if (word & (1u << (d & 31))) {
-                    const u32 r = emitted + pref[d >> 5] + __popc(word & ((1u << (d & 31)) - 1u));
-                    c_col[rec.base + r] = wbase + d;
-                    c_val[rec.base + r] = (T)vals[d];
+            if (total * 4u < ncols) {
+                // sparse window: a thread per bitmap word walks its set bits
+                for (u32 i = threadIdx.x; i < nwords; i += THREADS) {
+                    u32 word = bm[i], r = emitted + pref[i];
+                    if (word) bm[i] = 0;
+                    while (word) {
+                        const u32 d = i * 32u + (u32)__builtin_ctz(word);
+                        word &= word - 1u;
+                        c_col[rec.base + r] = wbase + d;
+                        c_val[rec.base + r] = (T)vals[d];
+                        vals[d] = 0;
+                        ++r;
+                    }
                 }
+            } else {
+                for (u32 d = threadIdx.x; d < ncols; d += THREADS) {
+                    const u32 word = bm[d >> 5];
+                    if (word & (1u << (d & 31))) {
+                        const u32 r = emitted + pref[d >> 5] + __popc(word & ((1u << (d & 31)) - 1u));
+                        c_col[rec.base + r] = wbase + d;
+                        c_val[rec.base + r] = (T)vals[d];
+                        vals[d] = 0;
+                    }
+                }
+                __syncthreads();
+                for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             }
             emitted += total;
             __syncthreads();
+            if (!multi) break;
         }
     }
 }
@@ -1009,7 +1044,7 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
     }
     if (cg.first[6] == 0) return;
-    const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data};
+    const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
     if (cg.first[3] == 0)
         hipLaunchKernelGGL((num_tiny_kernel<T>), dim3(cg.first[6]), dim3(256), lds, s, src, Av.row_offsets, w,
                            c_col, c_val, cg);
@@ -1024,7 +1059,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
 {
     if (count == 0) return;
     // (A, B) below = (product source, A.row_offsets): the kernels rebase the per-entry arrays
-    const ProductSrc<T> A{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data};
+    const ProductSrc<T> A{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
     const u32* B = Av.row_offsets;
     const u32 lds = numeric_lds_bytes_t<T>(cls);
     switch (cls) {

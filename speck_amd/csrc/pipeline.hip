@@ -144,13 +144,14 @@ struct Scratch {
     u8* cls;
     BlockPartial* partials;
     u32 *b_start, *b_len;  // per A entry: the referenced B row (written by the analysis)
+    u32 *w_start, *w_len;  // per A entry: its B entries inside the current column window (multi-window rows)
 };
 
 u32 partial_blocks(u32 m) { return std::max(analysis_blocks(m), scan_tiles(m)) + 2; }  // + PartialArrays padding
 
 size_t scratch_bytes(u32 m, u64 nnz_a)
 {
-    size_t b = 2 * Carver::need(nnz_a, 4);
+    size_t b = 4 * Carver::need(nnz_a, 4);
     b += 4 * Carver::need(m, 4);
     b += Carver::need(m, sizeof(RowRec));
     b += Carver::need(m, 1);
@@ -164,6 +165,8 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
     Scratch s;
     s.b_start = cv.take<u32>(nnz_a);
     s.b_len = cv.take<u32>(nnz_a);
+    s.w_start = cv.take<u32>(nnz_a);
+    s.w_len = cv.take<u32>(nnz_a);
     s.recs = cv.take<RowRec>(m);
     s.row_ops = cv.take<u32>(m);
     s.row_max_ops = cv.take<u32>(m);
@@ -348,7 +351,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
                     c->d_stats, cp, sc.b_start, sc.b_len);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
-    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, SpillBuffers{}, c->xcd_aware};
+    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, SpillBuffers{}, sc.w_start, sc.w_len, c->xcd_aware};
     // heaviest classes first: they have the longest tails
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
@@ -393,7 +396,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     CsrView<T> Av{A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
-    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, c->spill, c->xcd_aware};
+    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, c->spill, sc.w_start, sc.w_len, c->xcd_aware};
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;
     const u32* hint = counts ? counts : all_m;

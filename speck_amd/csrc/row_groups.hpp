@@ -174,12 +174,16 @@ struct ProductSrc {
     const T* __restrict__ a_val;
     const u32* __restrict__ b_col;
     const T* __restrict__ b_val;
+    u32* w_start;  // window cursors of multi-window rows (WindowCursors below), same indexing
+    u32* w_len;
     // rebase the per-entry arrays so that they can be indexed with absolute A entries
     __device__ __forceinline__ void rebase(const u32* a_row_offsets)
     {
         const u32 e_base = a_row_offsets[0];
         b_start -= e_base;
         b_len -= e_base;
+        w_start -= e_base;
+        w_len -= e_base;
     }
 };
 
@@ -380,6 +384,78 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
         PHASE_MARK(13);
     }
 }
+
+// ---- column windows over a heavy row: per-entry cursors ---------------------------------
+// A row whose reachable column range exceeds one LDS window (dense accumulator, bitmap) is produced
+// window by window.  B rows are sorted, so the B entries of A entry e that fall into the window are a
+// contiguous run behind the entry's cursor: every B entry is READ ONCE per row however many windows
+// there are (role of the reference's per-A-nnz resume cursors, include/GPU/spECK_HashSpGEMM.cuh:
+// 1175-1298, 1475-1569; kept in LDS there, spilled to a global cursor pool for long A rows, :1600-1619).
+// Here the cursors always live in global memory -- w_start / w_len, one pair per A entry, touched only
+// by the workgroup that owns the row -- because the windowed run lengths then plug into the same
+// flattened product walk (for_each_product reads them where it otherwise reads b_start / b_len).
+// A window starts at the SMALLEST column not yet consumed, so no window is empty.
+template <int THREADS>
+struct WindowCursors {
+    const u32* __restrict__ b_start;  // rebased like ProductSrc's
+    const u32* __restrict__ b_len;
+    const u32* __restrict__ b_col;
+    u32* __restrict__ w_start;
+    u32* __restrict__ w_len;
+    u32 a0, a1;
+
+    __device__ __forceinline__ void reset() const
+    {
+        for (u32 e = a0 + threadIdx.x; e < a1; e += THREADS) {
+            w_start[e] = b_start[e];
+            w_len[e] = 0;
+        }
+        __syncthreads();
+    }
+    // advances every cursor past the previous window and returns the first column of the next one
+    // (0xFFFFFFFF: the row is finished); `s_min` is one LDS word + THREADS/64 words of scratch
+    __device__ __forceinline__ u32 next_window(u32 wcols, u32* s_red) const
+    {
+        u32 mn = 0xFFFFFFFFu;
+        for (u32 e = a0 + threadIdx.x; e < a1; e += THREADS) {
+            const u32 lo = w_start[e] + w_len[e], hi = b_start[e] + b_len[e];
+            if (lo < hi) mn = min(mn, b_col[lo]);
+        }
+        mn = wave_reduce_min(mn);
+        __syncthreads();
+        if (lane_id() == 0) s_red[threadIdx.x >> 6] = mn;
+        __syncthreads();
+        mn = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) mn = min(mn, s_red[w]);
+        __syncthreads();
+        if (mn == 0xFFFFFFFFu) return mn;
+        const u64 wend = u64(mn) + wcols;  // exclusive
+        for (u32 e = a0 + threadIdx.x; e < a1; e += THREADS) {
+            const u32 first = w_start[e] + w_len[e], hi = b_start[e] + b_len[e];
+            u32 lo = first, up = hi;  // first entry with column >= wend: gallop from the cursor (a window
+            u32 stepw = 1;            //   usually takes a few entries of a B row), then bisect
+            while (lo < up) {
+                const u32 probe = min(lo + stepw - 1u, up - 1u);
+                if (u64(b_col[probe]) < wend) {
+                    lo = probe + 1;
+                    stepw <<= 1;
+                } else {
+                    up = probe;
+                    break;
+                }
+            }
+            while (lo < up) {
+                const u32 mid = lo + ((up - lo) >> 1);
+                if (u64(b_col[mid]) < wend) lo = mid + 1; else up = mid;
+            }
+            w_start[e] = first;
+            w_len[e] = lo - first;
+        }
+        __syncthreads();  // the walk below reads other threads' w_start / w_len (same CU, same L1)
+        return mn;
+    }
+};
 
 // ---- open-addressed structures (LDS or global memory) ---------------------------------
 // Batched forms: the first compare-and-swap of the kBatch products are issued back to back

@@ -83,14 +83,27 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
         const RowRec rec = next;  // fetched while the previous row was being processed
         if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
         u32 total = 0;
-        for (u64 w0 = rec.cmin; w0 <= rec.cmax; w0 += kWindowCols) {
-            const u64 left = u64(rec.cmax) - w0 + 1;
+        // a row wider than one window: per-entry cursors, every B entry is read once (WindowCursors)
+        const bool multi = u64(rec.cmax) - rec.cmin + 1 > kWindowCols;
+        const WindowCursors<THREADS> cur{src.b_start, src.b_len, src.b_col, src.w_start, src.w_len, rec.a0, rec.a1};
+        ProductSrc<float> wsrc = src;
+        if (multi) {
+            wsrc.b_start = src.w_start;
+            wsrc.b_len = src.w_len;
+            cur.reset();
+        }
+        u32 base = rec.cmin;
+        while (true) {
+            if (multi) {
+                base = cur.next_window((u32)kWindowCols, scratch);
+                if (base == 0xFFFFFFFFu) break;
+            }
+            const u64 left = u64(rec.cmax) - base + 1;
             const u32 ncols = left < kWindowCols ? (u32)left : (u32)kWindowCols;
             const u32 nwords = (ncols + 31) >> 5;
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
             __syncthreads();
-            const u32 base = (u32)w0;
-            for_each_product<false>(g, src, rec.a0, rec.a1, meta, scratch,
+            for_each_product<false>(g, wsrc, rec.a0, rec.a1, meta, scratch,
                                     [&](const u32(&c)[kBatch], const float(&)[kBatch], u32 n) {
 #pragma unroll
                                         for (int u = 0; u < kBatch; ++u) {
@@ -100,6 +113,7 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
                                     });
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) total += __popc(bm[i]);
             __syncthreads();
+            if (!multi) break;
         }
         total = g.reduce_add(total, scratch);
         if (threadIdx.x == 0) counts[rec.row] = total;
@@ -224,7 +238,7 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
     }
     if (cg.first[5] == 0) return;
-    const ProductSrc<float> src{b_start, b_len, nullptr, b_col, nullptr};
+    const ProductSrc<float> src{b_start, b_len, nullptr, b_col, nullptr, w.w_start, w.w_len};
     hipLaunchKernelGGL(sym_light_kernel, dim3(cg.first[5]), dim3(256), lds, s, src, a_ro, w, counts, cg);
 }
 
@@ -233,7 +247,7 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
 {
     if (count == 0) return;
     // (A, B) below = (product source, A.row_offsets): the kernels rebase the per-entry arrays
-    const ProductSrc<float> A{b_start, b_len, nullptr, b_col, nullptr};
+    const ProductSrc<float> A{b_start, b_len, nullptr, b_col, nullptr, w.w_start, w.w_len};
     const u32* B = a_ro;
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
