@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export PYTHONPATH=$PWD
-timeout 2400 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -n 40
-bash scripts/gpu_ab.sh "base"
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -n 5
+bash scripts/gpu_ab.sh "base" "base"

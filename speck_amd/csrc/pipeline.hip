@@ -71,6 +71,7 @@ struct speck_config {
     bool validate_inputs = true;  // eager path: B's rows strictly ascending and in range
     bool concurrent_classes = true;
     u32 max_side_streams = 12;
+    float split_min_us = 10.f; // both parts of a light launch must be at least this long to be launched apart
     float fork_min_us = 60.f;  // estimated duration from which a class launch gets its own stream
     bool merge_light = true;  // all 256-thread classes of a phase in one launch
     bool split_light = true;  // ... in two back-to-back launches, by LDS / register need
@@ -362,7 +363,18 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     // the launch's LDS size is the largest need among its classes and caps the waves per CU of all of
     // them: the 256-thread classes go in two launches, the big-LDS ones apart (split_light); the
     // first runs on a side stream next to the second
-    const u32 sym_big = c->split_light ? (1u << SYM_BM1) : kSymLightMask;
+    // ... unless one of the two parts is next to empty: then a second launch only adds a boundary
+    auto part_us = [](const u32* counts, const float* ns, u32 mask) {
+        float us = 0.f;
+        for (int k = 0; k < kMaxClasses; ++k)
+            if (mask >> k & 1u) us += counts[k] * ns[k] * 1e-3f;
+        return us;
+    };
+    bool split_sym = c->split_light;
+    if (split_sym && sym_hint)
+        split_sym = part_us(sym_hint, kSymNsPerRow, kSymLightMask & (1u << SYM_BM1)) >= c->split_min_us &&
+                    part_us(sym_hint, kSymNsPerRow, kSymLightMask & ~(1u << SYM_BM1)) >= c->split_min_us;
+    const u32 sym_big = split_sym ? (1u << SYM_BM1) : kSymLightMask;
     int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 5 : (int)SYM_CLASSES, sym_mask,
                          kSymLightMask & sym_big, kSymLightMask & ~sym_big, sym_hint, kSymNsPerRow,
                          tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr, [&](hipStream_t ks, int cls) {
@@ -403,7 +415,19 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     static const int merged[6] = {NUM_G, NUM_D2, NUM_B8K, NUM_W1K, kLightBig, kLightTiny};
     static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K,  NUM_B2K, NUM_W1K,
                                               NUM_D1, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
-    const u32 num_big = c->split_light ? (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) : kNumLightMask;
+    constexpr u32 kBigPart = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512);
+    bool split_num = c->split_light;
+    if (split_num && counts) {
+        auto part_us = [&](u32 mask) {
+            float us = 0.f;
+            for (int k = 0; k < kMaxClasses; ++k)
+                if (mask >> k & 1u) us += counts[k] * kNumNsPerRow[k] * 1e-3f;
+            return us;
+        };
+        split_num = part_us(kNumLightMask & kBigPart) >= c->split_min_us &&
+                    part_us(kNumLightMask & ~kBigPart) >= c->split_min_us;
+    }
+    const u32 num_big = split_num ? kBigPart : kNumLightMask;
     return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 6 : (int)NUM_CLASSES, num_mask,
                        kNumLightMask & num_big, kNumLightMask & ~num_big, counts, kNumNsPerRow,
                        tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr, [&](hipStream_t ks, int cls) {
