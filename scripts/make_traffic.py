@@ -35,6 +35,7 @@ def main():
     lines = ["kernel,FETCH_SIZE_KB_raw_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch=(2*FETCH+WRITE)*1024"]
     traffic = json.load(open(tjson)) if os.path.exists(tjson) else {}
     traffic = {k: v for k, v in traffic.items() if not k.startswith(workload + ":")}
+    traffic["_source"] = os.path.dirname(out_csv) + "/" + os.path.basename(out_csv).split("_")[0] + "_pmc_*_fetch_write.csv"
     for k in sorted(set(f) | set(w)):
         b = int((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024)
         lines.append(f"\"{k}\",{f.get(k, 0.0):.1f},{w.get(k, 0.0):.1f},{b}")
