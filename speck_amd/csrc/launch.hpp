@@ -12,7 +12,10 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 nnz_a, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
-                     u32* b_start, u32* b_len);
+                     u32* b_start, u32* b_len, hipEvent_t between = nullptr);
+
+// completion ticket of a replayed launch sequence (pinned host word the host spins on)
+void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket);
 
 // strictly ascending, in-range column ids in every row of B (sets DeviceStats::b_invalid)
 void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st);

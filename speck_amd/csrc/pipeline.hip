@@ -62,6 +62,11 @@ struct speck_config {
     DeviceStats* d_stats = nullptr;
     DeviceStats* h_stats = nullptr;  // pinned, mapped
     DeviceStats* h_stats_dev = nullptr;  // device address of h_stats
+    u32* d_ticket = nullptr;             // completion ticket of the replayed sequence: device counter,
+    u32* h_ticket = nullptr;             //   pinned host copy (the host spins on it),
+    u32* h_ticket_dev = nullptr;         //   its device address
+    u32 ticket_expected = 0;
+    bool spin_wait = true;
     ClassifyParams cp{};
     bool profile_kernels = false;
     std::vector<hipEvent_t> kev;   // kernel event pool (timing)
@@ -328,7 +333,7 @@ u32 mask_of(const u32* counts, int n)
 }
 
 struct Timing {
-    size_t ev = 0, ev_analysis = 0, ev_scan = 0, ev_num = 0;
+    size_t ev = 0, ev_analysis = 0, ev_between = 0, ev_analysis_end = 0, ev_scan = 0, ev_num = 0;
     std::vector<ClassTiming> sym, num;
 };
 
@@ -348,10 +353,18 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         tm->ev_analysis = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
+    hipEvent_t between = nullptr;
+    if (timed) {
+        tm->ev_between = tm->ev;
+        between = kernel_event(c, tm->ev++);
+    }
     launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
-                    c->d_stats, cp, sc.b_start, sc.b_len);
-    if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
+                    c->d_stats, cp, sc.b_start, sc.b_len, between);
+    if (timed) {
+        tm->ev_analysis_end = tm->ev;
+        (void)hipEventRecord(kernel_event(c, tm->ev++), s);
+    }
     RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, SpillBuffers{}, sc.w_start, sc.w_len, c->xcd_aware};
     // heaviest classes first: they have the longest tails
     u32 all_m[kMaxClasses];
@@ -496,6 +509,7 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
                              c->last_num_mask, c->last_num_counts, nullptr);
     // no copy node: the scan kernel mirrors the statistics block into pinned host memory
+    if (rc == SPECK_OK && c->spin_wait) launch_done(s, c->d_ticket, c->h_ticket_dev);
     hipError_t e = rc == SPECK_OK ? hipSuccess : hipErrorUnknown;
     hipGraph_t g = nullptr;
     hipError_t e2 = hipStreamEndCapture(s, &g);
@@ -549,6 +563,12 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         return SPECK_OK;
     };
     StageTimer st(c, t->measureAll != 0, s);
+    struct RestoreFlag {
+        bool& flag;
+        bool value;
+        ~RestoreFlag() { flag = value; }
+    } restore_profile{c->profile_kernels, c->profile_kernels};
+    if (t->measureAll) c->profile_kernels = true;  // per-stage times come from per-launch events
 
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
@@ -566,7 +586,20 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             have = capture_graph<T>(c, s, A, B, C, sc, key) == SPECK_OK;
         if (have) {
             HIP_TRY(hipGraphLaunch(c->graph_exec, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            if (c->spin_wait) {
+                // the last node of the sequence stores a ticket into pinned memory: spin on it (bounded),
+                // then fall back to the blocking synchronisation
+                const u32 want = ++c->ticket_expected;
+                volatile u32* flag = c->h_ticket;
+                for (u64 spins = 0; *flag != want && spins < (1ull << 24); ++spins) __builtin_ia32_pause();
+                if (*flag != want) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    c->ticket_expected = *flag;
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            } else {
+                HIP_TRY(hipStreamSynchronize(s));
+            }
             if (!c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 ++c->graph_replays;
                 publish_counts(c);
@@ -745,11 +778,16 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             (void)hipEventElapsedTime(&v, c->kev[a], c->kev[a + 1]);
             return v;
         };
-        c->last.analysis_ms = ms(tm.ev_analysis);
+        auto span = [&](size_t a, size_t b) {
+            float v = 0.f;
+            (void)hipEventElapsedTime(&v, c->kev[a], c->kev[b]);
+            return v;
+        };
+        c->last.analysis_ms = span(tm.ev_analysis, tm.ev_analysis_end);
         c->last.scan_ms = ms(tm.ev_scan);
         // phases: end of the analysis launches -> start of the scan (all symbolic branches joined);
         // before the first numeric launch -> after the last join
-        (void)hipEventElapsedTime(&c->last.sym_phase_ms, c->kev[tm.ev_analysis + 1], c->kev[tm.ev_scan]);
+        (void)hipEventElapsedTime(&c->last.sym_phase_ms, c->kev[tm.ev_analysis_end], c->kev[tm.ev_scan]);
         (void)hipEventElapsedTime(&c->last.num_phase_ms, c->kev[tm.ev_num], c->kev[ev_num_end]);
         for (const auto& ct : tm.sym) {
             if (ct.cls == kLightBig) c->last.sym_light_ms = ms(ct.ev);
@@ -762,6 +800,16 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             else c->last.num_bin_ms[ct.cls] = ms(ct.ev);
         }
         c->last.kernel_events_valid = 1;
+        if (t->measureAll) {
+            // the reference's eleven stage fields (Timings.h:7-18, filled at Multiply.cu:227-1073) from
+            // the kernel events: stages that are fused here report under the field of their role
+            t->countProducts = span(tm.ev_analysis, tm.ev_between);          // readOperations
+            t->loadBalanceCounting = span(tm.ev_between, tm.ev_analysis_end);  // symbolic binning (scatter)
+            t->spGEMMCounting = c->last.sym_phase_ms;                          // symbolic launches
+            t->loadBalanceNumeric = c->last.scan_ms;                           // scan + numeric binning
+            t->spGEMMNumeric = c->last.num_phase_ms;                           // numeric launches ...
+            t->sorting = 0.f;                                                  // ... which sort in-kernel
+        }
     }
     if (t->measureAll) {
         // same table the reference prints (Multiply.cu:1097-1113)
@@ -822,6 +870,11 @@ int speck_config_create(int device, speck_config** out)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(DeviceStats)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stats), sizeof(DeviceStats), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_stats_dev), c->h_stats, 0));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_ticket), sizeof(u32)));
+    HIP_TRY(hipMemset(c->d_ticket, 0, sizeof(u32)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_ticket), 64, hipHostMallocMapped));
+    *c->h_ticket = 0;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_ticket_dev), c->h_ticket, 0));
     c->cp.sym_bitmap_ratio = 32;
     c->cp.num_dense_ratio = 16;
     c->cp.num_global_passes = 4;  // heavy rows: dense windows up to 64 Ki columns, else global spill
@@ -850,6 +903,8 @@ int speck_config_destroy(speck_config* c)
     if (c->gpool) (void)hipFree(c->gpool);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->h_ticket) (void)hipHostFree(c->h_ticket);
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
     delete c;
     return SPECK_OK;
 }
@@ -886,6 +941,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
     else if (n == "validate_inputs") c->validate_inputs = value != 0;
+    else if (n == "spin_wait") {
+        c->spin_wait = value != 0;
+        drop_graph(c);
+    }
     else if (n == "fork_min_us") {
         c->fork_min_us = (float)value;
         drop_graph(c);

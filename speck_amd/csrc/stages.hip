@@ -704,6 +704,19 @@ void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_r
     hipLaunchKernelGGL(validate_b_kernel, dim3(blocks), dim3(256), 0, s, b_ro, b_col, b_rows, b_cols, st);
 }
 
+// Last node of a replayed launch sequence: a ticket in pinned host memory the host spins on (a blocking
+// stream synchronisation costs ~10-20 us of wake-up latency: a tenth of a 200 us multiply).
+__global__ void done_kernel(u32* __restrict__ dev_ticket, u32* __restrict__ host_ticket)
+{
+    const u32 t = *dev_ticket + 1u;
+    *dev_ticket = t;
+    __hip_atomic_store(host_ticket, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket)
+{
+    hipLaunchKernelGGL(done_kernel, dim3(1), dim3(1), 0, s, dev_ticket, host_ticket);
+}
+
 // --------------------------------------------------------------------------------
 // host launchers
 // --------------------------------------------------------------------------------
@@ -719,13 +732,14 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 /*nnz_a*/, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
-                     u32* b_start, u32* b_len)
+                     u32* b_start, u32* b_len, hipEvent_t between)
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
     hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kAnThreads), 0, s, a_ro, a_col, b_ro, b_col, m,
                        rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                        partials, cp, b_start, b_len, st);
+    if (between) (void)hipEventRecord(between, s);  // analysis | binning (Timings::countProducts / loadBalanceCounting)
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,
                        (const u8*)sym_cls, m, rows_per_block, st, partials, blocks, a_ro,
