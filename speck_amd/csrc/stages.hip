@@ -58,6 +58,7 @@ static inline void row_chunking(u32 m, u32* rows_per_block, u32* blocks)
 // HBM traffic (algorithmic): 4(m+1) + 4 nnzA + 8 nnzA [B.rowptr pair] + 8 nnzA
 // [first/last col of the B row] + 17 m written (+ 8 nnzA for b_start / b_len).
 // --------------------------------------------------------------------------------
+constexpr u32 kAnRowPathMax = 8;  // rows per lane up to this many entries (sub-chunk maximum)
 constexpr int kAnThreads = 512;  // 8 waves x 32 rows = one kChunk of rows per pass of the block
 __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     const u32* __restrict__ a_ro, const u32* __restrict__ a_col, const u32* __restrict__ b_ro,
@@ -114,6 +115,49 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
         wave_lds_fence();
         AN_MARK(0);
         const u32 e_begin = s_ro[0], e_end = s_ro[nrows];
+        // Sub-chunks of SHORT rows (two thirds of the webbase-like rows hold one entry): a lane per row, the
+        // row's entries in registers -- no row search, no LDS atomics, and the entry-parallel tile below
+        // would run at a fraction of its lanes (webbase stand-in: 172 -> ~60 us for this kernel).
+        const u32 my_len = lane < nrows ? s_ro[lane + 1] - s_ro[lane] : 0u;
+        const u32 max_len = wave_reduce_max(my_len);
+        if (max_len <= kAnRowPathMax) {
+            const u32 e_lo = lane < nrows ? s_ro[lane] : 0u;
+            u64 r_ops = 0;
+            u32 r_mx = 0, r_min = 0xFFFFFFFFu, r_max = 0;
+            for (u32 j0 = 0; j0 < max_len; j0 += U) {
+                u32 bs[U], be[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    ok[u] = j0 + u < my_len;
+                    const u32 e = e_lo + j0 + u;
+                    const u32 k = ok[u] ? a_col[e] : 0u;
+                    const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
+                    bs[u] = ok[u] ? pr.x : 0u;
+                    be[u] = ok[u] ? pr.y : 0u;
+                    if (ok[u] && b_start) {
+                        b_start[e - e_base] = bs[u];
+                        b_len[e - e_base] = be[u] - bs[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const u32 len = be[u] - bs[u];
+                    if (ok[u] && len) {
+                        r_ops += len;
+                        r_mx = max(r_mx, len);
+                        r_min = min(r_min, b_col[bs[u]]);
+                        r_max = max(r_max, b_col[be[u] - 1]);
+                    }
+                }
+            }
+            if (lane < nrows) {
+                s_ops[lane] = r_ops;
+                s_mx[lane] = r_mx;
+                s_cmin[lane] = r_min;
+                s_cmax[lane] = r_max;
+            }
+        } else
         for (u32 e0 = e_begin + lane; e0 < e_end; e0 += 64 * U) {
             u32 bs[U], be[U], first[U], last[U];
             bool ok[U];
