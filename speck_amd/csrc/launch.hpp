@@ -18,7 +18,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket);
 
 // strictly ascending, in-range column ids in every row of B (sets DeviceStats::b_invalid)
-void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st);
+void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st,
+                       u64 b_nnz);
 
 // exclusive scan of the row counts (+ numeric classification, stats fold, ordered scatter of the
 // numeric row records when num_cls != nullptr).

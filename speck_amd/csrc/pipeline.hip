@@ -630,7 +630,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     Timing tm;
     rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm);
     if (rc != SPECK_OK) return fail(rc);
-    if (c->validate_inputs) launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats);
+    if (c->validate_inputs) launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return fail(rc);
     if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);

@@ -708,43 +708,32 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
 __global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__ b_ro, const u32* __restrict__ b_col,
                                                          u32 b_rows, u32 b_cols, DeviceStats* __restrict__ st)
 {
-    __shared__ u32 s_ro_all[4][66];
-    const u32 lane = lane_id();
-    u32* s_ro = s_ro_all[threadIdx.x >> 6];
-    const u64 wave = (u64(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const u64 nwaves = (u64(gridDim.x) * blockDim.x) >> 6;
-    bool bad = false;
-    // a wave walks the entries of 64 consecutive rows as one range: entry e is checked against e + 1
-    // unless e + 1 starts a row (a search in the wave's 65 row offsets, staged in LDS)
-    for (u64 r0 = wave * 64; r0 < b_rows; r0 += nwaves * 64) {
-        const u32 nr = (u32)min((u64)64, b_rows - r0);
-        wave_lds_fence();
-        if (lane <= nr) s_ro[lane] = b_ro[r0 + lane];
-        if (lane == 0 && nr == 64) s_ro[64] = b_ro[r0 + 64];
-        wave_lds_fence();
-        const u32 e0 = s_ro[0], e1 = s_ro[nr];
-        if (e1 < e0) bad = true;
-        for (u32 e = e0 + lane; e < e1; e += 64) {
-            const u32 c = b_col[e];
-            if (c >= b_cols) bad = true;
-            if (e + 1 < e1 && b_col[e + 1] <= c) {
-                u32 lo = 0, hi = nr;  // first offset >= e + 1
-                while (lo < hi) {
-                    const u32 mid = (lo + hi) >> 1;
-                    if (s_ro[mid] < e + 1) lo = mid + 1; else hi = mid;
-                }
-                if (s_ro[lo] != e + 1) bad = true;
+    // a thread per entry: col[e] < col[e + 1] unless e + 1 starts a row -- looked up (binary search in the
+    // row offsets) only for the pairs that are NOT ascending, i.e. almost never
+    const u32 e_first = b_ro[0], e_last = b_ro[b_rows];
+    bool bad = e_last < e_first;
+    for (u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; e_first + i < e_last; i += u64(gridDim.x) * blockDim.x) {
+        const u32 e = e_first + (u32)i;
+        const u32 c = b_col[e];
+        if (c >= b_cols) bad = true;
+        if (e + 1 < e_last && b_col[e + 1] <= c) {
+            u32 lo = 0, hi = b_rows;  // first row whose offset is >= e + 1
+            while (lo < hi) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                if (b_ro[mid] < e + 1) lo = mid + 1; else hi = mid;
             }
+            if (b_ro[lo] != e + 1) bad = true;
         }
     }
-    if (__ballot(bad) != 0 && lane == 0) st->b_invalid = 1;  // plain store: every writer stores the same value
+    if (__ballot(bad) != 0 && lane_id() == 0) st->b_invalid = 1;  // plain store: every writer stores the same value
 }
 
-void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st)
+void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st,
+                       u64 b_nnz)
 {
     if (b_rows == 0) return;
-    u32 blocks = cdiv(b_rows, 64 * 4);
-    if (blocks > 4096) blocks = 4096;
+    u32 blocks = cdiv(b_nnz ? b_nnz : 1, 256 * 4);
+    if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(validate_b_kernel, dim3(blocks), dim3(256), 0, s, b_ro, b_col, b_rows, b_cols, st);
 }
 
