@@ -39,7 +39,10 @@ enum SymClass : u8 {
     SYM_B32K = 5,   // workgroup(1024) per row, 32768-key set (ops <= 26214), 128 KiB LDS
     SYM_BM1 = 6,    // column bitmap, workgroup(256), 256 Ki columns per window
     SYM_BM2 = 7,    // column bitmap, workgroup(1024), 1 Mi columns per window, multi-window
-    SYM_CLASSES = 8,
+    SYM_NF = 8,     // NUMERIC-FIRST: narrow column range -> the dense-window numeric kernel runs in the
+                    //   symbolic phase, writes the finished row to a scratch slot and counts it; no
+                    //   symbolic walk at all (numeric phase: NUM_NFCOPY moves the row to its place in C)
+    SYM_CLASSES = 9,
     SYM_NONE = 0xFF  // resolved by the analysis kernel itself (empty / single-entry A rows)
 };
 // Numeric classes: chosen from the EXACT nnz of the C row (symbolic result).
@@ -55,7 +58,8 @@ enum NumClass : u8 {
     NUM_G = 8,       // global-memory hash spill (heavy rows with a very wide column range)
     NUM_W1K = 9,     // wave per row, 1024-entry table, 2-level bitmap sort (nnz <= 682): no
                      //   workgroup barriers, 2.4x less LDS per row than NUM_B2K
-    NUM_CLASSES = 10,
+    NUM_NFCOPY = 10, // row already computed by the symbolic phase (SYM_NF): copy scratch slot -> C
+    NUM_CLASSES = 11,
     NUM_NONE = 0xFF
 };
 
@@ -83,15 +87,25 @@ struct ClassifyParams {
     u32 num_dense_ratio;    // use D1 when range <= kNumD1Cols and range <= ratio * nnz
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
     u32 num_wave1k;         // rows of 342..682 nnz: wave-per-row class (else they join NUM_B2K)
+    u32 nf_min_ops;         // numeric-first (SYM_NF) for rows with range <= kNumD1Cols and at least this many
+                            //   products; 0 = off
     u32 want_bytes;         // accumulate the per-class algorithmic byte counts (profiling)
     u32 sym_allowed;        // classes whose kernels are part of this launch sequence; a row
     u32 num_allowed;        //   outside them raises DeviceStats::capacity_miss (graph replay)
 };
 
+// Numeric-first rows: the reachable column range fits ONE dense window, so the numeric kernel needs no
+// nnz to size anything -- it can run before the scan.  Same predicate in both phases.
+__host__ __device__ inline bool is_numeric_first(u32 len_a, u32 ops, u32 cmin, u32 cmax, const ClassifyParams& p)
+{
+    return p.nf_min_ops != 0 && len_a > 1 && ops >= p.nf_min_ops && u64(cmax) - u64(cmin) + 1 <= kNumD1Cols;
+}
+
 __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u32 cmax,
                                                 const ClassifyParams& p)
 {
     if (ops == 0 || len_a <= 1) return SYM_NONE;
+    if (is_numeric_first(len_a, ops, cmin, cmax, p)) return SYM_NF;
     if (ops <= kSymG16MaxOps) return SYM_G16;
     if (ops <= kSymW256MaxOps) return SYM_W256;
     const u64 range = u64(cmax) - u64(cmin) + 1;
@@ -108,11 +122,12 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
     return SYM_BM2;
 }
 
-__host__ __device__ inline u8 classify_numeric(u32 len_a, u32 nnz, u32 cmin, u32 cmax,
+__host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 cmin, u32 cmax,
                                                const ClassifyParams& p)
 {
     if (nnz == 0) return NUM_NONE;
     if (len_a == 1) return NUM_DIRECT;
+    if (is_numeric_first(len_a, ops, cmin, cmax, p)) return NUM_NFCOPY;
     if (nnz <= kNumG16MaxNnz) return NUM_G16;
     if (nnz <= kNumW128MaxNnz) return NUM_W128;
     const u64 range = u64(cmax) - u64(cmin) + 1;
@@ -158,6 +173,7 @@ struct DeviceStats {
     BinTable sym;
     BinTable num;
     u64 g_products;          // products of the NUM_G rows (the host sizes the spill pool from it)
+    u64 nf_entries;          // scratch entries of the SYM_NF rows (sum of their column ranges)
     u32 b_invalid;           // a row of B is not strictly ascending / holds a column >= cols (eager path)
     u32 pad_;
 };
@@ -185,7 +201,7 @@ struct BlockPartial {
     u64 bytes[kMaxClasses];
     u64 g_ops;  // numeric phase: products of the block's NUM_G rows (sizes the spill pool)
     u64 pad2[2];
-};
+};  // (g_ops doubles as the scratch entries of the block's SYM_NF rows in the symbolic phase)
 struct PartialArrays {
     u64* products;  // [cap]   analysis: products of the block's rows; scan: nnz of the tile
     u64* g_ops;     // [cap]

@@ -12,7 +12,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 nnz_a, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
-                     u32* b_start, u32* b_len, hipEvent_t between = nullptr);
+                     u32* b_start, u32* b_len, hipEvent_t between = nullptr, u64* nf_off = nullptr,
+                     u64 expect_nf = ~0ull);
 
 // completion ticket of a replayed launch sequence (pinned host word the host spins on)
 void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket);
@@ -58,6 +59,9 @@ struct RowWork {
     const u32* b_start;     // per A entry (relative to the first entry of the A view):
     const u32* b_len;       //   start / length of the referenced B row, written by the analysis
     SpillBuffers spill;     // NUM_G class (all null when no row needs it)
+    const u64* nf_off;      // numeric-first rows (SYM_NF / NUM_NFCOPY): scratch slot of row r = nf_col/nf_val + nf_off[r]
+    u32* nf_col;
+    void* nf_val;
     u32* w_start;           // per A entry: start / length of its B row INSIDE the current column window
     u32* w_len;             //   (multi-window rows, row_groups.hpp WindowCursors); a row's entries belong to its workgroup
     u32 xcd_aware;          // class lists are walked in per-XCD contiguous slices (row_groups.hpp)
@@ -86,6 +90,11 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
 // device-side stats block, so the launch sequence is static and can be captured in a hipGraph.
 void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u32* b_start,
                      const u32* b_len, const u32* b_col, const RowWork& w, u32* counts, int cu_count);
+
+// SYM_NF: the dense-window numeric kernel in the symbolic phase (rows to their scratch slots, nnz to `counts`)
+template <typename T>
+void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& A, const CsrView<T>& B, const RowWork& w,
+                          u32* counts, int cu_count);
 
 // Launch the numeric kernel of class `cls` (same convention for `count`).
 template <typename T>

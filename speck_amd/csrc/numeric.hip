@@ -477,6 +477,92 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
     }
 }
 
+// ------------------------------------------------------------------ numeric-first rows (SYM_NF / NUM_NFCOPY)
+// A row whose reachable column range fits one dense window needs no nnz to size anything, so its numeric
+// kernel does not have to wait for the symbolic phase -- it REPLACES it: the row is accumulated in the dense
+// window (as NUM_D1), written sorted to a scratch slot (slot size = column range >= nnz, offsets from the
+// ordered scatter of the analysis) and counted.  After the scan NUM_NFCOPY moves it to its place in C.
+// For banded / FEM inputs (cant: every row) the whole symbolic walk -- as long as the numeric one --
+// turns into one copy of C.  (The reference always runs both phases; new functionality.)
+template <typename T, int THREADS>
+__global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                           u32* __restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr u32 WCOLS = kNumD1Cols, WORDS = WCOLS / 32;
+    if (w.st->capacity_miss) return;  // the scratch pool of this (replayed) sequence is too small
+    src.rebase(a_ro);
+    using G = Block<THREADS>;
+    const G g;
+    Acc<T>* vals = reinterpret_cast<Acc<T>*>(smem);
+    T* m_av = reinterpret_cast<T*>(vals + WCOLS);
+    u32* bm = reinterpret_cast<u32*>(m_av + THREADS);
+    u32* pref = bm + WORDS;
+    u32* scratch = pref + WORDS + 2 * THREADS;
+    RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av, scratch + THREADS / 64 + 2};
+    u32* __restrict__ o_col = w.nf_col;
+    T* __restrict__ o_val = static_cast<T*>(w.nf_val);
+    const RowSlice rs = row_slice(w.st->sym.count[SYM_NF], blockIdx.x, gridDim.x, 1u, 0u, (w.xcd_aware & 2u) != 0);
+    const RowRec* recs = w.recs + w.st->sym.offset[SYM_NF];
+    RowRec next{};
+    if (rs.idx < rs.end) next = recs[rs.idx];
+    for (u32 i = threadIdx.x; i < WCOLS; i += THREADS) vals[i] = 0;
+    for (u32 i = threadIdx.x; i < WORDS; i += THREADS) bm[i] = 0;
+    __syncthreads();
+    for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
+        const RowRec rec = next;  // fetched while the previous row was being processed
+        if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
+        const u64 slot = w.nf_off[rec.row];
+        const u32 wbase = rec.cmin, ncols = rec.cmax - rec.cmin + 1u, nwords = (ncols + 31) >> 5;
+        for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch,
+                               [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
+#pragma unroll
+                                   for (int u = 0; u < kBatch; ++u) {
+                                       const u32 d = c[u] - wbase;
+                                       if ((u32)u < n && d < ncols) {
+                                           atomicAdd(&vals[d], (Acc<T>)p[u]);
+                                           atomicOr(&bm[d >> 5], 1u << (d & 31));
+                                       }
+                                   }
+                               });
+        const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);
+        for (u32 d = threadIdx.x; d < ncols; d += THREADS) {
+            const u32 word = bm[d >> 5];
+            if (word & (1u << (d & 31))) {
+                const u32 r = pref[d >> 5] + __popc(word & ((1u << (d & 31)) - 1u));
+                o_col[slot + r] = wbase + d;
+                o_val[slot + r] = (T)vals[d];
+                vals[d] = 0;
+            }
+        }
+        if (threadIdx.x == 0) counts[rec.row] = total;
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
+        __syncthreads();
+    }
+}
+
+// a wave per row: scratch slot -> C
+template <typename T>
+__global__ __launch_bounds__(256) void nf_copy_kernel(RowWork w, u32* __restrict__ c_col, T* __restrict__ c_val)
+{
+    if (w.st->capacity_miss) return;
+    const u32 count = w.st->num.count[NUM_NFCOPY];
+    const RowRec* recs = w.recs + w.st->num.offset[NUM_NFCOPY];
+    const u32* __restrict__ s_col = w.nf_col;
+    const T* __restrict__ s_val = static_cast<const T*>(w.nf_val);
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (u32 idx = wave; idx < count; idx += nwaves) {
+        const RowRec rec = recs[idx];
+        const u64 slot = w.nf_off[rec.row];
+        for (u32 j = lane; j < rec.nnz; j += 64) {
+            c_col[size_t(rec.base) + j] = s_col[slot + j];
+            c_val[size_t(rec.base) + j] = s_val[slot + j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ kernels
 // Stand-alone kernels (one class per launch) and the merged "light" kernel: all classes whose
 // workgroups are 256 threads wide and need <= ~40 KiB of LDS share ONE launch -- block ranges map
@@ -1001,6 +1087,7 @@ u32 numeric_lds_bytes_t(int cls)
         case NUM_D1: return num_dense_lds<T, kNumD1Cols, 256>();
         case NUM_D2: return num_dense_lds<T, kNumD2Cols, 1024>();
         case NUM_G: return num_spill_reduce_lds<T, kNumB8KCap, 512>();
+        case NUM_NFCOPY: return 0;
     }
     return 0;
 }
@@ -1051,6 +1138,17 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
     else
         hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[6]), dim3(256), lds, s, src, Av.row_offsets, w,
                            c_col, c_val, cg);
+}
+
+template <typename T>
+void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& Av, const CsrView<T>& Bv, const RowWork& w,
+                          u32* counts, int cu_count)
+{
+    if (count == 0) return;
+    const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
+    const u32 lds = num_dense_lds<T, kNumD1Cols, 256>();
+    hipLaunchKernelGGL((nf_dense_kernel<T, 256>), dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s,
+                       src, Av.row_offsets, w, counts);
 }
 
 template <typename T>
@@ -1117,6 +1215,13 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                                w, c_col, c_val, cls);
             break;
         }
+        case NUM_NFCOPY: {
+            u32 blocks = (count + 3) / 4;  // four waves per workgroup, a row per wave
+            const u32 cap = (u32)cu_count * 8u * 4u;
+            if (blocks > cap) blocks = cap;
+            hipLaunchKernelGGL((nf_copy_kernel<T>), dim3(blocks ? blocks : 1), dim3(256), 0, s, w, c_col, c_val);
+            break;
+        }
         case NUM_G: {
             // same stream: the kernel boundaries are the grid-wide barriers between the steps
             const u32 rows = count < 8192u ? (count ? count : 1u) : 8192u;
@@ -1163,6 +1268,10 @@ template void launch_numeric_light<double>(hipStream_t, const u32*, u32, const C
                                            const CsrView<double>&, const RowWork&, u32*, double*, int);
 template void launch_numeric_light<float>(hipStream_t, const u32*, u32, const CsrView<float>&,
                                           const CsrView<float>&, const RowWork&, u32*, float*, int);
+template void launch_numeric_first<double>(hipStream_t, u32, const CsrView<double>&, const CsrView<double>&,
+                                           const RowWork&, u32*, int);
+template void launch_numeric_first<float>(hipStream_t, u32, const CsrView<float>&, const CsrView<float>&,
+                                          const RowWork&, u32*, int);
 template void launch_numeric<double>(hipStream_t, int, u32, const CsrView<double>&,
                                      const CsrView<double>&, const RowWork&, u32*, double*, int);
 template void launch_numeric<float>(hipStream_t, int, u32, const CsrView<float>&,

@@ -97,6 +97,9 @@ struct speck_config {
     int graph_replays = 0, graph_captures = 0, graph_misses = 0;
     void* gpool = nullptr;    // global-memory buffers of the NUM_G spill path, carved into `spill`
     size_t gpool_bytes = 0;
+    void* nfpool = nullptr;   // scratch slots of the numeric-first rows: col_ids | values (grow-only)
+    size_t nfpool_bytes = 0;
+    u64 nf_cap_entries = 0;
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
     speck_stats last{};
@@ -151,6 +154,7 @@ struct Scratch {
     BlockPartial* partials;
     u32 *b_start, *b_len;  // per A entry: the referenced B row (written by the analysis)
     u32 *w_start, *w_len;  // per A entry: its B entries inside the current column window (multi-window rows)
+    u64* nf_off;           // per row: scratch slot of a numeric-first row
 };
 
 u32 partial_blocks(u32 m) { return std::max(analysis_blocks(m), scan_tiles(m)) + 2; }  // + PartialArrays padding
@@ -159,6 +163,7 @@ size_t scratch_bytes(u32 m, u64 nnz_a)
 {
     size_t b = 4 * Carver::need(nnz_a, 4);
     b += 4 * Carver::need(m, 4);
+    b += Carver::need(m, 8);
     b += Carver::need(m, sizeof(RowRec));
     b += Carver::need(m, 1);
     b += Carver::need(partial_blocks(m), sizeof(BlockPartial));
@@ -173,6 +178,7 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
     s.b_len = cv.take<u32>(nnz_a);
     s.w_start = cv.take<u32>(nnz_a);
     s.w_len = cv.take<u32>(nnz_a);
+    s.nf_off = cv.take<u64>(m);
     s.recs = cv.take<RowRec>(m);
     s.row_ops = cv.take<u32>(m);
     s.row_max_ops = cv.take<u32>(m);
@@ -181,6 +187,45 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
     s.cls = cv.take<u8>(m);
     s.partials = cv.take<BlockPartial>(partial_blocks(m));
     return s;
+}
+
+// scratch pool of the numeric-first rows: `entries` column ids followed by `entries` values
+int ensure_nfpool(speck_config* c, u64 entries, size_t vsize)
+{
+    const size_t need = Carver::need(entries, 4) + Carver::need(entries, vsize) + 512;
+    if (entries <= c->nf_cap_entries && need <= c->nfpool_bytes) return SPECK_OK;
+    drop_graph(c);
+    c->last_key_valid = false;
+    if (c->nfpool) (void)hipFree(c->nfpool);
+    c->nfpool = nullptr;
+    c->nfpool_bytes = 0;
+    c->nf_cap_entries = 0;
+    const u64 cap = entries + entries / 8 + 1024;
+    const size_t bytes = Carver::need(cap, 4) + Carver::need(cap, 8) + 512;
+    if (hipMalloc(&c->nfpool, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return SPECK_ERR_OOM;
+    }
+    c->nfpool_bytes = bytes;
+    c->nf_cap_entries = cap;
+    return SPECK_OK;
+}
+
+RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill)
+{
+    RowWork w{};
+    w.recs = sc.recs;
+    w.st = c->d_stats;
+    w.b_start = sc.b_start;
+    w.b_len = sc.b_len;
+    w.spill = spill;
+    w.nf_off = sc.nf_off;
+    w.nf_col = static_cast<u32*>(c->nfpool);
+    w.nf_val = c->nfpool ? static_cast<unsigned char*>(c->nfpool) + Carver::need(c->nf_cap_entries, 4) : nullptr;
+    w.w_start = sc.w_start;
+    w.w_len = sc.w_len;
+    w.xcd_aware = c->xcd_aware;
+    return w;
 }
 
 struct StageTimer {
@@ -319,8 +364,8 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
 }
 
 // isolated cost per row of every class (ns, MI355X, scripts/class_times.py on the four stand-ins)
-constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 0, 0, 0, 0};
-constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 6.f, 0, 0};
+constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 0, 0, 0};
+constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 6.f, 1.5f, 0};
 constexpr u32 kAllSym = (1u << SYM_CLASSES) - 1u;
 constexpr u32 kAllNum = (1u << NUM_CLASSES) - 1u;
 
@@ -342,36 +387,41 @@ struct Timing {
 int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
                   const Scratch& sc, u32* c_ro, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
                   bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr,
-                  DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u)
+                  DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
+                  u32 parts = 3 /* 1: analysis + binning, 2: symbolic launches + scan */, u64 expect_nf = ~0ull)
 {
     const u32 m = (u32)A->rows;
     ClassifyParams cp = c->cp;
     cp.sym_allowed = sym_mask;
     cp.num_allowed = num_mask;
     const bool timed = c->profile_kernels && tm;
-    if (timed) {
-        tm->ev_analysis = tm->ev;
-        (void)hipEventRecord(kernel_event(c, tm->ev++), s);
+    if (parts & 1u) {
+        if (timed) {
+            tm->ev_analysis = tm->ev;
+            (void)hipEventRecord(kernel_event(c, tm->ev++), s);
+        }
+        hipEvent_t between = nullptr;
+        if (timed) {
+            tm->ev_between = tm->ev;
+            between = kernel_event(c, tm->ev++);
+        }
+        launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
+                        sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
+                        c->d_stats, cp, sc.b_start, sc.b_len, between, sc.nf_off, expect_nf);
+        if (timed) {
+            tm->ev_analysis_end = tm->ev;
+            (void)hipEventRecord(kernel_event(c, tm->ev++), s);
+        }
+        HIP_TRY(hipGetLastError());
     }
-    hipEvent_t between = nullptr;
-    if (timed) {
-        tm->ev_between = tm->ev;
-        between = kernel_event(c, tm->ev++);
-    }
-    launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
-                    sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
-                    c->d_stats, cp, sc.b_start, sc.b_len, between);
-    if (timed) {
-        tm->ev_analysis_end = tm->ev;
-        (void)hipEventRecord(kernel_event(c, tm->ev++), s);
-    }
-    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, SpillBuffers{}, sc.w_start, sc.w_len, c->xcd_aware};
+    if (!(parts & 2u)) return SPECK_OK;
+    const RowWork w = make_work(c, sc, SpillBuffers{});
     // heaviest classes first: they have the longest tails
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
     const u32* hint = sym_hint ? sym_hint : all_m;
-    static const int merged[5] = {SYM_BM2, SYM_B32K, SYM_B16K, kLightBig, kLightTiny};
-    static const int separate[SYM_CLASSES] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_B4K,
+    static const int merged[6] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, kLightBig, kLightTiny};
+    static const int separate[SYM_CLASSES] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, SYM_B4K,
                                               SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
     // the launch's LDS size is the largest need among its classes and caps the waves per CU of all of
     // them: the 256-thread classes go in two launches, the big-LDS ones apart (split_light); the
@@ -388,13 +438,24 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         split_sym = part_us(sym_hint, kSymNsPerRow, kSymLightMask & (1u << SYM_BM1)) >= c->split_min_us &&
                     part_us(sym_hint, kSymNsPerRow, kSymLightMask & ~(1u << SYM_BM1)) >= c->split_min_us;
     const u32 sym_big = split_sym ? (1u << SYM_BM1) : kSymLightMask;
-    int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 5 : (int)SYM_CLASSES, sym_mask,
+    int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 6 : (int)SYM_CLASSES, sym_mask,
                          kSymLightMask & sym_big, kSymLightMask & ~sym_big, sym_hint, kSymNsPerRow,
                          tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr, [&](hipStream_t ks, int cls) {
                              if (cls == kLightBig || cls == kLightTiny) {
                                  const u32 part = cls == kLightBig ? sym_big : ~sym_big;
                                  launch_symbolic_light(ks, hint, sym_mask & kSymLightMask & part, A->row_offsets,
                                                        sc.b_start, sc.b_len, B->col_ids, w, c_ro, c->sm);
+                             } else if (cls == SYM_NF) {
+                                 // the numeric dense-window kernel, in the symbolic phase (numeric.hip)
+                                 if (vsize == 8) {
+                                     CsrView<double> Av{A->row_offsets, A->col_ids, static_cast<const double*>(A->data), m, (u32)A->cols};
+                                     CsrView<double> Bv{B->row_offsets, B->col_ids, static_cast<const double*>(B->data), (u32)B->rows, (u32)B->cols};
+                                     launch_numeric_first<double>(ks, hint[cls], Av, Bv, w, c_ro, c->sm);
+                                 } else {
+                                     CsrView<float> Av{A->row_offsets, A->col_ids, static_cast<const float*>(A->data), m, (u32)A->cols};
+                                     CsrView<float> Bv{B->row_offsets, B->col_ids, static_cast<const float*>(B->data), (u32)B->rows, (u32)B->cols};
+                                     launch_numeric_first<float>(ks, hint[cls], Av, Bv, w, c_ro, c->sm);
+                                 }
                              } else
                                  launch_symbolic(ks, cls, hint[cls], A->row_offsets, sc.b_start, sc.b_len,
                                                  B->col_ids, w, c_ro, c->sm);
@@ -421,12 +482,12 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     CsrView<T> Av{A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
-    RowWork w{sc.recs, c->d_stats, sc.b_start, sc.b_len, c->spill, sc.w_start, sc.w_len, c->xcd_aware};
+    const RowWork w = make_work(c, sc, c->spill);
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;
     const u32* hint = counts ? counts : all_m;
-    static const int merged[6] = {NUM_G, NUM_D2, NUM_B8K, NUM_W1K, kLightBig, kLightTiny};
-    static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K,  NUM_B2K, NUM_W1K,
+    static const int merged[7] = {NUM_G, NUM_D2, NUM_B8K, NUM_W1K, NUM_NFCOPY, kLightBig, kLightTiny};
+    static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K,  NUM_B2K,  NUM_W1K,   NUM_NFCOPY,
                                               NUM_D1, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
     constexpr u32 kBigPart = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512);
     bool split_num = c->split_light;
@@ -441,7 +502,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
                     part_us(kNumLightMask & ~kBigPart) >= c->split_min_us;
     }
     const u32 num_big = split_num ? kBigPart : kNumLightMask;
-    return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 6 : (int)NUM_CLASSES, num_mask,
+    return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 7 : (int)NUM_CLASSES, num_mask,
                        kNumLightMask & num_big, kNumLightMask & ~num_big, counts, kNumNsPerRow,
                        tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr, [&](hipStream_t ks, int cls) {
                            if (cls == kLightBig || cls == kLightTiny) {
@@ -491,6 +552,7 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
     k.num[7] = (u64(c->cp.num_global_passes) << 32) | (u64(c->cp.num_wave1k) << 2) | (u64(c->cp.want_bytes) << 1) |
                (c->concurrent_classes ? 1u : 0u);
     k.num[7] ^= reinterpret_cast<u64>(s);
+    k.num[5] |= u64(c->cp.nf_min_ops) << 8;
     return k;
 }
 
@@ -504,7 +566,7 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
                            c->last_num_mask, true, nullptr, c->last_sym_counts, c->h_stats_dev,
-                           c->last_g_products, c->last_num_counts[NUM_G]);
+                           c->last_g_products, c->last_num_counts[NUM_G], 3u, c->nf_cap_entries);
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
                              c->last_num_mask, c->last_num_counts, nullptr);
@@ -628,7 +690,22 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     // ANALYSIS + binning + SYMBOLIC + SCAN (Multiply.cu:239-575) -- one read-back
     Timing tm;
-    rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm);
+    if (c->cp.nf_min_ops) {
+        // numeric-first rows need their scratch pool before the symbolic phase: one more read-back
+        // (the replayed sequence has none: the pool of the previous identical call is checked on the device)
+        rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr,
+                           ~0ull, ~0u, 1u);
+        if (rc != SPECK_OK) return fail(rc);
+        rc = read_stats(c, s);
+        if (rc != SPECK_OK) return fail(rc);
+        if (c->h_stats->nf_entries) {
+            rc = ensure_nfpool(c, c->h_stats->nf_entries, sizeof(T));
+            if (rc != SPECK_OK) return fail(rc);
+        }
+        rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr,
+                           ~0ull, ~0u, 2u);
+    } else
+        rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm);
     if (rc != SPECK_OK) return fail(rc);
     if (c->validate_inputs) launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
     rc = read_stats(c, s);
@@ -878,6 +955,7 @@ int speck_config_create(int device, speck_config** out)
     c->cp.sym_bitmap_ratio = 32;
     c->cp.num_dense_ratio = 16;
     c->cp.num_global_passes = 4;  // heavy rows: dense windows up to 64 Ki columns, else global spill
+    c->cp.nf_min_ops = 1024;  // numeric-first for narrow rows with at least this many products (0 = off)
     c->cp.num_wave1k = 0;  // measured: one launch (and fork/join) less beats the barrier-free rows
     c->cp.want_bytes = 0;
     *out = c;
@@ -901,6 +979,7 @@ int speck_config_destroy(speck_config* c)
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->arena) (void)hipFree(c->arena);
     if (c->gpool) (void)hipFree(c->gpool);
+    if (c->nfpool) (void)hipFree(c->nfpool);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->h_ticket) (void)hipHostFree(c->h_ticket);
@@ -933,6 +1012,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     if (n == "sym_bitmap_ratio") c->cp.sym_bitmap_ratio = (u32)value;
     else if (n == "num_dense_ratio") c->cp.num_dense_ratio = (u32)value;
     else if (n == "num_global_passes") c->cp.num_global_passes = (u32)value;
+    else if (n == "nf_min_ops") {
+        c->cp.nf_min_ops = (u32)value;
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
     else if (n == "num_wave1k") {
         c->cp.num_wave1k = value != 0;
         drop_graph(c);
@@ -1066,7 +1150,10 @@ int speck_symbolic(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
     Scratch sc = carve(c, m, A->nnz);
+    const u32 nf_was = c->cp.nf_min_ops;
+    c->cp.nf_min_ops = 0;  // structure only: no values here, every row through a symbolic kernel
     rc = enqueue_front(c, s, A, B, sc, d_row_offsets, 8, ~0ull, kAllSym, kAllNum, false, nullptr);
+    c->cp.nf_min_ops = nf_was;
     if (rc != SPECK_OK) return rc;
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return rc;

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     constexpr u32 R = 32;  // rows per sub-chunk (one per lane when they are finalised): the kernel
                            //   lasts as long as its slowest wave, so the waves are kept short and many
     static_assert(NW * R == kChunk, "one pass of a block covers one kChunk of rows");
+    static_assert(kChunk / 64 == 4, "sym_scatter_kernel sums four per-wave counters");
     // the statistics block of this call starts from zero (no memset node in the launch sequence;
     // nothing reads or writes it before the scatter kernel that follows)
     if (blockIdx.x == 0)
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     __shared__ u32 s_ro_all[NW][R + 1];
     __shared__ u64 s_ops_all[NW][R];
     __shared__ u32 s_mx_all[NW][R], s_cmin_all[NW][R], s_cmax_all[NW][R];
-    __shared__ u64 s_products[NW];
+    __shared__ u64 s_products[NW], s_nf[NW];
     __shared__ u32 s_max[NW];
     __shared__ u32 s_hist[NW][kMaxClasses];
     __shared__ u64 s_bytes[kMaxClasses];
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
 
     const u32 row_begin = blockIdx.x * rows_per_block;
     const u32 row_end = min(m, row_begin + rows_per_block);
-    u64 my_products = 0;
+    u64 my_products = 0, my_nf = 0;
     u32 my_max = 0;
     u32 hist[SYM_CLASSES];
 #pragma unroll
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
             if (sym_cls) {
                 cls = classify_symbolic(len_a, ops32, cmin, cmax, cp);
                 sym_cls[row] = cls;
+                if (cls == SYM_NF) my_nf += cmax - cmin + 1;  // scratch slot = the row's column range
                 if (cls == SYM_NONE) {
                     // empty row, or a single A entry: the C row is a scaled copy of one B row
                     counts[row] = ops32;
@@ -248,11 +250,13 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     }
     AN_MARK(5);
     my_products = wave_reduce_add(my_products);
+    my_nf = wave_reduce_add(my_nf);
     my_max = wave_reduce_max(my_max);
     __syncthreads();
     AN_MARK(6);
     if (lane == 0) {
         s_products[wid] = my_products;
+        s_nf[wid] = my_nf;
         s_max[wid] = my_max;
 #pragma unroll
         for (int c = 0; c < SYM_CLASSES; ++c) s_hist[wid][c] = hist[c];
@@ -260,15 +264,16 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     __syncthreads();
     const PartialArrays pa(partials, gridDim.x);
     if (t == 0) {
-        u64 p = 0;
+        u64 p = 0, nf = 0;
         u32 mxv = 0;
         for (int w = 0; w < NW; ++w) {
             p += s_products[w];
+            nf += s_nf[w];
             mxv = max(mxv, s_max[w]);
         }
         pa.products[blockIdx.x] = p;
         pa.max_val[blockIdx.x] = mxv;
-        pa.g_ops[blockIdx.x] = 0;
+        pa.g_ops[blockIdx.x] = nf;  // symbolic phase: scratch entries of the block's numeric-first rows
     }
     if (t < kMaxClasses) {
         u32 h = 0;
@@ -290,7 +295,8 @@ struct Fold {
     u32 prefix[kMaxClasses];  // rows of each class in the blocks before mine
     u32 total[kMaxClasses];   // rows of each class in all blocks
     u64 sum_prefix, sum_total;  // products (analysis) / nnz (numeric) before mine / overall
-    u64 g_total;                // products of the NUM_G rows (numeric)
+    u64 g_total;                // products of the NUM_G rows (numeric) / scratch entries of the SYM_NF rows
+    u64 g_prefix;               //   ... in the blocks before mine
     u32 max_val;
 };
 
@@ -301,17 +307,19 @@ __device__ __forceinline__ void fold_partials(BlockPartial* parts, u32 nb,
 {
     constexpr int NW = THREADS / 64;
     __shared__ u32 s_pre[NW][NCLS], s_tot[NW][NCLS], s_mx[NW];
-    __shared__ u64 s_sp[NW], s_st[NW], s_by[NW][NCLS], s_g[NW];
+    __shared__ u64 s_sp[NW], s_st[NW], s_by[NW][NCLS], s_g[NW], s_gp[NW];
     const PartialArrays pa(parts, nb);
     u32 pre[NCLS], tot[NCLS];
     u64 by[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) pre[c] = tot[c] = 0, by[c] = 0;
-    u64 sp = 0, stt = 0, gs = 0;
+    u64 sp = 0, stt = 0, gs = 0, gp = 0;
     u32 mx = 0;
     for (u32 b = threadIdx.x; b < nb; b += THREADS) {  // consecutive threads, consecutive blocks: coalesced
-        gs += pa.g_ops[b];
         const bool before = b < my_block;
+        const u64 gv = pa.g_ops[b];
+        gs += gv;
+        if (before) gp += gv;
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) {
             const u32 v = pa.count[c * pa.cap + b];
@@ -339,11 +347,13 @@ __device__ __forceinline__ void fold_partials(BlockPartial* parts, u32 nb,
     stt = wave_reduce_add(stt);
     mx = wave_reduce_max(mx);
     gs = wave_reduce_add(gs);
+    gp = wave_reduce_add(gp);
     if (lane == 0) {
         s_sp[wid] = sp;
         s_st[wid] = stt;
         s_mx[wid] = mx;
         s_g[wid] = gs;
+        s_gp[wid] = gp;
     }
     __syncthreads();
     if (threadIdx.x < kMaxClasses) {
@@ -360,17 +370,19 @@ __device__ __forceinline__ void fold_partials(BlockPartial* parts, u32 nb,
         s_bytes[threadIdx.x] = y;
     }
     if (threadIdx.x == 0) {
-        u64 a = 0, t = 0, gt = 0;
+        u64 a = 0, t = 0, gt = 0, gpre = 0;
         u32 m = 0;
         for (int w = 0; w < NW; ++w) {
             a += s_sp[w];
             t += s_st[w];
             gt += s_g[w];
+            gpre += s_gp[w];
             m = max(m, s_mx[w]);
         }
         s_fold->sum_prefix = a;
         s_fold->sum_total = t;
         s_fold->g_total = gt;
+        s_fold->g_prefix = gpre;
         s_fold->max_val = m;
     }
     __syncthreads();
@@ -405,13 +417,16 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
     const u8* __restrict__ cls, u32 m, u32 rows_per_block, DeviceStats* __restrict__ st,
     BlockPartial* __restrict__ parts, u32 nb, const u32* __restrict__ a_ro,
     const u32* __restrict__ row_ops, const u32* __restrict__ row_col_min,
-    const u32* __restrict__ row_col_max, RowRec* __restrict__ recs, ClassifyParams cp)
+    const u32* __restrict__ row_col_max, RowRec* __restrict__ recs, ClassifyParams cp,
+    u64* __restrict__ nf_off, u64 expect_nf)
 {
     constexpr int NW = kChunk / 64;
     __shared__ Fold s_fold;
     __shared__ u64 s_bytes[kMaxClasses];
     __shared__ u32 s_wcnt[SYM_CLASSES][NW];
     __shared__ u32 s_run[SYM_CLASSES];
+    __shared__ u32 s_nfscan[NW + 2];
+    __shared__ u64 s_nfrun;
     const u32 lane = lane_id(), wid = threadIdx.x >> 6;
     const u32 row_begin = blockIdx.x * rows_per_block;
     const u32 row_end = min(m, row_begin + rows_per_block);
@@ -431,9 +446,13 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->sum_products = s_fold.sum_total;
         st->max_row_ops = s_fold.max_val;
+        st->nf_entries = s_fold.g_total;
+        // the scratch pool of a replayed launch sequence was sized for `expect_nf` entries
+        if (expect_nf != ~0ull && s_fold.g_total > expect_nf) st->capacity_miss = 1;
         publish_bins(st->sym, s_fold, s_bytes, cp.sym_allowed, st);
     }
     if (!cls) return;
+    if (threadIdx.x == 0) s_nfrun = s_fold.g_prefix;
     if (threadIdx.x < SYM_CLASSES) s_run[threadIdx.x] = class_offset(s_fold, threadIdx.x) + s_fold.prefix[threadIdx.x];
     __syncthreads();
     for (u32 row0 = row_begin; row0 < row_end; row0 += kChunk) {
@@ -448,6 +467,8 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
             if (c == b) my_rank = __popcll(mask & lanemask_lt());
         }
         __syncthreads();
+        const u32 r_min = first ? p_min : (c < SYM_CLASSES ? row_col_min[row] : 0u);
+        const u32 r_max = first ? p_max : (c < SYM_CLASSES ? row_col_max[row] : 0u);
         if (c < SYM_CLASSES) {
             u32 pos = s_run[c] + my_rank;
             for (u32 w = 0; w < wid; ++w) pos += s_wcnt[c][w];
@@ -456,11 +477,20 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
             r.a0 = first ? p_a0 : a_ro[row];
             r.a1 = first ? p_a1 : a_ro[row + 1];
             r.base = 0;
-            r.cmin = first ? p_min : row_col_min[row];
-            r.cmax = first ? p_max : row_col_max[row];
+            r.cmin = r_min;
+            r.cmax = r_max;
             r.ops = first ? p_ops : row_ops[row];
             r.nnz = 0;
             recs[pos] = r;
+        }
+        // scratch slots of the numeric-first rows: exclusive prefix of their column ranges, in row order
+        if (s_wcnt[SYM_NF][0] + s_wcnt[SYM_NF][1] + s_wcnt[SYM_NF][2] + s_wcnt[SYM_NF][3] != 0) {  // uniform
+            const u32 ub = c == SYM_NF ? r_max - r_min + 1u : 0u;
+            u32 chunk_total;
+            const u32 excl = block_exclusive_scan<kChunk>(ub, s_nfscan, &chunk_total);
+            if (c == SYM_NF) nf_off[row] = s_nfrun + excl;
+            __syncthreads();
+            if (threadIdx.x == 0) s_nfrun += chunk_total;
         }
         __syncthreads();
         if (threadIdx.x < SYM_CLASSES) {
@@ -538,7 +568,7 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
             my_max = max(my_max, c);
             if (num_cls) {
                 const u32 len_a = a_ro[row + 1] - a_ro[row];
-                const u8 cls = classify_numeric(len_a, c, row_col_min[row], row_col_max[row], cp);
+                const u8 cls = classify_numeric(len_a, row_ops[row], c, row_col_min[row], row_col_max[row], cp);
                 num_cls[row] = cls;
                 if (cls == NUM_G) g_ops += row_ops[row];
                 if (cls != NUM_NONE) {
@@ -765,7 +795,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 /*nnz_a*/, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
-                     u32* b_start, u32* b_len, hipEvent_t between)
+                     u32* b_start, u32* b_len, hipEvent_t between, u64* nf_off, u64 expect_nf)
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
@@ -776,7 +806,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,
                        (const u8*)sym_cls, m, rows_per_block, st, partials, blocks, a_ro,
-                       (const u32*)row_ops, (const u32*)row_col_min, (const u32*)row_col_max, recs, cp);
+                       (const u32*)row_ops, (const u32*)row_col_min, (const u32*)row_col_max, recs, cp, nf_off,
+                       expect_nf);
 }
 
 void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,

@@ -225,12 +225,19 @@ def test_heavy_rows_with_narrow_range_stay_dense(cfg):
 
 def test_banded_dense_and_bitmap_classes(cfg):
     A = to_po(sa.gen_matrix("cant", 0.05, 3, signed=True))
-    _, st, _ = check(cfg, A, A, [("sym", "bitmap256k"), ("num", "dense4k")])
-    cfg.set_option("num_dense_ratio", 0)       # same input through the hash + rank-sort kernel
+    # narrow rows are numeric-first: computed in the symbolic phase, copied into C after the scan
+    _, st, _ = check(cfg, A, A, [("sym", "numeric_first"), ("num", "nfcopy")])
+    assert st["sym_bin_rows"]["numeric_first"] == st["num_bin_rows"]["nfcopy"] > A.rows // 2
+    cfg.set_option("nf_min_ops", 0)            # classic two-phase path: bitmap symbolic, dense-window numeric
     try:
+        check(cfg, A, A, [("sym", "bitmap256k"), ("num", "dense4k")])
+        cfg.set_option("num_dense_ratio", 0)   # same input through the hash + rank-sort kernel
         check(cfg, A, A, [("num", "wave512")])
     finally:
         cfg.set_option("num_dense_ratio", 16)
+        cfg.set_option("nf_min_ops", 1024)
+    A32 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float32))
+    check(cfg, A32, A32, [("sym", "numeric_first"), ("num", "nfcopy")], tol=TOL32)
 
 
 def to_po(m):
@@ -373,7 +380,7 @@ def test_compare_and_transpose(cfg):
 @pytest.mark.parametrize("kind,scale,expect", [
     ("scircuit", 1.0, [("num", "g16"), ("num", "wave512"), ("num", "block2k")]),
     ("mac_econ", 1.0, [("num", "g16"), ("num", "wave128")]),
-    ("cant", 1.0, [("sym", "bitmap256k"), ("num", "dense4k")]),
+    ("cant", 1.0, [("sym", "numeric_first"), ("num", "nfcopy")]),
     ("webbase", 1.0, [("num", "global"), ("num", "block8k"), ("num", "direct"), ("sym", "block16k")]),
     ("nlpkkt", 0.002, None)])
 def test_suitesparse_standins_full_parity(cfg, kind, scale, expect):
