@@ -11,6 +11,7 @@ import re
 import sys
 
 KEYS = [
+    (r"nf_dense_kernel", "num_numeric_first"), (r"nf_copy_kernel", "num_nfcopy"),
     (r"num_light_kernel", "num_light"), (r"num_tiny_kernel", "num_tiny"), (r"sym_light_kernel", "sym_light"),
     (r"num_hash_kernel<Block<512>", "num_block8k"), (r"num_hash_kernel<Block<256>", "num_block2k"),
     (r"num_hash_kernel<SubWave<64>, \w+, 1024u", "num_wave1k"), (r"num_hash_kernel<SubWave<64>, \w+, 512u", "num_wave512"),
