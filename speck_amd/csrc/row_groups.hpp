@@ -218,34 +218,40 @@ __device__ __forceinline__ u32 uniform_owner(const u32* incl, u32 cnt, u32 p)
     return lo;
 }
 
+// The 16-bit counters of a lane's kBatch positions (l, 64 + l, 128 + l, 192 + l) share one 8-byte LDS
+// word pair, and the scans run on PACKED pairs of counters (two 16-bit fields per register: a field never
+// exceeds the entries of a chunk) -- one LDS read and two DPP scans per window instead of four and four:
+// these kernels are bound by VALU issue.
 __device__ __forceinline__ void window_owners(const u32* incl, u32* win, u32 cnt, u32 base, u32& s0,
                                               u32 (&own)[kBatch])
 {
+    static_assert(kBatch == 4, "four counters per lane: one uint2");
     const u32 l = lane_id();
-#pragma unroll
-    for (u32 i = 0; i < kWinWords / 128; ++i) reinterpret_cast<uint2*>(win)[i * 64 + l] = make_uint2(0u, 0u);
+    reinterpret_cast<uint2*>(win)[l] = make_uint2(0u, 0u);
     wave_lds_fence();
     u32 sw = s0, at_end = 0;
     bool again;
     do {
         const u32 e = sw + l;
         const u32 b = e < cnt ? incl[e] - base : 0xFFFFFFFFu;  // >= 1: incl[s0] > base
-        if (b < kWinProducts) atomicAdd(&win[b >> 1], 1u << ((b & 1u) * 16u));
+        if (b < kWinProducts) {
+            const u32 slot = ((b & 63u) << 2) | (b >> 6);  // counter of position b: lane (b & 63), batch (b >> 6)
+            atomicAdd(&win[slot >> 1], 1u << ((slot & 1u) * 16u));
+        }
         at_end += (u32)__popcll(__ballot(b == kWinProducts));
         again = (u32)__builtin_amdgcn_readlane((int)b, 63) <= kWinProducts;
         sw += 64;
     } while (again);
     wave_lds_fence();
-    u32 carry = s0;
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-        const u32 pos = u * 64 + l;
-        const u32 x = (win[pos >> 1] >> ((pos & 1u) * 16u)) & 0xFFFFu;
-        const u32 inc = wave_inclusive_scan(x);
-        own[u] = carry + inc;
-        carry += (u32)__builtin_amdgcn_readlane((int)inc, 63);
-    }
-    s0 = carry + at_end;
+    const uint2 x = reinterpret_cast<const uint2*>(win)[l];
+    const u32 inc01 = wave_inclusive_scan(x.x), inc23 = wave_inclusive_scan(x.y);
+    const u32 t01 = (u32)__builtin_amdgcn_readlane((int)inc01, 63), t23 = (u32)__builtin_amdgcn_readlane((int)inc23, 63);
+    const u32 c1 = s0 + (t01 & 0xFFFFu), c2 = c1 + (t01 >> 16), c3 = c2 + (t23 & 0xFFFFu);
+    own[0] = s0 + (inc01 & 0xFFFFu);
+    own[1] = c1 + (inc01 >> 16);
+    own[2] = c2 + (inc23 & 0xFFFFu);
+    own[3] = c3 + (inc23 >> 16);
+    s0 = c3 + (t23 >> 16) + at_end;
     wave_lds_fence();
 }
 
@@ -339,27 +345,31 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
             u32* win = m.win;  // kBatch*L 16-bit counters of this group
             const bool mine = g.lane < cnt;
             for (u32 base = 0; base < total; base += kBatch * L) {
-#pragma unroll
-                for (u32 i = 0; i < (u32)kBatch / 4; ++i)
-                    reinterpret_cast<uint2*>(win)[i * L + g.lane] = make_uint2(0u, 0u);
+                reinterpret_cast<uint2*>(win)[g.lane] = make_uint2(0u, 0u);  // my four counters
                 wave_lds_fence();
                 const u32 before = (u32)__popcll(g.ballot(mine && incl <= base));
                 const u32 b = incl - base;  // position where my entry's products end
-                if (mine && incl > base && b < kBatch * L)
-                    atomicAdd(&win[b >> 1], 1u << ((b & 1u) * 16u));
+                if (mine && incl > base && b < kBatch * L) {
+                    const u32 slot = ((b & (L - 1u)) << 2) | (b / L);  // lane (b mod L), batch (b / L)
+                    atomicAdd(&win[slot >> 1], 1u << ((slot & 1u) * 16u));
+                }
                 wave_lds_fence();
+                // packed pairs of 16-bit counters: two group scans instead of four
+                const uint2 x = reinterpret_cast<const uint2*>(win)[g.lane];
+                u32 t01, t23;
+                const u32 inc01 = g.inclusive_scan(x.x, &t01, nullptr), inc23 = g.inclusive_scan(x.y, &t23, nullptr);
+                u32 ownv[kBatch];
+                ownv[0] = before + (inc01 & 0xFFFFu);
+                ownv[1] = before + (t01 & 0xFFFFu) + (inc01 >> 16);
+                ownv[2] = before + (t01 & 0xFFFFu) + (t01 >> 16) + (inc23 & 0xFFFFu);
+                ownv[3] = before + (t01 & 0xFFFFu) + (t01 >> 16) + (t23 & 0xFFFFu) + (inc23 >> 16);
                 u32 c[kBatch];
                 T bv[kBatch], a[kBatch], prod[kBatch];
-                u32 nvalid = 0, carry = before;
+                u32 nvalid = 0;
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
-                    const u32 pos = u * L + g.lane;
-                    const u32 x = (win[pos >> 1] >> ((pos & 1u) * 16u)) & 0xFFFFu;
-                    u32 tot;
-                    const u32 inc = g.inclusive_scan(x, &tot, nullptr);
-                    const u32 own = carry + inc;
-                    carry += tot;
-                    const u32 pu = base + pos;
+                    const u32 pu = base + u * L + g.lane;
+                    const u32 own = ownv[u];
                     c[u] = kEmptyKey;
                     bv[u] = T(0);
                     a[u] = T(0);
