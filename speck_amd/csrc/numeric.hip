@@ -603,9 +603,9 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
     num_dense_body<T, WCOLS, THREADS>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
 }
 
-constexpr u32 kW512W1 = 256;   // 256 Ki columns per sort window
-constexpr u32 kB2KW1 = 512;    // 512 Ki columns per sort window
-constexpr u32 kB8KW1 = 512;
+constexpr u32 kW512W1 = 768;   // 768 Ki columns per sort window (its level-1 pairs fill the 6 KiB table exactly)
+constexpr u32 kB2KW1 = 1024;   // 1 Mi columns per sort window
+constexpr u32 kB8KW1 = 2048;  // 2 Mi columns per sort window
 
 template <typename T>
 __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
