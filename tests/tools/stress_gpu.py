@@ -1,6 +1,7 @@
 """Randomised parity stress of the HIP path against the oracle (run by hand on a GPU box):
 power-law / uniform / clustered row lengths, empty rows and columns, rectangular shapes, fp32 and fp64,
-repeated calls (graph replay) with changing values.  usage: python tests/tools/stress_gpu.py [cases] [seed]"""
+repeated calls (graph replay) with changing values.
+usage: python tests/tools/stress_gpu.py [cases] [seed] [option=value ...]"""
 import os
 import sys
 
@@ -49,6 +50,9 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     cfg = sa.spECKConfig.initialize(0)
+    for opt in sys.argv[3:]:   # library options name=value, e.g. nf_min_ops=1 num_global_passes=1000000 xcd_aware=7
+        name, value = opt.split("=")
+        cfg.set_option(name, int(value))
     bad = 0
     for it in range(cases):
         dtype = np.float64 if rng.random() < 0.8 else np.float32
