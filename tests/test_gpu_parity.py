@@ -276,8 +276,9 @@ def test_matout_reuse_rules(cfg):
     check(cfg, A2, A, C_reuse=dC)
 
 
-def test_row_shards_concatenate(cfg):
-    A = to_po(sa.gen_matrix("scircuit", 0.05, 5, signed=True))
+@pytest.mark.parametrize("kind,scale", [("scircuit", 0.05), ("cant", 0.1)])   # cant: numeric-first rows in a row view
+def test_row_shards_concatenate(cfg, kind, scale):
+    A = to_po(sa.gen_matrix(kind, scale, 5, signed=True))
     dA = sa.dCSR.from_host(to_sa(A))
     dC = sa.dCSR()
     sa.MultiplyspECK(dA, dA, dC, cfg)
