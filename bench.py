@@ -224,7 +224,7 @@ def profile_prepass(job, split, merged, prof_steps=5):
         kernel_ms["tiny"] += s["num_tiny_ms"] / prof_steps
         # numeric-first rows: their NUMERIC kernel runs inside the symbolic phase; it is
         # accounted as a numeric launch, the symbolic phase is what remains
-        nf = s["sym_bin_ms"]["numeric_first"]
+        nf = s["sym_bin_ms"]["numeric_first"] if s["sym_bin_rows"]["numeric_first"] else 0.0
         kernel_ms["numeric_first"] = kernel_ms.get("numeric_first", 0.0) + nf / prof_steps
         sym_ms += (s["analysis_ms"] + s["scan_ms"] + max(s["sym_phase_ms"] - nf, 0.0)) / prof_steps
         num_ms += (s["num_phase_ms"] + nf) / prof_steps

@@ -491,6 +491,7 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 WCOLS = kNumD1Cols, WORDS = WCOLS / 32;
     if (w.st->capacity_miss) return;  // the scratch pool of this (replayed) sequence is too small
+    if (w.st->sym.count[SYM_NF] == 0) return;  // eager path: launched for every class, rows or not
     src.rebase(a_ro);
     using G = Block<THREADS>;
     const G g;
