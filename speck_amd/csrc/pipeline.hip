@@ -696,8 +696,11 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr,
                            ~0ull, ~0u, 1u);
         if (rc != SPECK_OK) return fail(rc);
+        if (c->validate_inputs)
+            launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
         rc = read_stats(c, s);
         if (rc != SPECK_OK) return fail(rc);
+        if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);  // before any kernel walks B's rows
         if (c->h_stats->nf_entries) {
             rc = ensure_nfpool(c, c->h_stats->nf_entries, sizeof(T));
             if (rc != SPECK_OK) return fail(rc);
@@ -707,7 +710,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     } else
         rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm);
     if (rc != SPECK_OK) return fail(rc);
-    if (c->validate_inputs) launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
+    if (c->validate_inputs && !c->cp.nf_min_ops)
+        launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return fail(rc);
     if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
