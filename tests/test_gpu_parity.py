@@ -374,6 +374,16 @@ def test_compare_and_transpose(cfg):
     assert sa.compare_bounded(dC1, dC2, dS, cfg, tol=1e-12) == (0, 0)
     bad_structure, bad_values = sa.compare_bounded(dC1, dC3, dS, cfg, tol=1e-12)
     assert bad_structure > 0
+    # one value off by 1e-9 of its product sum: structure equal, the bound fails exactly that row
+    h = dC2.to_host()
+    hs = dS.to_host()
+    vals = h.data.copy()
+    j = int(h.row_offsets[7])
+    vals[j] += 1e-9 * hs.data[j]
+    rc = _lib.load().speck_dcsr_update(ctypes.byref(dC2._c), None, None, vals.ctypes.data, 8)
+    assert rc == 0
+    assert sa.compare_bounded(dC1, dC2, dS, cfg, tol=1e-12) == (0, 1)
+    assert sa.compare_bounded(dC1, dC2, dS, cfg, tol=1e-8) == (0, 0)
 
 
 # BASELINE.json configs[1..3] at FULL size (the stand-ins fitted to the SuiteSparse figures), the
