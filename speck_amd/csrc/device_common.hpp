@@ -77,6 +77,9 @@ constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = 85;
 constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = 341;
 constexpr u32 kNumW1KCap = 1024, kNumW1KMaxNnz = 682;
 constexpr u32 kNumB2KCap = 2048, kNumB2KMaxNnz = 1365;
+// an under-filled NUM_B8K class (a handful of rows: a launch of its own just for one row's latency) is folded
+// into NUM_B2K when its rows fit the 2 Ki table at a load of 0.85 instead of 2/3 (pipeline.hip, capture)
+constexpr u32 kNumB2KStretchNnz = 1740;
 constexpr u32 kNumB8KCap = 8192, kNumB8KMaxNnz = 5461;
 constexpr u32 kNumD1Cols = 4096;
 constexpr u32 kNumD2Cols = 16384;
@@ -87,6 +90,7 @@ struct ClassifyParams {
     u32 num_dense_ratio;    // use D1 when range <= kNumD1Cols and range <= ratio * nnz
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
     u32 num_wave1k;         // rows of 342..682 nnz: wave-per-row class (else they join NUM_B2K)
+    u32 b2k_max_nnz;        // 0: kNumB2KMaxNnz; kNumB2KStretchNnz when the NUM_B8K class is folded into NUM_B2K
     u32 nf_min_ops;         // numeric-first (SYM_NF) for rows with range <= kNumD1Cols and at least this many
                             //   products; 0 = off
     u32 want_bytes;         // accumulate the per-class algorithmic byte counts (profiling)
@@ -134,7 +138,7 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     if (range <= kNumD1Cols && range <= u64(p.num_dense_ratio) * nnz) return NUM_D1;
     if (nnz <= kNumW512MaxNnz) return NUM_W512;
     if (p.num_wave1k && nnz <= kNumW1KMaxNnz) return NUM_W1K;
-    if (nnz <= kNumB2KMaxNnz) return NUM_B2K;
+    if (nnz <= (p.b2k_max_nnz ? p.b2k_max_nnz : kNumB2KMaxNnz)) return NUM_B2K;
     if (nnz <= kNumB8KMaxNnz) return NUM_B8K;
     const u64 passes = (range + kNumD2Cols - 1) / kNumD2Cols;
     if (passes > p.num_global_passes) return NUM_G;

@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     if (b < cg.first[1])
         num_dense_body<T, kNumD1Cols, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0]);
     else if (b < cg.first[2])
-        num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256>(
+        num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KStretchNnz, SORT_BITMAP, 256>(
             smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1]);
     else if (b < cg.first[3])
         num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
@@ -1185,7 +1185,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_B2K:
-            launch_num_hash<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256>(
+            launch_num_hash<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KStretchNnz, SORT_BITMAP, 256>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_B8K:

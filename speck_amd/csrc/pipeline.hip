@@ -92,6 +92,8 @@ struct speck_config {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     u32 last_sym_mask = 0, last_num_mask = 0;  // non-empty classes of the last eager call
+    u32 last_max_row_nnz = 0;                  // ... and its longest C row
+    bool fold_small_b8k = true;                // under-filled NUM_B8K class -> NUM_B2K in the replayed sequence
     GraphKey last_key;                         // ... and what it ran on
     bool last_key_valid = false;
     int graph_replays = 0, graph_captures = 0, graph_misses = 0;
@@ -563,13 +565,30 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                   const speck_dcsr* C, const Scratch& sc, const GraphKey& key)
 {
     drop_graph(c);
+    // Under-filled classes (role of the reference's bin shift-up when few blocks exist, Multiply.cu:439-482,
+    // 777-821): a NUM_B8K class of a handful of rows costs a launch of its own -- ~15 us of one row's latency
+    // on the pipeline stream.  If every row of the previous identical call fits the NUM_B2K table at a load
+    // of 0.85, the replayed sequence classifies them there and carries no NUM_B8K launch (a longer row in a
+    // changed input lands in the pruned class and raises capacity_miss).
+    u32 num_mask = c->last_num_mask;
+    u32 num_counts[kMaxClasses];
+    std::memcpy(num_counts, c->last_num_counts, sizeof(num_counts));
+    const u32 b2k_was = c->cp.b2k_max_nnz;
+    if (c->fold_small_b8k && num_counts[NUM_B8K] && num_counts[NUM_B8K] * 8u < (u32)c->sm &&
+        c->last_max_row_nnz <= kNumB2KStretchNnz) {
+        c->cp.b2k_max_nnz = kNumB2KStretchNnz;
+        num_counts[NUM_B2K] += num_counts[NUM_B8K];
+        num_counts[NUM_B8K] = 0;
+        num_mask = (num_mask & ~(1u << NUM_B8K)) | (1u << NUM_B2K);
+    }
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
-                           c->last_num_mask, true, nullptr, c->last_sym_counts, c->h_stats_dev,
+                           num_mask, true, nullptr, c->last_sym_counts, c->h_stats_dev,
                            c->last_g_products, c->last_num_counts[NUM_G], 3u, c->nf_cap_entries);
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
-                             c->last_num_mask, c->last_num_counts, nullptr);
+                             num_mask, num_counts, nullptr);
+    c->cp.b2k_max_nnz = b2k_was;
     // no copy node: the scan kernel mirrors the statistics block into pinned host memory
     if (rc == SPECK_OK && c->spin_wait) launch_done(s, c->d_ticket, c->h_ticket_dev);
     hipError_t e = rc == SPECK_OK ? hipSuccess : hipErrorUnknown;
@@ -844,6 +863,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // remember what this call ran on: an identical next call is captured and replayed
     c->last_sym_mask = mask_of(c->h_stats->sym.count, SYM_CLASSES);
     c->last_num_mask = num_mask;
+    c->last_max_row_nnz = c->h_stats->max_row_nnz_c;
     std::memcpy(c->last_sym_counts, c->h_stats->sym.count, sizeof(c->last_sym_counts));
     std::memcpy(c->last_num_counts, c->h_stats->num.count, sizeof(c->last_num_counts));
     c->last_key = make_key<T>(c, A, B, C, s);
@@ -1029,6 +1049,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
     else if (n == "validate_inputs") c->validate_inputs = value != 0;
+    else if (n == "fold_small_b8k") {
+        c->fold_small_b8k = value != 0;
+        drop_graph(c);
+    }
     else if (n == "spin_wait") {
         c->spin_wait = value != 0;
         drop_graph(c);
