@@ -44,7 +44,18 @@ print(f"{root}: NUM_D2, 123 windows of 16 Ki columns, 48 rows x 22.5 k products:
 cfg.set_option("sym_bitmap_ratio", 32)
 cfg.set_option("num_global_passes", 4)
 A2, B2 = rand_csr(24, 300, 300, 7), rand_csr(300, 1 << 27, 200, 8)
-ms, st = best_ms(cfg, sa.dCSR.from_host(A2), sa.dCSR.from_host(B2))
-print(f"{root}: SYM_BM2, 128 windows of 1 Mi columns, 24 rows x 60 k products (+ NUM_G): {ms:.3f} ms  "
-      f"(rows bitmap1m={st['sym_bin_rows']['bitmap1m']})")
+dA2, dB2 = sa.dCSR.from_host(A2), sa.dCSR.from_host(B2)
+for gh in (0, 8192):
+    try:
+        cfg.set_option("gh_per_window", gh)
+    except Exception:
+        if gh:
+            break
+    ms, st = best_ms(cfg, dA2, dB2)
+    t = sa.Timings(measureAll=True)
+    sa.MultiplyspECK(dA2, dB2, sa.dCSR(), cfg, t)
+    k = cfg.last_stats()["sym_bin_ms"]
+    print(f"{root}: 128 windows of 1 Mi columns, 24 rows x 60 k products (+ NUM_G), gh_per_window={gh}: {ms:.3f} ms  "
+          f"(rows bitmap1m={st['sym_bin_rows']['bitmap1m']} global_hash={st['sym_bin_rows'].get('global_hash', 0)}; "
+          f"symbolic kernel ms: { {n: round(v, 4) for n, v in k.items() if v} })")
 cfg.cleanup()

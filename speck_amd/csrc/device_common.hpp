@@ -42,7 +42,10 @@ enum SymClass : u8 {
     SYM_NF = 8,     // NUMERIC-FIRST: narrow column range -> the dense-window numeric kernel runs in the
                     //   symbolic phase, writes the finished row to a scratch slot and counts it; no
                     //   symbolic walk at all (numeric phase: NUM_NFCOPY moves the row to its place in C)
-    SYM_CLASSES = 9,
+    SYM_GH = 9,     // key set in GLOBAL memory (one workgroup(1024) per row, table in the scratch pool): rows wider
+                    //   than one SYM_BM2 window with few products per window -- every window of the bitmap costs a
+                    //   fixed ~8 us, a global compare-and-swap a fraction of a nanosecond at 4096 in flight
+    SYM_CLASSES = 10,
     SYM_NONE = 0xFF  // resolved by the analysis kernel itself (empty / single-entry A rows)
 };
 // Numeric classes: chosen from the EXACT nnz of the C row (symbolic result).
@@ -93,6 +96,8 @@ struct ClassifyParams {
     u32 b2k_max_nnz;        // 0: kNumB2KMaxNnz; kNumB2KStretchNnz when the NUM_B8K class is folded into NUM_B2K
     u32 nf_min_ops;         // numeric-first (SYM_NF) for rows with range <= kNumD1Cols and at least this many
                             //   products; 0 = off
+    u32 gh_per_window;      // SYM_GH instead of a multi-window SYM_BM2 when the row holds fewer products than this
+                            //   per bitmap window; 0 = off
     u32 want_bytes;         // accumulate the per-class algorithmic byte counts (profiling)
     u32 sym_allowed;        // classes whose kernels are part of this launch sequence; a row
     u32 num_allowed;        //   outside them raises DeviceStats::capacity_miss (graph replay)
@@ -103,6 +108,16 @@ struct ClassifyParams {
 __host__ __device__ inline bool is_numeric_first(u32 len_a, u32 ops, u32 cmin, u32 cmax, const ClassifyParams& p)
 {
     return p.nf_min_ops != 0 && len_a > 1 && ops >= p.nf_min_ops && u64(cmax) - u64(cmin) + 1 <= kNumD1Cols;
+}
+
+// Slots of a SYM_GH row's key set: a power of two, load <= 1/2.  The classifier keeps ops < 2^22 there.
+constexpr u32 kSymGhMinSlots = 65536, kSymGhMaxOps = 1u << 22;
+__host__ __device__ inline u32 gh_table_slots(u32 ops)
+{
+    const u32 want = 2u * (ops < kSymGhMaxOps ? ops : kSymGhMaxOps);
+    u32 slots = kSymGhMinSlots;
+    while (slots < want) slots <<= 1;
+    return slots;
 }
 
 __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u32 cmax,
@@ -121,9 +136,12 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
     // and count -- nothing against >= 3277 products -- and keeps the row in the merged launch
     if (range <= u64(kSymBm1Words) * 32) return SYM_BM1;
     if (ops <= kSymB16KMaxOps) return SYM_B16K;
-    if (bitmap_ok) return SYM_BM2;
+    constexpr u64 kWin = u64(kSymBm2Words) * 32;
+    const bool sparse_wide = p.gh_per_window != 0 && range > kWin && ops < kSymGhMaxOps &&
+                             u64(ops) < (range + kWin - 1) / kWin * p.gh_per_window;
+    if (bitmap_ok && !sparse_wide) return SYM_BM2;
     if (ops <= kSymB32KMaxOps) return SYM_B32K;
-    return SYM_BM2;
+    return sparse_wide ? SYM_GH : SYM_BM2;
 }
 
 __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 cmin, u32 cmax,
@@ -177,7 +195,8 @@ struct DeviceStats {
     BinTable sym;
     BinTable num;
     u64 g_products;          // products of the NUM_G rows (the host sizes the spill pool from it)
-    u64 nf_entries;          // scratch entries of the SYM_NF rows (sum of their column ranges)
+    u64 nf_entries;          // scratch entries of the SYM_NF rows (sum of their column ranges) and of the SYM_GH rows
+                             //   (slots of their key sets)
     u32 b_invalid;           // a row of B is not strictly ascending / holds a column >= cols (eager path)
     u32 pad_;
 };

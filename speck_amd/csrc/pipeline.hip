@@ -366,7 +366,7 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
 }
 
 // isolated cost per row of every class (ns, MI355X, scripts/class_times.py on the four stand-ins)
-constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 0, 0, 0};
+constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 50000.f, 0, 0};
 constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 6.f, 1.5f, 0};
 constexpr u32 kAllSym = (1u << SYM_CLASSES) - 1u;
 constexpr u32 kAllNum = (1u << NUM_CLASSES) - 1u;
@@ -422,9 +422,9 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
     const u32* hint = sym_hint ? sym_hint : all_m;
-    static const int merged[6] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, kLightBig, kLightTiny};
-    static const int separate[SYM_CLASSES] = {SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, SYM_B4K,
-                                              SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
+    static const int merged[7] = {SYM_GH, SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, kLightBig, kLightTiny};
+    static const int separate[SYM_CLASSES] = {SYM_GH,  SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF,
+                                              SYM_B4K, SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
     // the launch's LDS size is the largest need among its classes and caps the waves per CU of all of
     // them: the 256-thread classes go in two launches, the big-LDS ones apart (split_light); the
     // first runs on a side stream next to the second
@@ -440,7 +440,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         split_sym = part_us(sym_hint, kSymNsPerRow, kSymLightMask & (1u << SYM_BM1)) >= c->split_min_us &&
                     part_us(sym_hint, kSymNsPerRow, kSymLightMask & ~(1u << SYM_BM1)) >= c->split_min_us;
     const u32 sym_big = split_sym ? (1u << SYM_BM1) : kSymLightMask;
-    int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 6 : (int)SYM_CLASSES, sym_mask,
+    int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 7 : (int)SYM_CLASSES, sym_mask,
                          kSymLightMask & sym_big, kSymLightMask & ~sym_big, sym_hint, kSymNsPerRow,
                          tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr, [&](hipStream_t ks, int cls) {
                              if (cls == kLightBig || cls == kLightTiny) {
@@ -555,6 +555,7 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
                (c->concurrent_classes ? 1u : 0u);
     k.num[7] ^= reinterpret_cast<u64>(s);
     k.num[5] |= u64(c->cp.nf_min_ops) << 8;
+    k.num[4] |= u64(c->cp.gh_per_window) << 32;  // C->nnz fits 32 bits
     return k;
 }
 
@@ -709,8 +710,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     // ANALYSIS + binning + SYMBOLIC + SCAN (Multiply.cu:239-575) -- one read-back
     Timing tm;
-    if (c->cp.nf_min_ops) {
-        // numeric-first rows need their scratch pool before the symbolic phase: one more read-back
+    if (c->cp.nf_min_ops || c->cp.gh_per_window) {
+        // numeric-first rows (and the global key sets of SYM_GH rows) need their scratch pool before the
+        // symbolic phase: one more read-back
         // (the replayed sequence has none: the pool of the previous identical call is checked on the device)
         rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr,
                            ~0ull, ~0u, 1u);
@@ -722,6 +724,15 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);  // before any kernel walks B's rows
         if (c->h_stats->nf_entries) {
             rc = ensure_nfpool(c, c->h_stats->nf_entries, sizeof(T));
+            if (rc == SPECK_ERR_OOM && c->cp.gh_per_window && c->h_stats->sym.count[SYM_GH]) {
+                // no room for the global key sets: those rows take the multi-window bitmap (no memory at all)
+                // from now on -- classify again
+                c->cp.gh_per_window = 0;
+                rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr,
+                                   nullptr, ~0ull, ~0u, 1u);
+                if (rc == SPECK_OK) rc = read_stats(c, s);
+                if (rc == SPECK_OK && c->h_stats->nf_entries) rc = ensure_nfpool(c, c->h_stats->nf_entries, sizeof(T));
+            }
             if (rc != SPECK_OK) return fail(rc);
         }
         rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr,
@@ -729,7 +740,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     } else
         rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm);
     if (rc != SPECK_OK) return fail(rc);
-    if (c->validate_inputs && !c->cp.nf_min_ops)
+    if (c->validate_inputs && !(c->cp.nf_min_ops || c->cp.gh_per_window))
         launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return fail(rc);
@@ -980,6 +991,7 @@ int speck_config_create(int device, speck_config** out)
     c->cp.num_dense_ratio = 16;
     c->cp.num_global_passes = 4;  // heavy rows: dense windows up to 64 Ki columns, else global spill
     c->cp.nf_min_ops = 1024;  // numeric-first for narrow rows with at least this many products (0 = off)
+    c->cp.gh_per_window = 8192;  // global key set for rows with fewer products per 1 Mi-column bitmap window (0 = off)
     c->cp.num_wave1k = 0;  // measured: one launch (and fork/join) less beats the barrier-free rows
     c->cp.want_bytes = 0;
     *out = c;
@@ -1036,7 +1048,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     if (n == "sym_bitmap_ratio") c->cp.sym_bitmap_ratio = (u32)value;
     else if (n == "num_dense_ratio") c->cp.num_dense_ratio = (u32)value;
     else if (n == "num_global_passes") c->cp.num_global_passes = (u32)value;
-    else if (n == "nf_min_ops") {
+    else if (n == "gh_per_window") {
+        c->cp.gh_per_window = (u32)value;
+        drop_graph(c);
+        c->last_key_valid = false;
+    } else if (n == "nf_min_ops") {
         c->cp.nf_min_ops = (u32)value;
         drop_graph(c);
         c->last_key_valid = false;
@@ -1178,10 +1194,12 @@ int speck_symbolic(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
     Scratch sc = carve(c, m, A->nnz);
-    const u32 nf_was = c->cp.nf_min_ops;
+    const u32 nf_was = c->cp.nf_min_ops, gh_was = c->cp.gh_per_window;
     c->cp.nf_min_ops = 0;  // structure only: no values here, every row through a symbolic kernel
+    c->cp.gh_per_window = 0;  // ... one that needs no scratch pool
     rc = enqueue_front(c, s, A, B, sc, d_row_offsets, 8, ~0ull, kAllSym, kAllNum, false, nullptr);
     c->cp.nf_min_ops = nf_was;
+    c->cp.gh_per_window = gh_was;
     if (rc != SPECK_OK) return rc;
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return rc;

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
                 cls = classify_symbolic(len_a, ops32, cmin, cmax, cp);
                 sym_cls[row] = cls;
                 if (cls == SYM_NF) my_nf += cmax - cmin + 1;  // scratch slot = the row's column range
+                if (cls == SYM_GH) my_nf += gh_table_slots(ops32);  // ... = the row's key set in global memory
                 if (cls == SYM_NONE) {
                     // empty row, or a single A entry: the C row is a scaled copy of one B row
                     counts[row] = ops32;
@@ -483,12 +484,15 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
             r.nnz = 0;
             recs[pos] = r;
         }
-        // scratch slots of the numeric-first rows: exclusive prefix of their column ranges, in row order
-        if (s_wcnt[SYM_NF][0] + s_wcnt[SYM_NF][1] + s_wcnt[SYM_NF][2] + s_wcnt[SYM_NF][3] != 0) {  // uniform
-            const u32 ub = c == SYM_NF ? r_max - r_min + 1u : 0u;
+        // scratch slots of the numeric-first rows (and key sets of the SYM_GH rows): exclusive prefix of their
+        // column ranges (table sizes), in row order
+        if (s_wcnt[SYM_NF][0] + s_wcnt[SYM_NF][1] + s_wcnt[SYM_NF][2] + s_wcnt[SYM_NF][3] + s_wcnt[SYM_GH][0] +
+                s_wcnt[SYM_GH][1] + s_wcnt[SYM_GH][2] + s_wcnt[SYM_GH][3] != 0) {  // uniform
+            const u32 row_ops_v = first ? p_ops : (c == SYM_GH ? row_ops[row] : 0u);
+            const u32 ub = c == SYM_NF ? r_max - r_min + 1u : (c == SYM_GH ? gh_table_slots(row_ops_v) : 0u);
             u32 chunk_total;
             const u32 excl = block_exclusive_scan<kChunk>(ub, s_nfscan, &chunk_total);
-            if (c == SYM_NF) nf_off[row] = s_nfrun + excl;
+            if (c == SYM_NF || c == SYM_GH) nf_off[row] = s_nfrun + excl;
             __syncthreads();
             if (threadIdx.x == 0) s_nfrun += chunk_total;
         }

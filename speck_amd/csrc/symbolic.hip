@@ -7,8 +7,10 @@
 //   SYM_W256/W1K   : one wave per row, 256 / 1024-key set, no workgroup barrier
 //   SYM_B4K/16K/32K: one workgroup per row, 16 / 64 / 128 KiB key set
 //   SYM_BM1/BM2    : column bitmap (1 bit per column): one ds_or per product, no probing;
-//                    128 KiB of LDS cover 1 Mi columns per window, so the heaviest rows never
-//                    need a global-memory spill in this phase.
+//                    128 KiB of LDS cover 1 Mi columns per window (per-entry cursors between windows)
+//   SYM_GH         : key set in global memory for rows that are wide AND sparse (few products per bitmap
+//                    window) -- role of the reference's global hash maps for the symbolic phase
+//                    (include/GPU/spECK_HashSpGEMM.cuh:89-126, 1025-1057; include/HashMap.cuh:112-134)
 // Algorithmic bytes per row: 8 + 12*lenA + 4*ops + 4 (device_common.hpp).
 #include "device_common.hpp"
 #include "launch.hpp"
@@ -120,6 +122,90 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
     }
 }
 
+// SYM_GH: one workgroup per row, the key set is the row's slot of the scratch pool (sized by the analysis
+// pass from the product count, a power of two at load <= 1/2).  Every compare-and-swap of a row comes from
+// ONE workgroup, i.e. one XCD and one L2: workgroup-scope atomics (performed in that L2, no trip to the
+// memory side) are enough.  The batched form keeps 4 x 1024 independent atomics in flight; only a collision
+// enters the probing loop.
+__device__ __forceinline__ u32 gh_cas(u32* p, u32 key)
+{
+    u32 expected = kEmptyKey;
+    __hip_atomic_compare_exchange_strong(p, &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+    return expected;  // previous content
+}
+__device__ __forceinline__ u32 gh_insert_batch(u32* __restrict__ tab, u32 shift, u32 mask, const u32 (&key)[kBatch],
+                                               u32 nvalid)
+{
+    u32 slot[kBatch], old[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+        slot[u] = (key[u] * 0x9E3779B1u) >> shift;
+        old[u] = kEmptyKey;
+        if ((u32)u < nvalid) old[u] = gh_cas(&tab[slot[u]], key[u]);
+    }
+    // collisions: the next probes of ALL pending keys of the lane go out together -- the number of L2 round
+    // trips is the longest chain among the lane's keys, not the sum of the chains
+    u32 added = 0;
+    bool pending[kBatch];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+        added += ((u32)u < nvalid && old[u] == kEmptyKey) ? 1u : 0u;
+        pending[u] = (u32)u < nvalid && old[u] != kEmptyKey && old[u] != key[u];
+        any |= pending[u];
+    }
+    while (any) {
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+            if (pending[u]) {
+                slot[u] = (slot[u] + 1u) & mask;
+                old[u] = gh_cas(&tab[slot[u]], key[u]);
+            }
+        any = false;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+            if (pending[u]) {
+                added += old[u] == kEmptyKey ? 1u : 0u;
+                pending[u] = old[u] != kEmptyKey && old[u] != key[u];
+                any |= pending[u];
+            }
+    }
+    return added;
+}
+
+constexpr int kGhThreads = 1024;
+__global__ __launch_bounds__(kGhThreads) void sym_global_hash_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
+                                                                      u32* __restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    src.rebase(a_ro);
+    using G = Block<kGhThreads>;
+    const G g;
+    u32* lds = reinterpret_cast<u32*>(smem);
+    u32* scratch = lds + 2 * kGhThreads;
+    RowMeta<float> meta{lds, lds + kGhThreads, nullptr, scratch + kGhThreads / 64 + 2};
+    const u32 count = w.st->sym.count[SYM_GH];
+    const RowRec* recs = w.recs + w.st->sym.offset[SYM_GH];
+    for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const RowRec rec = recs[idx];
+        const u32 slots = gh_table_slots(rec.ops);
+        const u32 shift = 32u - (u32)__builtin_ctz(slots);
+        u32* tab = w.nf_col + w.nf_off[rec.row];
+        for (u32 i = threadIdx.x; i < slots; i += kGhThreads) tab[i] = kEmptyKey;
+        __threadfence();  // the stores are in the L2 before any wave of this workgroup sends an atomic there
+        __syncthreads();
+        u32 cnt = 0;
+        for_each_product<false>(g, src, rec.a0, rec.a1, meta, scratch,
+                                [&](const u32(&c)[kBatch], const float(&)[kBatch], u32 n) {
+                                    cnt += gh_insert_batch(tab, shift, slots - 1u, c, n);
+                                });
+        cnt = g.reduce_add(cnt, scratch);
+        if (threadIdx.x == 0) counts[rec.row] = cnt;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ kernels
 // Stand-alone kernels (one class per launch) and the merged "light" kernel (see numeric.hip):
 // every 256-thread class shares one launch, block ranges map to classes, heaviest first.
@@ -173,6 +259,7 @@ u32 symbolic_lds_bytes(int cls)
         case SYM_B32K: return sym_group_lds<Block<1024>, kSymB32KCap, 1024>();
         case SYM_BM1: return (kSymBm1Words + 2 * 256 + 8 + win_words<Block<256>>()) * 4;
         case SYM_BM2: return (kSymBm2Words + 2 * 1024 + 24 + win_words<Block<1024>>()) * 4;
+        case SYM_GH: return (2 * kGhThreads + kGhThreads / 64 + 8 + win_words<Block<kGhThreads>>()) * 4;
     }
     return 0;
 }
@@ -270,6 +357,10 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
                                B, w, counts, cls);
             break;
         }
+        case SYM_GH:
+            hipLaunchKernelGGL(sym_global_hash_kernel, dim3(grid_for(count, lds, kGhThreads, cu_count, 1)),
+                               dim3(kGhThreads), lds, s, A, B, w, counts);
+            break;
     }
 }
 

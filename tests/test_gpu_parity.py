@@ -216,6 +216,39 @@ def test_symbolic_bitmap_multiwindow_heavy_rows(cfg):
     check(cfg, A, B, [("sym", "bitmap1m"), ("num", "global")])
 
 
+def test_symbolic_global_key_set_for_wide_sparse_rows(cfg):
+    """SYM_GH (role of the reference's global hash maps in the symbolic phase, spECK_HashSpGEMM.cuh:89-126,
+    1025-1057): more products than the 128 KiB LDS set holds, spread thinly over many bitmap windows.  Rows of
+    very different sizes share the launch (tables of 64 Ki .. 256 Ki slots), duplicates are frequent (B has
+    300 rows only), and a replayed sequence reuses the pool."""
+    rng = np.random.default_rng(11)
+    kb, n = 300, 40 << 20
+    pool = np.unique(rng.integers(0, n, size=30000, dtype=np.int64))          # B's rows share 30 k columns
+    pick = np.sort(rng.integers(0, pool.size, size=(kb, 220)), axis=1)
+    keep = np.ones(pick.shape, dtype=bool)
+    keep[:, 1:] = pick[:, 1:] != pick[:, :-1]
+    bro = np.zeros(kb + 1, dtype=np.uint32)
+    bro[1:] = np.cumsum(keep.sum(axis=1))
+    bcol = pool[pick[keep]].astype(np.uint32)
+    B = po.HostCSR(kb, n, bro, bcol, (0.5 + rng.random(bcol.size)) * rng.choice([-1.0, 1.0], size=bcol.size))
+    lens = np.array([140, 300, 300, 200, 125, 300] * 3)           # 27.5k .. 66k products per row
+    aro = np.zeros(lens.size + 1, dtype=np.uint32)
+    aro[1:] = np.cumsum(lens)
+    acol = np.concatenate([np.sort(rng.choice(kb, size=k, replace=False)) for k in lens]).astype(np.uint32)
+    A = po.HostCSR(lens.size, kb, aro, acol, 0.5 + rng.random(acol.size))
+    dC, st, R = check(cfg, A, B, [("sym", "global_hash"), ("num", "global")], threads=2)
+    assert st["sym_bin_rows"]["global_hash"] == lens.size and st["sym_bin_rows"]["bitmap1m"] == 0
+    for _ in range(3):                                              # second call captures, third replays
+        check(cfg, A, B, [("sym", "global_hash")], C_reuse=dC, threads=2)
+    assert cfg.last_stats()["graph_replays"] > 0
+    cfg.set_option("gh_per_window", 0)
+    try:
+        _, st0, _ = check(cfg, A, B, [("sym", "bitmap1m")], threads=2)
+        assert st0["sym_bin_rows"]["global_hash"] == 0
+    finally:
+        cfg.set_option("gh_per_window", 8192)
+
+
 def test_heavy_rows_with_narrow_range_stay_dense(cfg):
     # > 5461 nnz per row but only 40k columns: 3 dense windows beat the global spill
     A = fast_random_csr(40, 3000, 200, 81, jitter=False)
@@ -568,8 +601,8 @@ def test_nnz_of_c_beyond_u32_is_reported_not_wrapped(cfg):
 
 def test_dimensions_exactly_at_the_2_27_limit(cfg):
     """rows(A) = cols(B) = 2^27, the largest sizes the reference accepts (Multiply.cu:57-66); four rows
-    reach columns over the WHOLE range: 128 one-Mi-column bitmap windows in the symbolic phase, the
-    global spill in the numeric one; the last row of A is non-empty too."""
+    reach columns over the WHOLE range: the global key set in the symbolic phase (and, with it switched off,
+    128 one-Mi-column bitmap windows), the global spill in the numeric one; the last row of A is non-empty too."""
     n = 1 << 27
     rng = np.random.default_rng(9)
     kb, lb = 300, 200
@@ -587,6 +620,12 @@ def test_dimensions_exactly_at_the_2_27_limit(cfg):
     aro[n] = kb * heavy + 3
     acol = np.concatenate([np.tile(np.arange(kb, dtype=np.uint32), heavy), np.array([1, 7, 250], np.uint32)])
     A = po.HostCSR(n, kb, aro, acol, 0.5 + rng.random(acol.size))
-    dC, st, R = check(cfg, A, B, [("sym", "bitmap1m"), ("num", "global")], threads=2)
+    dC, st, R = check(cfg, A, B, [("sym", "global_hash"), ("num", "global")], threads=2)
     assert dC.rows == n and dC.cols == n
     assert st["max_row_ops"] == int(np.diff(bro.astype(np.int64)).sum())
+    cfg.set_option("gh_per_window", 0)
+    try:
+        _, st2, _ = check(cfg, A, B, [("sym", "bitmap1m"), ("num", "global")], threads=2)
+        assert st2["sym_bin_rows"]["global_hash"] == 0 and st2["nnz_c"] == st["nnz_c"]
+    finally:
+        cfg.set_option("gh_per_window", 8192)

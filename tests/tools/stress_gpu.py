@@ -75,6 +75,7 @@ def main():
                 bool((np.abs(got.data.astype(np.float64) - R.data.astype(np.float64)) <= tol * ab + 1e-300).all())
         st = cfg.last_stats()
         cls = {k: v for k, v in st["num_bin_rows"].items() if v}
+        cls.update({"sym:" + k: v for k, v in st["sym_bin_rows"].items() if v and k in ("bitmap1m", "global_hash")})
         if not ok:
             bad += 1
         print(f"{it:4d} {'ok ' if ok else 'BAD'} {m}x{k}x{n} {ka}/{kb} {dtype.__name__} nnzC={R.nnz} {cls}", flush=True)
