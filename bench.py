@@ -200,7 +200,7 @@ class Job:
 
 def profile_prepass(job, split, merged, prof_steps=5):
     """Untimed eager steps with HIP events around every launch, each recorded on the stream the
-    launch runs on: algorithmic bytes per class, per-launch / per-phase ms."""
+    launch runs on (algorithmic bytes per class, per-launch ms), then with events around the phases only."""
     cfg = job.cfg
     cfg.profile_kernels(1)
     cfg.set_option("collect_bytes", 1)   # per-class algorithmic bytes: one call is enough
@@ -226,8 +226,15 @@ def profile_prepass(job, split, merged, prof_steps=5):
         # accounted as a numeric launch, the symbolic phase is what remains
         nf = s["sym_bin_ms"]["numeric_first"] if s["sym_bin_rows"]["numeric_first"] else 0.0
         kernel_ms["numeric_first"] = kernel_ms.get("numeric_first", 0.0) + nf / prof_steps
-        sym_ms += (s["analysis_ms"] + s["scan_ms"] + max(s["sym_phase_ms"] - nf, 0.0)) / prof_steps
-        num_ms += (s["num_phase_ms"] + nf) / prof_steps
+    # the phases, timed WITHOUT an event between their class launches (mode 2: one event pair per phase; an
+    # event record between two launches of a phase costs each a few us the replayed sequence does not pay)
+    cfg.profile_kernels(2)
+    nf_ms = kernel_ms.get("numeric_first", 0.0)
+    for _ in range(prof_steps):
+        job.step()
+        s = cfg.last_stats()
+        sym_ms += (s["analysis_ms"] + s["scan_ms"] + max(s["sym_phase_ms"] - nf_ms, 0.0)) / prof_steps
+        num_ms += (s["num_phase_ms"] + nf_ms) / prof_steps
     kernel_bytes = dict(st["num_bin_bytes"])
     # the algorithmic bytes of the numeric-first rows belong to the launch that computes them; the
     # copy of the finished rows into C is extra traffic outside the model (listed by time only)
@@ -364,9 +371,9 @@ def main():
             "parity": "oracle- and rocSPARSE-pinned (reference ships no golden vectors): indices bit-exact, "
                       "|c - c_ref| <= 1e-12 * sum|a*b| per entry",
             "phases_ms": {"symbolic": round(res["sym_ms"], 4), "numeric": round(res["num_ms"], 4),
-                          "note": "untimed profiled pre-pass; symbolic = analysis + binning + symbolic launches "
-                                  "+ scan, numeric = the numeric-first launch (it runs in the symbolic phase) + fork "
-                                  "to join of the numeric launches"},
+                          "note": "untimed profiled pre-pass (eager), one HIP event pair per phase; symbolic = "
+                                  "analysis + binning + symbolic launches + scan, numeric = the numeric-first launch "
+                                  "(it runs in the symbolic phase) + fork to join of the numeric launches"},
             "roofline": roofline_block(args.workload, st, res["kernel_ms"], res["num_ms"]),
             "kernels_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items() if v > 0},
             "rows_per_class": {k: v for k, v in st["num_bin_rows"].items() if v},

@@ -89,7 +89,8 @@ int speck_config_info(const speck_config *cfg, int *sm, int *max_static_lds, int
 int speck_config_set_stream(speck_config *cfg, void *hip_stream);
 /* Tunables (thresholds the reference hard-codes in Multiply.cu:128-131,321-324); name -> value. */
 int speck_config_set_option(speck_config *cfg, const char *name, int64_t value);
-/* Record HIP events around every kernel of the next calls (fills speck_stats.*_ms). */
+/* Record HIP events around every kernel of the next calls (fills speck_stats.*_ms); enable = 2: around the
+ * phases only (analysis_ms, scan_ms, sym_phase_ms, num_phase_ms -- no event between the launches of a phase). */
 int speck_config_profile_kernels(speck_config *cfg, int enable);
 int speck_last_stats(const speck_config *cfg, speck_stats *out);
 

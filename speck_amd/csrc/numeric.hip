@@ -200,6 +200,49 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
         }
 }
 
+// Narrow rows of the rank-sort classes: the reachable column range fits ONE bitmap word per lane of the
+// group (16 lanes: 512 columns, a wave: 2048).  Rank of a key = set bits below it: one ds_or per key, one
+// group scan of the word popcounts, one 8-byte LDS read + popcount per key -- ~60 wave instructions where
+// the compare loop above takes 150-400.  `bm` (SIZE words) may alias the table's keys, `bp` (SIZE uint2)
+// the A-row staging area.
+template <class G, typename T, u32 CAP>
+__device__ __forceinline__ void emit_narrow_sorted(const G& g, const u32* keys, const Acc<T>* vals, u32* bm,
+                                                   uint2* bp, u32 cap_row, u32 cmin, u32 base,
+                                                   u32* __restrict__ c_col, T* __restrict__ c_val)
+{
+    constexpr u32 OWN = CAP / G::SIZE;
+    u32 k[OWN];
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j) {
+        k[j] = kEmptyKey;
+        if (j * G::SIZE < cap_row) k[j] = keys[j * G::SIZE + g.lane];
+    }
+    g.sync();
+    bm[g.lane] = 0;
+    g.sync();
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j)
+        if (k[j] != kEmptyKey) {
+            const u32 d = k[j] - cmin;
+            atomicOr(&bm[d >> 5], 1u << (d & 31));
+        }
+    g.sync();
+    const u32 word = bm[g.lane];
+    u32 total;
+    const u32 incl = g.inclusive_scan((u32)__popc(word), &total, nullptr);
+    bp[g.lane] = make_uint2(word, incl - (u32)__popc(word));
+    g.sync();
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j)
+        if (k[j] != kEmptyKey) {
+            const u32 d = k[j] - cmin;
+            const uint2 e = bp[d >> 5];
+            const u32 r = e.y + (u32)__popc(e.x & ((1u << (d & 31)) - 1u));
+            c_col[base + r] = k[j];
+            c_val[base + r] = (T)vals[j * G::SIZE + g.lane];
+        }
+}
+
 // Two-level bitmap sort (see the header comment).  S: LDS scratch of max(2*W1, 2*NMAX) words;
 // it may alias the table (slots are loaded into registers first).
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX>
@@ -366,8 +409,14 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         PHASE_MARK(1);
         if constexpr (MODE == SORT_RANK) {
             // scratch: the compacted keys over the table's keys, their slot numbers over the A-row staging
-            emit_rank_sorted<G, T, CAP, NMAX>(g, keys, vals, keys, reinterpret_cast<u32*>(m_av), cap_row, rec.base,
-                                              c_col, c_val);
+            // the groups of a wave take the same sort (no wave ever runs both)
+            const bool narrow = __ballot(u64(rec.cmax) - rec.cmin >= u64(G::SIZE) * 32) == 0;
+            if (narrow)
+                emit_narrow_sorted<G, T, CAP>(g, keys, vals, keys, reinterpret_cast<uint2*>(m_av), cap_row, rec.cmin,
+                                              rec.base, c_col, c_val);
+            else
+                emit_rank_sorted<G, T, CAP, NMAX>(g, keys, vals, keys, reinterpret_cast<u32*>(m_av), cap_row, rec.base,
+                                                  c_col, c_val);
         } else {
             emit_bitmap_sorted<G, T, CAP, W1, NMAX>(g, keys, vals, S, scan_scratch, cap_row, rec.cmin,
                                                     rec.cmax, rec.base, c_col, c_val, cls);

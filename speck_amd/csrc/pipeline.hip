@@ -68,7 +68,8 @@ struct speck_config {
     u32 ticket_expected = 0;
     bool spin_wait = true;
     ClassifyParams cp{};
-    bool profile_kernels = false;
+    int profile_kernels = 0;  // 1: HIP events around every launch; 2: around the phases only (no event between
+                              //    the class launches of a phase: their spans are what a replayed sequence sees)
     std::vector<hipEvent_t> kev;   // kernel event pool (timing)
     std::vector<hipStream_t> aux;  // one stream per kernel class: classes run concurrently
     std::vector<hipEvent_t> aux_done;
@@ -348,7 +349,7 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
             }
             ++used;
         }
-        const bool timed = c->profile_kernels && timing;
+        const bool timed = c->profile_kernels == 1 && timing;
         if (timed) (void)hipEventRecord(kernel_event(c, *ev_idx), ks);
         launch(ks, cls);
         if (timed) {
@@ -646,11 +647,11 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     };
     StageTimer st(c, t->measureAll != 0, s);
     struct RestoreFlag {
-        bool& flag;
-        bool value;
+        int& flag;
+        int value;
         ~RestoreFlag() { flag = value; }
     } restore_profile{c->profile_kernels, c->profile_kernels};
-    if (t->measureAll) c->profile_kernels = true;  // per-stage times come from per-launch events
+    if (t->measureAll) c->profile_kernels = 1;  // per-stage times come from per-launch events
 
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
@@ -1109,7 +1110,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
 int speck_config_profile_kernels(speck_config* c, int enable)
 {
     if (!c) return SPECK_ERR_INVALID;
-    c->profile_kernels = enable != 0;
+    c->profile_kernels = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return SPECK_OK;
 }
 
