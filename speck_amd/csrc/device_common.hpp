@@ -37,7 +37,7 @@ enum SymClass : u8 {
     SYM_B4K = 3,    // workgroup(256) per row, 4096-key set   (ops <= 3276)
     SYM_B16K = 4,   // workgroup(512) per row, 16384-key set  (ops <= 13107)
     SYM_B32K = 5,   // workgroup(1024) per row, 32768-key set (ops <= 26214), 128 KiB LDS
-    SYM_BM1 = 6,    // column bitmap, workgroup(256), 256 Ki columns per window
+    SYM_BM1 = 6,    // column bitmap, workgroup(256), 128 Ki columns per window, rows up to 256 Ki columns
     SYM_BM2 = 7,    // column bitmap, workgroup(1024), 1 Mi columns per window, multi-window
     SYM_NF = 8,     // NUMERIC-FIRST: narrow column range -> the dense-window numeric kernel runs in the
                     //   symbolic phase, writes the finished row to a scratch slot and counts it; no
@@ -72,7 +72,10 @@ constexpr u32 kSymW1KCap = 1024, kSymW1KMaxOps = 819;
 constexpr u32 kSymB4KCap = 4096, kSymB4KMaxOps = 3276;
 constexpr u32 kSymB16KCap = 16384, kSymB16KMaxOps = 13107;
 constexpr u32 kSymB32KCap = 32768, kSymB32KMaxOps = 26214;
-constexpr u32 kSymBm1Words = 8192;    // 32 KiB  -> 262144 columns
+constexpr u32 kSymBm1Words = 4096;    // 16 KiB  -> 131072 columns per window: no more LDS than the hash classes it shares
+                                      //   the merged light launch with (a 32 KiB window capped that launch at 4
+                                      //   workgroups per CU for a handful of rows); wider rows take two windows
+constexpr u32 kSymBm1MaxCols = 262144;  // rows up to this column range are SYM_BM1
 constexpr u32 kSymBm2Words = 32768;   // 128 KiB -> 1048576 columns per window
 
 constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = 42;
@@ -129,12 +132,12 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
     if (ops <= kSymW256MaxOps) return SYM_W256;
     const u64 range = u64(cmax) - u64(cmin) + 1;
     const bool bitmap_ok = range <= u64(p.sym_bitmap_ratio) * ops;
-    if (bitmap_ok && range <= u64(kSymBm1Words) * 32) return SYM_BM1;
+    if (bitmap_ok && range <= kSymBm1MaxCols) return SYM_BM1;
     if (ops <= kSymW1KMaxOps) return SYM_W1K;
     if (ops <= kSymB4KMaxOps) return SYM_B4K;
     // heavier rows: one bitmap window of the 256-thread class costs 32 words per thread to clear
     // and count -- nothing against >= 3277 products -- and keeps the row in the merged launch
-    if (range <= u64(kSymBm1Words) * 32) return SYM_BM1;
+    if (range <= kSymBm1MaxCols) return SYM_BM1;
     if (ops <= kSymB16KMaxOps) return SYM_B16K;
     constexpr u64 kWin = u64(kSymBm2Words) * 32;
     const bool sparse_wide = p.gh_per_window != 0 && range > kWin && ops < kSymGhMaxOps &&

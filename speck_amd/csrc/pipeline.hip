@@ -1078,6 +1078,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->fork_min_us = (float)value;
         drop_graph(c);
     }
+    else if (n == "split_min_us") {
+        c->split_min_us = (float)value;
+        drop_graph(c);
+    }
     else if (n == "max_side_streams") {
         c->max_side_streams = (u32)value;
         drop_graph(c);
