@@ -87,7 +87,9 @@ constexpr u32 kNumB2KCap = 2048, kNumB2KMaxNnz = 1365;
 // into NUM_B2K when its rows fit the 2 Ki table at a load of 0.85 instead of 2/3 (pipeline.hip, capture)
 constexpr u32 kNumB2KStretchNnz = 1740;
 constexpr u32 kNumB8KCap = 8192, kNumB8KMaxNnz = 5461;
-constexpr u32 kNumD1Cols = 4096;
+constexpr u32 kNumD1Cols = 4096;   // rows up to this column range are NUM_D1 / numeric-first
+constexpr u32 kNumD1Win = 2560;    // NUM_D1's LDS window (wider rows take two windows): no more LDS than NUM_W512 /
+                                   //   NUM_B2K, which share the merged light launch with it (5 instead of 4 workgroups per CU)
 constexpr u32 kNumD2Cols = 16384;
 
 // Tunables that travel to the classifying kernels.

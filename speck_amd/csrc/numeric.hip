@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     const u32 b = blockIdx.x;
     // launch order (ClassGrid slots): D1, B2K, W512, W128, G16, DIRECT
     if (b < cg.first[1])
-        num_dense_body<T, kNumD1Cols, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0]);
+        num_dense_body<T, kNumD1Win, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0]);
     else if (b < cg.first[2])
         num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KStretchNnz, SORT_BITMAP, 256>(
             smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1]);
@@ -1134,7 +1134,7 @@ u32 numeric_lds_bytes_t(int cls)
         case NUM_W1K: return 4 * num_group_lds<SubWave<64>, T, kNumW1KCap, 256>();
         case NUM_B2K: return num_group_lds<Block<256>, T, kNumB2KCap, 256>();
         case NUM_B8K: return num_group_lds<Block<512>, T, kNumB8KCap, 512>();
-        case NUM_D1: return num_dense_lds<T, kNumD1Cols, 256>();
+        case NUM_D1: return num_dense_lds<T, kNumD1Win, 256>();
         case NUM_D2: return num_dense_lds<T, kNumD2Cols, 1024>();
         case NUM_G: return num_spill_reduce_lds<T, kNumB8KCap, 512>();
         case NUM_NFCOPY: return 0;
@@ -1252,7 +1252,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_D1: {
-            auto k = num_dense_kernel<T, kNumD1Cols, 256>;
+            auto k = num_dense_kernel<T, kNumD1Win, 256>;
             set_dyn_lds(k, lds);
             hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, A, B, w,
                                c_col, c_val, cls);
