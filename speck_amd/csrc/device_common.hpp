@@ -203,7 +203,7 @@ struct DeviceStats {
     u64 nf_entries;          // scratch entries of the SYM_NF rows (sum of their column ranges) and of the SYM_GH rows
                              //   (slots of their key sets)
     u32 b_invalid;           // a row of B is not strictly ascending / holds a column >= cols (eager path)
-    u32 pad_;
+    u32 nf_max_range;        // widest column range among the SYM_NF rows (sizes the LDS window of their kernel)
 };
 
 // One row of work as the class kernels see it: written in class order by the scatter kernels,
@@ -236,6 +236,7 @@ struct PartialArrays {
     u64* bytes;     // [kMaxClasses][cap]  (only with ClassifyParams::want_bytes)
     u32* count;     // [kMaxClasses][cap]  rows per class
     u32* max_val;   // [cap]
+    u32* aux_max;   // [cap]   analysis: widest column range among the block's SYM_NF rows
     u32 cap;
     __host__ __device__ PartialArrays(BlockPartial* base, u32 blocks)
     {
@@ -245,9 +246,10 @@ struct PartialArrays {
         bytes = g_ops + cap;
         count = reinterpret_cast<u32*>(bytes + size_t(kMaxClasses) * cap);
         max_val = count + size_t(kMaxClasses) * cap;
+        aux_max = max_val + cap;
     }
 };
-static_assert(sizeof(BlockPartial) >= 8 + 8 + 8 * kMaxClasses + 4 * kMaxClasses + 4 + 8, "PartialArrays fits");
+static_assert(sizeof(BlockPartial) >= 8 + 8 + 8 * kMaxClasses + 4 * kMaxClasses + 4 + 4 + 8, "PartialArrays fits");
 
 #ifdef __HIPCC__
 // ---- wave64 primitives ---------------------------------------------------------

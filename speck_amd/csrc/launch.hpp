@@ -94,7 +94,7 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
 // SYM_NF: the dense-window numeric kernel in the symbolic phase (rows to their scratch slots, nnz to `counts`)
 template <typename T>
 void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& A, const CsrView<T>& B, const RowWork& w,
-                          u32* counts, int cu_count);
+                          u32* counts, int cu_count, u32 wcols);
 
 // Launch the numeric kernel of class `cls` (same convention for `count`).
 template <typename T>

@@ -535,10 +535,14 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
 // turns into one copy of C.  (The reference always runs both phases; new functionality.)
 template <typename T, int THREADS>
 __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
-                                                           u32* __restrict__ counts)
+                                                           u32* __restrict__ counts, u32 wcols)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr u32 WCOLS = kNumD1Cols, WORDS = WCOLS / 32;
+    // The window is as wide as the widest numeric-first row of the previous identical call / of the analysis
+    // read-back (a multiple of 256 columns), not kNumD1Cols: the launch holds 160 KiB / LDS workgroups per CU,
+    // and this kernel's time is ~ floor + latency / (waves per SIMD) -- cant stand-in, range 2187: 6 instead of
+    // 4 workgroups per CU.
+    const u32 WCOLS = wcols, WORDS = WCOLS / 32;
     if (w.st->capacity_miss) return;  // the scratch pool of this (replayed) sequence is too small
     if (w.st->sym.count[SYM_NF] == 0) return;  // eager path: launched for every class, rows or not
     src.rebase(a_ro);
@@ -564,6 +568,10 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
         if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
         const u64 slot = w.nf_off[rec.row];
         const u32 wbase = rec.cmin, ncols = rec.cmax - rec.cmin + 1u, nwords = (ncols + 31) >> 5;
+        if (ncols > WCOLS) {  // a replayed sequence met a wider row than its window was sized for: eager re-run
+            if (threadIdx.x == 0) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
+            continue;
+        }
         for_each_product<true>(g, src, rec.a0, rec.a1, meta, scratch,
                                [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
 #pragma unroll
@@ -1192,13 +1200,16 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
 
 template <typename T>
 void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& Av, const CsrView<T>& Bv, const RowWork& w,
-                          u32* counts, int cu_count)
+                          u32* counts, int cu_count, u32 wcols)
 {
     if (count == 0) return;
     const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
-    const u32 lds = num_dense_lds<T, kNumD1Cols, 256>();
+    wcols = wcols < 256u ? 256u : (wcols > kNumD1Cols ? kNumD1Cols : (wcols + 255u) & ~255u);
+    const u32 lds = (wcols + 256) * (u32)sizeof(Acc<T>) +
+                    (2 * (wcols / 32) + 2 * 256 + 256 / 64 + 2 + win_words<Block<256>>() + 3) / 4 * 16;
+    set_dyn_lds((nf_dense_kernel<T, 256>), lds);
     hipLaunchKernelGGL((nf_dense_kernel<T, 256>), dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s,
-                       src, Av.row_offsets, w, counts);
+                       src, Av.row_offsets, w, counts, wcols);
 }
 
 template <typename T>
@@ -1319,9 +1330,9 @@ template void launch_numeric_light<double>(hipStream_t, const u32*, u32, const C
 template void launch_numeric_light<float>(hipStream_t, const u32*, u32, const CsrView<float>&,
                                           const CsrView<float>&, const RowWork&, u32*, float*, int);
 template void launch_numeric_first<double>(hipStream_t, u32, const CsrView<double>&, const CsrView<double>&,
-                                           const RowWork&, u32*, int);
+                                           const RowWork&, u32*, int, u32);
 template void launch_numeric_first<float>(hipStream_t, u32, const CsrView<float>&, const CsrView<float>&,
-                                          const RowWork&, u32*, int);
+                                          const RowWork&, u32*, int, u32);
 template void launch_numeric<double>(hipStream_t, int, u32, const CsrView<double>&,
                                      const CsrView<double>&, const RowWork&, u32*, double*, int);
 template void launch_numeric<float>(hipStream_t, int, u32, const CsrView<float>&,

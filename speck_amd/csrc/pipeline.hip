@@ -103,6 +103,7 @@ struct speck_config {
     void* nfpool = nullptr;   // scratch slots of the numeric-first rows: col_ids | values (grow-only)
     size_t nfpool_bytes = 0;
     u64 nf_cap_entries = 0;
+    u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
     speck_stats last{};
@@ -453,11 +454,11 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                                  if (vsize == 8) {
                                      CsrView<double> Av{A->row_offsets, A->col_ids, static_cast<const double*>(A->data), m, (u32)A->cols};
                                      CsrView<double> Bv{B->row_offsets, B->col_ids, static_cast<const double*>(B->data), (u32)B->rows, (u32)B->cols};
-                                     launch_numeric_first<double>(ks, hint[cls], Av, Bv, w, c_ro, c->sm);
+                                     launch_numeric_first<double>(ks, hint[cls], Av, Bv, w, c_ro, c->sm, c->nf_wcols);
                                  } else {
                                      CsrView<float> Av{A->row_offsets, A->col_ids, static_cast<const float*>(A->data), m, (u32)A->cols};
                                      CsrView<float> Bv{B->row_offsets, B->col_ids, static_cast<const float*>(B->data), (u32)B->rows, (u32)B->cols};
-                                     launch_numeric_first<float>(ks, hint[cls], Av, Bv, w, c_ro, c->sm);
+                                     launch_numeric_first<float>(ks, hint[cls], Av, Bv, w, c_ro, c->sm, c->nf_wcols);
                                  }
                              } else
                                  launch_symbolic(ks, cls, hint[cls], A->row_offsets, sc.b_start, sc.b_len,
@@ -723,6 +724,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         rc = read_stats(c, s);
         if (rc != SPECK_OK) return fail(rc);
         if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);  // before any kernel walks B's rows
+        c->nf_wcols = c->h_stats->nf_max_range ? c->h_stats->nf_max_range : kNumD1Cols;
         if (c->h_stats->nf_entries) {
             rc = ensure_nfpool(c, c->h_stats->nf_entries, sizeof(T));
             if (rc == SPECK_ERR_OOM && c->cp.gh_per_window && c->h_stats->sym.count[SYM_GH]) {

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     __shared__ u64 s_ops_all[NW][R];
     __shared__ u32 s_mx_all[NW][R], s_cmin_all[NW][R], s_cmax_all[NW][R];
     __shared__ u64 s_products[NW], s_nf[NW];
-    __shared__ u32 s_max[NW];
+    __shared__ u32 s_max[NW], s_nfr[NW];
     __shared__ u32 s_hist[NW][kMaxClasses];
     __shared__ u64 s_bytes[kMaxClasses];
     const u32 t = threadIdx.x, lane = lane_id(), wid = t >> 6;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     const u32 row_begin = blockIdx.x * rows_per_block;
     const u32 row_end = min(m, row_begin + rows_per_block);
     u64 my_products = 0, my_nf = 0;
-    u32 my_max = 0;
+    u32 my_max = 0, my_nfr = 0;
     u32 hist[SYM_CLASSES];
 #pragma unroll
     for (int c = 0; c < SYM_CLASSES; ++c) hist[c] = 0;
@@ -234,7 +234,10 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
             if (sym_cls) {
                 cls = classify_symbolic(len_a, ops32, cmin, cmax, cp);
                 sym_cls[row] = cls;
-                if (cls == SYM_NF) my_nf += cmax - cmin + 1;  // scratch slot = the row's column range
+                if (cls == SYM_NF) {
+                    my_nf += cmax - cmin + 1;  // scratch slot = the row's column range
+                    my_nfr = max(my_nfr, cmax - cmin + 1);
+                }
                 if (cls == SYM_GH) my_nf += gh_table_slots(ops32);  // ... = the row's key set in global memory
                 if (cls == SYM_NONE) {
                     // empty row, or a single A entry: the C row is a scaled copy of one B row
@@ -253,12 +256,14 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     my_products = wave_reduce_add(my_products);
     my_nf = wave_reduce_add(my_nf);
     my_max = wave_reduce_max(my_max);
+    my_nfr = wave_reduce_max(my_nfr);
     __syncthreads();
     AN_MARK(6);
     if (lane == 0) {
         s_products[wid] = my_products;
         s_nf[wid] = my_nf;
         s_max[wid] = my_max;
+        s_nfr[wid] = my_nfr;
 #pragma unroll
         for (int c = 0; c < SYM_CLASSES; ++c) s_hist[wid][c] = hist[c];
     }
@@ -266,14 +271,16 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     const PartialArrays pa(partials, gridDim.x);
     if (t == 0) {
         u64 p = 0, nf = 0;
-        u32 mxv = 0;
+        u32 mxv = 0, nfr = 0;
         for (int w = 0; w < NW; ++w) {
             p += s_products[w];
             nf += s_nf[w];
             mxv = max(mxv, s_max[w]);
+            nfr = max(nfr, s_nfr[w]);
         }
         pa.products[blockIdx.x] = p;
         pa.max_val[blockIdx.x] = mxv;
+        pa.aux_max[blockIdx.x] = nfr;
         pa.g_ops[blockIdx.x] = nf;  // symbolic phase: scratch entries of the block's numeric-first rows
     }
     if (t < kMaxClasses) {
@@ -299,6 +306,7 @@ struct Fold {
     u64 g_total;                // products of the NUM_G rows (numeric) / scratch entries of the SYM_NF rows
     u64 g_prefix;               //   ... in the blocks before mine
     u32 max_val;
+    u32 aux_max;                // analysis: widest SYM_NF row
 };
 
 template <int THREADS, int NCLS>
@@ -307,7 +315,7 @@ __device__ __forceinline__ void fold_partials(BlockPartial* parts, u32 nb,
                                               bool want_bytes)
 {
     constexpr int NW = THREADS / 64;
-    __shared__ u32 s_pre[NW][NCLS], s_tot[NW][NCLS], s_mx[NW];
+    __shared__ u32 s_pre[NW][NCLS], s_tot[NW][NCLS], s_mx[NW], s_ax[NW];
     __shared__ u64 s_sp[NW], s_st[NW], s_by[NW][NCLS], s_g[NW], s_gp[NW];
     const PartialArrays pa(parts, nb);
     u32 pre[NCLS], tot[NCLS];
@@ -315,7 +323,7 @@ __device__ __forceinline__ void fold_partials(BlockPartial* parts, u32 nb,
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) pre[c] = tot[c] = 0, by[c] = 0;
     u64 sp = 0, stt = 0, gs = 0, gp = 0;
-    u32 mx = 0;
+    u32 mx = 0, ax = 0;
     for (u32 b = threadIdx.x; b < nb; b += THREADS) {  // consecutive threads, consecutive blocks: coalesced
         const bool before = b < my_block;
         const u64 gv = pa.g_ops[b];
@@ -332,6 +340,7 @@ __device__ __forceinline__ void fold_partials(BlockPartial* parts, u32 nb,
         stt += p;
         if (before) sp += p;
         mx = max(mx, pa.max_val[b]);
+        ax = max(ax, pa.aux_max[b]);
     }
     const u32 wid = threadIdx.x >> 6, lane = lane_id();
 #pragma unroll
@@ -347,12 +356,14 @@ __device__ __forceinline__ void fold_partials(BlockPartial* parts, u32 nb,
     sp = wave_reduce_add(sp);
     stt = wave_reduce_add(stt);
     mx = wave_reduce_max(mx);
+    ax = wave_reduce_max(ax);
     gs = wave_reduce_add(gs);
     gp = wave_reduce_add(gp);
     if (lane == 0) {
         s_sp[wid] = sp;
         s_st[wid] = stt;
         s_mx[wid] = mx;
+        s_ax[wid] = ax;
         s_g[wid] = gs;
         s_gp[wid] = gp;
     }
@@ -372,14 +383,16 @@ __device__ __forceinline__ void fold_partials(BlockPartial* parts, u32 nb,
     }
     if (threadIdx.x == 0) {
         u64 a = 0, t = 0, gt = 0, gpre = 0;
-        u32 m = 0;
+        u32 m = 0, axm = 0;
         for (int w = 0; w < NW; ++w) {
             a += s_sp[w];
             t += s_st[w];
             gt += s_g[w];
             gpre += s_gp[w];
             m = max(m, s_mx[w]);
+            axm = max(axm, s_ax[w]);
         }
+        s_fold->aux_max = axm;
         s_fold->sum_prefix = a;
         s_fold->sum_total = t;
         s_fold->g_total = gt;
@@ -448,6 +461,7 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
         st->sum_products = s_fold.sum_total;
         st->max_row_ops = s_fold.max_val;
         st->nf_entries = s_fold.g_total;
+        st->nf_max_range = s_fold.aux_max;
         // the scratch pool of a replayed launch sequence was sized for `expect_nf` entries
         if (expect_nf != ~0ull && s_fold.g_total > expect_nf) st->capacity_miss = 1;
         publish_bins(st->sym, s_fold, s_bytes, cp.sym_allowed, st);
@@ -616,6 +630,7 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
         }
         pa.products[blockIdx.x] = s;  // numeric phase: the tile's nnz sum
         pa.max_val[blockIdx.x] = mxv;
+        pa.aux_max[blockIdx.x] = 0;
         pa.g_ops[blockIdx.x] = gsum;
     }
 }
