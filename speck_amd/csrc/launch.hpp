@@ -31,6 +31,7 @@ void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const
 
 // Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
 // and two product pools (expanded by column bucket; reduced and sorted).
+constexpr u32 kGCellsPerBucket = 32;  // fine column cells per wanted bucket (plan kernel and host pool sizing)
 constexpr u32 kGBucketTarget = 1024;  // products per bucket aimed at (skewed columns exceed it)
 struct GRowPlan {
     u64 pbase;        // first pool slot of the row's products

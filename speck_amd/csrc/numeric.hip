@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const 
 // 2 ms for the 39 M atomics of the webbase-like input.  So the products of such a row are not
 // accumulated in global memory at all.  They are PARTITIONED by column into buckets of
 // ~2-4 k products with plain stores, and every bucket is then reduced in LDS like a NUM_B8K row:
-//   plan    : per row a FINE column grid (width 2^shift, up to 8 cells per wanted bucket), pool
+//   plan    : per row a FINE column grid (width 2^shift, up to kGCellsPerBucket cells per wanted bucket), pool
 //             offsets (one workgroup)
 //   count   : products per fine cell         -- column walk, LDS histogram, one global add per
 //                                               (workgroup, cell)
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(1024) void num_spill_plan_kernel(RowWork w, int cls
             nb = (ops + kGBucketTarget - 1) / kGBucketTarget;
             nb = nb < 1u ? 1u : (nb > kGMaxBuckets ? kGMaxBuckets : nb);
             unit = (ops + nb - 1) / nb;  // products per bucket (kGBucketTarget unless nb was clamped)
-            const u32 cells = min(kGMaxCells, 8u * nb);
+            const u32 cells = min(kGMaxCells, kGCellsPerBucket * nb);
             while ((range_m1 >> shift) + 1u > cells) ++shift;
             nf = (range_m1 >> shift) + 1u;
         }

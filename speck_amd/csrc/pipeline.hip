@@ -776,7 +776,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         const u64 pg = c->h_stats->g_products;
         const u32 rows_g = c->h_stats->num.count[NUM_G];
         const u64 buckets = pg / kGBucketTarget + rows_g + 16;
-        const u64 cells = 8 * buckets;
+        const u64 cells = u64(kGCellsPerBucket) * buckets;
         if (cells > 0x7FFFFFFFull) return fail(SPECK_ERR_OOM);
         const size_t need = Carver::need(rows_g, sizeof(GRowPlan)) + Carver::need(cells + 3 * buckets + 4, 4) +
                             Carver::need(buckets, 8) +
