@@ -496,6 +496,44 @@ def test_replay_detects_changed_inputs_under_the_same_pointers(cfg):
     _assert_matches_oracle(dC, A2, A2)
 
 
+def test_replay_detects_numeric_first_rows_wider_than_the_captured_window(cfg):
+    """The numeric-first kernel's LDS window is as wide as the widest such row of the call the sequence was
+    captured from (512 columns here).  B changes in place to rows spread over 3500 columns (still
+    numeric-first, <= 4096): the kernel must not touch its window, the device-side check rejects the
+    replay and the eager path re-runs with a wider window."""
+    import ctypes as C_
+    rng = np.random.default_rng(123)
+    kb, n, lb = 600, 5000, 30
+
+    def make_b(width, seed):
+        r = np.random.default_rng(seed)
+        c = np.stack([np.sort(r.choice(width, size=lb, replace=False)) for _ in range(kb)])
+        ro = (np.arange(kb + 1) * lb).astype(np.uint32)
+        return po.HostCSR(kb, n, ro, c.reshape(-1).astype(np.uint32), 0.5 + r.random(kb * lb))
+
+    B1, B2 = make_b(500, 1), make_b(3500, 2)
+    B2.data[:] = B1.data                                   # only the column ids change on the device
+    acol = np.stack([np.sort(rng.choice(kb, size=40, replace=False)) for _ in range(300)])
+    A = po.HostCSR(300, kb, (np.arange(301) * 40).astype(np.uint32), acol.reshape(-1).astype(np.uint32),
+                   0.5 + rng.random(300 * 40))
+    dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B1)), sa.dCSR()
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    st = cfg.last_stats()
+    assert st["sym_bin_rows"]["numeric_first"] == 300 and st["graph_replays"] > 0
+    _assert_matches_oracle(dC, A, B1)
+    src_cols = np.ascontiguousarray(B2.col_ids)
+    assert _lib.load().speck_dcsr_update(C_.byref(dB._c), None, src_cols.ctypes.data, None, 8) == 0
+    misses = st["numeric_reruns"]
+    sa.MultiplyspECK(dA, dB, dC, cfg)
+    _assert_matches_oracle(dC, A, B2)
+    assert cfg.last_stats()["numeric_reruns"] == misses + 1
+    for _ in range(3):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    _assert_matches_oracle(dC, A, B2)
+    assert cfg.last_stats()["sym_bin_rows"]["numeric_first"] == 300
+
+
 def _clustered_b(rows, cols, k, hot_cols, seed):
     """B whose even rows live in the first `hot_cols` columns and whose odd rows are spread over all
     of them: the products of a long A row pile up in one narrow column band (an oversized spill bucket
