@@ -210,7 +210,7 @@ def profile_prepass(job, split, merged, prof_steps=5):
     cfg.set_option("collect_bytes", 0)
     # the 256-thread numeric classes run as TWO launches: "light" (num_light_kernel: the big-LDS
     # classes) and "tiny" (num_tiny_kernel); the other classes launch separately
-    LIGHT, TINY = ("dense4k", "block2k", "wave512"), ("wave128", "g16", "direct")
+    LIGHT, TINY = ("dense4k", "block2k", "wave512"), ("wave128", "g16", "g8", "direct")
     if not split:
         LIGHT, TINY = LIGHT + TINY, ()
     kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny"]}

@@ -45,7 +45,8 @@ enum SymClass : u8 {
     SYM_GH = 9,     // key set in GLOBAL memory (one workgroup(1024) per row, table in the scratch pool): rows wider
                     //   than one SYM_BM2 window with few products per window -- every window of the bitmap costs a
                     //   fixed ~8 us, a global compare-and-swap a fraction of a nanosecond at 4096 in flight
-    SYM_CLASSES = 10,
+    SYM_G8 = 10,    // 8 lanes per row (8 rows per wave), 32-key LDS set (ops <= 25)
+    SYM_CLASSES = 11,
     SYM_NONE = 0xFF  // resolved by the analysis kernel itself (empty / single-entry A rows)
 };
 // Numeric classes: chosen from the EXACT nnz of the C row (symbolic result).
@@ -62,10 +63,13 @@ enum NumClass : u8 {
     NUM_W1K = 9,     // wave per row, 1024-entry table, 2-level bitmap sort (nnz <= 682): no
                      //   workgroup barriers, 2.4x less LDS per row than NUM_B2K
     NUM_NFCOPY = 10, // row already computed by the symbolic phase (SYM_NF): copy scratch slot -> C
-    NUM_CLASSES = 11,
+    NUM_G8 = 11,     // 8 lanes per row (8 rows per wave), 32-entry table, rank sort   (nnz <= 21): the small-row
+                     //   kernel is latency x occupancy bound -- twice the rows in flight per wave
+    NUM_CLASSES = 12,
     NUM_NONE = 0xFF
 };
 
+constexpr u32 kSymG8Cap = 32, kSymG8MaxOps = 25;
 constexpr u32 kSymG16Cap = 64, kSymG16MaxOps = 51;
 constexpr u32 kSymW256Cap = 256, kSymW256MaxOps = 204;
 constexpr u32 kSymW1KCap = 1024, kSymW1KMaxOps = 819;
@@ -78,6 +82,7 @@ constexpr u32 kSymBm1Words = 4096;    // 16 KiB  -> 131072 columns per window: n
 constexpr u32 kSymBm1MaxCols = 262144;  // rows up to this column range are SYM_BM1
 constexpr u32 kSymBm2Words = 32768;   // 128 KiB -> 1048576 columns per window
 
+constexpr u32 kNumG8Cap = 32, kNumG8MaxNnz = 21;
 constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = 42;
 constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = 85;
 constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = 341;
@@ -99,6 +104,8 @@ struct ClassifyParams {
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
     u32 num_wave1k;         // rows of 342..682 nnz: wave-per-row class (else they join NUM_B2K)
     u32 b2k_max_nnz;        // 0: kNumB2KMaxNnz; kNumB2KStretchNnz when the NUM_B8K class is folded into NUM_B2K
+    u32 num_g8;             // rows of <= kNumG8MaxNnz entries: 8 lanes per row (else they join NUM_G16)
+    u32 sym_g8;             // rows of <= kSymG8MaxOps products: 8 lanes per row (else they join SYM_G16)
     u32 nf_min_ops;         // numeric-first (SYM_NF) for rows with range <= kNumD1Cols and at least this many
                             //   products; 0 = off
     u32 gh_per_window;      // SYM_GH instead of a multi-window SYM_BM2 when the row holds fewer products than this
@@ -130,6 +137,7 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
 {
     if (ops == 0 || len_a <= 1) return SYM_NONE;
     if (is_numeric_first(len_a, ops, cmin, cmax, p)) return SYM_NF;
+    if (p.sym_g8 && ops <= kSymG8MaxOps) return SYM_G8;
     if (ops <= kSymG16MaxOps) return SYM_G16;
     if (ops <= kSymW256MaxOps) return SYM_W256;
     const u64 range = u64(cmax) - u64(cmin) + 1;
@@ -155,6 +163,7 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     if (nnz == 0) return NUM_NONE;
     if (len_a == 1) return NUM_DIRECT;
     if (is_numeric_first(len_a, ops, cmin, cmax, p)) return NUM_NFCOPY;
+    if (p.num_g8 && nnz <= kNumG8MaxNnz) return NUM_G8;
     if (nnz <= kNumG16MaxNnz) return NUM_G16;
     if (nnz <= kNumW128MaxNnz) return NUM_W128;
     const u64 range = u64(cmax) - u64(cmin) + 1;

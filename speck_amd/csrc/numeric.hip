@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    // launch order (ClassGrid slots): D1, B2K, W512, W128, G16, DIRECT
+    // launch order (ClassGrid slots): D1, B2K, W512, W128, G16, G8, DIRECT
     if (b < cg.first[1])
         num_dense_body<T, kNumD1Win, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0]);
     else if (b < cg.first[2])
@@ -689,8 +689,11 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     else if (b < cg.first[5])
         num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
             smem, src, w, c_col, c_val, NUM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
+    else if (b < cg.first[6])
+        num_hash_body<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[5], cg.first[6] - cg.first[5]);
     else
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[5], cg.first[6] - cg.first[5]);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[6], cg.first[7] - cg.first[6]);
 }
 
 // The three smallest classes alone: the merged kernel above takes the register count of its
@@ -711,8 +714,11 @@ __global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const 
     else if (b < cg.first[5])
         num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
             smem, src, w, c_col, c_val, NUM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
+    else if (b < cg.first[6])
+        num_hash_body<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[5], cg.first[6] - cg.first[5]);
     else
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[5], cg.first[6] - cg.first[5]);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[6], cg.first[7] - cg.first[6]);
 }
 
 // ------------------------------------------------------------------ NUM_G
@@ -1136,6 +1142,7 @@ u32 numeric_lds_bytes_t(int cls)
 {
     switch (cls) {
         case NUM_DIRECT: return num_direct_lds<T, 256>();
+        case NUM_G8: return 32 * num_group_lds<SubWave<8>, T, kNumG8Cap, 256>();
         case NUM_G16: return 16 * num_group_lds<SubWave<16>, T, kNumG16Cap, 256>();
         case NUM_W128: return 8 * num_group_lds<SubWave<32>, T, kNumW128Cap, 256>();
         case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, 256>();
@@ -1178,23 +1185,23 @@ template <typename T>
 void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const CsrView<T>& Av,
                           const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
-    static const int slots[6] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
-    static const u32 rows_per_block[6] = {1, 1, 4, 8, 16, 256};
+    static const int slots[7] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
+    static const u32 rows_per_block[7] = {1, 1, 4, 8, 16, 32, 256};
     u32 lds = 0;
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 7; ++k)
         if (mask >> slots[k] & 1u) lds = lds > numeric_lds_bytes_t<T>(slots[k]) ? lds : numeric_lds_bytes_t<T>(slots[k]);
     ClassGrid cg{};
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 7; ++k) {
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
     }
-    if (cg.first[6] == 0) return;
+    if (cg.first[7] == 0) return;
     const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
     if (cg.first[3] == 0)
-        hipLaunchKernelGGL((num_tiny_kernel<T>), dim3(cg.first[6]), dim3(256), lds, s, src, Av.row_offsets, w,
+        hipLaunchKernelGGL((num_tiny_kernel<T>), dim3(cg.first[7]), dim3(256), lds, s, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else
-        hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[6]), dim3(256), lds, s, src, Av.row_offsets, w,
+        hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[7]), dim3(256), lds, s, src, Av.row_offsets, w,
                            c_col, c_val, cg);
 }
 
@@ -1228,6 +1235,10 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                                dim3(TH), lds, s, A, B, w, c_col, c_val);
             break;
         }
+        case NUM_G8:
+            launch_num_hash<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, 256>(
+                s, cls, count, A, B, w, c_col, c_val, cu_count);
+            break;
         case NUM_G16:
             launch_num_hash<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);

@@ -368,8 +368,8 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
 }
 
 // isolated cost per row of every class (ns, MI355X, scripts/class_times.py on the four stand-ins)
-constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 50000.f, 0, 0};
-constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 6.f, 1.5f, 0};
+constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 50000.f, 0.1f, 0};
+constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 6.f, 1.5f, 0.2f};
 constexpr u32 kAllSym = (1u << SYM_CLASSES) - 1u;
 constexpr u32 kAllNum = (1u << NUM_CLASSES) - 1u;
 
@@ -425,8 +425,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
     const u32* hint = sym_hint ? sym_hint : all_m;
     static const int merged[7] = {SYM_GH, SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, kLightBig, kLightTiny};
-    static const int separate[SYM_CLASSES] = {SYM_GH,  SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF,
-                                              SYM_B4K, SYM_BM1, SYM_W1K,  SYM_W256, SYM_G16};
+    static const int separate[SYM_CLASSES] = {SYM_GH,  SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, SYM_B4K,
+                                              SYM_BM1, SYM_W1K, SYM_W256, SYM_G16,  SYM_G8};
     // the launch's LDS size is the largest need among its classes and caps the waves per CU of all of
     // them: the 256-thread classes go in two launches, the big-LDS ones apart (split_light); the
     // first runs on a side stream next to the second
@@ -492,7 +492,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     const u32* hint = counts ? counts : all_m;
     static const int merged[7] = {NUM_G, NUM_D2, NUM_B8K, NUM_W1K, NUM_NFCOPY, kLightBig, kLightTiny};
     static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K,  NUM_B2K,  NUM_W1K,   NUM_NFCOPY,
-                                              NUM_D1, NUM_W512, NUM_W128, NUM_G16, NUM_DIRECT};
+                                              NUM_D1, NUM_W512, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
     constexpr u32 kBigPart = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512);
     bool split_num = c->split_light;
     if (split_num && counts) {
@@ -553,7 +553,8 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
     k.num[0] = A->rows; k.num[1] = A->nnz; k.num[2] = B->rows; k.num[3] = B->cols; k.num[4] = C->nnz;
     k.num[5] = sizeof(T);
     k.num[6] = (u64(c->cp.sym_bitmap_ratio) << 32) | c->cp.num_dense_ratio;
-    k.num[7] = (u64(c->cp.num_global_passes) << 32) | (u64(c->cp.num_wave1k) << 2) | (u64(c->cp.want_bytes) << 1) |
+    k.num[7] = (u64(c->cp.num_global_passes) << 32) | (u64(c->cp.sym_g8) << 4) | (u64(c->cp.num_g8) << 3) | (u64(c->cp.num_wave1k) << 2) |
+               (u64(c->cp.want_bytes) << 1) |
                (c->concurrent_classes ? 1u : 0u);
     k.num[7] ^= reinterpret_cast<u64>(s);
     k.num[5] |= u64(c->cp.nf_min_ops) << 8;
@@ -995,6 +996,8 @@ int speck_config_create(int device, speck_config** out)
     c->cp.num_global_passes = 4;  // heavy rows: dense windows up to 64 Ki columns, else global spill
     c->cp.nf_min_ops = 1024;  // numeric-first for narrow rows with at least this many products (0 = off)
     c->cp.gh_per_window = 8192;  // global key set for rows with fewer products per 1 Mi-column bitmap window (0 = off)
+    c->cp.num_g8 = 1;      // rows of <= 21 entries: 8 lanes per row
+    c->cp.sym_g8 = 1;      // rows of <= 25 products: 8 lanes per row
     c->cp.num_wave1k = 0;  // measured: one launch (and fork/join) less beats the barrier-free rows
     c->cp.want_bytes = 0;
     *out = c;
@@ -1057,6 +1060,16 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->last_key_valid = false;
     } else if (n == "nf_min_ops") {
         c->cp.nf_min_ops = (u32)value;
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
+    else if (n == "sym_g8") {
+        c->cp.sym_g8 = value != 0;
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
+    else if (n == "num_g8") {
+        c->cp.num_g8 = value != 0;
         drop_graph(c);
         c->last_key_valid = false;
     }

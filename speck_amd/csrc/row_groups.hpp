@@ -42,7 +42,7 @@ static __device__ unsigned long long g_phase_clk[kPhaseSlots * kMaxClasses * 16]
 // ---- group policies -------------------------------------------------------------
 template <int L>
 struct SubWave {
-    static_assert(L == 16 || L == 32 || L == 64, "sub-wave width");
+    static_assert(L == 8 || L == 16 || L == 32 || L == 64, "sub-wave width");
     static constexpr int SIZE = L;
     static constexpr bool kIsBlock = false;
     u32 lane;       // index inside the group
@@ -64,10 +64,20 @@ struct SubWave {
             v += dpp_move<kDppRowBcast15, 0xA>(0, v);  // rows 1 and 3 take the total of rows 0 and 2
             // lane 31 of the own 32-lane half: ds_swizzle bit mode, lane' = (lane & 0) | 0x1F
             *total = (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x1F << 5);
-        } else {
+        } else if constexpr (L == 16) {
             v = row16_inclusive_scan(v);
             // lane 15 of the own 16-lane row: ds_swizzle bit mode, lane' = (lane & 0x10) | 0x0F
             *total = (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (0x0F << 5));
+        } else {
+            // halves of a 16-lane DPP row: a shifted-in value from the other half is dropped
+            u32 t = dpp_move<kDppRowShr + 1>(0, v);
+            v += lane >= 1u ? t : 0u;
+            t = dpp_move<kDppRowShr + 2>(0, v);
+            v += lane >= 2u ? t : 0u;
+            t = dpp_move<kDppRowShr + 4>(0, v);
+            v += lane >= 4u ? t : 0u;
+            // lane 7 of the own 8-lane group: lane' = (lane & 0x18) | 0x07
+            *total = (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x18 | (0x07 << 5));
         }
         return v;
     }
@@ -340,7 +350,7 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
             // The chunk has at most SIZE entries and lane e holds incl[e] in a register, so the
             // ends need no LDS read and the entries before the window are a ballot.
             constexpr u32 L = G::SIZE;
-            static_assert(L == 16 || L == 32, "sub-wave groups");
+            static_assert(L == 8 || L == 16 || L == 32, "sub-wave groups");
             PHASE_MARK(11);
             u32* win = m.win;  // kBatch*L 16-bit counters of this group
             const bool mine = g.lane < cnt;

@@ -139,6 +139,27 @@ def test_random_small_rows_wave_and_direct(cfg, seed):
     check(cfg, A, B, [("sym", "g16"), ("num", "g16"), ("num", "direct")])
 
 
+def test_eight_lane_rows(cfg):
+    """NUM_G8 (8 lanes per row, 32-entry table, nnz <= 21) next to NUM_G16 (22..42): rows with more A entries
+    than lanes (two staging chunks), more products than one window of 32, duplicates, empty rows; fp32; and
+    the same input with the class switched off."""
+    A = random_csr(3000, 800, 6, 5, empty_row_frac=0.1)
+    B = random_csr(800, 300, 5, 55, empty_row_frac=0.1)            # 300 columns: many duplicate products
+    _, st, _ = check(cfg, A, B, [("num", "g8"), ("num", "g16")])
+    A32 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float32))
+    B32 = po.HostCSR(B.rows, B.cols, B.row_offsets, B.col_ids, B.data.astype(np.float32))
+    check(cfg, A32, B32, [("num", "g8")], tol=TOL32)
+    A2 = fast_random_csr(500, 4000, 14, 63)                          # 9..14 entries per row: two chunks of 8
+    B2 = fast_random_csr(4000, 1 << 20, 2, 64, jitter=False)         # wide range: the compare-loop sort
+    check(cfg, A2, B2, [("num", "g8")])
+    cfg.set_option("num_g8", 0)
+    try:
+        _, st0, _ = check(cfg, A, B, [("num", "g16")])
+        assert st0["num_bin_rows"]["g8"] == 0 and st0["num_bin_rows"]["g16"] == st["num_bin_rows"]["g8"] + st["num_bin_rows"]["g16"]
+    finally:
+        cfg.set_option("num_g8", 1)
+
+
 def test_wave_classes(cfg):
     A = fast_random_csr(900, 3000, 10, 61)
     B = fast_random_csr(3000, 20000, 12, 62)
@@ -582,7 +603,7 @@ def test_more_than_two_million_rows_in_one_class(cfg):
     ro = (np.arange(m + 1, dtype=np.int64) * 2).astype(np.uint32)
     val = 0.5 + rng.random(2 * m)
     A = po.HostCSR(m, m, ro, col, val)
-    check(cfg, A, A, [("num", "g16")])
+    check(cfg, A, A, [("num", "g8")])
 
 
 def test_unsorted_or_out_of_range_b_is_rejected(cfg):
