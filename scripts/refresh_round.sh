@@ -1,0 +1,25 @@
+#!/bin/bash
+# Regenerates every measured artefact of a round on the GPU box (results under gpurun_out/profiles/, copy them
+# into profiles/):  bash scripts/refresh_round.sh r02
+ROUND=${1:-r02}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export PYTHONPATH=$PWD
+OUT=gpurun_out/profiles
+mkdir -p $OUT
+bash scripts/collect_profiles.sh $ROUND "scircuit mac_econ cant webbase" > $OUT/collect.log 2>&1
+for w in scircuit mac_econ cant webbase uniform; do
+  timeout 600 python bench.py --workload $w --no-cpu-baseline --no-config5 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_$w.json
+done
+timeout 900 python bench.py 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_default.json
+timeout 300 python scripts/multiwindow_time.py 2>&1 | grep windows > $OUT/${ROUND}_multiwindow_now.txt
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/profiles/*_bench_*.json")):
+    try:
+        d = json.load(open(f))
+    except Exception as e:
+        print(f, "unreadable", e); continue
+    r = d.get("roofline") or {}
+    print(f.split("/")[-1], d["ms_per_step"], d["value"], d["phases_ms"]["symbolic"], d["phases_ms"]["numeric"], r.get("kernel"), r.get("frac"),
+          "phase", r.get("numeric_phase_frac"), "traffic", r.get("traffic"), json.dumps(r.get("launches")), d.get("config5", {}).get("value"), d.get("cpu_baseline"))
+PY
