@@ -45,7 +45,7 @@ SUITESPARSE_FILES = {"scircuit": "scircuit", "webbase": "webbase-1M", "mac_econ"
                      "cant": "cant", "nlpkkt": "nlpkkt160"}
 # numeric launches as bench.py names them -> key in profiles/traffic.json (scripts/make_traffic.py)
 TRAFFIC_KEYS = {"light": "num_light", "tiny": "num_tiny", "block8k": "num_block8k", "dense16k": "num_dense16k",
-                "global": "num_global", "wave1k": "num_wave1k", "numeric_first": "num_numeric_first"}
+                "global": "num_global", "numeric_first": "num_numeric_first"}
 
 
 class _DevArray:
@@ -210,7 +210,7 @@ def profile_prepass(job, split, merged, prof_steps=5):
     cfg.set_option("collect_bytes", 0)
     # the 256-thread numeric classes run as TWO launches: "light" (num_light_kernel: the big-LDS
     # classes) and "tiny" (num_tiny_kernel); the other classes launch separately
-    LIGHT, TINY = ("dense4k", "block2k", "wave512"), ("wave128", "g16", "g8", "direct")
+    LIGHT, TINY = ("dense4k", "block2k", "wave512", "wave256"), ("wave128", "g16", "g8", "direct")
     if not split:
         LIGHT, TINY = LIGHT + TINY, ()
     kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny"]}

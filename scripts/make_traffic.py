@@ -14,7 +14,7 @@ KEYS = [
     (r"nf_dense_kernel", "num_numeric_first"), (r"nf_copy_kernel", "num_nfcopy"),
     (r"num_light_kernel", "num_light"), (r"num_tiny_kernel", "num_tiny"), (r"sym_light_kernel", "sym_light"),
     (r"num_hash_kernel<Block<512>", "num_block8k"), (r"num_hash_kernel<Block<256>", "num_block2k"),
-    (r"num_hash_kernel<SubWave<64>, \w+, 1024u", "num_wave1k"), (r"num_hash_kernel<SubWave<64>, \w+, 512u", "num_wave512"),
+    (r"num_hash_kernel<SubWave<64>, \w+, 512u", "num_wave512"),
     (r"num_hash_kernel<SubWave<64>, \w+, 128u", "num_wave128"), (r"num_hash_kernel<SubWave<16>", "num_g16"),
     (r"num_direct_kernel", "num_direct"), (r"num_dense_kernel<\w+, 4096u", "num_dense4k"),
     (r"num_dense_kernel<\w+, 16384u", "num_dense16k"), (r"num_global_kernel", "num_global"),

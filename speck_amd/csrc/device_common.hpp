@@ -60,8 +60,8 @@ enum NumClass : u8 {
     NUM_D1 = 6,      // dense column-window accumulator, narrow column range, workgroup(256)
     NUM_D2 = 7,      // dense accumulator, 16 Ki columns/window, multi-window, workgroup(1024)
     NUM_G = 8,       // global-memory hash spill (heavy rows with a very wide column range)
-    NUM_W1K = 9,     // wave per row, 1024-entry table, 2-level bitmap sort (nnz <= 682): no
-                     //   workgroup barriers, 2.4x less LDS per row than NUM_B2K
+    NUM_W256 = 9,    // half a wave per row (two rows per wave), 256-entry table, 2-level bitmap sort (nnz <= 170):
+                     //   the lower half of what used to be NUM_W512, at twice the rows in flight per wave
     NUM_NFCOPY = 10, // row already computed by the symbolic phase (SYM_NF): copy scratch slot -> C
     NUM_G8 = 11,     // 8 lanes per row (8 rows per wave), 32-entry table, rank sort   (nnz <= 21): the small-row
                      //   kernel is latency x occupancy bound -- twice the rows in flight per wave
@@ -86,7 +86,7 @@ constexpr u32 kNumG8Cap = 32, kNumG8MaxNnz = 21;
 constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = 42;
 constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = 85;
 constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = 341;
-constexpr u32 kNumW1KCap = 1024, kNumW1KMaxNnz = 682;
+constexpr u32 kNumW256Cap = 256, kNumW256MaxNnz = 170;
 constexpr u32 kNumB2KCap = 2048, kNumB2KMaxNnz = 1365;
 // an under-filled NUM_B8K class (a handful of rows: a launch of its own just for one row's latency) is folded
 // into NUM_B2K when its rows fit the 2 Ki table at a load of 0.85 instead of 2/3 (pipeline.hip, capture)
@@ -102,7 +102,7 @@ struct ClassifyParams {
     u32 sym_bitmap_ratio;   // use a bitmap when range <= ratio * ops (and ops > wave limit)
     u32 num_dense_ratio;    // use D1 when range <= kNumD1Cols and range <= ratio * nnz
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
-    u32 num_wave1k;         // rows of 342..682 nnz: wave-per-row class (else they join NUM_B2K)
+    u32 num_w256;           // rows of 86..170 nnz: 32 lanes per row (else they join NUM_W512)
     u32 b2k_max_nnz;        // 0: kNumB2KMaxNnz; kNumB2KStretchNnz when the NUM_B8K class is folded into NUM_B2K
     u32 num_g8;             // rows of <= kNumG8MaxNnz entries: 8 lanes per row (else they join NUM_G16)
     u32 sym_g8;             // rows of <= kSymG8MaxOps products: 8 lanes per row (else they join SYM_G16)
@@ -168,8 +168,8 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     if (nnz <= kNumW128MaxNnz) return NUM_W128;
     const u64 range = u64(cmax) - u64(cmin) + 1;
     if (range <= kNumD1Cols && range <= u64(p.num_dense_ratio) * nnz) return NUM_D1;
+    if (p.num_w256 && nnz <= kNumW256MaxNnz) return NUM_W256;
     if (nnz <= kNumW512MaxNnz) return NUM_W512;
-    if (p.num_wave1k && nnz <= kNumW1KMaxNnz) return NUM_W1K;
     if (nnz <= (p.b2k_max_nnz ? p.b2k_max_nnz : kNumB2KMaxNnz)) return NUM_B2K;
     if (nnz <= kNumB8KMaxNnz) return NUM_B8K;
     const u64 passes = (range + kNumD2Cols - 1) / kNumD2Cols;

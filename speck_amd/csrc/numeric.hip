@@ -661,6 +661,7 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
     num_dense_body<T, WCOLS, THREADS>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
 }
 
+constexpr u32 kW256W1 = 256;   // 256 Ki columns per sort window
 constexpr u32 kW512W1 = 768;   // 768 Ki columns per sort window (its level-1 pairs fill the 6 KiB table exactly)
 constexpr u32 kB2KW1 = 1024;   // 1 Mi columns per sort window
 constexpr u32 kB8KW1 = 2048;  // 2 Mi columns per sort window
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    // launch order (ClassGrid slots): D1, B2K, W512, W128, G16, G8, DIRECT
+    // launch order (ClassGrid slots): D1, B2K, W512, W256, W128, G16, G8, DIRECT
     if (b < cg.first[1])
         num_dense_body<T, kNumD1Win, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0]);
     else if (b < cg.first[2])
@@ -684,16 +685,19 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
         num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
             smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2]);
     else if (b < cg.first[4])
-        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[3], cg.first[4] - cg.first[3]);
+        num_hash_body<SubWave<32>, T, kNumW256Cap, kW256W1, kNumW256MaxNnz, SORT_BITMAP, 256>(
+            smem, src, w, c_col, c_val, NUM_W256, b - cg.first[3], cg.first[4] - cg.first[3]);
     else if (b < cg.first[5])
-        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
+        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4]);
     else if (b < cg.first[6])
+        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5]);
+    else if (b < cg.first[7])
         num_hash_body<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[5], cg.first[6] - cg.first[5]);
+            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6]);
     else
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[6], cg.first[7] - cg.first[6]);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7]);
 }
 
 // The three smallest classes alone: the merged kernel above takes the register count of its
@@ -708,17 +712,17 @@ __global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const 
     if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    if (b < cg.first[4])
+    if (b < cg.first[5])
         num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[3], cg.first[4] - cg.first[3]);
-    else if (b < cg.first[5])
-        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4]);
     else if (b < cg.first[6])
+        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5]);
+    else if (b < cg.first[7])
         num_hash_body<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[5], cg.first[6] - cg.first[5]);
+            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6]);
     else
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[6], cg.first[7] - cg.first[6]);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7]);
 }
 
 // ------------------------------------------------------------------ NUM_G
@@ -1146,7 +1150,7 @@ u32 numeric_lds_bytes_t(int cls)
         case NUM_G16: return 16 * num_group_lds<SubWave<16>, T, kNumG16Cap, 256>();
         case NUM_W128: return 8 * num_group_lds<SubWave<32>, T, kNumW128Cap, 256>();
         case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, 256>();
-        case NUM_W1K: return 4 * num_group_lds<SubWave<64>, T, kNumW1KCap, 256>();
+        case NUM_W256: return 8 * num_group_lds<SubWave<32>, T, kNumW256Cap, 256>();
         case NUM_B2K: return num_group_lds<Block<256>, T, kNumB2KCap, 256>();
         case NUM_B8K: return num_group_lds<Block<512>, T, kNumB8KCap, 512>();
         case NUM_D1: return num_dense_lds<T, kNumD1Win, 256>();
@@ -1185,23 +1189,23 @@ template <typename T>
 void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const CsrView<T>& Av,
                           const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
-    static const int slots[7] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
-    static const u32 rows_per_block[7] = {1, 1, 4, 8, 16, 32, 256};
+    static const int slots[8] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W256, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
+    static const u32 rows_per_block[8] = {1, 1, 4, 8, 8, 16, 32, 256};
     u32 lds = 0;
-    for (int k = 0; k < 7; ++k)
+    for (int k = 0; k < 8; ++k)
         if (mask >> slots[k] & 1u) lds = lds > numeric_lds_bytes_t<T>(slots[k]) ? lds : numeric_lds_bytes_t<T>(slots[k]);
     ClassGrid cg{};
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 8; ++k) {
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
     }
-    if (cg.first[7] == 0) return;
+    if (cg.first[8] == 0) return;
     const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
-    if (cg.first[3] == 0)
-        hipLaunchKernelGGL((num_tiny_kernel<T>), dim3(cg.first[7]), dim3(256), lds, s, src, Av.row_offsets, w,
+    if (cg.first[4] == 0)
+        hipLaunchKernelGGL((num_tiny_kernel<T>), dim3(cg.first[8]), dim3(256), lds, s, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else
-        hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[7]), dim3(256), lds, s, src, Av.row_offsets, w,
+        hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[8]), dim3(256), lds, s, src, Av.row_offsets, w,
                            c_col, c_val, cg);
 }
 
@@ -1251,8 +1255,8 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             launch_num_hash<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
-        case NUM_W1K:
-            launch_num_hash<SubWave<64>, T, kNumW1KCap, kW512W1, kNumW1KMaxNnz, SORT_BITMAP, 256>(
+        case NUM_W256:
+            launch_num_hash<SubWave<32>, T, kNumW256Cap, kW256W1, kNumW256MaxNnz, SORT_BITMAP, 256>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_B2K:

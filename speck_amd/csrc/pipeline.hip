@@ -369,7 +369,7 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
 
 // isolated cost per row of every class (ns, MI355X, scripts/class_times.py on the four stand-ins)
 constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 50000.f, 0.1f, 0};
-constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 6.f, 1.5f, 0.2f};
+constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 2.5f, 1.5f, 0.2f};
 constexpr u32 kAllSym = (1u << SYM_CLASSES) - 1u;
 constexpr u32 kAllNum = (1u << NUM_CLASSES) - 1u;
 
@@ -490,10 +490,10 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;
     const u32* hint = counts ? counts : all_m;
-    static const int merged[7] = {NUM_G, NUM_D2, NUM_B8K, NUM_W1K, NUM_NFCOPY, kLightBig, kLightTiny};
-    static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K,  NUM_B2K,  NUM_W1K,   NUM_NFCOPY,
+    static const int merged[6] = {NUM_G, NUM_D2, NUM_B8K, NUM_NFCOPY, kLightBig, kLightTiny};
+    static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K,  NUM_B2K,  NUM_W256,  NUM_NFCOPY,
                                               NUM_D1, NUM_W512, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
-    constexpr u32 kBigPart = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512);
+    constexpr u32 kBigPart = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256);
     bool split_num = c->split_light;
     if (split_num && counts) {
         auto part_us = [&](u32 mask) {
@@ -506,7 +506,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
                     part_us(kNumLightMask & ~kBigPart) >= c->split_min_us;
     }
     const u32 num_big = split_num ? kBigPart : kNumLightMask;
-    return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 7 : (int)NUM_CLASSES, num_mask,
+    return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 6 : (int)NUM_CLASSES, num_mask,
                        kNumLightMask & num_big, kNumLightMask & ~num_big, counts, kNumNsPerRow,
                        tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr, [&](hipStream_t ks, int cls) {
                            if (cls == kLightBig || cls == kLightTiny) {
@@ -553,7 +553,7 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
     k.num[0] = A->rows; k.num[1] = A->nnz; k.num[2] = B->rows; k.num[3] = B->cols; k.num[4] = C->nnz;
     k.num[5] = sizeof(T);
     k.num[6] = (u64(c->cp.sym_bitmap_ratio) << 32) | c->cp.num_dense_ratio;
-    k.num[7] = (u64(c->cp.num_global_passes) << 32) | (u64(c->cp.sym_g8) << 4) | (u64(c->cp.num_g8) << 3) | (u64(c->cp.num_wave1k) << 2) |
+    k.num[7] = (u64(c->cp.num_global_passes) << 32) | (u64(c->cp.sym_g8) << 4) | (u64(c->cp.num_g8) << 3) | (u64(c->cp.num_w256) << 2) |
                (u64(c->cp.want_bytes) << 1) |
                (c->concurrent_classes ? 1u : 0u);
     k.num[7] ^= reinterpret_cast<u64>(s);
@@ -998,7 +998,7 @@ int speck_config_create(int device, speck_config** out)
     c->cp.gh_per_window = 8192;  // global key set for rows with fewer products per 1 Mi-column bitmap window (0 = off)
     c->cp.num_g8 = 1;      // rows of <= 21 entries: 8 lanes per row
     c->cp.sym_g8 = 1;      // rows of <= 25 products: 8 lanes per row
-    c->cp.num_wave1k = 0;  // measured: one launch (and fork/join) less beats the barrier-free rows
+    c->cp.num_w256 = 1;    // rows of 86..170 entries: 32 lanes per row
     c->cp.want_bytes = 0;
     *out = c;
     return SPECK_OK;
@@ -1073,8 +1073,8 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         drop_graph(c);
         c->last_key_valid = false;
     }
-    else if (n == "num_wave1k") {
-        c->cp.num_wave1k = value != 0;
+    else if (n == "num_w256") {
+        c->cp.num_w256 = value != 0;
         drop_graph(c);
         c->last_key_valid = false;
     }

@@ -166,19 +166,30 @@ def test_wave_classes(cfg):
     check(cfg, A, B, [("sym", "wave256"), ("num", "wave128"), ("num", "g16")])
 
 
-def test_hash_classes_wave1k_wave512_block2k(cfg):
+def test_hash_classes_wave256_wave512_block2k(cfg):
     A = fast_random_csr(600, 4000, 20, 1)
     B = fast_random_csr(4000, 30000, 30, 2)
     check(cfg, A, B, [("sym", "wave1k"), ("num", "wave512"), ("num", "block2k")])
     A2 = fast_random_csr(300, 4000, 44, 3)
     B2 = fast_random_csr(4000, 30000, 40, 4)
     check(cfg, A2, B2, [("sym", "block4k"), ("num", "block2k")])
-    cfg.set_option("num_wave1k", 1)   # optional class: a wave per row for 342..682 nnz
+    # NUM_W256: rows of 86..170 entries at 32 lanes per row (two rows per wave), bitmap sort in a 256-entry table;
+    # narrow and very wide column ranges (one and several sort windows), fp32, and the class switched off
+    A3 = fast_random_csr(800, 4000, 12, 5)
+    B3 = fast_random_csr(4000, 3000000, 14, 6)
+    _, st, _ = check(cfg, A3, B3, [("num", "wave256"), ("num", "wave128")])
+    B4 = fast_random_csr(4000, 9000, 14, 7)                           # range < 16 x nnz is NUM_D1's: stay above
+    check(cfg, A3, B4, [("num", "wave256")])
+    A32 = po.HostCSR(A3.rows, A3.cols, A3.row_offsets, A3.col_ids, A3.data.astype(np.float32))
+    B32 = po.HostCSR(B3.rows, B3.cols, B3.row_offsets, B3.col_ids, B3.data.astype(np.float32))
+    check(cfg, A32, B32, [("num", "wave256")], tol=TOL32)
+    cfg.set_option("num_w256", 0)
     try:
-        check(cfg, A, B, [("num", "wave512"), ("num", "wave1k")])
-        check(cfg, A2, B2, [("num", "wave1k"), ("num", "block2k")])
+        _, st0, _ = check(cfg, A3, B3, [("num", "wave512")])
+        assert st0["num_bin_rows"]["wave256"] == 0
+        assert st0["num_bin_rows"]["wave512"] == st["num_bin_rows"]["wave512"] + st["num_bin_rows"]["wave256"]
     finally:
-        cfg.set_option("num_wave1k", 0)
+        cfg.set_option("num_w256", 1)
 
 
 def test_empty_b_rows_and_long_a_rows(cfg):
