@@ -46,7 +46,8 @@ enum SymClass : u8 {
                     //   than one SYM_BM2 window with few products per window -- every window of the bitmap costs a
                     //   fixed ~8 us, a global compare-and-swap a fraction of a nanosecond at 4096 in flight
     SYM_G8 = 10,    // 8 lanes per row (8 rows per wave), 32-key LDS set (ops <= 25)
-    SYM_CLASSES = 11,
+    SYM_W128 = 11,  // 16 lanes per row (four rows per wave), 128-key LDS set (ops <= 102)
+    SYM_CLASSES = 12,
     SYM_NONE = 0xFF  // resolved by the analysis kernel itself (empty / single-entry A rows)
 };
 // Numeric classes: chosen from the EXACT nnz of the C row (symbolic result).
@@ -71,6 +72,7 @@ enum NumClass : u8 {
 
 constexpr u32 kSymG8Cap = 32, kSymG8MaxOps = 25;
 constexpr u32 kSymG16Cap = 64, kSymG16MaxOps = 51;
+constexpr u32 kSymW128Cap = 128, kSymW128MaxOps = 102;
 constexpr u32 kSymW256Cap = 256, kSymW256MaxOps = 204;
 constexpr u32 kSymW1KCap = 1024, kSymW1KMaxOps = 819;
 constexpr u32 kSymB4KCap = 4096, kSymB4KMaxOps = 3276;
@@ -106,6 +108,7 @@ struct ClassifyParams {
     u32 b2k_max_nnz;        // 0: kNumB2KMaxNnz; kNumB2KStretchNnz when the NUM_B8K class is folded into NUM_B2K
     u32 num_g8;             // rows of <= kNumG8MaxNnz entries: 8 lanes per row (else they join NUM_G16)
     u32 sym_g8;             // rows of <= kSymG8MaxOps products: 8 lanes per row (else they join SYM_G16)
+    u32 sym_w128;           // rows of 52..102 products: 16 lanes per row (else they join SYM_W256)
     u32 nf_min_ops;         // numeric-first (SYM_NF) for rows with range <= kNumD1Cols and at least this many
                             //   products; 0 = off
     u32 gh_per_window;      // SYM_GH instead of a multi-window SYM_BM2 when the row holds fewer products than this
@@ -139,6 +142,7 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
     if (is_numeric_first(len_a, ops, cmin, cmax, p)) return SYM_NF;
     if (p.sym_g8 && ops <= kSymG8MaxOps) return SYM_G8;
     if (ops <= kSymG16MaxOps) return SYM_G16;
+    if (p.sym_w128 && ops <= kSymW128MaxOps) return SYM_W128;
     if (ops <= kSymW256MaxOps) return SYM_W256;
     const u64 range = u64(cmax) - u64(cmin) + 1;
     const bool bitmap_ok = range <= u64(p.sym_bitmap_ratio) * ops;

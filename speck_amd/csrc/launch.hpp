@@ -74,7 +74,7 @@ struct ClassGrid {
     u32 first[10];
 };
 constexpr u32 kSymLightMask = (1u << SYM_BM1) | (1u << SYM_B4K) | (1u << SYM_W1K) | (1u << SYM_W256) | (1u << SYM_G16) |
-                              (1u << SYM_G8);
+                              (1u << SYM_G8) | (1u << SYM_W128);
 constexpr u32 kNumLightMask = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256) | (1u << NUM_W128) |
                               (1u << NUM_G16) | (1u << NUM_G8) | (1u << NUM_DIRECT);
 

@@ -368,7 +368,7 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
 }
 
 // isolated cost per row of every class (ns, MI355X, scripts/class_times.py on the four stand-ins)
-constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 50000.f, 0.1f, 0};
+constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 50000.f, 0.1f, 0.4f};
 constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 2.5f, 1.5f, 0.2f};
 constexpr u32 kAllSym = (1u << SYM_CLASSES) - 1u;
 constexpr u32 kAllNum = (1u << NUM_CLASSES) - 1u;
@@ -426,7 +426,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     const u32* hint = sym_hint ? sym_hint : all_m;
     static const int merged[7] = {SYM_GH, SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, kLightBig, kLightTiny};
     static const int separate[SYM_CLASSES] = {SYM_GH,  SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, SYM_B4K,
-                                              SYM_BM1, SYM_W1K, SYM_W256, SYM_G16,  SYM_G8};
+                                              SYM_BM1, SYM_W1K, SYM_W256, SYM_W128, SYM_G16, SYM_G8};
     // the launch's LDS size is the largest need among its classes and caps the waves per CU of all of
     // them: the 256-thread classes go in two launches, the big-LDS ones apart (split_light); the
     // first runs on a side stream next to the second
@@ -553,7 +553,7 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
     k.num[0] = A->rows; k.num[1] = A->nnz; k.num[2] = B->rows; k.num[3] = B->cols; k.num[4] = C->nnz;
     k.num[5] = sizeof(T);
     k.num[6] = (u64(c->cp.sym_bitmap_ratio) << 32) | c->cp.num_dense_ratio;
-    k.num[7] = (u64(c->cp.num_global_passes) << 32) | (u64(c->cp.sym_g8) << 4) | (u64(c->cp.num_g8) << 3) | (u64(c->cp.num_w256) << 2) |
+    k.num[7] = (u64(c->cp.num_global_passes) << 32) | (u64(c->cp.sym_w128) << 5) | (u64(c->cp.sym_g8) << 4) | (u64(c->cp.num_g8) << 3) | (u64(c->cp.num_w256) << 2) |
                (u64(c->cp.want_bytes) << 1) |
                (c->concurrent_classes ? 1u : 0u);
     k.num[7] ^= reinterpret_cast<u64>(s);
@@ -998,6 +998,7 @@ int speck_config_create(int device, speck_config** out)
     c->cp.gh_per_window = 8192;  // global key set for rows with fewer products per 1 Mi-column bitmap window (0 = off)
     c->cp.num_g8 = 1;      // rows of <= 21 entries: 8 lanes per row
     c->cp.sym_g8 = 1;      // rows of <= 25 products: 8 lanes per row
+    c->cp.sym_w128 = 1;    // rows of 52..102 products: 16 lanes per row
     c->cp.num_w256 = 1;    // rows of 86..170 entries: 32 lanes per row
     c->cp.want_bytes = 0;
     *out = c;
@@ -1060,6 +1061,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->last_key_valid = false;
     } else if (n == "nf_min_ops") {
         c->cp.nf_min_ops = (u32)value;
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
+    else if (n == "sym_w128") {
+        c->cp.sym_w128 = value != 0;
         drop_graph(c);
         c->last_key_valid = false;
     }

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    // launch order (ClassGrid slots): BM1, B4K, W1K, W256, G16, G8
+    // launch order (ClassGrid slots): BM1, B4K, W1K, W256, W128, G16, G8
     if (b < cg.first[1])
         sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0]);
     else if (b < cg.first[2])
@@ -245,9 +245,11 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     else if (b < cg.first[4])
         sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3]);
     else if (b < cg.first[5])
-        sym_hash_body<SubWave<16>, kSymG16Cap, 256>(smem, src, w, counts, SYM_G16, b - cg.first[4], cg.first[5] - cg.first[4]);
+        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[4], cg.first[5] - cg.first[4]);
+    else if (b < cg.first[6])
+        sym_hash_body<SubWave<16>, kSymG16Cap, 256>(smem, src, w, counts, SYM_G16, b - cg.first[5], cg.first[6] - cg.first[5]);
     else
-        sym_hash_body<SubWave<8>, kSymG8Cap, 256>(smem, src, w, counts, SYM_G8, b - cg.first[5], cg.first[6] - cg.first[5]);
+        sym_hash_body<SubWave<8>, kSymG8Cap, 256>(smem, src, w, counts, SYM_G8, b - cg.first[6], cg.first[7] - cg.first[6]);
 }
 
 u32 symbolic_lds_bytes(int cls)
@@ -255,6 +257,7 @@ u32 symbolic_lds_bytes(int cls)
     switch (cls) {
         case SYM_G8: return 32 * sym_group_lds<SubWave<8>, kSymG8Cap, 256>();
         case SYM_G16: return 16 * sym_group_lds<SubWave<16>, kSymG16Cap, 256>();
+        case SYM_W128: return 16 * sym_group_lds<SubWave<16>, kSymW128Cap, 256>();
         case SYM_W256: return 8 * sym_group_lds<SubWave<32>, kSymW256Cap, 256>();
         case SYM_W1K: return 4 * sym_group_lds<SubWave<64>, kSymW1KCap, 256>();
         case SYM_B4K: return sym_group_lds<Block<256>, kSymB4KCap, 256>();
@@ -317,19 +320,19 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
                            const u32* b_start, const u32* b_len, const u32* b_col, const RowWork& w,
                            u32* counts, int cu_count)
 {
-    static const int slots[6] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_G16, SYM_G8};
-    static const u32 rows_per_block[6] = {1, 1, 4, 8, 16, 32};
+    static const int slots[7] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_W128, SYM_G16, SYM_G8};
+    static const u32 rows_per_block[7] = {1, 1, 4, 8, 16, 16, 32};
     u32 lds = 0;
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 7; ++k)
         if (mask >> slots[k] & 1u) lds = lds > symbolic_lds_bytes(slots[k]) ? lds : symbolic_lds_bytes(slots[k]);
     ClassGrid cg{};
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 7; ++k) {
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
     }
-    if (cg.first[6] == 0) return;
+    if (cg.first[7] == 0) return;
     const ProductSrc<float> src{b_start, b_len, nullptr, b_col, nullptr, w.w_start, w.w_len};
-    hipLaunchKernelGGL(sym_light_kernel, dim3(cg.first[6]), dim3(256), lds, s, src, a_ro, w, counts, cg);
+    hipLaunchKernelGGL(sym_light_kernel, dim3(cg.first[7]), dim3(256), lds, s, src, a_ro, w, counts, cg);
 }
 
 void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u32* b_start,
@@ -343,6 +346,7 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
     switch (cls) {
         case SYM_G8: launch_sym_hash<SubWave<8>, kSymG8Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_G16: launch_sym_hash<SubWave<16>, kSymG16Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
+        case SYM_W128: launch_sym_hash<SubWave<16>, kSymW128Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_W256: launch_sym_hash<SubWave<32>, kSymW256Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_W1K: launch_sym_hash<SubWave<64>, kSymW1KCap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_B4K: launch_sym_hash<Block<256>, kSymB4KCap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
