@@ -602,9 +602,14 @@ def test_spill_path_skewed_columns_and_fp32(cfg):
 
 
 def test_more_than_two_million_rows_in_one_class(cfg):
-    """rows(A) > 2^21 switches the scan kernels to 32 rows per thread: 8192 rows per block, here all
-    of one numeric class (the per-class counters of a block once were 12 bits wide)."""
-    m = (1 << 21) + 70001
+    """rows(A) > 2^23 switches the scan kernels to 32 rows per thread: 8192 rows per block, here all
+    of one numeric class (the per-class counters of a block once were 12 bits wide); 2^21 + 70001 rows take
+    4100 tiles of 8 rows per thread."""
+    _rows_in_one_class(cfg, (1 << 21) + 70001)
+    _rows_in_one_class(cfg, (1 << 23) + 70001)
+
+
+def _rows_in_one_class(cfg, m):
     rng = np.random.default_rng(11)
     c0 = rng.integers(0, m - 1, size=m, dtype=np.int64)
     c1 = c0 + 1 + rng.integers(0, 3, size=m)
