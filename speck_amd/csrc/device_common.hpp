@@ -285,7 +285,7 @@ __device__ __forceinline__ u32 dpp_move(u32 old, u32 v)
 {
     return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
-constexpr int kDppRowShr = 0x110, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+constexpr int kDppRowShl = 0x100, kDppRowShr = 0x110, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
 
 // inclusive scan inside every 16-lane row
 __device__ __forceinline__ u32 row16_inclusive_scan(u32 v)
