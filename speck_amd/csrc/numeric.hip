@@ -485,10 +485,9 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
 #pragma unroll
                                        for (int u = 0; u < kBatch; ++u) {
                                            const u32 d = c[u] - wbase;
-                                           if ((u32)u < n && d < ncols) {
-                                               atomicAdd(&vals[d], (Acc<T>)p[u]);
-                                               atomicOr(&bm[d >> 5], 1u << (d & 31));
-                                           }
+                                           const bool in = (u32)u < n && d < ncols;
+                                           if (in) atomicAdd(&vals[d], (Acc<T>)p[u]);
+                                           bitmap_or_runs(bm, in ? d >> 5 : 0xFFFFFFFFu, 1u << (d & 31));
                                        }
                                    });
             const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);
@@ -577,10 +576,9 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
 #pragma unroll
                                    for (int u = 0; u < kBatch; ++u) {
                                        const u32 d = c[u] - wbase;
-                                       if ((u32)u < n && d < ncols) {
-                                           atomicAdd(&vals[d], (Acc<T>)p[u]);
-                                           atomicOr(&bm[d >> 5], 1u << (d & 31));
-                                       }
+                                       const bool in = (u32)u < n && d < ncols;
+                                       if (in) atomicAdd(&vals[d], (Acc<T>)p[u]);
+                                       bitmap_or_runs(bm, in ? d >> 5 : 0xFFFFFFFFu, 1u << (d & 31));
                                    }
                                });
         const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);

@@ -528,6 +528,27 @@ __device__ __forceinline__ void table_accumulate_batch(u32* keys, T* vals, u32 b
     }
 }
 
+// Bitmap marks of a batch of products: neighbouring lanes hold neighbouring columns of one B row, i.e. mostly
+// the SAME bitmap word -- up to 32 lanes per address for every ds_or.  The bits of equal neighbouring words are
+// OR-ed together inside the 16-lane DPP rows first (OR is idempotent, so merging runs that are not adjacent is
+// harmless) and only the last lane of a run touches the LDS.  `word` = 0xFFFFFFFF for a lane with nothing to mark.
+__device__ __forceinline__ void bitmap_or_runs(u32* bm, u32 word, u32 bits)
+{
+#define SPECK_OR_STEP(S_)                                                             \
+    {                                                                                 \
+        const bool same = dpp_move<kDppRowShr + S_>(0xFFFFFFFEu, word) == word;       \
+        const u32 t = dpp_move<kDppRowShr + S_>(0u, bits);                            \
+        bits |= same ? t : 0u;                                                        \
+    }
+    SPECK_OR_STEP(1)
+    SPECK_OR_STEP(2)
+    SPECK_OR_STEP(4)
+    SPECK_OR_STEP(8)
+#undef SPECK_OR_STEP
+    const bool tail = dpp_move<kDppRowShl + 1>(0xFFFFFFFEu, word) != word;
+    if (tail && word != 0xFFFFFFFFu) atomicOr(&bm[word], bits);
+}
+
 // Exclusive prefix of popcounts over bm[0..nwords) into pref[]; returns the total.
 // Every lane owns a contiguous run of words.
 // STRIDE 2: words and prefixes interleaved ({word, prefix} pairs: bm = base, pref = base + 1), so that a

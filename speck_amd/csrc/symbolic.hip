@@ -110,7 +110,7 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
 #pragma unroll
                                         for (int u = 0; u < kBatch; ++u) {
                                             const u32 d = c[u] - base;  // wraps when left of the window
-                                            if ((u32)u < n && d < ncols) atomicOr(&bm[d >> 5], 1u << (d & 31));
+                                            bitmap_or_runs(bm, ((u32)u < n && d < ncols) ? d >> 5 : 0xFFFFFFFFu, 1u << (d & 31));
                                         }
                                     });
             for (u32 i = threadIdx.x; i < nwords; i += THREADS) total += __popc(bm[i]);
