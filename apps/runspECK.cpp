@@ -233,6 +233,13 @@ int main(int argc, char* argv[])
                 std::printf("Error: rocSPARSE reference failed\n");
                 return 2;
             }
+            // golden vectors for the CPU-side oracle tests (tests/golden/make_rocsparse_golden.py): the rocSPARSE
+            // product as a .hicsr file
+            if (const char* dump = std::getenv("SPECK_DUMP_ROCSPARSE")) {
+                CSR<double> cpuRef;
+                convert(cpuRef, dCsrReference, 0);
+                storeCSR(cpuRef, dump);
+            }
         }
         Timings timings, warmupTimings, benchTimings;
         int errors = 0;

@@ -122,3 +122,20 @@ def test_transpose_and_f32():
     C64, _ = po.spgemm(A, T)
     assert C32.data.dtype == np.float32 and (C32.col_ids == C64.col_ids).all()
     assert np.allclose(C32.data, C64.data, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "scircuit", "mac_econ", "webbase", "cant", "nlpkkt"])
+def test_oracle_matches_the_rocsparse_golden_vectors(kind):
+    """A third-party pin that travels without a GPU: rocSPARSE's C = A*A of small stand-in inputs
+    (tests/golden/make_rocsparse_golden.py wrote the vectors on an MI355X through apps/runspECK's compare path,
+    the stand-in of the reference's cuSPARSE check, source/Executor.cpp:29-40).  Structure bit-exact
+    (SHA-256 of row_offsets / col_ids), values within 1e-12 * sum|a*b| per entry."""
+    import speck_amd as sa   # host-side generator only (speck_gen_matrix): no GPU call
+    g = np.load(os.path.join(G, "rocsparse", kind + ".npz"))
+    A = sa.gen_matrix(kind, float(g["scale"]), int(g["seed"]), signed=True)
+    Ao = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data)
+    C, ab = po.spgemm(Ao, Ao)
+    assert (C.rows, C.cols, C.nnz) == (int(g["rows"]), int(g["cols"]), int(g["nnz"]))
+    assert hashlib.sha256(np.ascontiguousarray(C.row_offsets, dtype=np.uint32).tobytes()).hexdigest() == str(g["sha_row_offsets"])
+    assert hashlib.sha256(np.ascontiguousarray(C.col_ids, dtype=np.uint32).tobytes()).hexdigest() == str(g["sha_col_ids"])
+    assert (np.abs(C.data - g["data"]) <= 1e-12 * ab + 1e-300).all()
