@@ -15,7 +15,11 @@
  *        SURVEY.md section 8d (tests/golden/synth10k.json),
  *   (ii) scipy.sparse on cancellation-free inputs (tests/test_oracle.py),
  *   (iii) the reference's own host-side C++ (CSR.cpp / COO.cpp), compiled
- *        into oracle/_ref/ for the on-disk formats.
+ *        into oracle/_ref/ for the on-disk formats,
+ *   (iv) golden vectors of a third-party SpGEMM: rocSPARSE's products of six
+ *        small stand-in inputs (tests/golden/rocsparse/, written on an MI355X
+ *        by tests/golden/make_rocsparse_golden.py; the stand-in for the
+ *        reference's cuSPARSE compare path, source/Executor.cpp:29-40).
  */
 #ifndef SPECK_ORACLE_H
 #define SPECK_ORACLE_H
