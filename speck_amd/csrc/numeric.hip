@@ -4,12 +4,16 @@
 // (include/GPU/spECK_HashSpGEMM.cuh:1714-1794, 1439-1472, 1856-1925) and HashMap
 // (include/HashMap.cuh:23-110).  Designed for wave64 + 160 KiB LDS:
 //   NUM_DIRECT : A row with one entry -> scaled copy of a (sorted) B row, 16 lanes per row
+//   NUM_G8     : 8 lanes per row (8 rows per wave), 32-entry table, rank sort (bitmap rank for narrow rows)
 //   NUM_G16    : 16 lanes per row (4 rows per wave), 64-entry table, rank sort
-//   NUM_W128   : one wave per row, 128-entry table, ballot compaction + rank sort
+//   NUM_W128   : 32 lanes per row (2 rows per wave), 128-entry table, ballot compaction + rank sort
+//   NUM_W256   : 32 lanes per row, 256-entry table, two-level bitmap sort
 //   NUM_W512   : one wave per row, 512-entry table, two-level bitmap sort
 //   NUM_B2K/B8K: one workgroup per row, 2048/8192-entry table, two-level bitmap sort
 //   NUM_D1/D2  : dense column-window accumulator (value per column + presence bitmap):
-//                one ds_add_f64 + one ds_or per product, no probing, output sorted for free.
+//                one ds_add_f64 per product + one ds_or per run of neighbouring lanes, no probing, output
+//                sorted for free; also the numeric-first rows' kernel (nf_dense_kernel, window sized at run time)
+//   NUM_G      : bucketed global-memory spill for heavy, wide rows (seven kernels)
 // Two-level bitmap sort: the keys of a row are DISTINCT, so their sorted position is a prefix
 // popcount.  Level 1 marks the occupied 32-column buckets (range/32 bits), its prefix ranks
 // the occupied buckets; level 2 holds one 32-bit mask per OCCUPIED bucket (<= nnz words).

@@ -3,8 +3,9 @@
 // Role of the reference's spGEMMCountLauncher / denseSpGEMMCount
 // (include/GPU/spECK_HashSpGEMM.cuh:1797-1853, 1681-1711) and HashMapNoValue
 // (include/HashMap.cuh:136-229); designed for 64-lane waves and 160 KiB of LDS:
-//   SYM_G16        : 16 lanes per row (4 rows per wave), 64-key set, no barrier
-//   SYM_W256/W1K   : one wave per row, 256 / 1024-key set, no workgroup barrier
+//   SYM_G8 / G16   : 8 / 16 lanes per row (8 / 4 rows per wave), 32 / 64-key set, no barrier
+//   SYM_W128/W256  : 16 / 32 lanes per row, 128 / 256-key set
+//   SYM_W1K        : one wave per row, 1024-key set, no workgroup barrier
 //   SYM_B4K/16K/32K: one workgroup per row, 16 / 64 / 128 KiB key set
 //   SYM_BM1/BM2    : column bitmap (1 bit per column): one ds_or per product, no probing;
 //                    128 KiB of LDS cover 1 Mi columns per window (per-entry cursors between windows)
