@@ -551,12 +551,20 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
     src.rebase(a_ro);
     using G = Block<THREADS>;
     const G g;
+    // LDS: values | a_ik staging | one FLAG BYTE per column | A-row staging (incl, off) | scan scratch | owner windows.
+    // A product marks its column with a plain byte store -- no atomic, no run detection in registers (this kernel
+    // sits at its VALU ceiling on the cant stand-in); the bitmap the emit step ranks with is built from the flags
+    // once per row, over the A-row staging area, which is dead between the walk and the next row.
     Acc<T>* vals = reinterpret_cast<Acc<T>*>(smem);
     T* m_av = reinterpret_cast<T*>(vals + WCOLS);
-    u32* bm = reinterpret_cast<u32*>(m_av + THREADS);
-    u32* pref = bm + WORDS;
-    u32* scratch = pref + WORDS + 2 * THREADS;
-    RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av, scratch + THREADS / 64 + 2};
+    unsigned char* flags = reinterpret_cast<unsigned char*>(m_av + THREADS);
+    u32* flag_words = reinterpret_cast<u32*>(flags);
+    u32* stage = reinterpret_cast<u32*>(flags + WCOLS);
+    u32* bm = stage;
+    u32* pref = stage + WORDS;
+    u32* scratch = stage + 2 * THREADS;
+    RowMeta<T> meta{stage, stage + THREADS, m_av, scratch + THREADS / 64 + 2};
+    static_assert(THREADS >= kNumD1Cols / 32, "bitmap + prefix fit the staging area");
     u32* __restrict__ o_col = w.nf_col;
     T* __restrict__ o_val = static_cast<T*>(w.nf_val);
     const RowSlice rs = row_slice(w.st->sym.count[SYM_NF], blockIdx.x, gridDim.x, 1u, 0u, (w.xcd_aware & 2u) != 0);
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
     RowRec next{};
     if (rs.idx < rs.end) next = recs[rs.idx];
     for (u32 i = threadIdx.x; i < WCOLS; i += THREADS) vals[i] = 0;
-    for (u32 i = threadIdx.x; i < WORDS; i += THREADS) bm[i] = 0;
+    for (u32 i = threadIdx.x; i < WCOLS / 4; i += THREADS) flag_words[i] = 0;
     __syncthreads();
     for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
         const RowRec rec = next;  // fetched while the previous row was being processed
@@ -580,11 +588,24 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
 #pragma unroll
                                    for (int u = 0; u < kBatch; ++u) {
                                        const u32 d = c[u] - wbase;
-                                       const bool in = (u32)u < n && d < ncols;
-                                       if (in) atomicAdd(&vals[d], (Acc<T>)p[u]);
-                                       bitmap_or_runs(bm, in ? d >> 5 : 0xFFFFFFFFu, 1u << (d & 31));
+                                       if ((u32)u < n && d < ncols) {
+                                           atomicAdd(&vals[d], (Acc<T>)p[u]);
+                                           flags[d] = 1;
+                                       }
                                    }
                                });
+        // flags -> bitmap (8 flag words per bitmap word; the flags are cleared on the way)
+        for (u32 i = threadIdx.x; i < nwords; i += THREADS) {
+            u32 mask = 0;
+#pragma unroll
+            for (u32 j = 0; j < 8; ++j) {
+                const u32 x = flag_words[i * 8 + j];
+                if (x) flag_words[i * 8 + j] = 0;
+                mask |= ((x * 0x01020408u) >> 24 & 0xFu) << (4 * j);
+            }
+            bm[i] = mask;
+        }
+        __syncthreads();
         const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);
         for (u32 d = threadIdx.x; d < ncols; d += THREADS) {
             const u32 word = bm[d >> 5];
@@ -596,9 +617,7 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
             }
         }
         if (threadIdx.x == 0) counts[rec.row] = total;
-        __syncthreads();
-        for (u32 i = threadIdx.x; i < nwords; i += THREADS) bm[i] = 0;
-        __syncthreads();
+        __syncthreads();  // bitmap and prefix are dead: the next row stages its A entries over them
     }
 }
 
@@ -1218,8 +1237,8 @@ void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& Av, const 
     if (count == 0) return;
     const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
     wcols = wcols < 256u ? 256u : (wcols > kNumD1Cols ? kNumD1Cols : (wcols + 255u) & ~255u);
-    const u32 lds = (wcols + 256) * (u32)sizeof(Acc<T>) +
-                    (2 * (wcols / 32) + 2 * 256 + 256 / 64 + 2 + win_words<Block<256>>() + 3) / 4 * 16;
+    const u32 lds = (wcols + 256) * (u32)sizeof(Acc<T>) + wcols +
+                    (2 * 256 + 256 / 64 + 2 + win_words<Block<256>>() + 3) / 4 * 16;
     set_dyn_lds((nf_dense_kernel<T, 256>), lds);
     hipLaunchKernelGGL((nf_dense_kernel<T, 256>), dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s,
                        src, Av.row_offsets, w, counts, wcols);
