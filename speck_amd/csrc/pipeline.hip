@@ -994,7 +994,8 @@ int speck_config_create(int device, speck_config** out)
     c->cp.sym_bitmap_ratio = 32;
     c->cp.num_dense_ratio = 16;
     c->cp.num_global_passes = 4;  // heavy rows: dense windows up to 64 Ki columns, else global spill
-    c->cp.nf_min_ops = 1024;  // numeric-first for narrow rows with at least this many products (0 = off)
+    c->cp.nf_min_ops = 512;   // numeric-first for narrow rows with at least this many products (0 = off; 256 costs the
+                              // scircuit stand-in 5 %, 1024 leaves the boundary rows of the cant one a launch of their own)
     c->cp.gh_per_window = 8192;  // global key set for rows with fewer products per 1 Mi-column bitmap window (0 = off)
     c->cp.num_g8 = 1;      // rows of <= 21 entries: 8 lanes per row
     c->cp.sym_g8 = 1;      // rows of <= 25 products: 8 lanes per row

@@ -317,7 +317,7 @@ def test_banded_dense_and_bitmap_classes(cfg):
         check(cfg, A, A, [("num", "wave512")])
     finally:
         cfg.set_option("num_dense_ratio", 16)
-        cfg.set_option("nf_min_ops", 1024)
+        cfg.set_option("nf_min_ops", 512)
     A32 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float32))
     check(cfg, A32, A32, [("sym", "numeric_first"), ("num", "nfcopy")], tol=TOL32)
 
