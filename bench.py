@@ -18,6 +18,14 @@ timed region ends only when the last exchange has completed on every rank).
 Unless --no-config5 is given the line also carries `config5`: a short strong-scaling measurement
 of the nlpkkt160 stand-in at this N (value with the exchange + multiply_only), so that the
 driver's `--gpus 1,2,4,8` sweep yields that curve without extra flags.
+At N = 1 the line also carries `configs`: every single-GPU configuration of BASELINE.json (scircuit, webbase,
+mac_econ, cant) with its own ms_per_step / eager_ms_per_step / value / roofline (--no-configs skips them).
+
+The output of the LAST timed step -- the replayed launch sequence -- is downloaded and checked (the reference
+compares after every iteration, source/Executor.cpp:51-55, 67-71): against the CPU oracle in full (indices
+bit-exact, values within 1e-12 * sum|a*b|), the nlpkkt leg through size-independent properties on the device
+plus the oracle on sampled row blocks (oracle/verify.py).  `verified` is false -- and the exit code non-zero --
+if any check fails (--no-verify skips them: `verified` is then null).
 
 Inputs: $SPECK_MTX_DIR/<name>.mtx (scircuit, webbase-1M, mac_econ_fwd500, cant, nlpkkt160) is used
 when present ("data": "suitesparse"); SuiteSparse files do not exist offline, so the default is the
@@ -160,11 +168,18 @@ class Job:
             self.slots.append((env.new_config(), sa.dCSR()))
         self.plan = None
         self.n_step = 0
+        self.last = None  # (config, output matrix) of the last step
+        self.bounds = (0, A.rows) if env.world == 1 else (bounds[env.rank], bounds[env.rank + 1])
+
+    def set_graph(self, on):
+        for scfg, _ in self.slots:
+            scfg.set_option("use_graph", int(on))
 
     def step(self, exchange=True):
         slot = self.n_step % len(self.slots)
         self.n_step += 1
         scfg, sC = self.slots[slot]
+        self.last = (scfg, sC)
         if self.plan is not None:
             self.plan.wait(slot)  # the exchange that still reads this slot's output matrix
         sa.MultiplyspECK(self.mine, self.dA, sC, scfg)  # returns with C complete in HBM
@@ -285,7 +300,37 @@ def roofline_block(workload, st, kernel_ms, num_ms):
     }
 
 
-def measure(env, A, steps, warmup, gather, profile):
+def verify_last_output(env, job, A, mode):
+    """Check the output matrix of the last step of `job` (this rank's row shard).  mode "oracle": the whole
+    shard against the CPU oracle; "properties": device-side properties + the oracle on sampled row blocks."""
+    from oracle import verify as ov
+    scfg, sC = job.last
+    r0, r1 = job.bounds
+    st = scfg.last_stats()
+    info = {"mode": mode, "checked": "output of the last timed step", "replayed": st["replayed"],
+            "b8k_folded": st["b8k_folded"]}
+    try:
+        if mode == "oracle":
+            got = sC.to_host()
+            from oracle import pyoracle as po
+            H = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data)
+            ok, d = ov.compare_with_oracle(H.row_slice(r0, r1) if (r0, r1) != (0, A.rows) else H, H,
+                                           got.row_offsets, got.col_ids, got.data)
+        else:
+            ro, col, val = shard_tensors(sC)
+            ok, d = ov.device_properties(torch, job.t_ro, job.t_col, job.t_val, r0, r1, ro, col, val, A.cols)
+            if ok and (r0, r1) == (0, A.rows):
+                ok2, d2 = ov.sampled_blocks(torch, A, ro, col, val, blocks=3)
+                ok, d = ok and ok2, dict(d, **d2)
+        info.update(d)
+    except Exception as e:  # a failed check must not hide the measurement; it fails the run instead
+        ok = False
+        info["error"] = repr(e)
+    info["ok"] = bool(ok)
+    return info
+
+
+def measure(env, A, steps, warmup, gather, profile, verify=None, eager=False):
     """Returns (result dict on every rank)."""
     job = Job(env, A, gather)
     out = {}
@@ -302,6 +347,12 @@ def measure(env, A, steps, warmup, gather, profile):
         job.step()
     elapsed = job.timed(steps)
     out["replays"] = job.cfg.last_stats()["graph_replays"]
+    out["verify"] = None
+    if verify:
+        job.drain()
+        out["verify"] = verify_last_output(env, job, A, verify)
+        bad = 0 if out["verify"]["ok"] else 1
+        out["verify"]["ok_all_ranks"] = env.sum_over_ranks(bad)[0] == 0
     out["P"], out["nnzC"] = env.sum_over_ranks(P_local, nnzc_local)
     out["elapsed"] = elapsed
     out["ms_per_step"] = elapsed * 1e3 / steps
@@ -314,8 +365,36 @@ def measure(env, A, steps, warmup, gather, profile):
         out["multiply_only"] = {"value": round(2.0 * out["P"] / (e2 / steps) / 1e9, 3), "unit": "GFLOP/s",
                                 "ms_per_step": round(e2 * 1e3 / steps, 4),
                                 "note": "same steps without the gatherv (C left row-sharded); not the job metric"}
+    # the same steps WITHOUT the replayed graph: what a caller pays whose structure changes from call to call
+    out["eager_ms_per_step"] = None
+    if eager:
+        job.set_graph(False)
+        job.step(exchange=False)
+        e3 = job.timed(steps, exchange=False)
+        out["eager_ms_per_step"] = e3 * 1e3 / steps
+        job.set_graph(True)
     job.close()
     return out
+
+
+def config_entry(env, workload, wl_name, data_label, A, res, steps):
+    """One single-GPU configuration as an object of `configs` (and the body of the headline)."""
+    st = res["st"]
+    roof = roofline_block(workload, st, res["kernel_ms"], res["num_ms"])
+    return {
+        "workload": wl_name, "name": workload, "data": data_label, "rows": A.rows, "nnzA": A.nnz,
+        "products": res["P"], "nnzC": res["nnzC"], "steps": steps,
+        "ms_per_step": round(res["ms_per_step"], 4),
+        "eager_ms_per_step": round(res["eager_ms_per_step"], 4) if res["eager_ms_per_step"] else None,
+        "value": round(res["gflops"], 3), "unit": "GFLOP/s",
+        "phases_ms": {"symbolic": round(res["sym_ms"], 4), "numeric": round(res["num_ms"], 4)},
+        "roofline": roof,
+        "kernels_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items() if v > 0},
+        "rows_per_class": {k: v for k, v in st["num_bin_rows"].items() if v},
+        "graph_replays": res["replays"],
+        "verified": res["verify"]["ok_all_ranks"] if res["verify"] else None,
+        "verify": res["verify"],
+    }
 
 
 def main():
@@ -331,6 +410,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gatherv exchange")
     ap.add_argument("--no-config5", action="store_true", help="skip the nlpkkt160 strong-scaling leg")
+    ap.add_argument("--no-configs", action="store_true", help="N=1: skip the other single-GPU configurations")
+    ap.add_argument("--no-verify", action="store_true", help="do not check the output of the last timed step")
+    ap.add_argument("--configs-steps", type=int, default=20)
     ap.add_argument("--config5-scale", type=float, default=1.0)
     ap.add_argument("--config5-steps", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (tuning)")
@@ -344,19 +426,28 @@ def main():
     if data_label == "suitesparse" and args.scaling == "weak" and n_gpus > 1:
         args.scaling = "strong"  # a file has one size
     assert A.rows == A.cols, "A*A needs a square matrix (use the transpose for rectangular inputs)"
-    res = measure(env, A, args.steps, args.warmup, gather=not args.no_gather, profile=True)
+    # oracle in full wherever it finishes in seconds; the big stencil through properties + sampled blocks
+    def verify_mode(w, A_):
+        if args.no_verify:
+            return None
+        return "properties" if (w == "nlpkkt" and A_.rows > 2_000_000) or A_.nnz > 40_000_000 else "oracle"
+
+    res = measure(env, A, args.steps, args.warmup, gather=not args.no_gather, profile=True,
+                  verify=verify_mode(args.workload, A), eager=n_gpus == 1)
+    verdicts = []
 
     out = None
     if rank == 0:
-        st = res["st"]
+        head = config_entry(env, args.workload, wl_name, data_label, A, res, args.steps)
         out = {
             "metric": "SpGEMM GFLOP/s (2*flops_intermediate/s), A*A",
-            "value": round(res["gflops"], 3),
+            "value": head["value"],
             "unit": "GFLOP/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(res["ms_per_step"], 4),
+            "ms_per_step": head["ms_per_step"],
+            "eager_ms_per_step": head["eager_ms_per_step"],
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -368,25 +459,44 @@ def main():
                 "gather": bool(n_gpus > 1 and not args.no_gather),
                 "exchange": "pipelined gatherv to rank 0" if n_gpus > 1 and not args.no_gather else None,
             },
+            "verified": None,
+            "verify": head["verify"],
             "parity": "oracle- and rocSPARSE-pinned (reference ships no golden vectors): indices bit-exact, "
                       "|c - c_ref| <= 1e-12 * sum|a*b| per entry",
-            "phases_ms": {"symbolic": round(res["sym_ms"], 4), "numeric": round(res["num_ms"], 4),
-                          "note": "untimed profiled pre-pass (eager), one HIP event pair per phase; symbolic = "
-                                  "analysis + binning + symbolic launches + scan, numeric = the numeric-first launch "
-                                  "(it runs in the symbolic phase) + fork to join of the numeric launches"},
-            "roofline": roofline_block(args.workload, st, res["kernel_ms"], res["num_ms"]),
-            "kernels_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items() if v > 0},
-            "rows_per_class": {k: v for k, v in st["num_bin_rows"].items() if v},
+            "phases_ms": dict(head["phases_ms"],
+                              note="untimed profiled pre-pass (eager), one HIP event pair per phase; symbolic = "
+                                   "analysis + binning + symbolic launches + scan, numeric = the numeric-first launch "
+                                   "(it runs in the symbolic phase) + fork to join of the numeric launches"),
+            "roofline": head["roofline"],
+            "kernels_ms": head["kernels_ms"],
+            "rows_per_class": head["rows_per_class"],
             "graph_replays": res["replays"],
         }
         if res["multiply_only"] is not None:
             out["multiply_only"] = res["multiply_only"]
+        verdicts.append(head["verified"])
     del res
+
+    # ---- N = 1: every single-GPU configuration of BASELINE.json (configs[1..3]) in the same line
+    if n_gpus == 1 and not args.no_configs:
+        entries = []
+        for w in ("scircuit", "webbase", "mac_econ", "cant"):
+            if w == args.workload and args.scale == 1.0 and not args.mtx:
+                entries.append(head)
+                continue
+            Aw, label_w, name_w = load_workload(w, 1.0, args.seed)
+            rw = measure(env, Aw, args.configs_steps, 3, gather=False, profile=True, verify=verify_mode(w, Aw),
+                         eager=True)
+            entries.append(config_entry(env, w, name_w, label_w, Aw, rw, args.configs_steps))
+            verdicts.append(entries[-1]["verified"])
+            del Aw, rw
+        out["configs"] = entries
 
     # ---- BASELINE.json configs[4]: the nlpkkt160 stand-in, STRONG scaling, at this N
     if not args.no_config5 and not (args.workload == "nlpkkt" and args.scaling == "strong"):
         A5, label5, name5 = load_workload("nlpkkt", args.config5_scale, args.seed)
-        r5 = measure(env, A5, args.config5_steps, 2, gather=not args.no_gather, profile=False)
+        r5 = measure(env, A5, args.config5_steps, 2, gather=not args.no_gather, profile=False,
+                     verify=verify_mode("nlpkkt", A5))
         if rank == 0:
             out["config5"] = {
                 "workload": name5, "data": label5, "scaling": "strong", "n_gpus": n_gpus, "rows": A5.rows,
@@ -395,15 +505,23 @@ def main():
                 "multiply_only": r5["multiply_only"] if r5["multiply_only"] is not None else
                 {"value": round(r5["gflops"], 3), "unit": "GFLOP/s", "ms_per_step": round(r5["ms_per_step"], 4),
                  "note": "N = 1: nothing to exchange"},
+                "verified": r5["verify"]["ok_all_ranks"] if r5["verify"] else None,
+                "verify": r5["verify"],
             }
+            verdicts.append(out["config5"]["verified"])
         del A5, r5
 
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, out["config"]["products"])
+        checked = [v for v in verdicts if v is not None]
+        out["verified"] = all(checked) if checked else None
         print(json.dumps(out), flush=True)
+    failed = rank == 0 and out["verified"] is False
     if n_gpus > 1:
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 def cpu_baseline(A, P):

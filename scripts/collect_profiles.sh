@@ -11,11 +11,11 @@ OUT=gpurun_out/profiles
 mkdir -p $OUT
 for w in $WORKLOADS; do
   rm -rf gpurun_out/_p_$w
-  rocprofv3 --kernel-trace --stats -d gpurun_out/_p_$w/trace -o r -- python bench.py --workload $w --no-cpu-baseline --no-config5 \
+  rocprofv3 --kernel-trace --stats -d gpurun_out/_p_$w/trace -o r -- python bench.py --workload $w --no-cpu-baseline --no-config5 --no-configs --no-verify \
       > $OUT/${ROUND}_bench_${w}_under_rocprof.log 2>&1
   python scripts/rocpd_summary.py $(find gpurun_out/_p_$w/trace -name "*.db" | head -1) $OUT/${ROUND}_bench_${w}_kernel_stats.csv > /dev/null
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c -d gpurun_out/_p_$w/$c -o r -- python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-config5 \
+    rocprofv3 --kernel-trace --pmc $c -d gpurun_out/_p_$w/$c -o r -- python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-config5 --no-configs --no-verify \
         > gpurun_out/_p_$w/$c.log 2>&1
     python scripts/rocpd_pmc.py $(find gpurun_out/_p_$w/$c -name "*.db" | head -1) gpurun_out/_p_$w/$c.csv > /dev/null
   done

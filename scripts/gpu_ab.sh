@@ -8,7 +8,7 @@ for w in $WL; do
   for variant in "$@"; do
     opts=""
     for o in $variant; do [ "$o" != "base" ] && opts="$opts --opt $o"; done
-    timeout 600 python bench.py --workload $w --no-cpu-baseline --no-config5 $BENCH_ARGS $opts 2>&1 | tail -n 1 | python -c "
+    timeout 600 python bench.py --workload $w --no-cpu-baseline --no-config5 --no-configs --no-verify $BENCH_ARGS $opts 2>&1 | tail -n 1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('%-9s %-34s %.4f ms  %7.1f GF  sym %.3f num %.3f  %s' % ('$w', '$variant', d['ms_per_step'], d['value'], d['phases_ms']['symbolic'], d['phases_ms']['numeric'], d['kernels_ms']))

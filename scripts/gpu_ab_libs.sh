@@ -8,7 +8,7 @@ cp speck_amd/libspeck_amd.so /tmp/lib_keep.so
 for w in $WL; do
   for v in "$@"; do
     cp speck_amd/variants/$v.so speck_amd/libspeck_amd.so
-    timeout 300 python bench.py --workload $w --no-cpu-baseline --no-config5 $BENCH_ARGS 2>&1 | tail -n 1 | python -c "
+    timeout 300 python bench.py --workload $w --no-cpu-baseline --no-config5 --no-configs --no-verify $BENCH_ARGS 2>&1 | tail -n 1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('%-9s %-20s %.4f ms  %7.1f GF  sym %.3f num %.3f  %s' % ('$w', '$v', d['ms_per_step'], d['value'], d['phases_ms']['symbolic'], d['phases_ms']['numeric'], d['kernels_ms']))

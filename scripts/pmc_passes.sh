@@ -17,7 +17,7 @@ i=0
 for p in "${PASSES[@]}"; do
   i=$((i+1))
   rm -rf gpurun_out/_pmc_tmp
-  timeout 600 rocprofv3 --kernel-trace --pmc $p -d gpurun_out/_pmc_tmp -o r -- python bench.py --workload $W --steps 3 --warmup 2 --no-cpu-baseline --no-config5 "$@" > gpurun_out/pmc/${TAG}_pass$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $p -d gpurun_out/_pmc_tmp -o r -- python bench.py --workload $W --steps 3 --warmup 2 --no-cpu-baseline --no-config5 --no-configs --no-verify "$@" > gpurun_out/pmc/${TAG}_pass$i.log 2>&1
   db=$(find gpurun_out/_pmc_tmp -name "*.db" | head -n 1)
   if [ -n "$db" ]; then python scripts/rocpd_pmc.py $db gpurun_out/pmc/${TAG}_pass$i.csv > /dev/null; else echo "pass $i: no db"; tail -n 3 gpurun_out/pmc/${TAG}_pass$i.log; fi
 done

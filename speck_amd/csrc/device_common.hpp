@@ -125,6 +125,13 @@ __host__ __device__ inline bool is_numeric_first(u32 len_a, u32 ops, u32 cmin, u
     return p.nf_min_ops != 0 && len_a > 1 && ops >= p.nf_min_ops && u64(cmax) - u64(cmin) + 1 <= kNumD1Cols;
 }
 
+// Scratch slot of a numeric-first row: its nnz can exceed neither its column range nor its product count.
+__host__ __device__ inline u32 nf_slot_entries(u32 cmin, u32 cmax, u32 ops)
+{
+    const u32 range = cmax - cmin + 1u;
+    return range < ops ? range : ops;
+}
+
 // Slots of a SYM_GH row's key set: a power of two, load <= 1/2.  The classifier keeps ops < 2^22 there.
 constexpr u32 kSymGhMinSlots = 65536, kSymGhMaxOps = 1u << 22;
 __host__ __device__ inline u32 gh_table_slots(u32 ops)
@@ -213,11 +220,14 @@ struct DeviceStats {
     BinTable sym;
     BinTable num;
     u64 g_products;          // products of the NUM_G rows (the host sizes the spill pool from it)
-    u64 nf_entries;          // scratch entries of the SYM_NF rows (sum of their column ranges) and of the SYM_GH rows
-                             //   (slots of their key sets)
+    u64 nf_entries;          // scratch entries of the SYM_NF rows (sum of min(column range, products)) and of the
+                             //   SYM_GH rows (slots of their key sets)
     u32 b_invalid;           // a row of B is not strictly ascending / holds a column >= cols (eager path)
     u32 nf_max_range;        // widest column range among the SYM_NF rows (sizes the LDS window of their kernel)
+    u32 a_invalid;           // a column id of A is >= rows(B) (the analysis clamps it, so nothing reads out of bounds)
+    u32 pad_;
 };
+static_assert(sizeof(DeviceStats) % 8 == 0, "mirrored to the host in 8-byte words");
 
 // One row of work as the class kernels see it: written in class order by the scatter kernels,
 // read with a single 32-byte load (the next row's record is fetched while the current one runs).

@@ -13,10 +13,11 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
                      u32* b_start, u32* b_len, hipEvent_t between = nullptr, u64* nf_off = nullptr,
-                     u64 expect_nf = ~0ull);
+                     u64 expect_nf = ~0ull, u32 b_rows = ~0u);
 
 // completion ticket of a replayed launch sequence (pinned host word the host spins on)
-void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket);
+// (the kernel also copies the statistics block into its pinned mirror, before the ticket)
+void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceStats* st, DeviceStats* host_mirror);
 
 // strictly ascending, in-range column ids in every row of B (sets DeviceStats::b_invalid)
 void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st,
@@ -63,6 +64,7 @@ struct RowWork {
     const u64* nf_off;      // numeric-first rows (SYM_NF / NUM_NFCOPY): scratch slot of row r = nf_col/nf_val + nf_off[r]
     u32* nf_col;
     void* nf_val;
+    u64 nf_cap;             // entries the pool holds (a slot never ends beyond it)
     u32* w_start;           // per A entry: start / length of its B row INSIDE the current column window
     u32* w_len;             //   (multi-window rows, row_groups.hpp WindowCursors); a row's entries belong to its workgroup
     u32 xcd_aware;          // class lists are walked in per-XCD contiguous slices (row_groups.hpp)

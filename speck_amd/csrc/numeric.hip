@@ -532,7 +532,7 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
 // ------------------------------------------------------------------ numeric-first rows (SYM_NF / NUM_NFCOPY)
 // A row whose reachable column range fits one dense window needs no nnz to size anything, so its numeric
 // kernel does not have to wait for the symbolic phase -- it REPLACES it: the row is accumulated in the dense
-// window (as NUM_D1), written sorted to a scratch slot (slot size = column range >= nnz, offsets from the
+// window (as NUM_D1), written sorted to a scratch slot (slot size = min(column range, products) >= nnz, offsets from the
 // ordered scatter of the analysis) and counted.  After the scan NUM_NFCOPY moves it to its place in C.
 // For banded / FEM inputs (cant: every row) the whole symbolic walk -- as long as the numeric one --
 // turns into one copy of C.  (The reference always runs both phases; new functionality.)
@@ -579,7 +579,9 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
         if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
         const u64 slot = w.nf_off[rec.row];
         const u32 wbase = rec.cmin, ncols = rec.cmax - rec.cmin + 1u, nwords = (ncols + 31) >> 5;
-        if (ncols > WCOLS) {  // a replayed sequence met a wider row than its window was sized for: eager re-run
+        // a replayed sequence met a wider row than its window was sized for, or a slot past the pool it was
+        // captured with: eager re-run
+        if (ncols > WCOLS || slot + nf_slot_entries(rec.cmin, rec.cmax, rec.ops) > w.nf_cap) {
             if (threadIdx.x == 0) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
             continue;
         }

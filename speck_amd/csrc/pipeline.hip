@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,6 +96,7 @@ struct speck_config {
     u32 last_sym_mask = 0, last_num_mask = 0;  // non-empty classes of the last eager call
     u32 last_max_row_nnz = 0;                  // ... and its longest C row
     bool fold_small_b8k = true;                // under-filled NUM_B8K class -> NUM_B2K in the replayed sequence
+    bool graph_folded_b8k = false;             // ... and the captured sequence does so
     GraphKey last_key;                         // ... and what it ran on
     bool last_key_valid = false;
     int graph_replays = 0, graph_captures = 0, graph_misses = 0;
@@ -103,6 +105,8 @@ struct speck_config {
     void* nfpool = nullptr;   // scratch slots of the numeric-first rows: col_ids | values (grow-only)
     size_t nfpool_bytes = 0;
     u64 nf_cap_entries = 0;
+    size_t nf_pool_max_bytes = 0;  // 0: half of the free device memory at allocation time
+    int pool_fallbacks = 0;        // times a scratch-pool class was switched off because the pool did not fit
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
@@ -110,6 +114,19 @@ struct speck_config {
 };
 
 namespace {
+
+// polite busy-wait step of the host thread that waits for the completion ticket
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+constexpr std::chrono::microseconds kSpinBudget{2000};
 
 hipStream_t main_stream(speck_config* c) { return c->use_user_stream ? c->user_stream : c->streams[0]; }
 
@@ -206,6 +223,12 @@ int ensure_nfpool(speck_config* c, u64 entries, size_t vsize)
     c->nf_cap_entries = 0;
     const u64 cap = entries + entries / 8 + 1024;
     const size_t bytes = Carver::need(cap, 4) + Carver::need(cap, 8) + 512;
+    // budget: an explicit cap (option nf_pool_max_mb) or half of what the device has free -- hidden scratch must
+    // not be what makes a later allocation of C fail
+    size_t free_b = 0, total_b = 0;
+    size_t budget = c->nf_pool_max_bytes;
+    if (!budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = free_b / 2;
+    if (budget && bytes > budget) return SPECK_ERR_OOM;
     if (hipMalloc(&c->nfpool, bytes) != hipSuccess) {
         (void)hipGetLastError();
         return SPECK_ERR_OOM;
@@ -226,6 +249,7 @@ RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill)
     w.nf_off = sc.nf_off;
     w.nf_col = static_cast<u32*>(c->nfpool);
     w.nf_val = c->nfpool ? static_cast<unsigned char*>(c->nfpool) + Carver::need(c->nf_cap_entries, 4) : nullptr;
+    w.nf_cap = c->nfpool ? c->nf_cap_entries : 0;
     w.w_start = sc.w_start;
     w.w_len = sc.w_len;
     w.xcd_aware = c->xcd_aware;
@@ -411,7 +435,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         }
         launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
                         sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
-                        c->d_stats, cp, sc.b_start, sc.b_len, between, sc.nf_off, expect_nf);
+                        c->d_stats, cp, sc.b_start, sc.b_len, between, sc.nf_off, expect_nf, (u32)B->rows);
         if (timed) {
             tm->ev_analysis_end = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -578,23 +602,26 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     u32 num_counts[kMaxClasses];
     std::memcpy(num_counts, c->last_num_counts, sizeof(num_counts));
     const u32 b2k_was = c->cp.b2k_max_nnz;
+    c->graph_folded_b8k = false;
     if (c->fold_small_b8k && num_counts[NUM_B8K] && num_counts[NUM_B8K] * 8u < (u32)c->sm &&
         c->last_max_row_nnz <= kNumB2KStretchNnz) {
         c->cp.b2k_max_nnz = kNumB2KStretchNnz;
+        c->graph_folded_b8k = true;
         num_counts[NUM_B2K] += num_counts[NUM_B8K];
         num_counts[NUM_B8K] = 0;
         num_mask = (num_mask & ~(1u << NUM_B8K)) | (1u << NUM_B2K);
     }
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
-                           num_mask, true, nullptr, c->last_sym_counts, c->h_stats_dev,
+                           num_mask, true, nullptr, c->last_sym_counts, nullptr,
                            c->last_g_products, c->last_num_counts[NUM_G], 3u, c->nf_cap_entries);
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
                              num_mask, num_counts, nullptr);
     c->cp.b2k_max_nnz = b2k_was;
-    // no copy node: the scan kernel mirrors the statistics block into pinned host memory
-    if (rc == SPECK_OK && c->spin_wait) launch_done(s, c->d_ticket, c->h_ticket_dev);
+    // no copy node: the last kernel mirrors the (final) statistics block into pinned host memory, then stores
+    // the completion ticket
+    if (rc == SPECK_OK) launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
     hipError_t e = rc == SPECK_OK ? hipSuccess : hipErrorUnknown;
     hipGraph_t g = nullptr;
     hipError_t e2 = hipStreamEndCapture(s, &g);
@@ -674,20 +701,25 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             if (c->spin_wait) {
                 // the last node of the sequence stores a ticket into pinned memory: spin on it (bounded),
                 // then fall back to the blocking synchronisation
+                // (bounded by TIME: a multiply that is still running after kSpinBudget is long enough for the
+                //  wake-up latency of the blocking call not to matter)
                 const u32 want = ++c->ticket_expected;
-                volatile u32* flag = c->h_ticket;
-                for (u64 spins = 0; *flag != want && spins < (1ull << 24); ++spins) __builtin_ia32_pause();
-                if (*flag != want) {
-                    HIP_TRY(hipStreamSynchronize(s));
-                    c->ticket_expected = *flag;
+                const auto t0 = std::chrono::steady_clock::now();
+                bool seen = false;
+                while (!(seen = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE) == want)) {
+                    for (int i = 0; i < 64; ++i) cpu_relax();
+                    if (std::chrono::steady_clock::now() - t0 > kSpinBudget) break;
                 }
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                if (!seen) HIP_TRY(hipStreamSynchronize(s));
             } else {
                 HIP_TRY(hipStreamSynchronize(s));
             }
+            c->ticket_expected = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE);
             if (!c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 ++c->graph_replays;
                 publish_counts(c);
+                c->last.replayed = 1;
+                c->last.b8k_folded = c->graph_folded_b8k ? 1 : 0;
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -713,41 +745,50 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     // ANALYSIS + binning + SYMBOLIC + SCAN (Multiply.cu:239-575) -- one read-back
     Timing tm;
+    auto front = [&](u32 parts) {
+        return enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr,
+                             ~0ull, ~0u, parts);
+    };
+    // analysis + binning, then the input check: B's rows strictly ascending and in range (one coalesced pass;
+    // A's column ids are checked -- and clamped -- by the analysis itself).  The check sits behind the analysis
+    // because block 0 of the analysis kernel is what zeroes the statistics block it reports into.
+    rc = front(1u);
+    if (rc != SPECK_OK) return fail(rc);
+    if (c->validate_inputs)
+        launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
     if (c->cp.nf_min_ops || c->cp.gh_per_window) {
         // numeric-first rows (and the global key sets of SYM_GH rows) need their scratch pool before the
-        // symbolic phase: one more read-back
+        // symbolic phase: one more read-back -- which also stops an invalid input before any kernel walks B's rows
         // (the replayed sequence has none: the pool of the previous identical call is checked on the device)
-        rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr,
-                           ~0ull, ~0u, 1u);
-        if (rc != SPECK_OK) return fail(rc);
-        if (c->validate_inputs)
-            launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
         rc = read_stats(c, s);
         if (rc != SPECK_OK) return fail(rc);
-        if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);  // before any kernel walks B's rows
-        c->nf_wcols = c->h_stats->nf_max_range ? c->h_stats->nf_max_range : kNumD1Cols;
-        if (c->h_stats->nf_entries) {
+        if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
+        if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
+        // No room (or no budget) for the pool: first the global key sets go (those rows take the multi-window
+        // bitmap, which needs no memory), then the numeric-first rows (they take the two-phase path) -- for this
+        // config from now on; the rows are classified again.
+        while (c->h_stats->nf_entries) {
             rc = ensure_nfpool(c, c->h_stats->nf_entries, sizeof(T));
-            if (rc == SPECK_ERR_OOM && c->cp.gh_per_window && c->h_stats->sym.count[SYM_GH]) {
-                // no room for the global key sets: those rows take the multi-window bitmap (no memory at all)
-                // from now on -- classify again
-                c->cp.gh_per_window = 0;
-                rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr,
-                                   nullptr, ~0ull, ~0u, 1u);
-                if (rc == SPECK_OK) rc = read_stats(c, s);
-                if (rc == SPECK_OK && c->h_stats->nf_entries) rc = ensure_nfpool(c, c->h_stats->nf_entries, sizeof(T));
-            }
-            if (rc != SPECK_OK) return fail(rc);
+            if (rc != SPECK_ERR_OOM) break;
+            if (c->cp.gh_per_window && c->h_stats->sym.count[SYM_GH]) c->cp.gh_per_window = 0;
+            else if (c->cp.nf_min_ops && c->h_stats->sym.count[SYM_NF]) c->cp.nf_min_ops = 0;
+            else break;
+            ++c->pool_fallbacks;
+            rc = front(1u);
+            if (rc == SPECK_OK) rc = read_stats(c, s);
+            if (rc != SPECK_OK) break;
         }
-        rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr,
-                           ~0ull, ~0u, 2u);
-    } else
-        rc = enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm);
+        if (rc != SPECK_OK) return fail(rc);
+        c->nf_wcols = c->h_stats->nf_max_range ? c->h_stats->nf_max_range : kNumD1Cols;
+    }
+    // (with both scratch-pool classes off the symbolic kernels run before the host has seen the verdict of the
+    //  check: they stay inside their tables and windows whatever B holds, and nothing of C is written before the
+    //  read-back below)
+    rc = front(2u);
     if (rc != SPECK_OK) return fail(rc);
-    if (c->validate_inputs && !(c->cp.nf_min_ops || c->cp.gh_per_window))
-        launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return fail(rc);
+    if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
     if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
     t->countProducts = 0.f;
     t->loadBalanceCounting = 0.f;
@@ -1065,6 +1106,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         drop_graph(c);
         c->last_key_valid = false;
     }
+    else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
     else if (n == "sym_w128") {
         c->cp.sym_w128 = value != 0;
         drop_graph(c);
@@ -1147,6 +1189,8 @@ int speck_last_stats(const speck_config* c, speck_stats* out)
     out->numeric_reruns = c->graph_misses;
     out->graph_replays = c->graph_replays;
     out->graph_captures = c->graph_captures;
+    out->pool_fallbacks = c->pool_fallbacks;
+    out->scratch_pool_bytes = c->nfpool_bytes;
     return SPECK_OK;
 }
 
@@ -1194,10 +1238,11 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
                         ClassifyParams cp = c->cp;
                         cp.sym_allowed = cp.num_allowed = 0xFFFFFFFFu;
                         return cp;
-                    }(), nullptr, nullptr);
+                    }(), nullptr, nullptr, nullptr, nullptr, ~0ull, (u32)B->rows);
     HIP_TRY(hipGetLastError());
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return rc;
+    if (c->h_stats->a_invalid) return SPECK_ERR_INVALID;
     if (h_sum_products) *h_sum_products = c->h_stats->sum_products;
     if (h_max_row_ops) *h_max_row_ops = c->h_stats->max_row_ops;
     return SPECK_OK;

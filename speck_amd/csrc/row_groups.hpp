@@ -179,8 +179,8 @@ constexpr int kBatch = 4;  // products per lane fetched before accumulating (mem
 // dependent global round trip less per row.  Both are indexed by (absolute A entry - e_base).
 template <typename T>
 struct ProductSrc {
-    const u32* __restrict__ b_start;
-    const u32* __restrict__ b_len;
+    const u32* b_start;  // (no __restrict__: the windowed walk of a multi-window row points these at w_start /
+    const u32* b_len;    //  w_len, which the same workgroup rewrites between two windows)
     const T* __restrict__ a_val;
     const u32* __restrict__ b_col;
     const T* __restrict__ b_val;

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* __restrict__ row_ops,
     u32* __restrict__ row_max_ops, u32* __restrict__ row_col_min, u32* __restrict__ row_col_max,
     u8* __restrict__ sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
-    ClassifyParams cp, u32* __restrict__ b_start, u32* __restrict__ b_len, DeviceStats* __restrict__ st)
+    ClassifyParams cp, u32* __restrict__ b_start, u32* __restrict__ b_len, DeviceStats* __restrict__ st, u32 b_rows)
 {
     constexpr int NW = kAnThreads / 64;
     constexpr int U = 4;   // entries per lane and tile: 256 entries cover most 32-row sub-chunks in ONE
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     const u32 row_end = min(m, row_begin + rows_per_block);
     u64 my_products = 0, my_nf = 0;
     u32 my_max = 0, my_nfr = 0;
+    bool bad_col = false;  // a column id of A beyond the rows of B: clamped here, reported through the partials
     u32 hist[SYM_CLASSES];
 #pragma unroll
     for (int c = 0; c < SYM_CLASSES; ++c) hist[c] = 0;
@@ -132,7 +133,11 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
                 for (int u = 0; u < U; ++u) {
                     ok[u] = j0 + u < my_len;
                     const u32 e = e_lo + j0 + u;
-                    const u32 k = ok[u] ? a_col[e] : 0u;
+                    u32 k = ok[u] ? a_col[e] : 0u;
+                    if (k >= b_rows) {
+                        bad_col = true;
+                        k = 0;
+                    }
                     const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
                     bs[u] = ok[u] ? pr.x : 0u;
                     be[u] = ok[u] ? pr.y : 0u;
@@ -166,7 +171,11 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
             for (int u = 0; u < U; ++u) {
                 const u32 e = e0 + u * 64;
                 ok[u] = e < e_end;
-                const u32 k = ok[u] ? a_col[e] : 0u;
+                u32 k = ok[u] ? a_col[e] : 0u;
+                if (k >= b_rows) {
+                    bad_col = true;
+                    k = 0;
+                }
                 // B.rowptr[k], B.rowptr[k+1] as ONE 8-byte gather (4-byte aligned): the random
                 // gathers of this kernel are bound by addresses per cycle, not by bytes
                 const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
                 cls = classify_symbolic(len_a, ops32, cmin, cmax, cp);
                 sym_cls[row] = cls;
                 if (cls == SYM_NF) {
-                    my_nf += cmax - cmin + 1;  // scratch slot = the row's column range
+                    my_nf += nf_slot_entries(cmin, cmax, ops32);  // scratch slot: nnz <= min(column range, products)
                     my_nfr = max(my_nfr, cmax - cmin + 1);
                 }
                 if (cls == SYM_GH) my_nf += gh_table_slots(ops32);  // ... = the row's key set in global memory
@@ -282,6 +291,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     my_nf = wave_reduce_add(my_nf);
     my_max = wave_reduce_max(my_max);
     my_nfr = wave_reduce_max(my_nfr);
+    if (__ballot(bad_col) != 0) my_nfr = 0xFFFFFFFFu;  // folded with max: survives to the scatter kernel
     __syncthreads();
     AN_MARK(6);
     if (lane == 0) {
@@ -487,6 +497,11 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
         st->max_row_ops = s_fold.max_val;
         st->nf_entries = s_fold.g_total;
         st->nf_max_range = s_fold.aux_max;
+        if (s_fold.aux_max == 0xFFFFFFFFu) {  // the analysis met a column id of A >= rows(B)
+            st->nf_max_range = 0;
+            st->a_invalid = 1;
+            st->capacity_miss = 1;  // a replayed sequence stops here; the eager path returns the status
+        }
         // the scratch pool of a replayed launch sequence was sized for `expect_nf` entries
         if (expect_nf != ~0ull && s_fold.g_total > expect_nf) st->capacity_miss = 1;
         publish_bins(st->sym, s_fold, s_bytes, cp.sym_allowed, st);
@@ -527,8 +542,8 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
         // column ranges (table sizes), in row order
         if (s_wcnt[SYM_NF][0] + s_wcnt[SYM_NF][1] + s_wcnt[SYM_NF][2] + s_wcnt[SYM_NF][3] + s_wcnt[SYM_GH][0] +
                 s_wcnt[SYM_GH][1] + s_wcnt[SYM_GH][2] + s_wcnt[SYM_GH][3] != 0) {  // uniform
-            const u32 row_ops_v = first ? p_ops : (c == SYM_GH ? row_ops[row] : 0u);
-            const u32 ub = c == SYM_NF ? r_max - r_min + 1u : (c == SYM_GH ? gh_table_slots(row_ops_v) : 0u);
+            const u32 row_ops_v = first ? p_ops : ((c == SYM_GH || c == SYM_NF) ? row_ops[row] : 0u);
+            const u32 ub = c == SYM_NF ? nf_slot_entries(r_min, r_max, row_ops_v) : (c == SYM_GH ? gh_table_slots(row_ops_v) : 0u);
             u32 chunk_total;
             const u32 excl = block_exclusive_scan<kChunk>(ub, s_nfscan, &chunk_total);
             if (c == SYM_NF || c == SYM_GH) nf_off[row] = s_nfrun + excl;
@@ -816,15 +831,27 @@ void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_r
 
 // Last node of a replayed launch sequence: a ticket in pinned host memory the host spins on (a blocking
 // stream synchronisation costs ~10-20 us of wake-up latency: a tenth of a 200 us multiply).
-__global__ void done_kernel(u32* __restrict__ dev_ticket, u32* __restrict__ host_ticket)
+// The same wave first copies the (final) statistics block into the pinned mirror with system-scope stores, so
+// the host may read it as soon as it sees the ticket: nothing relies on an earlier kernel's plain stores to
+// host memory being visible by then.
+__global__ __launch_bounds__(64) void done_kernel(u32* __restrict__ dev_ticket, u32* __restrict__ host_ticket,
+                                                  const DeviceStats* __restrict__ st, DeviceStats* __restrict__ host_mirror)
 {
-    const u32 t = *dev_ticket + 1u;
-    *dev_ticket = t;
-    __hip_atomic_store(host_ticket, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const u64* src = reinterpret_cast<const u64*>(st);
+    u64* dst = reinterpret_cast<u64*>(host_mirror);
+    for (u32 i = threadIdx.x; i < sizeof(DeviceStats) / 8; i += 64)
+        __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the mirror is written before the ticket
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) {
+        const u32 t = *dev_ticket + 1u;
+        *dev_ticket = t;
+        __hip_atomic_store(host_ticket, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
-void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket)
+void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceStats* st, DeviceStats* host_mirror)
 {
-    hipLaunchKernelGGL(done_kernel, dim3(1), dim3(1), 0, s, dev_ticket, host_ticket);
+    hipLaunchKernelGGL(done_kernel, dim3(1), dim3(64), 0, s, dev_ticket, host_ticket, st, host_mirror);
 }
 
 // --------------------------------------------------------------------------------
@@ -842,13 +869,13 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 /*nnz_a*/, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
-                     u32* b_start, u32* b_len, hipEvent_t between, u64* nf_off, u64 expect_nf)
+                     u32* b_start, u32* b_len, hipEvent_t between, u64* nf_off, u64 expect_nf, u32 b_rows)
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
     hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kAnThreads), 0, s, a_ro, a_col, b_ro, b_col, m,
                        rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                       partials, cp, b_start, b_len, st);
+                       partials, cp, b_start, b_len, st, b_rows);
     if (between) (void)hipEventRecord(between, s);  // analysis | binning (Timings::countProducts / loadBalanceCounting)
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,

@@ -180,6 +180,9 @@ __global__ __launch_bounds__(kGhThreads) void sym_global_hash_kernel(ProductSrc<
                                                                       u32* __restrict__ counts)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // a replayed sequence whose scratch pool no longer holds the key sets (sym_scatter_kernel raised the flag)
+    // must not clear or probe them: the eager path re-runs with a pool of the right size
+    if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     using G = Block<kGhThreads>;
     const G g;
@@ -192,7 +195,12 @@ __global__ __launch_bounds__(kGhThreads) void sym_global_hash_kernel(ProductSrc<
         const RowRec rec = recs[idx];
         const u32 slots = gh_table_slots(rec.ops);
         const u32 shift = 32u - (u32)__builtin_ctz(slots);
-        u32* tab = w.nf_col + w.nf_off[rec.row];
+        const u64 slot0 = w.nf_off[rec.row];
+        if (slot0 + slots > w.nf_cap) {  // never past the end of the pool, whatever the flag said
+            if (threadIdx.x == 0) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
+            continue;
+        }
+        u32* tab = w.nf_col + slot0;
         for (u32 i = threadIdx.x; i < slots; i += kGhThreads) tab[i] = kEmptyKey;
         __threadfence();  // the stores are in the L2 before any wave of this workgroup sends an atomic there
         __syncthreads();

@@ -92,9 +92,12 @@ def test_bench_two_ranks_share_the_gpu():
     assert d["n_gpus"] == 2 and d["config"]["gather"] and d["value"] > 0 and d["scaling"] == "weak"
     assert d["graph_replays"] > 0 and d["config"]["parallelism"] == "rows2"
     assert d["multiply_only"]["value"] > 0
+    # every rank checked its row shard of the last step against the oracle
+    assert d["verified"] is True and d["verify"]["ok_all_ranks"] and d["verify"]["mode"] == "oracle"
     # the BASELINE.json configs[4] leg: nlpkkt stand-in, strong scaling, with and without the exchange
     c5 = d["config5"]
     assert c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["value"] > 0 and c5["multiply_only"]["value"] > 0
+    assert c5["verified"] is True
 
 
 def test_bench_strong_scaling_mode_two_ranks_share_the_gpu():
@@ -109,11 +112,12 @@ def test_bench_strong_scaling_mode_two_ranks_share_the_gpu():
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
              "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")]
         p = subprocess.run(cmd + ["--gpus", str(n), "--steps", "3", "--warmup", "2", "--workload", "nlpkkt", "--scale",
-                                  "0.004", "--scaling", "strong", "--no-cpu-baseline"],
+                                  "0.004", "--scaling", "strong", "--no-cpu-baseline", "--no-configs"],
                            cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         out = p.stdout.decode()
         assert p.returncode == 0, out[-2000:]
         d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
         assert d["scaling"] == "strong" and d["n_gpus"] == n and d["value"] > 0 and "config5" not in d
+        assert d["verified"] is True
         sizes[n] = (d["config"]["rows"], d["config"]["products"], d["config"]["nnzC"])
     assert sizes[1] == sizes[2]          # strong scaling: the same job at every N

@@ -469,26 +469,148 @@ def test_compare_and_transpose(cfg):
 
 
 # BASELINE.json configs[1..3] at FULL size (the stand-ins fitted to the SuiteSparse figures), the
-# nlpkkt one at a size the oracle finishes in seconds (its full size runs in bench.py's config5 leg)
+# nlpkkt one at a size the oracle finishes in seconds (its full size: test_nlpkkt_full_size_properties below).
+# The sequence bench.py TIMES is the replayed one (a hipGraph specialised to the classes / counts of the previous
+# identical call, with the under-filled NUM_B8K class folded into NUM_B2K on the scircuit stand-in): the eager
+# result and the output of the replayed sequence are both compared with the oracle.
 @pytest.mark.parametrize("kind,scale,expect", [
-    ("scircuit", 1.0, [("num", "g16"), ("num", "wave512"), ("num", "block2k")]),
+    ("scircuit", 1.0, [("num", "g16"), ("num", "wave512"), ("num", "block2k"), ("num", "block8k")]),
     ("mac_econ", 1.0, [("num", "g16"), ("num", "wave128")]),
     ("cant", 1.0, [("sym", "numeric_first"), ("num", "nfcopy")]),
     ("webbase", 1.0, [("num", "global"), ("num", "block8k"), ("num", "direct"), ("sym", "block16k")]),
     ("nlpkkt", 0.002, None)])
 def test_suitesparse_standins_full_parity(cfg, kind, scale, expect):
     A = to_po(sa.gen_matrix(kind, scale, 1, signed=True))
-    dC, st, R = check(cfg, A, A, expect)
+    dA = sa.dCSR.from_host(to_sa(A))
+    dC = sa.dCSR()
+    sa.MultiplyspECK(dA, dA, dC, cfg)                       # eager
+    st = cfg.last_stats()
+    assert not st["replayed"]
+    R, ab = po.spgemm(A, A)
+
+    def same_as_oracle(tag):
+        got = dC.to_host()
+        assert got.nnz == R.nnz and (got.row_offsets == R.row_offsets).all(), tag
+        assert (got.col_ids == R.col_ids).all(), tag
+        err = np.abs(got.data - R.data)
+        assert (err <= TOL64 * ab + 1e-300).all(), f"{tag}: max err/bound {np.max(err / (TOL64 * ab + 1e-300))}"
+        return got
+
+    lhs = same_as_oracle("eager")
+    for knd, name in expect or []:
+        assert st["sym_bin_rows" if knd == "sym" else "num_bin_rows"][name] > 0, (knd, name, st)
     # size-independent properties: sorted rows, row-sum identity (C*1 == A*(A*1))
     ones = np.ones(A.cols)
     S = A.to_scipy()
-    lhs = dC.to_host()
     csum = np.add.reduceat(np.concatenate([lhs.data, [0.0]]),
                            np.minimum(lhs.row_offsets[:-1], lhs.nnz).astype(np.int64))
     csum[np.diff(lhs.row_offsets.astype(np.int64)) == 0] = 0.0
     ref = S @ (S @ ones)
     scale_ = np.abs(S) @ (np.abs(S) @ ones) + 1e-300
     assert np.max(np.abs(csum - ref) / scale_) < 1e-11
+    # ... and the REPLAYED sequence: five more calls on the same buffers
+    replays0 = st["graph_replays"]
+    for i in range(5):
+        if i == 3:   # scribble over C: the replayed sequence must rewrite every entry
+            junk = np.full(dC.nnz, 0xFFFFFFF0, dtype=np.uint32)
+            assert _lib.load().speck_dcsr_update(ctypes.byref(dC._c), None, junk.ctypes.data,
+                                                 np.full(dC.nnz, np.nan).ctypes.data, 8) == 0
+        sa.MultiplyspECK(dA, dA, dC, cfg)
+    st2 = cfg.last_stats()
+    assert st2["replayed"] and st2["graph_replays"] >= replays0 + 3
+    same_as_oracle("replayed")
+    if kind == "scircuit":
+        # two NUM_B8K rows in the eager call; the replayed sequence runs them in NUM_B2K at a load of 0.85
+        assert st["num_bin_rows"]["block8k"] > 0 and st2["b8k_folded"]
+        assert st2["num_bin_rows"]["block8k"] == 0
+        assert st2["num_bin_rows"]["block2k"] == st["num_bin_rows"]["block2k"] + st["num_bin_rows"]["block8k"]
+    else:
+        assert not st2["b8k_folded"] or st["num_bin_rows"]["block8k"] * 8 < cfg.sm
+
+
+def test_under_filled_b8k_class_is_folded_at_load_085(cfg):
+    """A handful of rows with 1366..1740 distinct columns (NUM_B8K by the 2/3 rule) next to many NUM_B2K rows:
+    the replayed sequence classifies them into NUM_B2K (2 Ki table, load up to 0.85).  Checked against the oracle
+    eagerly, replayed, and with the fold switched off; a row beyond 1740 keeps the class alive."""
+    rng = np.random.default_rng(17)
+    kb, n = 4000, 3_000_000
+    B = fast_random_csr(kb, n, 12, 18, jitter=False)
+
+    def a_with(heavy_lens):
+        lens = np.concatenate([np.full(400, 60), np.array(heavy_lens)])      # 400 rows of ~700 nnz: NUM_B2K
+        ro = np.zeros(lens.size + 1, dtype=np.uint32)
+        ro[1:] = np.cumsum(lens)
+        col = np.concatenate([np.sort(rng.choice(kb, size=k, replace=False)) for k in lens]).astype(np.uint32)
+        return po.HostCSR(lens.size, kb, ro, col, (0.5 + rng.random(col.size)) * rng.choice([-1.0, 1.0], size=col.size))
+
+    A = a_with([115, 120, 128, 135, 140, 145])         # ~1380 .. ~1740 distinct columns per heavy row
+    R, _ = po.spgemm(A, B)
+    heavy = np.diff(R.row_offsets.astype(np.int64))[400:]
+    assert heavy.min() > 1365 and heavy.max() <= 1740, heavy
+    dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR()
+    sa.MultiplyspECK(dA, dB, dC, cfg)
+    st = cfg.last_stats()
+    assert st["num_bin_rows"]["block8k"] == 6 and not st["b8k_folded"]
+    _assert_matches_oracle(dC, A, B)
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    st2 = cfg.last_stats()
+    assert st2["replayed"] and st2["b8k_folded"] and st2["num_bin_rows"]["block8k"] == 0
+    assert st2["num_bin_rows"]["block2k"] == st["num_bin_rows"]["block2k"] + 6
+    _assert_matches_oracle(dC, A, B)
+    cfg.set_option("fold_small_b8k", 0)
+    try:
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        st3 = cfg.last_stats()
+        assert st3["replayed"] and not st3["b8k_folded"] and st3["num_bin_rows"]["block8k"] == 6
+        _assert_matches_oracle(dC, A, B)
+    finally:
+        cfg.set_option("fold_small_b8k", 1)
+    A2 = a_with([115, 120, 128, 135, 140, 160])         # one row beyond the stretched table: no fold
+    dA2, dC2 = sa.dCSR.from_host(to_sa(A2)), sa.dCSR()
+    for _ in range(4):
+        sa.MultiplyspECK(dA2, dB, dC2, cfg)
+    st4 = cfg.last_stats()
+    assert st4["replayed"] and not st4["b8k_folded"] and st4["num_bin_rows"]["block8k"] == 6
+    _assert_matches_oracle(dC2, A2, B)
+
+
+def test_nlpkkt_full_size_properties_and_sampled_blocks(cfg):
+    """BASELINE.json configs[4] at FULL size (8.4 M rows, 6.0 G products, 1.03 G entries in C) on one GPU, replayed:
+    too large for the oracle in seconds, so the size-independent properties are checked on the device (row
+    offsets, every row strictly ascending and in range, C*1 == A*(A*1)) and the oracle runs on three row blocks."""
+    import torch
+    from oracle import verify as ov
+    A = sa.gen_matrix("nlpkkt", 1.0, 1, signed=True)
+    dev = torch.device("cuda", 0)
+    t_ro = torch.from_numpy(A.row_offsets.view(np.int32)).to(dev)
+    t_col = torch.from_numpy(A.col_ids.view(np.int32)).to(dev)
+    t_val = torch.from_numpy(A.data).to(dev)
+    dA = sa.dCSR.from_device(A.rows, A.cols, A.nnz, t_ro.data_ptr(), t_col.data_ptr(), t_val.data_ptr(),
+                             keep=(t_ro, t_col, t_val), host_row_offsets=A.row_offsets)
+    c = sa.spECKConfig.initialize(0)
+    try:
+        dC = sa.dCSR()
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dA, dC, c)
+        st = c.last_stats()
+        assert st["replayed"] and st["sum_products"] > 2 ** 32 and st["nnz_c"] == dC.nnz > 10 ** 9
+
+        class _Dev:
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = dict(shape=(int(n),), typestr=typestr, data=(int(ptr), False),
+                                                     version=2, strides=None)
+        c_ro = torch.as_tensor(_Dev(dC._c.row_offsets, dC.rows + 1, "<i4"), device=dev)
+        c_col = torch.as_tensor(_Dev(dC._c.col_ids, dC.nnz, "<i4"), device=dev)
+        c_val = torch.as_tensor(_Dev(dC._c.data, dC.nnz, "<f8"), device=dev)
+        ok, d = ov.device_properties(torch, t_ro, t_col, t_val, 0, A.rows, c_ro, c_col, c_val, A.cols)
+        assert ok, d
+        ok, d = ov.sampled_blocks(torch, A, c_ro, c_col, c_val, blocks=3, rows_per_block=20000)
+        assert ok, d
+        torch.cuda.synchronize()
+    finally:
+        c.cleanup()
 
 
 def _assert_matches_oracle(dC, A, B):
@@ -721,3 +843,96 @@ def test_dimensions_exactly_at_the_2_27_limit(cfg):
         assert st2["sym_bin_rows"]["global_hash"] == 0 and st2["nnz_c"] == st["nnz_c"]
     finally:
         cfg.set_option("gh_per_window", 8192)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: input checks, scratch-pool fallbacks, replayed sequences at full size
+def test_column_of_a_beyond_the_rows_of_b_is_rejected(cfg):
+    """A.col_ids index B.row_offsets directly (include/common.cuh:321-459 does the same, unchecked): the analysis
+    clamps an id >= rows(B) and the call returns SPECK_ERR_INVALID with C untouched."""
+    A = random_csr(200, 50, 4, 3)
+    B = random_csr(50, 80, 5, 4)
+    dB = sa.dCSR.from_host(to_sa(B))
+    bad = A.col_ids.copy()
+    bad[len(bad) // 2] = 50                      # == rows(B)
+    Ax = po.HostCSR(A.rows, A.cols, A.row_offsets, bad, A.data)
+    dAx = sa.dCSR.from_host(to_sa(Ax))
+    dC = sa.dCSR()
+    with pytest.raises(sa.SpeckError) as e:
+        sa.MultiplyspECK(dAx, dB, dC, cfg)
+    assert e.value.status == 1
+    assert dC.nnz == 0 and not dC._c.data and not dC._c.col_ids
+    # ... also when the same buffers were multiplied (and replayed) before with valid ids
+    dA = sa.dCSR.from_host(to_sa(A))
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    _assert_matches_oracle(dC, A, B)
+    before = dC.to_host()
+    assert _lib.load().speck_dcsr_update(ctypes.byref(dA._c), None, np.ascontiguousarray(bad).ctypes.data, None, 8) == 0
+    with pytest.raises(sa.SpeckError) as e:
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert e.value.status == 1
+    after = dC.to_host()
+    assert after.nnz == before.nnz and (after.col_ids == before.col_ids).all()
+    check(cfg, A, B)
+
+
+def test_scratch_pool_budget_falls_back_to_the_two_phase_path():
+    """The numeric-first rows' scratch pool is hidden memory: when it does not fit the budget (option
+    nf_pool_max_mb; by default half of the free device memory) the rows are classified again for the two-phase
+    path instead of failing with SPECK_ERR_OOM."""
+    c = sa.spECKConfig.initialize(0)
+    try:
+        A = to_po(sa.gen_matrix("cant", 0.05, 3, signed=True))
+        _, st, _ = check(c, A, A, [("sym", "numeric_first"), ("num", "nfcopy")])
+        pool = st["scratch_pool_bytes"]
+        # slots are min(column range, products) entries of 12 bytes, + 12.5 % slack
+        an = po.analysis(A, A)
+        nf = ((an["row_ops"] >= 512) & (np.diff(A.row_offsets.astype(np.int64)) > 1) &
+              (an["row_col_max"].astype(np.int64) - an["row_col_min"] + 1 <= 4096))
+        slots = np.minimum(an["row_col_max"].astype(np.int64) - an["row_col_min"] + 1, an["row_ops"])[nf].sum()
+        assert 12 * slots <= pool <= 12 * slots * 1.2 + 65536
+        assert st["pool_fallbacks"] == 0
+    finally:
+        c.cleanup()
+    c = sa.spECKConfig.initialize(0)
+    try:
+        c.set_option("nf_pool_max_mb", 1)
+        _, st, _ = check(c, A, A, [("sym", "bitmap256k"), ("num", "dense4k")])
+        assert st["sym_bin_rows"]["numeric_first"] == 0 and st["pool_fallbacks"] == 1
+        for _ in range(3):
+            check(c, A, A)
+        assert c.last_stats()["pool_fallbacks"] == 1      # decided once for the config
+    finally:
+        c.cleanup()
+
+
+def test_replay_with_grown_global_key_sets_does_not_touch_the_old_pool(cfg):
+    """SYM_GH rows whose product count grows under the same pointers (A now references the long rows of B): the
+    key sets no longer fit the pool baked into the replayed sequence; the scatter kernel raises the miss, the
+    key-set kernel must not clear or probe past the pool, and the eager path re-runs."""
+    rng = np.random.default_rng(21)
+    n, kb = 40 << 20, 600
+    lens = np.array([100] * 300 + [330] * 300)
+    bro = np.zeros(kb + 1, dtype=np.uint32)
+    bro[1:] = np.cumsum(lens)
+    bcol = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in lens]).astype(np.uint32)
+    B = po.HostCSR(kb, n, bro, bcol, 0.5 + rng.random(bcol.size))
+    rows, la = 6, 280
+    aro = (np.arange(rows + 1) * la).astype(np.uint32)
+    a1 = np.concatenate([np.sort(rng.choice(300, size=la, replace=False)) for _ in range(rows)]).astype(np.uint32)
+    a2 = (a1 + 300).astype(np.uint32)
+    av = 0.5 + rng.random(rows * la)
+    A1, A2 = po.HostCSR(rows, kb, aro, a1, av), po.HostCSR(rows, kb, aro, a2, av)
+    dA, dB, dC = sa.dCSR.from_host(to_sa(A1)), sa.dCSR.from_host(to_sa(B)), sa.dCSR()
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    st = cfg.last_stats()
+    assert st["sym_bin_rows"]["global_hash"] == rows and st["replayed"]
+    _assert_matches_oracle(dC, A1, B)
+    assert _lib.load().speck_dcsr_update(ctypes.byref(dA._c), None, np.ascontiguousarray(a2).ctypes.data, None, 8) == 0
+    misses = st["numeric_reruns"]
+    sa.MultiplyspECK(dA, dB, dC, cfg)
+    _assert_matches_oracle(dC, A2, B)
+    st = cfg.last_stats()
+    assert st["numeric_reruns"] == misses + 1 and st["sym_bin_rows"]["global_hash"] == rows
