@@ -23,9 +23,10 @@ void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceS
 void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st,
                        u64 b_nnz);
 
-// exclusive scan of the row counts (+ numeric classification, stats fold, ordered scatter of the
-// numeric row records when num_cls != nullptr).
-void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
+// exclusive scan of the row counts into offsets_out (may alias counts; + numeric classification, stats fold,
+// ordered scatter of the numeric row records when num_cls != nullptr).  offsets_out is left as it was when a
+// check of the call fails (capacity_miss, invalid input, nnz overflow).
+void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
                  DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u);

@@ -176,6 +176,8 @@ struct Scratch {
     u32 *b_start, *b_len;  // per A entry: the referenced B row (written by the analysis)
     u32 *w_start, *w_len;  // per A entry: its B entries inside the current column window (multi-window rows)
     u64* nf_off;           // per row: scratch slot of a numeric-first row
+    u32* counts;           // per row (+1): nnz of the C row, written by the symbolic kernels
+    u32* offsets;          // per row (+1): C.row_offsets of an eager call until C is known to be allocated
 };
 
 u32 partial_blocks(u32 m) { return std::max(analysis_blocks(m), scan_tiles(m)) + 2; }  // + PartialArrays padding
@@ -184,6 +186,7 @@ size_t scratch_bytes(u32 m, u64 nnz_a)
 {
     size_t b = 4 * Carver::need(nnz_a, 4);
     b += 4 * Carver::need(m, 4);
+    b += 2 * Carver::need(size_t(m) + 1, 4);
     b += Carver::need(m, 8);
     b += Carver::need(m, sizeof(RowRec));
     b += Carver::need(m, 1);
@@ -206,6 +209,8 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
     s.row_col_min = cv.take<u32>(m);
     s.row_col_max = cv.take<u32>(m);
     s.cls = cv.take<u8>(m);
+    s.counts = cv.take<u32>(size_t(m) + 1);
+    s.offsets = cv.take<u32>(size_t(m) + 1);
     s.partials = cv.take<BlockPartial>(partial_blocks(m));
     return s;
 }
@@ -413,12 +418,13 @@ struct Timing {
 // analysis -> symbolic classes -> scan + numeric classification.  Nothing here needs a host
 // decision: `sym_mask` only prunes kernels of classes known to be empty (eager path: all).
 int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
-                  const Scratch& sc, u32* c_ro, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
+                  const Scratch& sc, u32* offsets_out, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
                   bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr,
                   DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
                   u32 parts = 3 /* 1: analysis + binning, 2: symbolic launches + scan */, u64 expect_nf = ~0ull)
 {
     const u32 m = (u32)A->rows;
+    u32* const c_ro = sc.counts;  // the symbolic kernels count into scratch; the scan writes offsets_out
     ClassifyParams cp = c->cp;
     cp.sym_allowed = sym_mask;
     cp.num_allowed = num_mask;
@@ -493,7 +499,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         tm->ev_scan = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
-    launch_scan(s, c_ro, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
+    launch_scan(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                 classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
                 host_mirror, expect_g, expect_g_rows);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -746,8 +752,10 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // ANALYSIS + binning + SYMBOLIC + SCAN (Multiply.cu:239-575) -- one read-back
     Timing tm;
     auto front = [&](u32 parts) {
-        return enqueue_front(c, s, A, B, sc, c_ro, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr,
-                             ~0ull, ~0u, parts);
+        // (the offsets go to scratch: C.row_offsets -- possibly the caller's reused buffer -- is written only once
+        //  nothing can fail any more)
+        return enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr,
+                             nullptr, ~0ull, ~0u, parts);
     };
     // analysis + binning, then the input check: B's rows strictly ascending and in range (one coalesced pass;
     // A's column ids are checked -- and clamped -- by the analysis itself).  The check sits behind the analysis
@@ -893,6 +901,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     C->col_ids = c_col;
     C->row_offsets = c_ro;
     own_ro = false;
+    HIP_TRY(hipMemcpyAsync(c_ro, sc.offsets, (size_t(m) + 1) * sizeof(u32), hipMemcpyDeviceToDevice, s));
     t->allocC = st.lap();
     t->loadBalanceNumeric = 0.f;
 

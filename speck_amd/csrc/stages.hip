@@ -680,7 +680,7 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
 
 template <int ITEMS>
 __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
-    u32* __restrict__ counts_inout, u32 m, DeviceStats* __restrict__ st,
+    const u32* counts, u32* offsets_out /* may alias counts */, u32 m, DeviceStats* __restrict__ st,
     BlockPartial* __restrict__ parts, u32 nb, const u8* __restrict__ num_cls,
     const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
     const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
@@ -700,11 +700,16 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     u32 tsum = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        c[i] = (base + i) < m ? counts_inout[base + i] : 0;
+        c[i] = (base + i) < m ? counts[base + i] : 0;
         cls[i] = (num_cls && (base + i) < m) ? num_cls[base + i] : (u8)NUM_NONE;
     }
     fold_partials<kScanThreads, NUM_CLASSES>(parts, nb, blockIdx.x, &s_fold, s_bytes, cp.want_bytes != 0);
     const u64 nnz_c = s_fold.sum_total;
+    // C.row_offsets of a replayed sequence is the caller's buffer: it is rewritten only when this call will
+    // complete -- every block sees the flags earlier kernels raised and evaluates this kernel's own checks itself
+    const bool miss = st->capacity_miss || st->b_invalid || st->a_invalid || nnz_c > 0xFFFFFFFFull ||
+                      (exact_nnz != ~0ull && nnz_c != exact_nnz) || (expect_g != ~0ull && s_fold.g_total != expect_g) ||
+                      (expect_g_rows != ~0u && s_fold.total[NUM_G] != expect_g_rows);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->nnz_c = nnz_c;
         st->max_row_nnz_c = s_fold.max_val;
@@ -734,10 +739,10 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         off[i] = run;
-        if (base + i < m) counts_inout[base + i] = run;
+        if (base + i < m && !miss) offsets_out[base + i] = run;
         run += c[i];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts_inout[m] = (u32)nnz_c;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && !miss) offsets_out[m] = (u32)nnz_c;
     if (!num_cls) return;
 
     // class of my rows, packed per-thread histogram, exclusive scan over the threads
@@ -884,7 +889,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                        expect_nf);
 }
 
-void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const u32* row_ops,
+void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
                  DeviceStats* host_mirror, u64 expect_g, u32 expect_g_rows)
@@ -893,9 +898,9 @@ void launch_scan(hipStream_t s, u32* counts_inout, u32 m, const u32* a_ro, const
     auto go = [&](auto items) {
         constexpr int I = decltype(items)::value;
         hipLaunchKernelGGL(num_count_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s,
-                           (const u32*)counts_inout, m, a_ro, row_ops, row_col_min, row_col_max, num_cls,
+                           counts, m, a_ro, row_ops, row_col_min, row_col_max, num_cls,
                            partials, cp, vsize);
-        hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts_inout, m, st,
+        hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, st,
                            partials, tiles, (const u8*)num_cls, a_ro, row_ops,
                            row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, expect_g_rows, host_mirror);
     };
