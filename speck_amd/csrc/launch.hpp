@@ -12,7 +12,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 nnz_a, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
-                     u32* b_start, u32* b_len, hipEvent_t between = nullptr, u64* nf_off = nullptr,
+                     uint2* b_sl, hipEvent_t between = nullptr, u64* nf_off = nullptr,
                      u64 expect_nf = ~0ull, u32 b_rows = ~0u);
 
 // completion ticket of a replayed launch sequence (pinned host word the host spins on)
@@ -59,22 +59,30 @@ struct SpillBuffers {
 struct RowWork {
     const RowRec* recs;     // row records grouped by class (device)
     const DeviceStats* st;  // offsets/counts live here (device)
-    const u32* b_start;     // per A entry (relative to the first entry of the A view):
-    const u32* b_len;       //   start / length of the referenced B row, written by the analysis
+    const uint2* b_sl;      // per A entry (relative to the first entry of the A view): (start, length) of the
+                            //   referenced B row, written by the analysis
     SpillBuffers spill;     // NUM_G class (all null when no row needs it)
     const u64* nf_off;      // numeric-first rows (SYM_NF / NUM_NFCOPY): scratch slot of row r = nf_col/nf_val + nf_off[r]
     u32* nf_col;
     void* nf_val;
     u64 nf_cap;             // entries the pool holds (a slot never ends beyond it)
-    u32* w_start;           // per A entry: start / length of its B row INSIDE the current column window
-    u32* w_len;             //   (multi-window rows, row_groups.hpp WindowCursors); a row's entries belong to its workgroup
+    uint2* w_sl;            // per A entry: (start, length) of its B row INSIDE the current column window
+                            //   (multi-window rows, row_groups.hpp WindowCursors); a row's entries belong to its workgroup
     u32 xcd_aware;          // class lists are walked in per-XCD contiguous slices (row_groups.hpp)
 };
 
 // Block ranges of the classes inside a merged ("light") launch: class slot k owns the blocks
 // [first[k], first[k+1]).
+// Host-known position of a class list inside the record array (exact counts of the previous identical call, or
+// of a read-back of this one): lets a workgroup request its first record without waiting for the device-side
+// table -- the table is still what decides (a stale hint only costs the second request).  cnt = ~0: unknown.
+struct ClassHint {
+    u32 off, cnt;
+};
+constexpr ClassHint kNoHint{0xFFFFFFFFu, 0xFFFFFFFFu};
 struct ClassGrid {
     u32 first[10];
+    ClassHint hint[9];
 };
 constexpr u32 kSymLightMask = (1u << SYM_BM1) | (1u << SYM_B4K) | (1u << SYM_W1K) | (1u << SYM_W256) | (1u << SYM_G16) |
                               (1u << SYM_G8) | (1u << SYM_W128);
@@ -83,18 +91,20 @@ constexpr u32 kNumLightMask = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512
 
 // One launch for all 256-thread classes in `mask`.  counts_hint[cls] sizes each class' block range
 // (the kernels read the real counts on the device and stride, so a stale hint only costs speed).
+// `exact`: counts_hint holds the exact rows of EVERY class (the kernels then get ClassHints).
 void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, const u32* a_ro,
-                           const u32* b_start, const u32* b_len, const u32* b_col, const RowWork& w,
-                           u32* counts, int cu_count);
+                           const uint2* b_sl, const u32* b_col, const RowWork& w,
+                           u32* counts, int cu_count, bool exact = false);
 template <typename T>
 void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const CsrView<T>& A,
-                          const CsrView<T>& B, const RowWork& w, u32* c_col, T* c_val, int cu_count);
+                          const CsrView<T>& B, const RowWork& w, u32* c_col, T* c_val, int cu_count,
+                          bool exact = false);
 
 // Launch the symbolic kernel of class `cls`.  `count` is an UPPER BOUND of the class' row count
 // (the rows of A): the grid depends only on it, the kernels read the real count from the
 // device-side stats block, so the launch sequence is static and can be captured in a hipGraph.
-void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u32* b_start,
-                     const u32* b_len, const u32* b_col, const RowWork& w, u32* counts, int cu_count);
+void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const uint2* b_sl,
+                     const u32* b_col, const RowWork& w, u32* counts, int cu_count);
 
 // SYM_NF: the dense-window numeric kernel in the symbolic phase (rows to their scratch slots, nnz to `counts`)
 template <typename T>
@@ -109,6 +119,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& A, cons
 u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block);
 // resident-set multiples a class grid may reach before its workgroups start striding over rows
 void set_grid_rounds(u32 block_classes, u32 subwave_classes);
+void set_tiny_threads(int threads);  // workgroup size of the merged small-row numeric launch (64 / 128 / 256)
 
 // LDS bytes a class needs (for occupancy-aware grid sizing and DESIGN.md tables)
 u32 symbolic_lds_bytes(int cls);

@@ -47,7 +47,7 @@ constexpr u32 num_direct_lds()
 template <typename T, int THREADS>
 __device__ __forceinline__ void num_direct_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                                 u32* __restrict__ c_col, T* __restrict__ c_val, u32 bidx,
-                                                u32 nblk)
+                                                u32 nblk, ClassHint hint = kNoHint)
 {
     using G = Block<THREADS>;
     const G g;
@@ -57,21 +57,33 @@ __device__ __forceinline__ void num_direct_body(unsigned char* smem, const Produ
     u32* m_dst = m_src + THREADS;
     u32* scratch = m_dst + THREADS;
     u32* win_all = scratch + THREADS / 64 + 2;
-    const u32 count = w.st->num.count[NUM_DIRECT];
-    const RowRec* recs = w.recs + w.st->num.offset[NUM_DIRECT];
     const u32 l = lane_id();
     u32* win = win_all + (threadIdx.x >> 6) * kWinWords;
-    const RowSlice rs = row_slice(count, bidx, nblk, THREADS, 0u, (w.xcd_aware & 1u) != 0);
+    // (a thread per row of the chunk: the speculative first record of open_list is that of thread 0's row only,
+    //  so the records are requested here, from the hinted position, and re-requested if the table disagrees)
+    const u32 miss = w.st->capacity_miss;
+    u32 off = w.st->num.offset[NUM_DIRECT], count = w.st->num.count[NUM_DIRECT];
+    RowSlice rs{};
+    RowRec first_rec{};
+    const bool hinted = hint.cnt != 0xFFFFFFFFu;
+    if (hinted) {
+        rs = row_slice(hint.cnt, bidx, nblk, THREADS, 0u, (w.xcd_aware & 1u) != 0);
+        if (rs.idx + threadIdx.x < rs.end) first_rec = (w.recs + hint.off)[rs.idx + threadIdx.x];
+    }
+    if (miss) return;
+    const bool spec_ok = hinted && off == hint.off && count == hint.cnt;
+    const RowRec* recs = w.recs + off;
+    if (!spec_ok) rs = row_slice(count, bidx, nblk, THREADS, 0u, (w.xcd_aware & 1u) != 0);
     for (u32 first = rs.idx; first < rs.end; first += rs.stride) {
         const u32 cnt = min((u32)THREADS, rs.end - first);
         u32 len = 0, bs = 0, base = 0;
         T av = T(0);
         if (threadIdx.x < cnt) {
-            const RowRec rec = recs[first + threadIdx.x];
+            const RowRec rec = (spec_ok && first == rs.idx) ? first_rec : recs[first + threadIdx.x];
             len = rec.nnz;
             base = rec.base;
             av = src.a_val[rec.a0];
-            bs = src.b_start[rec.a0];
+            bs = src.b_sl[rec.a0].x;
         }
         u32 total;
         const u32 incl = g.inclusive_scan(len, &total, scratch);
@@ -357,7 +369,7 @@ constexpr u32 num_group_lds()
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0>
 __device__ __forceinline__ void num_hash_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                               u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
-                                              u32 bidx, u32 nblk)
+                                              u32 bidx, u32 nblk, ClassHint hint = kNoHint)
 {
     constexpr u32 NG = THREADS / G::SIZE;
     constexpr u32 kGroupBytes = num_group_lds<G, T, CAP, THREADS>();
@@ -377,12 +389,12 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     u32* scan_scratch = m_incl + 2 * G::SIZE;
     RowMeta<T> meta{m_incl, m_incl + G::SIZE, m_av, scan_scratch + scan_scratch_words<G, THREADS>()};
     u32* S = reinterpret_cast<u32*>(mine);
-    const RowRec* recs = w.recs + w.st->num.offset[cls];
-    const RowSlice rs = row_slice(w.st->num.count[cls], bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
-    u32 idx = rs.idx;
-    const u32 stride = rs.stride, count = rs.end;
-    RowRec next{};
-    if (idx < count) next = recs[idx];
+    const ListHead head = open_list<false>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
+    if (head.miss) return;
+    const RowRec* recs = head.recs;
+    u32 idx = head.rs.idx;
+    const u32 stride = head.rs.stride, count = head.rs.end;
+    RowRec next = head.next;
     while (idx < count) {
         PHASE_BEGIN(cls);
         const RowRec rec = next;  // fetched while the previous row was being processed
@@ -442,7 +454,7 @@ constexpr u32 num_dense_lds()
 template <typename T, u32 WCOLS, int THREADS>
 __device__ __forceinline__ void num_dense_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                                u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
-                                               u32 bidx, u32 nblk)
+                                               u32 bidx, u32 nblk, ClassHint hint = kNoHint)
 {
     constexpr u32 WORDS = WCOLS / 32;
     using G = Block<THREADS>;
@@ -453,10 +465,11 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
     u32* pref = bm + WORDS;
     u32* scratch = pref + WORDS + 2 * THREADS;
     RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av, scratch + THREADS / 64 + 2};
-    const RowSlice rs = row_slice(w.st->num.count[cls], bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
-    const RowRec* recs = w.recs + w.st->num.offset[cls];
-    RowRec next{};
-    if (rs.idx < rs.end) next = recs[rs.idx];
+    const ListHead head = open_list<false>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
+    if (head.miss) return;
+    const RowSlice rs = head.rs;
+    const RowRec* recs = head.recs;
+    RowRec next = head.next;
     for (u32 i = threadIdx.x; i < WCOLS; i += THREADS) vals[i] = 0;
     for (u32 i = threadIdx.x; i < WORDS; i += THREADS) bm[i] = 0;
     __syncthreads();
@@ -466,11 +479,10 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
         u32 emitted = 0;
         // a row wider than one window: per-entry cursors, every B entry is read once (WindowCursors)
         const bool multi = u64(rec.cmax) - rec.cmin + 1 > WCOLS;
-        const WindowCursors<THREADS> cur{src.b_start, src.b_len, src.b_col, src.w_start, src.w_len, rec.a0, rec.a1};
+        const WindowCursors<THREADS> cur{src.b_sl, src.b_col, src.w_sl, rec.a0, rec.a1};
         ProductSrc<T> wsrc = src;
         if (multi) {
-            wsrc.b_start = src.w_start;
-            wsrc.b_len = src.w_len;
+            wsrc.b_sl = src.w_sl;
             cur.reset();
         }
         u32 wbase = rec.cmin;
@@ -655,7 +667,6 @@ __global__ __launch_bounds__(THREADS) void num_direct_kernel(ProductSrc<T> src, 
                                                              u32* __restrict__ c_col,
                                                              T* __restrict__ c_val)
 {
-    if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     num_direct_body<T, THREADS>(smem, src, w, c_col, c_val, blockIdx.x, gridDim.x);
@@ -667,7 +678,6 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, co
                                                            T* __restrict__ c_val, int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     num_hash_body<G, T, CAP, W1, NMAX, MODE, THREADS, NLO>(smem, src, w, c_col, c_val, cls, blockIdx.x,
                                                            gridDim.x);
@@ -679,7 +689,6 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
                                                             T* __restrict__ c_val, int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     num_dense_body<T, WCOLS, THREADS>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
 }
@@ -695,57 +704,57 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
                                                         ClassGrid cg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
     // launch order (ClassGrid slots): D1, B2K, W512, W256, W128, G16, G8, DIRECT
+    // (every body starts with open_list: its first record is requested from the hinted list position while the
+    //  device-side table and the capacity_miss flag are still on their way)
     if (b < cg.first[1])
-        num_dense_body<T, kNumD1Win, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0]);
+        num_dense_body<T, kNumD1Win, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0], cg.hint[0]);
     else if (b < cg.first[2])
         num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KStretchNnz, SORT_BITMAP, 256>(
-            smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1]);
+            smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1], cg.hint[1]);
     else if (b < cg.first[3])
         num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
-            smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2]);
+            smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2], cg.hint[2]);
     else if (b < cg.first[4])
         num_hash_body<SubWave<32>, T, kNumW256Cap, kW256W1, kNumW256MaxNnz, SORT_BITMAP, 256>(
-            smem, src, w, c_col, c_val, NUM_W256, b - cg.first[3], cg.first[4] - cg.first[3]);
+            smem, src, w, c_col, c_val, NUM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.hint[3]);
     else if (b < cg.first[5])
         num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4]);
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
     else if (b < cg.first[6])
         num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5]);
+            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else if (b < cg.first[7])
         num_hash_body<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6]);
+            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
     else
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7]);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
 }
 
 // The three smallest classes alone: the merged kernel above takes the register count of its
 // hungriest body (5 waves per SIMD); these bodies need 70 VGPRs, and a launch of their own
 // reaches 7 waves per SIMD -- what rows that are one short chain of dependent loads need.
-template <typename T>
-__global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
-                                                       u32* __restrict__ c_col, T* __restrict__ c_val,
-                                                       ClassGrid cg)
+template <typename T, int TT>
+__global__ __launch_bounds__(TT) void num_tiny_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                      u32* __restrict__ c_col, T* __restrict__ c_val,
+                                                      ClassGrid cg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (w.st->capacity_miss) return;
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
     if (b < cg.first[5])
-        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4]);
+        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, TT>(
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
     else if (b < cg.first[6])
-        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5]);
+        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, TT>(
+            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else if (b < cg.first[7])
-        num_hash_body<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6]);
+        num_hash_body<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, TT>(
+            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
     else
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7]);
+        num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
 }
 
 // ------------------------------------------------------------------ NUM_G
@@ -1208,27 +1217,56 @@ static void launch_num_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
                        dim3(THREADS), lds, s, A, B, w, c_col, c_val, cls);
 }
 
+static int g_tiny_threads = 256;
+void set_tiny_threads(int t) { g_tiny_threads = (t == 64 || t == 128) ? t : 256; }
+
 template <typename T>
 void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const CsrView<T>& Av,
-                          const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count)
+                          const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count, bool exact)
 {
     static const int slots[8] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W256, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
     static const u32 rows_per_block[8] = {1, 1, 4, 8, 8, 16, 32, 256};
+    bool tiny_only = true;
+    for (int k = 0; k < 4; ++k)
+        if ((mask >> slots[k] & 1u) && counts_hint[slots[k]]) tiny_only = false;
+    // the small classes alone run in workgroups of g_tiny_threads threads (their groups never meet at a barrier
+    // except in the scaled-copy class, whose chunk is the workgroup)
+    const int threads = tiny_only ? g_tiny_threads : 256;
+    const u32 div = 256u / (u32)threads;
+    auto class_lds = [&](int cls) -> u32 {
+        if (!tiny_only) return numeric_lds_bytes_t<T>(cls);
+        if (cls != NUM_DIRECT) return numeric_lds_bytes_t<T>(cls) / div;
+        return threads == 64 ? num_direct_lds<T, 64>() : threads == 128 ? num_direct_lds<T, 128>() : num_direct_lds<T, 256>();
+    };
     u32 lds = 0;
     for (int k = 0; k < 8; ++k)
-        if (mask >> slots[k] & 1u) lds = lds > numeric_lds_bytes_t<T>(slots[k]) ? lds : numeric_lds_bytes_t<T>(slots[k]);
+        if (mask >> slots[k] & 1u) lds = lds > class_lds(slots[k]) ? lds : class_lds(slots[k]);
     ClassGrid cg{};
     for (int k = 0; k < 8; ++k) {
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
-        cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
+        const u32 rpb = rows_per_block[k] >= div ? rows_per_block[k] / div : 1u;
+        cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, threads, cu_count, rpb) : 0u);
     }
     if (cg.first[8] == 0) return;
-    const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
-    if (cg.first[4] == 0)
-        hipLaunchKernelGGL((num_tiny_kernel<T>), dim3(cg.first[8]), dim3(256), lds, s, src, Av.row_offsets, w,
+    for (int k = 0; k < 8; ++k) {
+        cg.hint[k] = kNoHint;
+        if (!exact) continue;
+        u32 off = 0;  // class lists follow each other in class order (publish_bins)
+        for (int c = 0; c < slots[k]; ++c) off += counts_hint[c];
+        cg.hint[k] = ClassHint{off, counts_hint[slots[k]]};
+    }
+    const ProductSrc<T> src{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
+    if (!tiny_only)
+        hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[8]), dim3(256), lds, s, src, Av.row_offsets, w,
+                           c_col, c_val, cg);
+    else if (threads == 64)
+        hipLaunchKernelGGL((num_tiny_kernel<T, 64>), dim3(cg.first[8]), dim3(64), lds, s, src, Av.row_offsets, w,
+                           c_col, c_val, cg);
+    else if (threads == 128)
+        hipLaunchKernelGGL((num_tiny_kernel<T, 128>), dim3(cg.first[8]), dim3(128), lds, s, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else
-        hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[8]), dim3(256), lds, s, src, Av.row_offsets, w,
+        hipLaunchKernelGGL((num_tiny_kernel<T, 256>), dim3(cg.first[8]), dim3(256), lds, s, src, Av.row_offsets, w,
                            c_col, c_val, cg);
 }
 
@@ -1237,7 +1275,7 @@ void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& Av, const 
                           u32* counts, int cu_count, u32 wcols)
 {
     if (count == 0) return;
-    const ProductSrc<T> src{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
+    const ProductSrc<T> src{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
     wcols = wcols < 256u ? 256u : (wcols > kNumD1Cols ? kNumD1Cols : (wcols + 255u) & ~255u);
     const u32 lds = (wcols + 256) * (u32)sizeof(Acc<T>) + wcols +
                     (2 * 256 + 256 / 64 + 2 + win_words<Block<256>>() + 3) / 4 * 16;
@@ -1252,7 +1290,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
 {
     if (count == 0) return;
     // (A, B) below = (product source, A.row_offsets): the kernels rebase the per-entry arrays
-    const ProductSrc<T> A{w.b_start, w.b_len, Av.data, Bv.col_ids, Bv.data, w.w_start, w.w_len};
+    const ProductSrc<T> A{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
     const u32* B = Av.row_offsets;
     const u32 lds = numeric_lds_bytes_t<T>(cls);
     switch (cls) {
@@ -1364,9 +1402,9 @@ extern "C" int speck_debug_phase_clocks(unsigned long long* out)
 namespace speck {
 
 template void launch_numeric_light<double>(hipStream_t, const u32*, u32, const CsrView<double>&,
-                                           const CsrView<double>&, const RowWork&, u32*, double*, int);
+                                           const CsrView<double>&, const RowWork&, u32*, double*, int, bool);
 template void launch_numeric_light<float>(hipStream_t, const u32*, u32, const CsrView<float>&,
-                                          const CsrView<float>&, const RowWork&, u32*, float*, int);
+                                          const CsrView<float>&, const RowWork&, u32*, float*, int, bool);
 template void launch_numeric_first<double>(hipStream_t, u32, const CsrView<double>&, const CsrView<double>&,
                                            const RowWork&, u32*, int, u32);
 template void launch_numeric_first<float>(hipStream_t, u32, const CsrView<float>&, const CsrView<float>&,

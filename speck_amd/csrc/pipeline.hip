@@ -173,8 +173,8 @@ struct Scratch {
     RowRec* recs;  // one 32-byte record per row, grouped by kernel class
     u8* cls;
     BlockPartial* partials;
-    u32 *b_start, *b_len;  // per A entry: the referenced B row (written by the analysis)
-    u32 *w_start, *w_len;  // per A entry: its B entries inside the current column window (multi-window rows)
+    uint2* b_sl;  // per A entry: (start, length) of the referenced B row (written by the analysis)
+    uint2* w_sl;  // per A entry: its B entries inside the current column window (multi-window rows)
     u64* nf_off;           // per row: scratch slot of a numeric-first row
     u32* counts;           // per row (+1): nnz of the C row, written by the symbolic kernels
     u32* offsets;          // per row (+1): C.row_offsets of an eager call until C is known to be allocated
@@ -184,7 +184,7 @@ u32 partial_blocks(u32 m) { return std::max(analysis_blocks(m), scan_tiles(m)) +
 
 size_t scratch_bytes(u32 m, u64 nnz_a)
 {
-    size_t b = 4 * Carver::need(nnz_a, 4);
+    size_t b = 2 * Carver::need(nnz_a, 8);
     b += 4 * Carver::need(m, 4);
     b += 2 * Carver::need(size_t(m) + 1, 4);
     b += Carver::need(m, 8);
@@ -198,10 +198,8 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
 {
     Carver cv(c->arena);
     Scratch s;
-    s.b_start = cv.take<u32>(nnz_a);
-    s.b_len = cv.take<u32>(nnz_a);
-    s.w_start = cv.take<u32>(nnz_a);
-    s.w_len = cv.take<u32>(nnz_a);
+    s.b_sl = cv.take<uint2>(nnz_a);
+    s.w_sl = cv.take<uint2>(nnz_a);
     s.nf_off = cv.take<u64>(m);
     s.recs = cv.take<RowRec>(m);
     s.row_ops = cv.take<u32>(m);
@@ -248,15 +246,13 @@ RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill)
     RowWork w{};
     w.recs = sc.recs;
     w.st = c->d_stats;
-    w.b_start = sc.b_start;
-    w.b_len = sc.b_len;
+    w.b_sl = sc.b_sl;
     w.spill = spill;
     w.nf_off = sc.nf_off;
     w.nf_col = static_cast<u32*>(c->nfpool);
     w.nf_val = c->nfpool ? static_cast<unsigned char*>(c->nfpool) + Carver::need(c->nf_cap_entries, 4) : nullptr;
     w.nf_cap = c->nfpool ? c->nf_cap_entries : 0;
-    w.w_start = sc.w_start;
-    w.w_len = sc.w_len;
+    w.w_sl = sc.w_sl;
     w.xcd_aware = c->xcd_aware;
     return w;
 }
@@ -441,7 +437,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         }
         launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
                         sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
-                        c->d_stats, cp, sc.b_start, sc.b_len, between, sc.nf_off, expect_nf, (u32)B->rows);
+                        c->d_stats, cp, sc.b_sl, between, sc.nf_off, expect_nf, (u32)B->rows);
         if (timed) {
             tm->ev_analysis_end = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -478,7 +474,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                              if (cls == kLightBig || cls == kLightTiny) {
                                  const u32 part = cls == kLightBig ? sym_big : ~sym_big;
                                  launch_symbolic_light(ks, hint, sym_mask & kSymLightMask & part, A->row_offsets,
-                                                       sc.b_start, sc.b_len, B->col_ids, w, c_ro, c->sm);
+                                                       sc.b_sl, B->col_ids, w, c_ro, c->sm,
+                                                       sym_hint != nullptr);
                              } else if (cls == SYM_NF) {
                                  // the numeric dense-window kernel, in the symbolic phase (numeric.hip)
                                  if (vsize == 8) {
@@ -491,7 +488,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                                      launch_numeric_first<float>(ks, hint[cls], Av, Bv, w, c_ro, c->sm, c->nf_wcols);
                                  }
                              } else
-                                 launch_symbolic(ks, cls, hint[cls], A->row_offsets, sc.b_start, sc.b_len,
+                                 launch_symbolic(ks, cls, hint[cls], A->row_offsets, sc.b_sl,
                                                  B->col_ids, w, c_ro, c->sm);
                          });
     if (rc != SPECK_OK) return rc;
@@ -542,7 +539,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
                            if (cls == kLightBig || cls == kLightTiny) {
                                const u32 part = cls == kLightBig ? num_big : ~num_big;
                                launch_numeric_light<T>(ks, hint, num_mask & kNumLightMask & part, Av, Bv, w, c_col,
-                                                       c_val, c->sm);
+                                                       c_val, c->sm, counts != nullptr);
                            } else
                                launch_numeric<T>(ks, cls, hint[cls], Av, Bv, w, c_col, c_val, c->sm);
                        });
@@ -751,11 +748,13 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     // ANALYSIS + binning + SYMBOLIC + SCAN (Multiply.cu:239-575) -- one read-back
     Timing tm;
+    u32 sym_now[kMaxClasses];
+    const u32* sym_known = nullptr;  // rows per symbolic class, once a read-back of this call has them
     auto front = [&](u32 parts) {
         // (the offsets go to scratch: C.row_offsets -- possibly the caller's reused buffer -- is written only once
         //  nothing can fail any more)
-        return enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr,
-                             nullptr, ~0ull, ~0u, parts);
+        return enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm,
+                             parts == 2u ? sym_known : nullptr, nullptr, ~0ull, ~0u, parts);
     };
     // analysis + binning, then the input check: B's rows strictly ascending and in range (one coalesced pass;
     // A's column ids are checked -- and clamped -- by the analysis itself).  The check sits behind the analysis
@@ -788,6 +787,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         }
         if (rc != SPECK_OK) return fail(rc);
         c->nf_wcols = c->h_stats->nf_max_range ? c->h_stats->nf_max_range : kNumD1Cols;
+        // the read-back also buys right-sized grids, fork decisions and list positions for the symbolic launches
+        std::memcpy(sym_now, c->h_stats->sym.count, sizeof(sym_now));
+        sym_known = sym_now;
     }
     // (with both scratch-pool classes off the symbolic kernels run before the host has seen the verdict of the
     //  check: they stay inside their tables and windows whatever B holds, and nothing of C is written before the
@@ -1168,6 +1170,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         set_grid_rounds(0, (u32)value);
         drop_graph(c);
     }
+    else if (n == "tiny_threads") {
+        set_tiny_threads((int)value);
+        drop_graph(c);
+    }
     else if (n == "split_light") {
         c->split_light = value != 0;
         drop_graph(c);
@@ -1247,7 +1253,7 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
                         ClassifyParams cp = c->cp;
                         cp.sym_allowed = cp.num_allowed = 0xFFFFFFFFu;
                         return cp;
-                    }(), nullptr, nullptr, nullptr, nullptr, ~0ull, (u32)B->rows);
+                    }(), nullptr, nullptr, nullptr, ~0ull, (u32)B->rows);
     HIP_TRY(hipGetLastError());
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return rc;

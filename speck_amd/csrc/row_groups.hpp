@@ -13,6 +13,7 @@
 //   3. the kBatch gathers of a lane are all issued before the first of them is accumulated.
 #pragma once
 #include "device_common.hpp"
+#include "launch.hpp"
 
 namespace speck {
 
@@ -161,6 +162,38 @@ __device__ __forceinline__ RowSlice row_slice(u32 count, u32 bidx, u32 nblk, u32
     return RowSlice{lo + j * groups + gid, hi, nb_x * groups};
 }
 
+// First step of every class body: where the class' row list starts, which of its rows this group walks, the
+// first record -- and whether the (replayed) launch sequence was declared void by an earlier kernel.  With a
+// host-known position of the list (ClassHint) the first record is requested AT ONCE, next to the device-side
+// table that confirms the position: a workgroup of the sub-wave classes lives for one or two rows, and the
+// chain table -> record -> A entries -> B entries is most of that life.
+struct ListHead {
+    const RowRec* recs;
+    RowSlice rs;
+    RowRec next;
+    u32 miss;
+};
+template <bool SYM>
+__device__ __forceinline__ ListHead open_list(const RowWork& w, int cls, ClassHint h, u32 bidx, u32 nblk, u32 groups,
+                                              u32 gid, bool xcd_aware)
+{
+    const BinTable& bt = SYM ? w.st->sym : w.st->num;
+    ListHead L;
+    L.miss = w.st->capacity_miss;
+    const u32 off = bt.offset[cls], cnt = bt.count[cls];
+    L.next = RowRec{};
+    if (h.cnt != 0xFFFFFFFFu) {
+        L.recs = w.recs + h.off;
+        L.rs = row_slice(h.cnt, bidx, nblk, groups, gid, xcd_aware);
+        if (L.rs.idx < L.rs.end) L.next = L.recs[L.rs.idx];
+        if (off == h.off && cnt == h.cnt) return L;
+    }
+    L.recs = w.recs + off;
+    L.rs = row_slice(cnt, bidx, nblk, groups, gid, xcd_aware);
+    if (L.rs.idx < L.rs.end) L.next = L.recs[L.rs.idx];
+    return L;
+}
+
 // Per-group LDS staging area for one chunk of A entries (SIZE entries).
 template <typename T>
 struct RowMeta {
@@ -172,28 +205,25 @@ struct RowMeta {
 
 constexpr int kBatch = 4;  // products per lane fetched before accumulating (memory-level parallelism)
 
-// Where the products of a row come from.  b_start / b_len hold, per entry of A, the first entry
-// and the length of the B row it references: the analysis pass reads B.row_offsets for every A
-// entry anyway and writes them out (8 B per A entry), so the symbolic and numeric kernels load
-// them coalesced next to a_ik instead of gathering B.row_offsets behind A.col_ids -- one
-// dependent global round trip less per row.  Both are indexed by (absolute A entry - e_base).
+// Where the products of a row come from.  b_sl holds, per entry of A, the first entry (x) and the length (y)
+// of the B row it references: the analysis pass reads B.row_offsets for every A entry anyway and writes the
+// pair out (8 B per A entry, ONE load for the class kernels), so the symbolic and numeric kernels load it
+// coalesced next to a_ik instead of gathering B.row_offsets behind A.col_ids -- one dependent global round
+// trip less per row.  Indexed by (absolute A entry - e_base).
 template <typename T>
 struct ProductSrc {
-    const u32* b_start;  // (no __restrict__: the windowed walk of a multi-window row points these at w_start /
-    const u32* b_len;    //  w_len, which the same workgroup rewrites between two windows)
+    const uint2* b_sl;  // (no __restrict__: the windowed walk of a multi-window row points this at w_sl, which
+                        //  the same workgroup rewrites between two windows)
     const T* __restrict__ a_val;
     const u32* __restrict__ b_col;
     const T* __restrict__ b_val;
-    u32* w_start;  // window cursors of multi-window rows (WindowCursors below), same indexing
-    u32* w_len;
+    uint2* w_sl;  // window cursors of multi-window rows (WindowCursors below), same indexing
     // rebase the per-entry arrays so that they can be indexed with absolute A entries
     __device__ __forceinline__ void rebase(const u32* a_row_offsets)
     {
         const u32 e_base = a_row_offsets[0];
-        b_start -= e_base;
-        b_len -= e_base;
-        w_start -= e_base;
-        w_len -= e_base;
+        b_sl -= e_base;
+        w_sl -= e_base;
     }
 };
 
@@ -277,8 +307,9 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
     if (a0 + g.lane < a1) {
         const u32 e = a0 + g.lane;
         if (WITH_VALUES) nav = src.a_val[e];
-        nbs = src.b_start[e];
-        nlen = src.b_len[e];
+        const uint2 sl = src.b_sl[e];
+        nbs = sl.x;
+        nlen = sl.y;
     }
     for (u32 chunk = a0; chunk < a1; chunk += G::SIZE) {
         const u32 cnt = min((u32)G::SIZE, a1 - chunk);
@@ -298,8 +329,9 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
         if (chunk + G::SIZE + g.lane < a1) {
             const u32 e = chunk + G::SIZE + g.lane;
             if (WITH_VALUES) nav = src.a_val[e];
-            nbs = src.b_start[e];
-            nlen = src.b_len[e];
+            const uint2 sl = src.b_sl[e];
+            nbs = sl.x;
+            nlen = sl.y;
         }
         PHASE_MARK(10);
         u32 p, step, end;
@@ -411,25 +443,20 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
 // contiguous run behind the entry's cursor: every B entry is READ ONCE per row however many windows
 // there are (role of the reference's per-A-nnz resume cursors, include/GPU/spECK_HashSpGEMM.cuh:
 // 1175-1298, 1475-1569; kept in LDS there, spilled to a global cursor pool for long A rows, :1600-1619).
-// Here the cursors always live in global memory -- w_start / w_len, one pair per A entry, touched only
+// Here the cursors always live in global memory -- w_sl, one (start, length) pair per A entry, touched only
 // by the workgroup that owns the row -- because the windowed run lengths then plug into the same
-// flattened product walk (for_each_product reads them where it otherwise reads b_start / b_len).
+// flattened product walk (for_each_product reads them where it otherwise reads b_sl).
 // A window starts at the SMALLEST column not yet consumed, so no window is empty.
 template <int THREADS>
 struct WindowCursors {
-    const u32* __restrict__ b_start;  // rebased like ProductSrc's
-    const u32* __restrict__ b_len;
+    const uint2* __restrict__ b_sl;  // rebased like ProductSrc's
     const u32* __restrict__ b_col;
-    u32* __restrict__ w_start;
-    u32* __restrict__ w_len;
+    uint2* __restrict__ w_sl;
     u32 a0, a1;
 
     __device__ __forceinline__ void reset() const
     {
-        for (u32 e = a0 + threadIdx.x; e < a1; e += THREADS) {
-            w_start[e] = b_start[e];
-            w_len[e] = 0;
-        }
+        for (u32 e = a0 + threadIdx.x; e < a1; e += THREADS) w_sl[e] = make_uint2(b_sl[e].x, 0u);
         __syncthreads();
     }
     // advances every cursor past the previous window and returns the first column of the next one
@@ -438,7 +465,8 @@ struct WindowCursors {
     {
         u32 mn = 0xFFFFFFFFu;
         for (u32 e = a0 + threadIdx.x; e < a1; e += THREADS) {
-            const u32 lo = w_start[e] + w_len[e], hi = b_start[e] + b_len[e];
+            const uint2 ws = w_sl[e], bs = b_sl[e];
+            const u32 lo = ws.x + ws.y, hi = bs.x + bs.y;
             if (lo < hi) mn = min(mn, b_col[lo]);
         }
         mn = wave_reduce_min(mn);
@@ -452,7 +480,8 @@ struct WindowCursors {
         if (mn == 0xFFFFFFFFu) return mn;
         const u64 wend = u64(mn) + wcols;  // exclusive
         for (u32 e = a0 + threadIdx.x; e < a1; e += THREADS) {
-            const u32 first = w_start[e] + w_len[e], hi = b_start[e] + b_len[e];
+            const uint2 ws = w_sl[e], bs = b_sl[e];
+            const u32 first = ws.x + ws.y, hi = bs.x + bs.y;
             u32 lo = first, up = hi;  // first entry with column >= wend: gallop from the cursor (a window
             u32 stepw = 1;            //   usually takes a few entries of a B row), then bisect
             while (lo < up) {
@@ -469,10 +498,9 @@ struct WindowCursors {
                 const u32 mid = lo + ((up - lo) >> 1);
                 if (u64(b_col[mid]) < wend) lo = mid + 1; else up = mid;
             }
-            w_start[e] = first;
-            w_len[e] = lo - first;
+            w_sl[e] = make_uint2(first, lo - first);
         }
-        __syncthreads();  // the walk below reads other threads' w_start / w_len (same CU, same L1)
+        __syncthreads();  // the walk below reads other threads' w_sl (same CU, same L1)
         return mn;
     }
 };

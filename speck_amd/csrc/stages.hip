@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* __restrict__ row_ops,
     u32* __restrict__ row_max_ops, u32* __restrict__ row_col_min, u32* __restrict__ row_col_max,
     u8* __restrict__ sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
-    ClassifyParams cp, u32* __restrict__ b_start, u32* __restrict__ b_len, DeviceStats* __restrict__ st, u32 b_rows)
+    ClassifyParams cp, uint2* __restrict__ b_sl, DeviceStats* __restrict__ st, u32 b_rows)
 {
     constexpr int NW = kAnThreads / 64;
     constexpr int U = 4;   // entries per lane and tile: 256 entries cover most 32-row sub-chunks in ONE
@@ -141,10 +141,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
                     const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
                     bs[u] = ok[u] ? pr.x : 0u;
                     be[u] = ok[u] ? pr.y : 0u;
-                    if (ok[u] && b_start) {
-                        b_start[e - e_base] = bs[u];
-                        b_len[e - e_base] = be[u] - bs[u];
-                    }
+                    if (ok[u] && b_sl) b_sl[e - e_base] = make_uint2(bs[u], be[u] - bs[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -181,10 +178,8 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
                 const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
                 bs[u] = ok[u] ? pr.x : 0u;
                 be[u] = ok[u] ? pr.y : 0u;
-                if (ok[u] && b_start) {  // hand the B-row bounds to the symbolic / numeric kernels
-                    b_start[e - e_base] = bs[u];
-                    b_len[e - e_base] = be[u] - bs[u];
-                }
+                // hand the B-row bounds to the symbolic / numeric kernels
+                if (ok[u] && b_sl) b_sl[e - e_base] = make_uint2(bs[u], be[u] - bs[u]);
             }
             AN_MARK(1);
 #pragma unroll
@@ -874,13 +869,13 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 /*nnz_a*/, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
-                     u32* b_start, u32* b_len, hipEvent_t between, u64* nf_off, u64 expect_nf, u32 b_rows)
+                     uint2* b_sl, hipEvent_t between, u64* nf_off, u64 expect_nf, u32 b_rows)
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
     hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kAnThreads), 0, s, a_ro, a_col, b_ro, b_col, m,
                        rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                       partials, cp, b_start, b_len, st, b_rows);
+                       partials, cp, b_sl, st, b_rows);
     if (between) (void)hipEventRecord(between, s);  // analysis | binning (Timings::countProducts / loadBalanceCounting)
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,

@@ -35,7 +35,7 @@ constexpr u32 sym_group_lds()
 template <class G, u32 CAP, int THREADS>
 __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const ProductSrc<float>& src,
                                               const RowWork& w, u32* __restrict__ counts, int cls, u32 bidx,
-                                              u32 nblk)
+                                              u32 nblk, ClassHint hint = kNoHint)
 {
     constexpr u32 NG = THREADS / G::SIZE;
     constexpr u32 kGroupBytes = sym_group_lds<G, CAP, THREADS>();
@@ -44,12 +44,11 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
     u32* tab = reinterpret_cast<u32*>(smem + gid * kGroupBytes);
     u32* scratch = tab + CAP + 2 * G::SIZE;
     RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr, scratch + sym_scratch_words<G, THREADS>()};
-    const RowSlice rs = row_slice(w.st->sym.count[cls], bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
-    const RowRec* recs = w.recs + w.st->sym.offset[cls];
-    u32 idx = rs.idx;
-    const u32 stride = rs.stride, count = rs.end;
-    RowRec next{};
-    if (idx < count) next = recs[idx];
+    const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
+    const RowRec* recs = head.recs;
+    u32 idx = head.rs.idx;
+    const u32 stride = head.rs.stride, count = head.rs.end;
+    RowRec next = head.next;
     while (idx < count) {
         const RowRec rec = next;  // fetched while the previous row was being processed
         if (idx + stride < count) next = recs[idx + stride];
@@ -70,7 +69,7 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
 template <u32 WORDS, int THREADS>
 __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const ProductSrc<float>& src,
                                                 const RowWork& w, u32* __restrict__ counts, int cls, u32 bidx,
-                                                u32 nblk)
+                                                u32 nblk, ClassHint hint = kNoHint)
 {
     using G = Block<THREADS>;
     const G g;
@@ -78,21 +77,20 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
     u32* scratch = bm + WORDS + 2 * THREADS;
     RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr, scratch + THREADS / 64 + 2};
     constexpr u64 kWindowCols = u64(WORDS) * 32;
-    const RowSlice rs = row_slice(w.st->sym.count[cls], bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
-    const RowRec* recs = w.recs + w.st->sym.offset[cls];
-    RowRec next{};
-    if (rs.idx < rs.end) next = recs[rs.idx];
+    const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
+    const RowSlice rs = head.rs;
+    const RowRec* recs = head.recs;
+    RowRec next = head.next;
     for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
         const RowRec rec = next;  // fetched while the previous row was being processed
         if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
         u32 total = 0;
         // a row wider than one window: per-entry cursors, every B entry is read once (WindowCursors)
         const bool multi = u64(rec.cmax) - rec.cmin + 1 > kWindowCols;
-        const WindowCursors<THREADS> cur{src.b_start, src.b_len, src.b_col, src.w_start, src.w_len, rec.a0, rec.a1};
+        const WindowCursors<THREADS> cur{src.b_sl, src.b_col, src.w_sl, rec.a0, rec.a1};
         ProductSrc<float> wsrc = src;
         if (multi) {
-            wsrc.b_start = src.w_start;
-            wsrc.b_len = src.w_len;
+            wsrc.b_sl = src.w_sl;
             cur.reset();
         }
         u32 base = rec.cmin;
@@ -246,19 +244,19 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     const u32 b = blockIdx.x;
     // launch order (ClassGrid slots): BM1, B4K, W1K, W256, W128, G16, G8
     if (b < cg.first[1])
-        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0]);
+        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], cg.hint[0]);
     else if (b < cg.first[2])
-        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1]);
+        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], cg.hint[1]);
     else if (b < cg.first[3])
-        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2]);
+        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], cg.hint[2]);
     else if (b < cg.first[4])
-        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3]);
+        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.hint[3]);
     else if (b < cg.first[5])
-        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[4], cg.first[5] - cg.first[4]);
+        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
     else if (b < cg.first[6])
-        sym_hash_body<SubWave<16>, kSymG16Cap, 256>(smem, src, w, counts, SYM_G16, b - cg.first[5], cg.first[6] - cg.first[5]);
+        sym_hash_body<SubWave<16>, kSymG16Cap, 256>(smem, src, w, counts, SYM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else
-        sym_hash_body<SubWave<8>, kSymG8Cap, 256>(smem, src, w, counts, SYM_G8, b - cg.first[6], cg.first[7] - cg.first[6]);
+        sym_hash_body<SubWave<8>, kSymG8Cap, 256>(smem, src, w, counts, SYM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
 }
 
 u32 symbolic_lds_bytes(int cls)
@@ -326,8 +324,8 @@ static void launch_sym_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
 }
 
 void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, const u32* a_ro,
-                           const u32* b_start, const u32* b_len, const u32* b_col, const RowWork& w,
-                           u32* counts, int cu_count)
+                           const uint2* b_sl, const u32* b_col, const RowWork& w,
+                           u32* counts, int cu_count, bool exact)
 {
     static const int slots[7] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_W128, SYM_G16, SYM_G8};
     static const u32 rows_per_block[7] = {1, 1, 4, 8, 16, 16, 32};
@@ -340,16 +338,23 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
     }
     if (cg.first[7] == 0) return;
-    const ProductSrc<float> src{b_start, b_len, nullptr, b_col, nullptr, w.w_start, w.w_len};
+    for (int k = 0; k < 7; ++k) {
+        cg.hint[k] = kNoHint;
+        if (!exact) continue;
+        u32 off = 0;  // class lists follow each other in class order (publish_bins)
+        for (int c = 0; c < slots[k]; ++c) off += counts_hint[c];
+        cg.hint[k] = ClassHint{off, counts_hint[slots[k]]};
+    }
+    const ProductSrc<float> src{b_sl, nullptr, b_col, nullptr, w.w_sl};
     hipLaunchKernelGGL(sym_light_kernel, dim3(cg.first[7]), dim3(256), lds, s, src, a_ro, w, counts, cg);
 }
 
-void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u32* b_start,
-                     const u32* b_len, const u32* b_col, const RowWork& w, u32* counts, int cu_count)
+void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const uint2* b_sl,
+                     const u32* b_col, const RowWork& w, u32* counts, int cu_count)
 {
     if (count == 0) return;
     // (A, B) below = (product source, A.row_offsets): the kernels rebase the per-entry arrays
-    const ProductSrc<float> A{b_start, b_len, nullptr, b_col, nullptr, w.w_start, w.w_len};
+    const ProductSrc<float> A{b_sl, nullptr, b_col, nullptr, w.w_sl};
     const u32* B = a_ro;
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
