@@ -1,7 +1,15 @@
 // runspECK -- the reference's benchmark driver (source/runspECK.cpp:13-32, source/Executor.cpp:13-81,
 // source/RunConfig.cpp:8-23, source/DataLoader.cpp:24-75) on top of the MI355X backend.
 //
-//   runspECK <matrix.mtx | gen:<kind>[:scale[:seed]]> [config.ini]
+//   runspECK <matrix.mtx | gen:<kind>[:scale[:seed]]> [config.ini] [--gpus N] [--shared-gpu]
+//
+// --gpus N (new: the reference is single-GPU, source/Executor.cpp:25): the driver re-launches itself as N rank
+// processes, one per GPU.  Every rank loads the matrix, multiplies its row range of A (speck_partition_rows: equal
+// intermediate products) with the replicated B, and ONE exchange per multiply concatenates the shards on rank 0 --
+// speck_gather_plan of the C ABI: RCCL all-gather of the sizes + grouped send / recv over xGMI, two slots so that
+// the exchange of iteration k runs under the multiply of iteration k + 1.  Rank 0 prints the usual two lines for
+// the CONCATENATED product (and compares it with rocSPARSE when CompareResult is on).  --shared-gpu puts every
+// rank on GPU 0 with the library's host-staged transport (plumbing check on a one-GPU box).
 //
 // Same behaviour: loads "<path>d_.hicsr" if present, else the .mtx (and writes the cache);
 // B = A when square, else A^T; IterationsWarmUp + IterationsExecution calls of
@@ -15,6 +23,9 @@
 // "gen:" inputs are the synthetic SuiteSparse stand-ins (no network in the build image).
 #include <hip/hip_runtime.h>
 #include <rocsparse/rocsparse.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -24,14 +35,18 @@
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <chrono>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "CSR.h"
 #include "Compare.h"
 #include "Multiply.h"
 #include "Transpose.h"
+
+extern char** environ;
 
 namespace {
 
@@ -188,10 +203,82 @@ CSR<double> load_input(const std::string& path)
     return m;
 }
 
+// launcher: N copies of this executable, SPECK_RANK / SPECK_WORLD / SPECK_RENDEZVOUS in their environment
+int launch_ranks(int argc, char* argv[], int gpus)
+{
+    char exe[4096];
+    const ssize_t n = readlink("/proc/self/exe", exe, sizeof(exe) - 1);
+    if (n <= 0) return 1;
+    exe[n] = 0;
+    const std::string rdv = "/tmp/speck_rdv_" + std::to_string(getpid());
+    std::remove(rdv.c_str());
+    std::vector<pid_t> pids;
+    for (int r = 0; r < gpus; ++r) {
+        std::vector<std::string> env_s;
+        for (char** e = environ; *e; ++e) env_s.push_back(*e);
+        env_s.push_back("SPECK_RANK=" + std::to_string(r));
+        env_s.push_back("SPECK_WORLD=" + std::to_string(gpus));
+        env_s.push_back("SPECK_RENDEZVOUS=" + rdv);
+        std::vector<char*> envp;
+        for (auto& x : env_s) envp.push_back(const_cast<char*>(x.c_str()));
+        envp.push_back(nullptr);
+        std::vector<char*> av(argv, argv + argc);
+        av.push_back(nullptr);
+        pid_t pid;
+        if (posix_spawn(&pid, exe, nullptr, nullptr, av.data(), envp.data()) != 0) return 1;
+        pids.push_back(pid);
+    }
+    int worst = 0;
+    for (pid_t pid : pids) {
+        int st = 0;
+        waitpid(pid, &st, 0);
+        const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
+        worst = std::max(worst, rc);
+    }
+    std::remove(rdv.c_str());
+    return worst;
+}
+
+// rank 0 writes the 128-byte id (temp file + rename: readers never see a partial file), the others poll for it
+bool rendezvous_id(const std::string& path, int rank, int transport, unsigned char (&id)[128])
+{
+    if (rank == 0) {
+        if (speck_comm_unique_id(transport, id) != SPECK_OK) return false;
+        const std::string tmp = path + ".tmp";
+        std::ofstream f(tmp, std::ios::binary);
+        f.write(reinterpret_cast<const char*>(id), 128);
+        f.close();
+        return std::rename(tmp.c_str(), path.c_str()) == 0;
+    }
+    for (int i = 0; i < 60000; ++i) {
+        std::ifstream f(path, std::ios::binary);
+        if (f && f.read(reinterpret_cast<char*>(id), 128)) return true;
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    return false;
+}
+
 }  // namespace
 
 int main(int argc, char* argv[])
 {
+    // ---- options behind the two positional arguments of the reference
+    int gpus = 1;
+    bool shared_gpu = false;
+    std::vector<char*> pos;
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--gpus" && i + 1 < argc) gpus = std::atoi(argv[++i]);
+        else if (a == "--shared-gpu") shared_gpu = true;
+        else pos.push_back(argv[i]);
+    }
+    const char* env_rank = std::getenv("SPECK_RANK");
+    if (gpus > 1 && !env_rank) return launch_ranks(argc, argv, gpus);
+    const int rank = env_rank ? std::atoi(env_rank) : 0;
+    const int world = env_rank ? std::atoi(std::getenv("SPECK_WORLD")) : 1;
+    const int device = shared_gpu ? 0 : rank;
+    argc = (int)pos.size();
+    argv = pos.data();
     if (argc < 2) {
         std::printf("no .mtx file path set. please call using 'runspECK /path/to/matrix.mtx [config.ini]'");
         return -1;
@@ -211,13 +298,95 @@ int main(int argc, char* argv[])
         CSR<double> cpuA = load_input(filePath);
         std::cout << "Matrix: " << cpuA.rows << "x" << cpuA.cols << ": " << cpuA.nnz << " nonzeros\n";
         dCSR<double> gpuA, gpuB, dCsrHiRes, dCsrReference, dCsrAbs;
+        if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("no such HIP device for this rank");
         convert(gpuA, cpuA, 0);
         if (gpuA.rows != gpuA.cols)
             spECK::Transpose(gpuA, gpuB);  // DataLoader.cpp:65-69
         else
             convert(gpuB, cpuA, 0);
 
-        auto config = spECK::spECKConfig::initialize(0);
+        auto config = spECK::spECKConfig::initialize(device);
+        if (world > 1) {
+            // ------------------------------------------------------------ row-sharded run (one process per GPU)
+            const int transport = shared_gpu ? SPECK_TRANSPORT_HOSTMEM : SPECK_TRANSPORT_RCCL;
+            unsigned char id[128];
+            if (!rendezvous_id(std::getenv("SPECK_RENDEZVOUS"), rank, transport, id)) throw std::runtime_error("rendezvous failed");
+            speck_comm* comm = nullptr;
+            if (speck_comm_init(device, world, rank, transport, id, &comm) != SPECK_OK) throw std::runtime_error("speck_comm_init failed");
+            speck_dcsr a = gpuA.raw(), b = gpuB.raw();
+            std::vector<uint64_t> bounds(world + 1);
+            if (speck_partition_rows(config.handle, &a, &b, world, bounds.data()) != SPECK_OK) throw std::runtime_error("partition failed");
+            uint64_t products = 0;
+            speck_analysis(config.handle, &a, &b, nullptr, nullptr, nullptr, nullptr, &products, nullptr);
+            speck_dcsr mine = a;  // a VIEW of my rows: offsets stay absolute
+            mine.rows = bounds[rank + 1] - bounds[rank];
+            mine.row_offsets = a.row_offsets + bounds[rank];
+            mine.nnz = cpuA.row_offsets[bounds[rank + 1]] - cpuA.row_offsets[bounds[rank]];
+            // two output matrices (each with its own config: a replayed launch sequence is tied to its buffers)
+            spECK::spECKConfig cfgs[2] = {config, spECK::spECKConfig::initialize(device)};
+            speck_dcsr out[2] = {speck_dcsr{}, speck_dcsr{}};
+            speck_gather_plan* plan = nullptr;
+            speck_dcsr full{};
+            int errors = 0;
+            const int total = iterationsWarmup + iterationsExecution;
+            std::chrono::steady_clock::time_point t0;
+            for (int it = 0; it < total; ++it) {
+                const int slot = it & 1;
+                if (it == iterationsWarmup) {
+                    if (plan) {  // drain, so that the timed region starts from an idle exchange
+                        speck_gather_wait(plan, 0, nullptr);
+                        speck_gather_wait(plan, 1, nullptr);
+                    }
+                    t0 = std::chrono::steady_clock::now();
+                }
+                if (plan && speck_gather_wait(plan, slot, nullptr) != SPECK_OK) throw std::runtime_error("gather wait failed");
+                speck_timings tm{};
+                int rc = speck_multiply_f64(cfgs[slot].handle, &mine, &b, &out[slot], &tm);
+                if (rc != SPECK_OK) throw std::runtime_error(speck_status_string(rc));
+                if (!plan && speck_gather_plan_create(comm, 0, out[slot].rows, b.cols, out[slot].nnz, 8, 2, &plan) != SPECK_OK)
+                    throw std::runtime_error("gather plan failed");
+                if (speck_gather_start(plan, slot, &out[slot]) != SPECK_OK) throw std::runtime_error("gather start failed");
+            }
+            speck_gather_wait(plan, total & 1, nullptr);
+            if (speck_gather_wait(plan, (total - 1) & 1, &full) != SPECK_OK) throw std::runtime_error("gather wait failed");
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() /
+                              std::max(1, iterationsExecution);
+            if (rank == 0) {
+                if (compareResult) {
+                    dCSR<double> absA, absB, got;
+                    CSR<double> cpuAbs;
+                    convert(cpuAbs, cpuA, 0);
+                    for (size_t i = 0; i < cpuAbs.nnz; ++i) cpuAbs.data[i] = std::fabs(cpuAbs.data[i]);
+                    convert(absA, cpuAbs, 0);
+                    if (gpuA.rows != gpuA.cols) spECK::Transpose(absA, absB); else convert(absB, cpuAbs, 0);
+                    if (!rocsparse_reference(gpuA, gpuB, dCsrReference) || !rocsparse_reference(absA, absB, dCsrAbs)) {
+                        std::printf("Error: rocSPARSE reference failed\n");
+                        return 2;
+                    }
+                    speck_dcsr ref = dCsrReference.raw(), sc = dCsrAbs.raw();
+                    uint64_t bad = 1, badv = 1;
+                    speck_compare_bounded_f64(nullptr, &ref, &full, &sc, 1e-12, &bad, &badv);
+                    if (bad || badv) {
+                        std::printf("Error: concatenated matrix incorrect (%llu structure rows, %llu value rows)\n",
+                                    (unsigned long long)bad, (unsigned long long)badv);
+                        ++errors;
+                    }
+                }
+                std::cout << std::setw(20) << "var-SpGEMM -> NNZ: " << full.nnz << std::endl;
+                std::cout << std::setw(20) << "var-SpGEMM SpGEMM: " << ms << " ms" << std::endl;
+                std::cout << std::setw(20) << "var-SpGEMM GFLOPS: " << 2.0 * (double)products / (ms * 1e6) << std::endl;
+                std::cout << "row shards: " << world << " ranks, gatherv to rank 0 ("
+                          << (shared_gpu ? "host-staged, ranks share GPU 0" : "RCCL") << ")" << std::endl;
+                if (compareResult) std::cout << "compare vs rocSPARSE: " << (errors ? "FAILED" : "ok") << std::endl;
+            }
+            speck_gather_plan_destroy(plan);
+            speck_comm_destroy(comm);
+            speck_dcsr_free(&out[0]);
+            speck_dcsr_free(&out[1]);
+            cfgs[1].cleanup();
+            config.cleanup();
+            return errors ? 3 : 0;
+        }
         if (compareResult) {
             // reference product and, for the value bound, |A| * |B| = sum |a*b| per entry (rocSPARSE both)
             dCSR<double> absA, absB;

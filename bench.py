@@ -46,7 +46,7 @@ import torch.distributed as dist  # noqa: E402
 
 import speck_amd as sa  # noqa: E402
 from speck_amd.api import NUM_CLASS_NAMES  # noqa: E402
-from speck_amd.sharding import GatherPlan  # noqa: E402
+from speck_amd.sharding import GatherPlan, NativeComm, NativeGatherPlan, TRANSPORT_HOSTMEM, TRANSPORT_RCCL  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SUITESPARSE_FILES = {"scircuit": "scircuit", "webbase": "webbase-1M", "mac_econ": "mac_econ_fwd500",
@@ -115,6 +115,12 @@ class Env:
         assert self.world == args.gpus or self.world == 1, "launch with torch.distributed.run for --gpus > 1"
         self.dev = torch.device("cuda", self.local_rank)
         self.opts = [o.split("=") for o in args.opt]
+        # the exchange itself: the library's own RCCL gatherv (C ABI); ranks that share one GPU cannot form an
+        # RCCL communicator and take the library's host-staged transport -- same plan / displacement code
+        self.exchange = args.exchange
+        self.comm = None
+        if self.world > 1 and self.exchange == "native":
+            self.comm = NativeComm(self.local_rank, TRANSPORT_HOSTMEM if self.shared_gpu else TRANSPORT_RCCL)
 
     def new_config(self):
         cfg = sa.spECKConfig.initialize(self.local_rank)
@@ -184,11 +190,17 @@ class Job:
             self.plan.wait(slot)  # the exchange that still reads this slot's output matrix
         sa.MultiplyspECK(self.mine, self.dA, sC, scfg)  # returns with C complete in HBM
         if self.gather and exchange:
-            ro, col, val = shard_tensors(sC)
-            if self.plan is None:
-                self.plan = GatherPlan(sC.rows, sC.nnz, col.dtype, val.dtype, self.env.dev, root=0,
-                                       slots=len(self.slots), stage_on_host=self.env.shared_gpu)
-            self.plan.start(slot, ro[1:] - ro[:-1], col, val)
+            if self.env.comm is not None:
+                if self.plan is None:
+                    self.plan = NativeGatherPlan(self.env.comm, sC.rows, sC.cols, sC.nnz, 8, root=0,
+                                                 slots=len(self.slots))
+                self.plan.start(slot, sC)
+            else:
+                ro, col, val = shard_tensors(sC)
+                if self.plan is None:
+                    self.plan = GatherPlan(sC.rows, sC.nnz, col.dtype, val.dtype, self.env.dev, root=0,
+                                           slots=len(self.slots), stage_on_host=self.env.shared_gpu)
+                self.plan.start(slot, ro[1:] - ro[:-1], col, val)
 
     def drain(self):
         if self.plan is not None:
@@ -209,6 +221,8 @@ class Job:
 
     def close(self):
         self.drain()
+        if isinstance(self.plan, NativeGatherPlan):
+            self.plan.close()
         for scfg, _ in self.slots:
             scfg.cleanup()
 
@@ -409,6 +423,8 @@ def main():
     ap.add_argument("--mtx", default=None, help="real MatrixMarket file instead of the stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gatherv exchange")
+    ap.add_argument("--exchange", choices=("native", "torch"), default="native",
+                    help="N>1: speck_gather_* of the C ABI (RCCL inside the library) or torch.distributed")
     ap.add_argument("--no-config5", action="store_true", help="skip the nlpkkt160 strong-scaling leg")
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the other single-GPU configurations")
     ap.add_argument("--no-verify", action="store_true", help="do not check the output of the last timed step")
@@ -457,7 +473,10 @@ def main():
                 "workload": wl_name, "rows": A.rows, "nnzA": A.nnz, "products": res["P"],
                 "nnzC": res["nnzC"], "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",
                 "gather": bool(n_gpus > 1 and not args.no_gather),
-                "exchange": "pipelined gatherv to rank 0" if n_gpus > 1 and not args.no_gather else None,
+                "exchange": (f"pipelined gatherv to rank 0 ({env.exchange}: " +
+                             ("speck_gather_* of the C ABI, " + ("host-staged transport" if env.shared_gpu else "RCCL")
+                              if env.exchange == "native" else "torch.distributed") + ")")
+                if n_gpus > 1 and not args.no_gather else None,
             },
             "verified": None,
             "verify": head["verify"],
@@ -518,6 +537,8 @@ def main():
         out["verified"] = all(checked) if checked else None
         print(json.dumps(out), flush=True)
     failed = rank == 0 and out["verified"] is False
+    if env.comm is not None:
+        env.comm.close()
     if n_gpus > 1:
         dist.destroy_process_group()
     if failed:

@@ -27,8 +27,9 @@ enum {
     SPECK_ERR_NNZ_OVERFLOW = 5,   /* nnz(C) does not fit the u32 row_offsets of dCSR */
     SPECK_ERR_NO_DEVICE = 6,
     SPECK_ERR_IO = 7,
-    SPECK_ERR_UNSORTED = 8        /* a row of B is not strictly ascending / column >= cols: the reference's
+    SPECK_ERR_UNSORTED = 8,       /* a row of B is not strictly ascending / column >= cols: the reference's
                                    * undocumented precondition (its loader sorts, source/CSR.cpp:173-212) */
+    SPECK_ERR_COMM = 9            /* RCCL / shared-memory transport failure (row-sharded multi-GPU exchange) */
 };
 
 /* ---- device CSR: field-for-field the reference's dCSR<T> / dCSRNoDealloc<T>
@@ -161,6 +162,43 @@ int speck_compare_bounded_f64(speck_config *cfg, const speck_dcsr *ref, const sp
 int speck_transpose_f64(speck_config *cfg, const speck_dcsr *A, speck_dcsr *At);
 /* ... and its float instantiation (source/GPU/Transpose.cu:116) */
 int speck_transpose_f32(speck_config *cfg, const speck_dcsr *A, speck_dcsr *At);
+
+/* ---- row-sharded multi-GPU (new: the reference is single-GPU, source/Executor.cpp:25).  One process per GPU;
+ *      rank p multiplies the row range [b_p, b_{p+1}) of A (a view with absolute offsets, boundaries from
+ *      speck_partition_rows) with a replicated B, then ONE exchange concatenates the shards on a root rank:
+ *      ncclAllGather of the shard sizes + a gatherv built from grouped ncclSend / ncclRecv over xGMI (RCCL has no
+ *      gatherv) + a rebase of the received row offsets.  librccl is resolved with dlopen at the first call. ---- */
+enum {
+    SPECK_TRANSPORT_RCCL = 0,     /* device-to-device over xGMI */
+    SPECK_TRANSPORT_HOSTMEM = 1   /* staged through POSIX shared memory: ranks that cannot form an RCCL
+                                   * communicator (several ranks on one GPU -- plumbing checks) */
+};
+typedef struct speck_comm speck_comm;
+typedef struct speck_gather_plan speck_gather_plan;
+/* ncclGetUniqueId: 128 bytes made by ONE rank and handed to the others by the launcher (file, pipe, MPI, ...) */
+int speck_comm_unique_id(int transport, void *id128);
+/* ncclCommInitRank on `device`; collective over all ranks of the job */
+int speck_comm_init(int device, int nranks, int rank, int transport, const void *id128, speck_comm **out);
+int speck_comm_destroy(speck_comm *comm);
+int speck_comm_info(const speck_comm *comm, int *nranks, int *rank, int *transport);
+/* One-shot gatherv (collective): every rank passes its shard of C (local row offsets, as speck_multiply returns
+ * it for a row-range view of A); on `root`, *full receives the concatenated matrix (callee allocates, caller
+ * frees with speck_dcsr_free); other ranks may pass NULL. */
+int speck_gatherv_csr(speck_comm *comm, int root, const speck_dcsr *shard, uint64_t cols, size_t value_size,
+                      speck_dcsr *full);
+/* Repeated exchange of shards whose sizes do not change (the benchmark loop): sizes are exchanged and the
+ * root's buffers allocated ONCE (collective; create plans in the same order on every rank), start() posts the
+ * transfers of a slot on the communicator's own stream and returns -- they overlap the next multiply -- and
+ * wait() blocks on the slot's event.  A slot's shard must stay untouched between start() and wait() (alternate
+ * two output matrices).  On the root, wait() fills *full_view with a VIEW of the slot's buffers (owned by the
+ * plan, valid until the slot is started again). */
+int speck_gather_plan_create(speck_comm *comm, int root, uint64_t rows_local, uint64_t cols, uint64_t nnz_local,
+                             size_t value_size, int slots, speck_gather_plan **out);
+int speck_gather_start(speck_gather_plan *plan, int slot, const speck_dcsr *shard);
+int speck_gather_wait(speck_gather_plan *plan, int slot, speck_dcsr *full_view);
+/* displacements of every rank's rows / entries in the concatenation (nranks + 1 entries each; either may be NULL) */
+int speck_gather_plan_layout(const speck_gather_plan *plan, uint64_t *row_displs, uint64_t *nnz_displs);
+int speck_gather_plan_destroy(speck_gather_plan *plan);
 
 /* ---- host-side synthetic inputs and on-disk formats ---- */
 typedef struct speck_host_csr speck_host_csr; /* opaque host CSR<double>, include/CSR.h */

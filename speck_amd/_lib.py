@@ -77,6 +77,17 @@ _SIGS = {
     "speck_host_csr_from_arrays": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
                                              C.c_void_p, _P(C.c_void_p)]),
     "speck_host_csr_free": (C.c_int, [C.c_void_p]),
+    "speck_comm_unique_id": (C.c_int, [C.c_int, C.c_void_p]),
+    "speck_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, _P(C.c_void_p)]),
+    "speck_comm_destroy": (C.c_int, [C.c_void_p]),
+    "speck_comm_info": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
+    "speck_gatherv_csr": (C.c_int, [C.c_void_p, C.c_int, _P(DCsr), C.c_uint64, C.c_size_t, _P(DCsr)]),
+    "speck_gather_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t,
+                                           C.c_int, _P(C.c_void_p)]),
+    "speck_gather_start": (C.c_int, [C.c_void_p, C.c_int, _P(DCsr)]),
+    "speck_gather_wait": (C.c_int, [C.c_void_p, C.c_int, _P(DCsr)]),
+    "speck_gather_plan_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "speck_gather_plan_destroy": (C.c_int, [C.c_void_p]),
     "speck_status_string": (C.c_char_p, [C.c_int]),
     "speck_version": (C.c_char_p, []),
 }

@@ -1405,6 +1405,7 @@ const char* speck_status_string(int status)
         case SPECK_ERR_NO_DEVICE: return "no such HIP device";
         case SPECK_ERR_IO: return "I/O error";
         case SPECK_ERR_UNSORTED: return "a row of B is not strictly ascending (or holds a column >= cols)";
+        case SPECK_ERR_COMM: return "multi-GPU exchange failed (RCCL / shared-memory transport)";
     }
     return "unknown";
 }

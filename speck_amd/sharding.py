@@ -157,9 +157,12 @@ class GatherPlan:
         for w in works:
             w.wait()
         if _keep[1].is_cuda:
-            # RCCL work.wait() only orders the current stream behind the transfer; the caller is
-            # about to overwrite the sources from another stream, so complete it on the host
-            torch.cuda.current_stream().synchronize()
+            # RCCL work.wait() only orders the current stream behind the transfer; the caller is about to
+            # overwrite the sources from another stream, so complete it on the host -- with an EVENT recorded
+            # behind the transfer, not a synchronisation of everything else queued on the stream
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            ev.synchronize()
         self.pending[slot] = None
         if self.rank != self.root:
             return None
@@ -172,3 +175,95 @@ class GatherPlan:
 
     def wait_all(self):
         return [self.wait(s) for s in range(len(self.pending))]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The exchange through the library's own C ABI (speck_comm_* / speck_gather_*: RCCL resolved inside
+# libspeck_amd.so, or its host-staged transport when the ranks share one GPU).  torch.distributed is only the
+# LAUNCHER here: it carries the 128-byte unique id from rank 0 to the others.
+TRANSPORT_RCCL, TRANSPORT_HOSTMEM = 0, 1
+
+
+class NativeComm:
+    """speck_comm over all ranks of the default (or given) process group."""
+
+    def __init__(self, device_index, transport=TRANSPORT_RCCL, group=None):
+        import ctypes as C
+        from . import _lib
+        from .api import _check
+        self._lib = _lib.load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            _check(self._lib.speck_comm_unique_id(int(transport), ident), "speck_comm_unique_id")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0, group=group)   # launcher duty: hand the id to every rank
+        ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self._h = C.c_void_p()
+        _check(self._lib.speck_comm_init(int(device_index), self.world, self.rank, int(transport), ident,
+                                         C.byref(self._h)), "speck_comm_init")
+        self.transport = transport
+
+    def gatherv(self, shard, cols, root=0):
+        """One-shot speck_gatherv_csr: returns the concatenated dCSR on root, None elsewhere."""
+        import ctypes as C
+        from .api import _check, dCSR
+        full = dCSR(shard.dtype)
+        _check(self._lib.speck_gatherv_csr(self._h, root, C.byref(shard._c), int(cols), shard.dtype.itemsize,
+                                           C.byref(full._c)), "speck_gatherv_csr")
+        return full if self.rank == root else None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.speck_comm_destroy(self._h)
+            self._h = None
+
+
+class NativeGatherPlan:
+    """speck_gather_plan: same start / wait / wait_all protocol as GatherPlan, on dCSR shards."""
+
+    def __init__(self, comm, rows_local, cols, nnz_local, value_size=8, root=0, slots=2):
+        import ctypes as C
+        from .api import _check
+        self.comm, self.root, self.slots = comm, root, slots
+        self._dtype = np.float64 if value_size == 8 else np.float32
+        self._lib = comm._lib
+        self._h = C.c_void_p()
+        _check(self._lib.speck_gather_plan_create(comm._h, root, int(rows_local), int(cols), int(nnz_local),
+                                                  int(value_size), int(slots), C.byref(self._h)),
+               "speck_gather_plan_create")
+        self._keep = [None] * slots
+        r = (C.c_uint64 * (comm.world + 1))()
+        n = (C.c_uint64 * (comm.world + 1))()
+        _check(self._lib.speck_gather_plan_layout(self._h, r, n))
+        self.r_off, self.n_off = [int(x) for x in r], [int(x) for x in n]
+
+    def start(self, slot, shard):
+        import ctypes as C
+        from .api import _check
+        _check(self._lib.speck_gather_start(self._h, int(slot), C.byref(shard._c)), "speck_gather_start")
+        self._keep[slot] = shard
+
+    def wait(self, slot):
+        """Completes the slot; on the root returns a non-owning dCSR view of the concatenated matrix."""
+        import ctypes as C
+        from .api import _check, dCSR
+        from ._lib import DCsr
+        view = DCsr()
+        _check(self._lib.speck_gather_wait(self._h, int(slot), C.byref(view)), "speck_gather_wait")
+        self._keep[slot] = None
+        if self.comm.rank != self.root or not view.row_offsets:
+            return None
+        v = dCSR(self._dtype)
+        v._owner = False
+        v._keep = self
+        v._c = view
+        return v
+
+    def wait_all(self):
+        return [self.wait(s) for s in range(self.slots)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.speck_gather_plan_destroy(self._h)
+            self._h = None

@@ -121,3 +121,47 @@ def test_bench_strong_scaling_mode_two_ranks_share_the_gpu():
         assert d["verified"] is True
         sizes[n] = (d["config"]["rows"], d["config"]["products"], d["config"]["nnzC"])
     assert sizes[1] == sizes[2]          # strong scaling: the same job at every N
+
+
+@pytest.mark.parametrize("world,kind,scale", [(2, "scircuit", 0.1), (3, "webbase", 0.02)])
+def test_native_gatherv_ranks_share_the_gpu(world, kind, scale):
+    """The library's own exchange (C ABI: speck_comm_*, speck_gatherv_csr, speck_gather_plan with two slots) on
+    2 / 3 ranks that share GPU 0 -- RCCL rejects duplicate devices, so the host-staged transport carries the
+    bytes; plan, displacements and the rebase kernel are the ones the RCCL transport uses."""
+    import sys
+    env = dict(os.environ, SPECK_SHARED_GPU="1")
+    port = 29000 + os.getpid() % 250 + world
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tests", "tools", "native_gather_check.py"), kind, str(scale)],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "NATIVE_GATHER_OK" in out, out[-3000:]
+
+
+def test_native_gatherv_rccl_single_rank():
+    """RCCL itself (dlopen'ed by the library): a communicator of one rank on GPU 0, the gatherv degenerates to the
+    root's own device-to-device copy + rebase.  (More ranks need more GPUs: the driver's scaling run.)"""
+    import sys
+    env = dict(os.environ, SPECK_SHARED_GPU="0")
+    port = 29500 + os.getpid() % 250
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tests", "tools", "native_gather_check.py"), "mac_econ", "0.05"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "NATIVE_GATHER_OK" in out, out[-3000:]
+
+
+def test_driver_row_sharded_ranks_share_the_gpu(tmp_path):
+    """runspECK --gpus 2 --shared-gpu: the driver re-launches itself as two rank processes (both on GPU 0, the
+    library's host-staged transport), each multiplies its row shard, rank 0 receives the concatenation through
+    speck_gather_plan and compares it with rocSPARSE."""
+    ini = tmp_path / "config.ini"
+    write_ini(ini, CompareResult="true", IterationsWarmUp=2, IterationsExecution=3)
+    rc, out = run(["gen:scircuit:0.2:3", str(ini), "--gpus", "2", "--shared-gpu"], tmp_path)
+    assert rc == 0, out
+    assert "compare vs rocSPARSE: ok" in out and "row shards: 2 ranks" in out
+    nnz_sharded = int(re.search(r"var-SpGEMM -> NNZ: (\d+)", out).group(1))
+    rc, out1 = run(["gen:scircuit:0.2:3", str(ini)], tmp_path)
+    assert rc == 0 and int(re.search(r"var-SpGEMM -> NNZ: (\d+)", out1).group(1)) == nnz_sharded

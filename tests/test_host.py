@@ -156,3 +156,14 @@ def test_reference_binary_reads_our_hicsr(tmp_path):
     assert [int(x) for x in dump[1].split()] == list(A.row_offsets)
     assert [int(x) for x in dump[2].split()] == list(A.col_ids)
     assert [float(x) for x in dump[3].split()] == list(A.data)
+
+
+def test_gather_layout_cpp_unit(tmp_path):
+    """Displacement arithmetic of the row-sharded gatherv (speck_amd/csrc/comm_layout.hpp), plain C++."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "t_layout")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "speck_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "test_gather_layout.cpp"), "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert "gather layout ok" in out
