@@ -208,6 +208,9 @@ int speck_gen_matrix(const char *kind, double scale, uint64_t seed, int signed_v
                      speck_host_csr **out);
 /* loadMTX + convert(COO->CSR) -- source/COO.cpp:53-164, source/CSR.cpp:173-212 */
 int speck_load_mtx(const char *path, speck_host_csr **out);
+/* MatrixMarket writer (no reference counterpart): coordinate real, general or -- symmetric_lower != 0 -- the
+ * lower triangle as `symmetric` (the caller vouches for the symmetry) */
+int speck_store_mtx(const speck_host_csr *m, const char *path, int symmetric_lower);
 /* loadCSR / storeCSR (.hicsr) -- source/CSR.cpp:88-137 */
 int speck_load_hicsr(const char *path, speck_host_csr **out);
 int speck_store_hicsr(const speck_host_csr *m, const char *path);

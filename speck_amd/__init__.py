@@ -6,6 +6,6 @@ reference's host interface used by the tests and the benchmark harness.
 """
 from .api import (  # noqa: F401
     SpeckError, Timings, dCSR, spECKConfig, HostCSR, MultiplyspECK, analysis, symbolic,
-    partition_rows, compare, compare_bounded, transpose, gen_matrix, load_matrix, load_mtx, load_hicsr,
+    partition_rows, compare, compare_bounded, transpose, gen_matrix, load_matrix, load_mtx, store_mtx, load_hicsr,
     store_hicsr, lib_path,
 )

@@ -69,6 +69,7 @@ _SIGS = {
                                             _P(C.c_uint64)]),
     "speck_gen_matrix": (C.c_int, [C.c_char_p, C.c_double, C.c_uint64, C.c_int, _P(C.c_void_p)]),
     "speck_load_mtx": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),
+    "speck_store_mtx": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "speck_load_hicsr": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),
     "speck_store_hicsr": (C.c_int, [C.c_void_p, C.c_char_p]),
     "speck_load_matrix": (C.c_int, [C.c_char_p, C.c_int, _P(C.c_void_p)]),

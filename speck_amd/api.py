@@ -88,6 +88,15 @@ def load_mtx(path):
     return HostCSR._from_handle(h)
 
 
+def store_mtx(mat, path, symmetric_lower=False):
+    """MatrixMarket coordinate real; symmetric_lower: only the lower triangle, banner `symmetric`."""
+    h = mat._to_handle()
+    try:
+        _check(_lib.load().speck_store_mtx(h, str(path).encode(), int(bool(symmetric_lower))), f"store_mtx({path})")
+    finally:
+        _lib.load().speck_host_csr_free(h)
+
+
 def load_hicsr(path):
     h = C.c_void_p()
     _check(_lib.load().speck_load_hicsr(str(path).encode(), C.byref(h)), f"load_hicsr({path})")

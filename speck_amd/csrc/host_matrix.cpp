@@ -9,7 +9,14 @@
 //     16-byte State<T>, then data, col_ids, row_offsets)
 //   * "<path>d_.hicsr" cache rule -- reference source/DataLoader.cpp:9-58
 // Synthetic generators follow SURVEY.md section 8d (no SuiteSparse files offline).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <charconv>
+#include <thread>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -402,12 +409,99 @@ int store_hicsr(const speck_host_csr& m, const char* path)
 }
 
 // ---- MatrixMarket ---------------------------------------------------------------
+// Semantics of the reference's loadMTX + convert(COO -> CSR) (source/COO.cpp:53-164, source/CSR.cpp:173-212):
+// coordinate format only; real / integer / double / pattern (value 1) / complex (real part); general, symmetric
+// and Hermitian -- the latter two mirror every off-diagonal entry WITHOUT deduplication; 1-based -> 0-based;
+// rows sorted by column, entries with the same (row, column) keep their file order.
+// Built for SuiteSparse-sized files (nlpkkt160: 115 M lines, 230 M mirrored entries): the file is mapped, cut
+// into chunks at line boundaries and parsed by all host threads with std::from_chars -- twice: the first pass
+// only counts the entries of every (chunk, row), the second writes each entry straight to its place in the CSR
+// arrays (offset of the row + entries of earlier chunks in that row: file order inside a row is kept without
+// sorting a 16-byte-per-entry COO copy).  Peak memory = the CSR itself + 4 B x rows x chunks of cursors.
+// Rows that are not already ascending (most files are written column-major, so they are) are sorted in place.
+struct MappedFile {
+    const char* p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    ~MappedFile()
+    {
+        if (p && n) munmap(const_cast<char*>(p), n);
+        if (fd >= 0) close(fd);
+    }
+};
+
+inline const char* skip_blank(const char* p, const char* e)
+{
+    while (p < e && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+    return p;
+}
+inline const char* line_end(const char* p, const char* e)
+{
+    const void* q = std::memchr(p, '\n', size_t(e - p));
+    return q ? static_cast<const char*>(q) : e;
+}
+// unsigned integer token (what `istream >> uint32_t` accepts for the files in question: an optional '+', digits)
+inline bool parse_u64(const char*& p, const char* e, uint64_t& v)
+{
+    p = skip_blank(p, e);
+    if (p < e && *p == '+') ++p;
+    auto r = std::from_chars(p, e, v);
+    if (r.ec != std::errc()) return false;
+    p = r.ptr;
+    return true;
+}
+inline bool parse_f64(const char*& p, const char* e, double& v)
+{
+    p = skip_blank(p, e);
+    if (p < e && *p == '+') ++p;
+    auto r = std::from_chars(p, e, v);
+    if (r.ec == std::errc::result_out_of_range) {  // denormal / overflow: strtod's answer, as iostreams give it
+        std::string tok(p, r.ptr);
+        v = std::strtod(tok.c_str(), nullptr);
+    } else if (r.ec != std::errc())
+        return false;
+    p = r.ptr;
+    return true;
+}
+
+// one data line: 0 = blank / comment, 1 = entry, -1 = malformed
+inline int parse_entry(const char* p, const char* e, bool pattern, bool need_value, uint64_t rows, uint64_t cols,
+                       uint32_t& r, uint32_t& c, double& d)
+{
+    p = skip_blank(p, e);
+    if (p == e || *p == '%') return 0;
+    uint64_t r64, c64;
+    if (!parse_u64(p, e, r64) || !parse_u64(p, e, c64)) return -1;
+    if (r64 == 0 || c64 == 0 || r64 > rows || c64 > cols) return -1;
+    r = (uint32_t)(r64 - 1);
+    c = (uint32_t)(c64 - 1);
+    d = 1.0;
+    // (a complex file: the real part, the rest of the line is ignored; the counting pass skips the value)
+    if (!pattern && need_value && !parse_f64(p, e, d)) return -1;
+    return 1;
+}
+
 int load_mtx(const char* path, speck_host_csr& m)
 {
-    std::ifstream f(path);
-    if (!f.is_open()) return SPECK_ERR_IO;
-    std::string line;
-    if (!std::getline(f, line)) return SPECK_ERR_IO;
+    MappedFile mf;
+    mf.fd = open(path, O_RDONLY);
+    if (mf.fd < 0) return SPECK_ERR_IO;
+    struct stat st;
+    if (fstat(mf.fd, &st) != 0 || st.st_size <= 0) return SPECK_ERR_IO;
+    mf.n = (size_t)st.st_size;
+    void* map = mmap(nullptr, mf.n, PROT_READ, MAP_PRIVATE, mf.fd, 0);
+    if (map == MAP_FAILED) {
+        mf.n = 0;
+        return SPECK_ERR_IO;
+    }
+    mf.p = static_cast<const char*>(map);
+    (void)madvise(map, mf.n, MADV_SEQUENTIAL);
+    const char* p = mf.p;
+    const char* const end = mf.p + mf.n;
+
+    // banner
+    const char* le = line_end(p, end);
+    std::string line(p, le);
     if (line.compare(0, 32, "%%MatrixMarket matrix coordinate") != 0) return SPECK_ERR_IO;
     std::istringstream hs(line);
     std::vector<std::string> tok;
@@ -420,56 +514,155 @@ int load_mtx(const char* path, speck_host_csr& m)
     if (tok[4] == "general") mirror = false;
     else if (tok[4] == "symmetric" || tok[4] == "Hermitian") mirror = true;
     else return SPECK_ERR_IO;
+    p = le < end ? le + 1 : end;
 
+    // size line: the first line that is not a comment
     uint64_t rows = 0, cols = 0, nnz = 0;
     bool have_size = false;
-    while (std::getline(f, line)) {
-        if (!line.empty() && line[0] == '%') continue;
-        std::istringstream ls(line);
-        ls >> rows >> cols >> nnz;
-        if (ls.fail()) return SPECK_ERR_IO;
-        have_size = true;
-        break;
+    while (p < end) {
+        le = line_end(p, end);
+        if (*p != '%') {
+            const char* q = p;
+            if (!parse_u64(q, le, rows) || !parse_u64(q, le, cols) || !parse_u64(q, le, nnz)) return SPECK_ERR_IO;
+            have_size = true;
+            p = le < end ? le + 1 : end;
+            break;
+        }
+        p = le < end ? le + 1 : end;
     }
     if (!have_size) return SPECK_ERR_IO;
-    struct Entry {
-        uint32_t r, c;
-        double v;
-    };
-    std::vector<Entry> e;
     if (rows > 0xFFFFFFFEull || cols > 0xFFFFFFFFull || nnz > 0x7FFFFFFFull) return SPECK_ERR_IO;
-    e.reserve(mirror ? nnz * 2 : nnz);
-    while (std::getline(f, line)) {
-        if (!line.empty() && line[0] == '%') continue;
-        size_t p = 0;
-        while (p < line.size() && std::isspace((unsigned char)line[p])) ++p;
-        if (p == line.size()) continue;
-        std::istringstream ls(line);
-        uint32_t r, c;
-        double d = 1.0;
-        ls >> r >> c;
-        if (!pattern) ls >> d;
-        if (ls.fail()) return SPECK_ERR_IO;
-        if (r > rows || c > cols || r == 0 || c == 0) return SPECK_ERR_IO;
-        e.push_back({r - 1, c - 1, d});
-        if (mirror && r != c) e.push_back({c - 1, r - 1, d});  // no dedup (reference COO.cpp:153-159)
+
+    // chunks of whole lines
+    const size_t body = size_t(end - p);
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nchunks = std::max<size_t>(1, std::min<size_t>({hw ? hw : 1u, 32u, body / (1u << 20) + 1}));
+    // the cursors cost 4 B x rows x chunks: keep them below ~half of the CSR they help to build
+    while (nchunks > 1 && nchunks * rows * 4 > 6 * (mirror ? 2 * nnz : nnz) + (64u << 20)) --nchunks;
+    std::vector<const char*> cut(nchunks + 1);
+    cut[0] = p;
+    cut[nchunks] = end;
+    for (size_t k = 1; k < nchunks; ++k) {
+        const char* q = p + body / nchunks * k;
+        q = line_end(q, end);
+        cut[k] = q < end ? q + 1 : end;
     }
-    // reference: std::sort by (r, c) -- the order of exact duplicates is unspecified there;
-    // stable_sort picks the file order.
-    std::stable_sort(e.begin(), e.end(), [](const Entry& a, const Entry& b) {
-        return a.r != b.r ? a.r < b.r : a.c < b.c;
+    for (size_t k = 1; k <= nchunks; ++k)
+        if (cut[k] < cut[k - 1]) cut[k] = cut[k - 1];
+
+    // pass 1: entries per (chunk, row)
+    std::vector<std::vector<uint32_t>> cnt(nchunks);
+    std::vector<int> bad(nchunks, 0);
+    auto run = [&](auto&& fn) {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < nchunks; ++k) th.emplace_back(fn, k);
+        fn(size_t(0));
+        for (auto& t : th) t.join();
+    };
+    run([&](size_t k) {
+        auto& c = cnt[k];
+        c.assign(rows, 0);
+        const char* q = cut[k];
+        const char* const qe = cut[k + 1];
+        while (q < qe) {
+            const char* l = line_end(q, qe);
+            uint32_t r, cc;
+            double d;
+            const int got = parse_entry(q, l, pattern, false, rows, cols, r, cc, d);
+            if (got < 0) {
+                bad[k] = 1;
+                return;
+            }
+            if (got > 0) {
+                ++c[r];
+                if (mirror && r != cc) {
+                    if (cc >= rows) {  // the mirrored entry needs a row: symmetric files are square
+                        bad[k] = 1;
+                        return;
+                    }
+                    ++c[cc];
+                }
+            }
+            q = l < qe ? l + 1 : qe;
+        }
     });
+    for (int b : bad)
+        if (b) return SPECK_ERR_IO;
+
+    // row offsets; cnt[k][r] becomes the cursor of chunk k in row r
     m.rows = rows;
     m.cols = cols;
     m.row_offsets.assign(rows + 1, 0);
-    m.col_ids.resize(e.size());
-    m.data.resize(e.size());
-    for (size_t i = 0; i < e.size(); ++i) {
-        m.col_ids[i] = e[i].c;
-        m.data[i] = e[i].v;
-        ++m.row_offsets[e[i].r + 1];
+    uint64_t total = 0;
+    for (uint64_t r = 0; r < rows; ++r) {
+        m.row_offsets[r] = (uint32_t)total;
+        for (size_t k = 0; k < nchunks; ++k) {
+            const uint32_t c = cnt[k][r];
+            cnt[k][r] = (uint32_t)total;
+            total += c;
+        }
+        if (total > 0xFFFFFFFFull) return SPECK_ERR_IO;
     }
-    for (uint64_t r = 0; r < rows; ++r) m.row_offsets[r + 1] += m.row_offsets[r];
+    m.row_offsets[rows] = (uint32_t)total;
+    m.col_ids.resize(total);
+    m.data.resize(total);
+
+    // pass 2: every entry to its place (file order inside a row)
+    run([&](size_t k) {
+        auto& cur = cnt[k];
+        const char* q = cut[k];
+        const char* const qe = cut[k + 1];
+        while (q < qe) {
+            const char* l = line_end(q, qe);
+            uint32_t r, cc;
+            double d;
+            const int got = parse_entry(q, l, pattern, true, rows, cols, r, cc, d);
+            if (got < 0) {
+                bad[k] = 1;
+                return;
+            }
+            if (got > 0) {
+                uint32_t at = cur[r]++;
+                m.col_ids[at] = cc;
+                m.data[at] = d;
+                if (mirror && r != cc) {  // no dedup (reference COO.cpp:153-159)
+                    at = cur[cc]++;
+                    m.col_ids[at] = r;
+                    m.data[at] = d;
+                }
+            }
+            q = l < qe ? l + 1 : qe;
+        }
+    });
+    cnt.clear();
+    cnt.shrink_to_fit();
+    for (int b : bad)
+        if (b) return SPECK_ERR_IO;
+
+    // rows ascending by column; equal columns keep their file order (the reference std::sorts by (row, column): the
+    // order of exact duplicates is unspecified there)
+    const size_t nsort = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1u, 32u));
+    std::vector<std::thread> th;
+    auto sort_rows = [&](size_t t) {
+        std::vector<std::pair<uint32_t, double>> tmp;
+        const uint64_t r0 = rows * t / nsort, r1 = rows * (t + 1) / nsort;
+        for (uint64_t r = r0; r < r1; ++r) {
+            const uint32_t a = m.row_offsets[r], b = m.row_offsets[r + 1];
+            bool sorted = true;
+            for (uint32_t i = a + 1; i < b && sorted; ++i) sorted = m.col_ids[i - 1] <= m.col_ids[i];
+            if (sorted) continue;
+            tmp.resize(b - a);
+            for (uint32_t i = a; i < b; ++i) tmp[i - a] = {m.col_ids[i], m.data[i]};
+            std::stable_sort(tmp.begin(), tmp.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+            for (uint32_t i = a; i < b; ++i) {
+                m.col_ids[i] = tmp[i - a].first;
+                m.data[i] = tmp[i - a].second;
+            }
+        }
+    };
+    for (size_t t = 1; t < nsort; ++t) th.emplace_back(sort_rows, t);
+    sort_rows(0);
+    for (auto& t : th) t.join();
     return SPECK_OK;
 }
 
@@ -554,6 +747,41 @@ int speck_load_hicsr(const char* path, speck_host_csr** out)
     }
     *out = m;
     return SPECK_OK;
+}
+
+// MatrixMarket writer (the reference has none; used to stage test inputs and to export stand-ins): coordinate
+// real, `general`, or `symmetric` with the LOWER triangle only (what SuiteSparse ships; the caller vouches for the
+// symmetry -- entries above the diagonal are simply not written).  Values with 17 significant digits: exact.
+int speck_store_mtx(const speck_host_csr* m, const char* path, int symmetric_lower)
+{
+    if (!m || !path) return SPECK_ERR_INVALID;
+    FILE* f = std::fopen(path, "w");
+    if (!f) return SPECK_ERR_IO;
+    std::vector<char> buf(1 << 22);
+    std::setvbuf(f, buf.data(), _IOFBF, buf.size());
+    uint64_t n = 0;
+    if (symmetric_lower) {
+        for (uint64_t r = 0; r < m->rows; ++r)
+            for (uint32_t e = m->row_offsets[r]; e < m->row_offsets[r + 1]; ++e) n += m->col_ids[e] <= r;
+    } else
+        n = m->col_ids.size();
+    std::fprintf(f, "%%%%MatrixMarket matrix coordinate real %s\n%llu %llu %llu\n", symmetric_lower ? "symmetric" : "general",
+                 (unsigned long long)m->rows, (unsigned long long)m->cols, (unsigned long long)n);
+    char line[96];
+    for (uint64_t r = 0; r < m->rows; ++r)
+        for (uint32_t e = m->row_offsets[r]; e < m->row_offsets[r + 1]; ++e) {
+            if (symmetric_lower && m->col_ids[e] > r) continue;
+            char* q = line;
+            q = std::to_chars(q, line + 32, r + 1).ptr;
+            *q++ = ' ';
+            q = std::to_chars(q, line + 64, (uint64_t)m->col_ids[e] + 1).ptr;
+            *q++ = ' ';
+            q += std::snprintf(q, 30, "%.17g", m->data[e]);
+            *q++ = '\n';
+            std::fwrite(line, 1, size_t(q - line), f);
+        }
+    const bool ok = std::ferror(f) == 0;
+    return (std::fclose(f) == 0 && ok) ? SPECK_OK : SPECK_ERR_IO;
 }
 
 int speck_store_hicsr(const speck_host_csr* m, const char* path)

@@ -165,3 +165,50 @@ def test_driver_row_sharded_ranks_share_the_gpu(tmp_path):
     nnz_sharded = int(re.search(r"var-SpGEMM -> NNZ: (\d+)", out).group(1))
     rc, out1 = run(["gen:scircuit:0.2:3", str(ini)], tmp_path)
     assert rc == 0 and int(re.search(r"var-SpGEMM -> NNZ: (\d+)", out1).group(1)) == nnz_sharded
+
+
+def test_bench_reads_a_symmetric_suitesparse_file(tmp_path):
+    """$SPECK_MTX_DIR/nlpkkt160.mtx (here: the stand-in at scale 0.05 written as a `symmetric` lower-triangle file,
+    the way SuiteSparse ships the original) goes through the parallel MatrixMarket reader into bench.py:
+    "data": "suitesparse", mirrored entry count, output verified against the oracle."""
+    import json
+    import sys
+    import numpy as np
+    import speck_amd as sa
+    A = sa.gen_matrix("nlpkkt", 0.05, 3, signed=True)
+    sa.store_mtx(A, tmp_path / "nlpkkt160.mtx", symmetric_lower=True)
+    ro = A.row_offsets.astype(np.int64)
+    rows_of = np.repeat(np.arange(A.rows), np.diff(ro))
+    n_lower = int((A.col_ids <= rows_of).sum())
+    n_diag = int((A.col_ids == rows_of).sum())
+    env = dict(os.environ, SPECK_MTX_DIR=str(tmp_path))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "nlpkkt", "--scaling", "strong",
+                        "--steps", "3", "--warmup", "2", "--no-configs", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert d["data"] == "suitesparse" and d["config"]["rows"] == A.rows
+    assert d["config"]["nnzA"] == 2 * n_lower - n_diag
+    assert d["verified"] is True and d["verify"]["mode"] == "oracle"
+
+
+def test_symmetric_file_with_both_triangles_is_rejected_end_to_end(tmp_path):
+    """A `symmetric` file that lists both (i, j) and (j, i): the loader mirrors without deduplication (as the
+    reference does), every off-diagonal column appears twice in its row, and the multiply refuses the input
+    (SPECK_ERR_UNSORTED) instead of computing garbage."""
+    import speck_amd as sa
+    p = tmp_path / "both.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n3 3 5\n1 1 1.0\n2 1 2.0\n1 2 3.0\n3 3 4.0\n3 2 5.0\n")
+    A = sa.load_mtx(p)
+    assert A.nnz == 8
+    cfg = sa.spECKConfig.initialize(0)
+    try:
+        dA, dC = sa.dCSR.from_host(A), sa.dCSR()
+        with pytest.raises(sa.SpeckError) as e:
+            sa.MultiplyspECK(dA, dA, dC, cfg)
+        assert e.value.status == 8 and dC.nnz == 0
+    finally:
+        cfg.cleanup()
+    rc, out = run([str(p)], tmp_path)
+    assert "ERROR" in out and "strictly ascending" in out
