@@ -3,6 +3,10 @@
 //       (A, B, matOut, config, timings)
 // The four integer template arguments are accepted for source compatibility with callers such as
 // the reference's Executor.cpp:48; this backend sizes its kernels for gfx950 (160 KiB LDS) itself.
+// libspeck_amd.so exports the two explicit instantiations the reference's library exports
+// (source/GPU/Multiply.cu:1130-1131): <float|double, 4, 1024, spECK_DYNAMIC_MEM_PER_BLOCK,
+// spECK_STATIC_MEM_PER_BLOCK>.  A caller that defines SPECK_DECLARATIONS_ONLY sees declarations only -- as with
+// the reference's header -- and links against those; otherwise the (thin) bodies are inline.
 #pragma once
 
 #include <cstdio>
@@ -15,6 +19,15 @@ static constexpr int spECK_STATIC_MEM_PER_BLOCK{65536};
 static constexpr int spECK_DYNAMIC_MEM_PER_BLOCK{163840};
 
 namespace spECK {
+template <typename DataType, int BLOCKS_PER_SM, int THREADS_PER_BLOCK, int MAX_DYNAMIC_SHARED, int MAX_STATIC_SHARED>
+void MultiplyspECK(const dCSR<DataType>& A, const dCSR<DataType>& B, dCSR<DataType>& matOut, spECKConfig& config,
+                   Timings& timings);
+
+template <typename DataType, int BLOCKS_PER_SM, int THREADS_PER_BLOCK, int MAX_DYNAMIC_SHARED, int MAX_STATIC_SHARED>
+void MultiplyspECKImplementation(const dCSR<DataType>& A, const dCSR<DataType>& B, dCSR<DataType>& matOut,
+                                 spECKConfig& config, Timings& timings);
+
+#ifndef SPECK_DECLARATIONS_ONLY
 template <typename DataType, int BLOCKS_PER_SM, int THREADS_PER_BLOCK, int MAX_DYNAMIC_SHARED, int MAX_STATIC_SHARED>
 void MultiplyspECKImplementation(const dCSR<DataType>& A, const dCSR<DataType>& B, dCSR<DataType>& matOut,
                                  spECKConfig& config, Timings& timings)
@@ -41,4 +54,11 @@ void MultiplyspECK(const dCSR<DataType>& A, const dCSR<DataType>& B, dCSR<DataTy
     MultiplyspECKImplementation<DataType, BLOCKS_PER_SM, THREADS_PER_BLOCK, MAX_DYNAMIC_SHARED, MAX_STATIC_SHARED>(
         A, B, matOut, config, timings);
 }
+#endif  // SPECK_DECLARATIONS_ONLY
+
+// exported by libspeck_amd.so (speck_amd/csrc/cxx_api.cpp)
+extern template void MultiplyspECK<float, 4, 1024, spECK_DYNAMIC_MEM_PER_BLOCK, spECK_STATIC_MEM_PER_BLOCK>(
+    const dCSR<float>&, const dCSR<float>&, dCSR<float>&, spECKConfig&, Timings&);
+extern template void MultiplyspECK<double, 4, 1024, spECK_DYNAMIC_MEM_PER_BLOCK, spECK_STATIC_MEM_PER_BLOCK>(
+    const dCSR<double>&, const dCSR<double>&, dCSR<double>&, spECKConfig&, Timings&);
 }  // namespace spECK

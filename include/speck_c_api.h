@@ -92,6 +92,9 @@ int speck_config_create(int device, speck_config **out);
 int speck_config_destroy(speck_config *cfg);
 /* spECKConfig::{sm,maxStaticSharedMemoryPerBlock,maxDynamicSharedMemoryPerBlock} */
 int speck_config_info(const speck_config *cfg, int *sm, int *max_static_lds, int *max_dynamic_lds);
+/* spECKConfig::{streams, completeStart, completeEnd, individualStart, individualEnd} (include/spECKConfig.h:12-13):
+ * the 6 hipStream_t and 4 hipEvent_t the config created, as void*; they stay owned by the config. */
+int speck_config_handles(const speck_config *cfg, void *streams6[6], void *events4[4]);
 /* Run the pipeline on a caller-owned stream (e.g. torch's current stream); NULL restores streams[0]. */
 int speck_config_set_stream(speck_config *cfg, void *hip_stream);
 /* Tunables (thresholds the reference hard-codes in Multiply.cu:128-131,321-324); name -> value. */

@@ -45,6 +45,7 @@ _SIGS = {
     "speck_config_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
     "speck_config_destroy": (C.c_int, [C.c_void_p]),
     "speck_config_info": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
+    "speck_config_handles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "speck_config_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "speck_config_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "speck_config_profile_kernels": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1093,6 +1093,20 @@ int speck_config_info(const speck_config* c, int* sm, int* max_static_lds, int* 
     return SPECK_OK;
 }
 
+int speck_config_handles(const speck_config* c, void* streams6[6], void* events4[4])
+{
+    if (!c) return SPECK_ERR_INVALID;
+    if (streams6)
+        for (int i = 0; i < 6; ++i) streams6[i] = c->streams[i];
+    if (events4) {
+        events4[0] = c->completeStart;
+        events4[1] = c->completeEnd;
+        events4[2] = c->individualStart;
+        events4[3] = c->individualEnd;
+    }
+    return SPECK_OK;
+}
+
 int speck_config_set_stream(speck_config* c, void* hip_stream)
 {
     if (!c) return SPECK_ERR_INVALID;

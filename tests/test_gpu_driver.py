@@ -212,3 +212,13 @@ def test_symmetric_file_with_both_triangles_is_rejected_end_to_end(tmp_path):
         cfg.cleanup()
     rc, out = run([str(p)], tmp_path)
     assert "ERROR" in out and "strictly ascending" in out
+
+
+def test_declarations_only_caller_runs(tmp_path):
+    """tests/cpp/caller_decl_only.cpp (g++, SPECK_DECLARATIONS_ONLY) against the exported instantiations: float and
+    double products, six live streams and four events in the public spECKConfig fields."""
+    from test_host import _build_decl_only_caller
+    exe = str(tmp_path / "caller")
+    _build_decl_only_caller(exe)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 0 and "decl-only caller ok" in p.stdout.decode(), p.stdout.decode()

@@ -238,3 +238,22 @@ def test_mtx_malformed_files_are_io_errors(tmp_path):
         with pytest.raises(speck_amd.SpeckError) as e:
             speck_amd.load_mtx(p)
         assert e.value.status == 7
+
+
+def _build_decl_only_caller(out):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-DSPECK_DECLARATIONS_ONLY", "-D__HIP_PLATFORM_AMD__",
+                           "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(root, "tests", "cpp", "caller_decl_only.cpp"),
+                           "-L", os.path.join(root, "speck_amd"), "-lspeck_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(root, "speck_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+
+
+def test_caller_that_sees_declarations_only_links(tmp_path):
+    """The library exports spECK::MultiplyspECK<float|double, 4, 1024, DYN, STATIC> (reference
+    source/GPU/Multiply.cu:1130-1131): a translation unit compiled with plain g++ against DECLARATIONS only
+    (SPECK_DECLARATIONS_ONLY) links; spECKConfig's public streams / events compile as hipStream_t / hipEvent_t."""
+    _build_decl_only_caller(str(tmp_path / "caller"))
+    syms = subprocess.check_output(["nm", "-DC", _lib.LIB_PATH]).decode()
+    for t in ("float", "double"):
+        assert f"void spECK::MultiplyspECK<{t}, 4, 1024, 163840, 65536>" in syms
