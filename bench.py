@@ -49,6 +49,10 @@ from speck_amd.api import NUM_CLASS_NAMES  # noqa: E402
 from speck_amd.sharding import GatherPlan, NativeComm, NativeGatherPlan, TRANSPORT_HOSTMEM, TRANSPORT_RCCL  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XCDs
+# LDS atomic issue ceiling, wave-instructions per second for the whole chip: ds_add_f64 takes 20.6 cycles per
+# wave-instruction and CU (scripts/ubench/lds_atomics.hip); 256 CUs at 2.4 GHz
+LDS_ATOMIC_PEAK_GWPS = 256 * 2.4 / 20.6
 SUITESPARSE_FILES = {"scircuit": "scircuit", "webbase": "webbase-1M", "mac_econ": "mac_econ_fwd500",
                      "cant": "cant", "nlpkkt": "nlpkkt160"}
 # numeric launches as bench.py names them -> key in profiles/traffic.json (scripts/make_traffic.py)
@@ -276,6 +280,36 @@ def profile_prepass(job, split, merged, prof_steps=5):
     return st, kernel_ms, sym_ms, num_ms
 
 
+def ceilings_for(counters, workload, launch_name, ms):
+    """Secondary ceilings of one launch from the committed rocprofv3 --pmc passes of the same command
+    (profiles/counters.json; NOT measured in this run -- only the duration is): HBM-side bytes, L1 -> L2 requests,
+    LDS atomic wave-instructions, VALU issue."""
+    c = counters.get(f"{workload}:{TRAFFIC_KEYS.get(launch_name, 'num_' + launch_name)}")
+    if not c or ms <= 0:
+        return None
+    sec = ms * 1e-3
+    out = {}
+    if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+        hbm = (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024
+        out["hbm_measured_GBps"] = round(hbm / sec / 1e9, 1)
+        out["hbm_measured_frac"] = round(hbm / sec / 1e9 / HBM_PEAK_GBS, 4)
+    if "TCP_TCC_READ_REQ_sum" in c:
+        l2 = (c.get("TCP_TCC_READ_REQ_sum", 0) + c.get("TCP_TCC_WRITE_REQ_sum", 0)) * 64
+        out["l2_GBps"] = round(l2 / sec / 1e9, 1)
+        out["l2_frac"] = round(l2 / sec / 1e9 / L2_PEAK_GBS, 4)
+    if "SQ_INSTS_LDS_ATOMIC" in c:
+        g = c["SQ_INSTS_LDS_ATOMIC"] / sec / 1e9
+        out["lds_atomic_Gwaveinst_per_s"] = round(g, 3)
+        out["lds_atomic_frac"] = round(g / LDS_ATOMIC_PEAK_GWPS, 4)
+    if c.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in c:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, SQ_BUSY_CYCLES per SE: report the raw ratio
+        # per SIMD-cycle as the guide's VALUBusy does (4 SIMDs per CU)
+        out["valu_insts_per_launch"] = int(c.get("SQ_INSTS_VALU", 0))
+    if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"]:
+        out["lds_bank_conflict_ratio"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 3)
+    return out or None
+
+
 def roofline_block(workload, st, kernel_ms, num_ms):
     """Every numeric launch with its algorithmic bytes, duration and fraction of the HBM peak; the
     headline `kernel` is the launch with the LONGEST duration (it bounds the phase), `largest` the one
@@ -296,6 +330,13 @@ def roofline_block(workload, st, kernel_ms, num_ms):
     if os.path.exists(tpath):
         traffic_tab = json.load(open(tpath))
         tsrc = traffic_tab.get("_source")
+    counters, csrc = {}, None
+    cpath = os.path.join(ROOT, "profiles", "counters.json")
+    if os.path.exists(cpath):
+        counters = json.load(open(cpath))
+        csrc = counters.get("_source")
+    for x in launches:
+        x["ceilings"] = ceilings_for(counters, workload, x["name"], x["ms"])
     dom, big = launches[0], max(launches, key=lambda x: x["bytes"])
     traffic = traffic_tab.get(f"{workload}:{TRAFFIC_KEYS.get(dom['name'], 'num_' + dom['name'])}")
     total_bytes = sum(x["bytes"] for x in launches)
@@ -310,6 +351,11 @@ def roofline_block(workload, st, kernel_ms, num_ms):
         "timed_with": "HIP events, profiled pre-pass (eager) of the same process",
         "largest": {"kernel": f"numeric:{big['name']}", "bytes": big["bytes"], "ms": big["ms"], "frac": big["frac"]},
         "numeric_phase_frac": round(total_bytes / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+        "ceilings": dom["ceilings"],
+        "ceilings_source": ((csrc or "profiles/counters.json") + ": separate rocprofv3 --pmc passes of the same command "
+                            "(counts per launch) over the duration measured in this run; peaks: HBM 8 TB/s, L2 34.5 TB/s "
+                            "(MI355X_MICROARCH.md), LDS atomics 29.8 G wave-instructions/s (ds_add_f64 microbenchmark)")
+        if dom["ceilings"] else None,
         "launches": launches,
     }
 
