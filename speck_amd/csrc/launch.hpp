@@ -33,7 +33,8 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
 
 // Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
 // and two product pools (expanded by column bucket; reduced and sorted).
-constexpr u32 kGCellsPerBucket = 32;  // fine column cells per wanted bucket (plan kernel and host pool sizing)
+constexpr u32 kGCellsPerBucket = 128;  // fine column cells per wanted bucket (plan kernel and host pool sizing): a
+                                       //   cell cannot be split, so coarse cells over clustered columns make oversized buckets
 constexpr u32 kGBucketTarget = 1024;  // products per bucket aimed at (skewed columns exceed it)
 struct GRowPlan {
     u64 pbase;        // first pool slot of the row's products

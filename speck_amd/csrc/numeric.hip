@@ -896,11 +896,18 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_count_kernel(ProductS
     }
 }
 
+// table entries a bucket can need: its distinct columns are bounded by its products and by its column span
+__device__ __forceinline__ u32 spill_bucket_need(u32 products, u32 c_lo, u32 c_hi)
+{
+    return products ? min(products, c_hi - c_lo + 1u) : 0u;
+}
+
 __global__ __launch_bounds__(256) void num_spill_offsets_kernel(RowWork w, int cls)
 {
     __shared__ u32 s_scan[256 / 64 + 2];
     __shared__ u32 s_map[256];
     __shared__ u32 s_bc[kGMaxBuckets];  // products per bucket of the row (this workgroup owns them all)
+    __shared__ u32 s_lo[kGMaxBuckets], s_hi[kGMaxBuckets];  // column span of every bucket
     if (w.st->capacity_miss) return;
     const u32 count = w.st->num.count[cls];
     const RowRec* recs = w.recs + w.st->num.offset[cls];
@@ -927,10 +934,10 @@ __global__ __launch_bounds__(256) void num_spill_offsets_kernel(RowWork w, int c
                 const u32 before = threadIdx.x ? s_map[threadIdx.x - 1] : prev_last;
                 if (before != b) {  // first cell of bucket b (and the end of the bucket before)
                     w.spill.bstart[pl.bbase + b] = pl.pbase + ex;
-                    w.spill.clo[pl.bbase + b] = rec.cmin + (f << pl.shift);
-                    if (before != 0xFFFFFFFFu) w.spill.chi[pl.bbase + before] = rec.cmin + (f << pl.shift) - 1u;
+                    w.spill.clo[pl.bbase + b] = s_lo[b] = rec.cmin + (f << pl.shift);
+                    if (before != 0xFFFFFFFFu) w.spill.chi[pl.bbase + before] = s_hi[before] = rec.cmin + (f << pl.shift) - 1u;
                 }
-                if (f == pl.nf - 1) w.spill.chi[pl.bbase + b] = rec.cmax;
+                if (f == pl.nf - 1) w.spill.chi[pl.bbase + b] = s_hi[b] = rec.cmax;
             }
             prev_last = s_map[255];
             run += total;
@@ -940,10 +947,13 @@ __global__ __launch_bounds__(256) void num_spill_offsets_kernel(RowWork w, int c
         // table runs over that list only (its workgroups own most of a CU's LDS; launching one per
         // bucket just to find it small costs more than the reduction itself)
         // (no device-scope fence anywhere here: on a multi-XCD part it writes the L2 back)
+        // (what a bucket needs of the table is its DISTINCT columns: at most its products, at most its column
+        //  span -- hub rows pile thousands of products on a few hundred columns)
+        __syncthreads();
         u32 mine = 0;
         for (u32 b = threadIdx.x; b < pl.nb; b += 256) {
             w.spill.bcount[pl.bbase + b] = s_bc[b];
-            mine += s_bc[b] > kNumB2KMaxNnz ? 1u : 0u;
+            mine += spill_bucket_need(s_bc[b], s_lo[b], s_hi[b]) > kNumB2KMaxNnz ? 1u : 0u;
         }
         u32 n_big;
         u32 at = block_exclusive_scan<256>(mine, s_scan, &n_big);
@@ -952,7 +962,7 @@ __global__ __launch_bounds__(256) void num_spill_offsets_kernel(RowWork w, int c
             __syncthreads();
             at += s_map[0];
             for (u32 b = threadIdx.x; b < pl.nb; b += 256)
-                if (s_bc[b] > kNumB2KMaxNnz) w.spill.big_list[at++] = (u64(idx) << 32) | b;
+                if (spill_bucket_need(s_bc[b], s_lo[b], s_hi[b]) > kNumB2KMaxNnz) w.spill.big_list[at++] = (u64(idx) << 32) | b;
         }
         __syncthreads();
     }
@@ -1049,7 +1059,7 @@ __global__ __launch_bounds__(THREADS) void num_spill_reduce_kernel(RowWork w, in
     u32* S = reinterpret_cast<u32*>(smem);
     static_assert(kGDenseCols * sizeof(Acc<T>) + 2 * (kGDenseCols / 32) * 4 <= CAP * (sizeof(Acc<T>) + 4),
                   "the dense fallback window aliases the table");
-    static_assert(N_HI + N_HI / 2 <= CAP, "load factor <= 2/3");
+    static_assert(u64(N_HI) * 100 <= u64(CAP) * 85, "load factor <= 0.85");
     if (w.st->capacity_miss) return;
     const u32* pcol = w.spill.pcol[0];
     const T* pval = static_cast<const T*>(w.spill.pval[0]);
@@ -1065,12 +1075,14 @@ __global__ __launch_bounds__(THREADS) void num_spill_reduce_kernel(RowWork w, in
         const u32 b_step = DENSE ? 0xFFFFFFFFu - b_first : gridDim.y;  // big: exactly one bucket
         for (u32 b = b_first; b < pl.nb; b += b_step) {
             const u32 n = w.spill.bcount[pl.bbase + b];
-            if (n <= N_LO || (!DENSE && n > N_HI)) continue;  // empty (dcount stays 0) or the other launch's
+            if (n == 0) continue;  // empty (dcount stays 0)
             const u64 s0 = w.spill.bstart[pl.bbase + b];
             const u32 c_lo = w.spill.clo[pl.bbase + b], c_hi = w.spill.chi[pl.bbase + b];
+            const u32 need = spill_bucket_need(n, c_lo, c_hi);
+            if (need <= N_LO || (!DENSE && need > N_HI)) continue;  // the other launch's
             u32 distinct = 0;
-            if (n <= N_HI) {
-                u32 bits = 32u - (u32)__clz((int)max(n + (n >> 1), 2u) - 1);
+            if (need <= N_HI) {
+                u32 bits = 32u - (u32)__clz((int)max(need + (need >> 1), 2u) - 1);
                 bits = min(max(bits, (u32)__builtin_ctz(kGReduceThreads)), (u32)__builtin_ctz(CAP));
                 bits = (u32)__builtin_amdgcn_readfirstlane((int)bits);
                 const u32 cap_row = 1u << bits;
@@ -1375,7 +1387,9 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             auto kr_small = num_spill_reduce_kernel<T, kNumB2KCap, kB2KW1, 256, 0, kNumB2KMaxNnz, false>;
             hipLaunchKernelGGL(kr_small, dim3(rows, 32), dim3(256), (num_spill_reduce_lds<T, kNumB2KCap, 256>()), s, w,
                                cls);
-            auto kr_big = num_spill_reduce_kernel<T, kNumB8KCap, kB8KW1, 512, kNumB2KMaxNnz, kNumB8KMaxNnz, true>;
+            // (the big table takes a bucket up to a load of 0.85: beyond it only the dense windows are left, and a bucket
+            //  that misses the 2/3 mark by a few entries would pay dozens of them over its column span)
+            auto kr_big = num_spill_reduce_kernel<T, kNumB8KCap, kB8KW1, 512, kNumB2KMaxNnz, kNumB8KCap * 85 / 100, true>;
             set_dyn_lds(kr_big, lds);
             hipLaunchKernelGGL(kr_big, dim3(2048), dim3(512), lds, s, w, cls);
             hipLaunchKernelGGL((num_spill_copy_kernel<T>), dim3(rows, 32), dim3(256), 0, s, w, c_col, c_val, cls);

@@ -508,6 +508,24 @@ struct WindowCursors {
 // ---- open-addressed structures (LDS or global memory) ---------------------------------
 // Batched forms: the first compare-and-swap of the kBatch products are issued back to back
 // (independent atomics in flight); only a collision enters the probing loop.
+// Collisions are resolved by DOUBLE HASHING when SPECK_PROBE_DOUBLE is set (probe step = an odd number derived
+// from the key: coprime with the power-of-two capacity): the lanes of a wave leave their probing loops together,
+// so what a batch costs is the LONGEST chain among 64 x kBatch keys -- and linear probing at a load of 2/3 grows
+// long primary clusters.
+#ifndef SPECK_PROBE_DOUBLE
+#define SPECK_PROBE_DOUBLE 1
+#endif
+__device__ __forceinline__ u32 probe_step(u32 key, u32 shift)
+{
+#if SPECK_PROBE_DOUBLE
+    return ((key * 0x85EBCA6Bu) >> shift) | 1u;
+#else
+    (void)key;
+    (void)shift;
+    return 1u;
+#endif
+}
+
 template <u32 CAP>
 __device__ __forceinline__ u32 set_insert_batch(u32* tab, const u32 (&key)[kBatch], u32 nvalid)
 {
@@ -522,9 +540,12 @@ __device__ __forceinline__ u32 set_insert_batch(u32* tab, const u32 (&key)[kBatc
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
         if ((u32)u >= nvalid) continue;
-        while (old[u] != kEmptyKey && old[u] != key[u]) {
-            slot[u] = (slot[u] + 1) & (CAP - 1);
-            old[u] = atomicCAS(&tab[slot[u]], kEmptyKey, key[u]);
+        if (old[u] != kEmptyKey && old[u] != key[u]) {
+            const u32 step = probe_step(key[u], 32u - (u32)__builtin_ctz(CAP));
+            do {
+                slot[u] = (slot[u] + step) & (CAP - 1);
+                old[u] = atomicCAS(&tab[slot[u]], kEmptyKey, key[u]);
+            } while (old[u] != kEmptyKey && old[u] != key[u]);
         }
         added += old[u] == kEmptyKey ? 1u : 0u;
     }
@@ -548,9 +569,12 @@ __device__ __forceinline__ void table_accumulate_batch(u32* keys, T* vals, u32 b
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
         if ((u32)u >= nvalid) continue;
-        while (old[u] != kEmptyKey && old[u] != key[u]) {
-            slot[u] = (slot[u] + 1) & mask;
-            old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
+        if (old[u] != kEmptyKey && old[u] != key[u]) {
+            const u32 step = probe_step(key[u], 32u - bits);
+            do {
+                slot[u] = (slot[u] + step) & mask;
+                old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
+            } while (old[u] != kEmptyKey && old[u] != key[u]);
         }
         atomicAdd(&vals[slot[u]], prod[u]);
     }
