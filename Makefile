@@ -3,6 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := speck_amd/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+HIPFLAGS += $(EXTRA)
 ifdef PHASE_CLOCKS
 HIPFLAGS += -DSPECK_PHASE_CLOCKS
 endif

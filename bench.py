@@ -367,8 +367,7 @@ def verify_last_output(env, job, A, mode):
     scfg, sC = job.last
     r0, r1 = job.bounds
     st = scfg.last_stats()
-    info = {"mode": mode, "checked": "output of the last timed step", "replayed": st["replayed"],
-            "b8k_folded": st["b8k_folded"]}
+    info = {"mode": mode, "checked": "output of the last timed step", "replayed": st["replayed"]}
     try:
         if mode == "oracle":
             got = sC.to_host()

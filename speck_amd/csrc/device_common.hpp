@@ -84,16 +84,40 @@ constexpr u32 kSymBm1Words = 4096;    // 16 KiB  -> 131072 columns per window: n
 constexpr u32 kSymBm1MaxCols = 262144;  // rows up to this column range are SYM_BM1
 constexpr u32 kSymBm2Words = 32768;   // 128 KiB -> 1048576 columns per window
 
-constexpr u32 kNumG8Cap = 32, kNumG8MaxNnz = 21;
-constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = 42;
-constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = 85;
-constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = 341;
-constexpr u32 kNumW256Cap = 256, kNumW256MaxNnz = 170;
-constexpr u32 kNumB2KCap = 2048, kNumB2KMaxNnz = 1365;
-// an under-filled NUM_B8K class (a handful of rows: a launch of its own just for one row's latency) is folded
-// into NUM_B2K when its rows fit the 2 Ki table at a load of 0.85 instead of 2/3 (pipeline.hip, capture)
-constexpr u32 kNumB2KStretchNnz = 1740;
-constexpr u32 kNumB8KCap = 8192, kNumB8KMaxNnz = 5461;
+// Highest load of a numeric hash table, in percent: a class takes rows up to this share of its capacity, and a
+// row's table is the smallest power of two that keeps it.  Two values, measured (gpurun_out/r3m):
+//   * the rank-sort classes (8 / 16 / 32 lanes per row) keep the reference's 2/3 (Multiply.cu:142) -- they are
+//     bound by VALU issue, a fuller table means longer probing loops for the whole wave, and a fourth key per
+//     lane in the rank sort costs the launch its seventh wave per SIMD;
+//     (so do the 32-lane and wave classes with the bitmap sort: at 0.85 their launch lost 10 % on the scircuit
+//     and mac_econ stand-ins);
+//   * the WORKGROUP classes (NUM_B2K / NUM_B8K and the buckets of NUM_G) go to 0.85: with double hashing the
+//     probing stays short, and what limits those launches is LDS capacity x row latency -- a smaller table per
+//     row (fewer slots to clear, load and rank) and rows moving to the class with half the LDS pay more
+//     (webbase stand-in -5 %).
+#ifndef SPECK_LOAD_PCT
+#define SPECK_LOAD_PCT 85
+#endif
+#ifndef SPECK_LOAD_TINY_PCT
+#define SPECK_LOAD_TINY_PCT 67
+#endif
+constexpr u32 max_nnz_of(u32 cap, u32 pct) { return pct == 67 ? cap * 2 / 3 : cap * pct / 100; }
+// log2 of the table a row with `nnz` entries gets (before the class clamps it to [group width, capacity])
+__host__ __device__ inline u32 table_bits(u32 nnz, u32 pct)
+{
+    const u32 want = pct == 67 ? nnz + (nnz >> 1) : (u32)((u64(nnz) * 100 + pct - 1) / pct);
+    u32 bits = 1;
+    while ((1u << bits) < want) ++bits;
+    return bits;
+}
+constexpr u32 kNumG8Cap = 32, kNumG8MaxNnz = max_nnz_of(32, SPECK_LOAD_TINY_PCT);
+constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = max_nnz_of(64, SPECK_LOAD_TINY_PCT);
+constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = max_nnz_of(128, SPECK_LOAD_TINY_PCT);
+constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = max_nnz_of(512, SPECK_LOAD_TINY_PCT);
+constexpr u32 kNumW256Cap = 256, kNumW256MaxNnz = max_nnz_of(256, SPECK_LOAD_TINY_PCT);
+constexpr u32 kNumB2KCap = 2048, kNumB2KMaxNnz = max_nnz_of(2048, SPECK_LOAD_PCT);
+constexpr u32 kNumB8KCap = 8192, kNumB8KMaxNnz = max_nnz_of(8192, SPECK_LOAD_PCT),
+              kNumB8KHalfMaxNnz = max_nnz_of(4096, SPECK_LOAD_PCT);
 constexpr u32 kNumD1Cols = 4096;   // rows up to this column range are NUM_D1 / numeric-first
 constexpr u32 kNumD1Win = 2560;    // NUM_D1's LDS window (wider rows take two windows): no more LDS than NUM_W512 /
                                    //   NUM_B2K, which share the merged light launch with it (5 instead of 4 workgroups per CU)
@@ -105,7 +129,6 @@ struct ClassifyParams {
     u32 num_dense_ratio;    // use D1 when range <= kNumD1Cols and range <= ratio * nnz
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
     u32 num_w256;           // rows of 86..170 nnz: 32 lanes per row (else they join NUM_W512)
-    u32 b2k_max_nnz;        // 0: kNumB2KMaxNnz; kNumB2KStretchNnz when the NUM_B8K class is folded into NUM_B2K
     u32 num_g8;             // rows of <= kNumG8MaxNnz entries: 8 lanes per row (else they join NUM_G16)
     u32 sym_g8;             // rows of <= kSymG8MaxOps products: 8 lanes per row (else they join SYM_G16)
     u32 sym_w128;           // rows of 52..102 products: 16 lanes per row (else they join SYM_W256)
@@ -181,7 +204,7 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     if (range <= kNumD1Cols && range <= u64(p.num_dense_ratio) * nnz) return NUM_D1;
     if (p.num_w256 && nnz <= kNumW256MaxNnz) return NUM_W256;
     if (nnz <= kNumW512MaxNnz) return NUM_W512;
-    if (nnz <= (p.b2k_max_nnz ? p.b2k_max_nnz : kNumB2KMaxNnz)) return NUM_B2K;
+    if (nnz <= kNumB2KMaxNnz) return NUM_B2K;
     if (nnz <= kNumB8KMaxNnz) return NUM_B8K;
     const u64 passes = (range + kNumD2Cols - 1) / kNumD2Cols;
     if (passes > p.num_global_passes) return NUM_G;

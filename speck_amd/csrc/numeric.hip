@@ -147,7 +147,7 @@ using Acc = double;
 // `cap_row` (a power of two, SIZE <= cap_row <= CAP) slots of the table are in use.
 template <class G, typename T, u32 CAP, u32 NMAX>
 __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, const Acc<T>* vals,
-                                                 u32* ckeys, u32* cslot, u32 cap_row, u32 base,
+                                                 u32* ckeys, u8* cslot, u32 cap_row, u32 base,
                                                  u32* __restrict__ c_col, T* __restrict__ c_val)
 {
     constexpr u32 OWN = CAP / G::SIZE;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
         if (k[j] != kEmptyKey) {
             const u32 pos = run + __popcll(mask & lt);
             ckeys[pos] = k[j];
-            cslot[pos] = j * G::SIZE + g.lane;
+            cslot[pos] = (u8)(j * G::SIZE + g.lane);
         }
         run += __popcll(mask);
     }
@@ -361,7 +361,8 @@ template <class G, typename T, u32 CAP, int THREADS>
 constexpr u32 num_group_lds()
 {
     const u32 words = 2 * G::SIZE + scan_scratch_words<G, THREADS>() + win_words<G>();
-    return CAP * ((u32)sizeof(Acc<T>) + 4u) + G::SIZE * (u32)sizeof(Acc<T>) + (words + 3u) / 4u * 16u;
+    u32 bytes = CAP * ((u32)sizeof(Acc<T>) + 4u) + G::SIZE * (u32)sizeof(Acc<T>) + (words + 3u) / 4u * 16u;
+    return bytes;
 }
 
 // Rows of the class with nnz <= NLO or nnz > NMAX are skipped: a class may be served by two
@@ -374,11 +375,11 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     constexpr u32 NG = THREADS / G::SIZE;
     constexpr u32 kGroupBytes = num_group_lds<G, T, CAP, THREADS>();
     // the sort scratch (rank: NMAX+8 words, bitmap: max(2*W1, 2*NMAX) words) fits in the table
-    static_assert((MODE == SORT_RANK ? NMAX + 8 : (2 * W1 > 2 * NMAX ? 2 * W1 : 2 * NMAX)) * 4 <=
+    static_assert((MODE == SORT_RANK ? NMAX + 4 : (2 * W1 > 2 * NMAX ? 2 * W1 : 2 * NMAX)) * 4 <=
                       CAP * (sizeof(Acc<T>) + 4),
                   "sort scratch must fit in the table it aliases");
-    static_assert(MODE != SORT_RANK || NMAX * 4 <= G::SIZE * (sizeof(T) + 8),
-                  "rank sort: the slot numbers of the compacted keys fit in the A-row staging area");
+    static_assert(MODE != SORT_RANK || (NMAX <= G::SIZE * (sizeof(T) + 8) && CAP <= 256),
+                  "rank sort: the slot numbers (one byte each) of the compacted keys fit in the A-row staging area");
     const G g;
     const u32 gid = G::kIsBlock ? 0u : threadIdx.x / G::SIZE;
     unsigned char* mine = smem + gid * kGroupBytes;
@@ -405,7 +406,7 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         }
         // table of this row: the smallest power of two >= 1.5 nnz (load <= 2/3), at least one slot
         // per lane; the class limit guarantees it fits (nnz <= 2/3 CAP)
-        u32 bits = 32u - (u32)__clz((int)max(rec.nnz + (rec.nnz >> 1), 2u) - 1);
+        u32 bits = table_bits(rec.nnz, G::kIsBlock ? SPECK_LOAD_PCT : SPECK_LOAD_TINY_PCT);
         bits = min(max(bits, (u32)__builtin_ctz(G::SIZE)), (u32)__builtin_ctz(CAP));
         if constexpr (G::SIZE >= 64) bits = (u32)__builtin_amdgcn_readfirstlane((int)bits);
         const u32 cap_row = 1u << bits;
@@ -431,7 +432,7 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
                 emit_narrow_sorted<G, T, CAP>(g, keys, vals, keys, reinterpret_cast<uint2*>(m_av), cap_row, rec.cmin,
                                               rec.base, c_col, c_val);
             else
-                emit_rank_sorted<G, T, CAP, NMAX>(g, keys, vals, keys, reinterpret_cast<u32*>(m_av), cap_row, rec.base,
+                emit_rank_sorted<G, T, CAP, NMAX>(g, keys, vals, keys, reinterpret_cast<u8*>(m_av), cap_row, rec.base,
                                                   c_col, c_val);
         } else {
             emit_bitmap_sorted<G, T, CAP, W1, NMAX>(g, keys, vals, S, scan_scratch, cap_row, rec.cmin,
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     if (b < cg.first[1])
         num_dense_body<T, kNumD1Win, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0], cg.hint[0]);
     else if (b < cg.first[2])
-        num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KStretchNnz, SORT_BITMAP, 256>(
+        num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256>(
             smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1], cg.hint[1]);
     else if (b < cg.first[3])
         num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
@@ -1082,7 +1083,7 @@ __global__ __launch_bounds__(THREADS) void num_spill_reduce_kernel(RowWork w, in
             if (need <= N_LO || (!DENSE && need > N_HI)) continue;  // the other launch's
             u32 distinct = 0;
             if (need <= N_HI) {
-                u32 bits = 32u - (u32)__clz((int)max(need + (need >> 1), 2u) - 1);
+                u32 bits = table_bits(need, SPECK_LOAD_PCT);
                 bits = min(max(bits, (u32)__builtin_ctz(kGReduceThreads)), (u32)__builtin_ctz(CAP));
                 bits = (u32)__builtin_amdgcn_readfirstlane((int)bits);
                 const u32 cap_row = 1u << bits;
@@ -1333,7 +1334,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_B2K:
-            launch_num_hash<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KStretchNnz, SORT_BITMAP, 256>(
+            launch_num_hash<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_B8K:
@@ -1345,9 +1346,9 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                     s, cls, count, A, B, w, c_col, c_val, cu_count);
                 break;
             }
-            launch_num_hash<Block<512>, T, kNumB8KCap / 2, kB8KW1, kNumB8KMaxNnz / 2, SORT_BITMAP, 512>(
+            launch_num_hash<Block<512>, T, kNumB8KCap / 2, kB8KW1, kNumB8KHalfMaxNnz, SORT_BITMAP, 512>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
-            launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KMaxNnz / 2>(
+            launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KHalfMaxNnz>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_D1: {

@@ -95,8 +95,6 @@ struct speck_config {
     hipGraphExec_t graph_exec = nullptr;
     u32 last_sym_mask = 0, last_num_mask = 0;  // non-empty classes of the last eager call
     u32 last_max_row_nnz = 0;                  // ... and its longest C row
-    bool fold_small_b8k = true;                // under-filled NUM_B8K class -> NUM_B2K in the replayed sequence
-    bool graph_folded_b8k = false;             // ... and the captured sequence does so
     GraphKey last_key;                         // ... and what it ran on
     bool last_key_valid = false;
     int graph_replays = 0, graph_captures = 0, graph_misses = 0;
@@ -596,24 +594,11 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                   const speck_dcsr* C, const Scratch& sc, const GraphKey& key)
 {
     drop_graph(c);
-    // Under-filled classes (role of the reference's bin shift-up when few blocks exist, Multiply.cu:439-482,
-    // 777-821): a NUM_B8K class of a handful of rows costs a launch of its own -- ~15 us of one row's latency
-    // on the pipeline stream.  If every row of the previous identical call fits the NUM_B2K table at a load
-    // of 0.85, the replayed sequence classifies them there and carries no NUM_B8K launch (a longer row in a
-    // changed input lands in the pruned class and raises capacity_miss).
-    u32 num_mask = c->last_num_mask;
-    u32 num_counts[kMaxClasses];
-    std::memcpy(num_counts, c->last_num_counts, sizeof(num_counts));
-    const u32 b2k_was = c->cp.b2k_max_nnz;
-    c->graph_folded_b8k = false;
-    if (c->fold_small_b8k && num_counts[NUM_B8K] && num_counts[NUM_B8K] * 8u < (u32)c->sm &&
-        c->last_max_row_nnz <= kNumB2KStretchNnz) {
-        c->cp.b2k_max_nnz = kNumB2KStretchNnz;
-        c->graph_folded_b8k = true;
-        num_counts[NUM_B2K] += num_counts[NUM_B8K];
-        num_counts[NUM_B8K] = 0;
-        num_mask = (num_mask & ~(1u << NUM_B8K)) | (1u << NUM_B2K);
-    }
+    // (The replayed sequence classifies exactly like the eager one.  Round 2 re-classified an under-filled NUM_B8K
+    //  class into NUM_B2K at a load of 0.85 here; since the workgroup classes take rows up to that load in every
+    //  call -- device_common.hpp, SPECK_LOAD_PCT -- there is nothing left to fold.)
+    const u32 num_mask = c->last_num_mask;
+    const u32* num_counts = c->last_num_counts;
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
                            num_mask, true, nullptr, c->last_sym_counts, nullptr,
@@ -621,7 +606,6 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
                              num_mask, num_counts, nullptr);
-    c->cp.b2k_max_nnz = b2k_was;
     // no copy node: the last kernel mirrors the (final) statistics block into pinned host memory, then stores
     // the completion ticket
     if (rc == SPECK_OK) launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
@@ -722,7 +706,6 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 ++c->graph_replays;
                 publish_counts(c);
                 c->last.replayed = 1;
-                c->last.b8k_folded = c->graph_folded_b8k ? 1 : 0;
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -1155,10 +1138,6 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
     else if (n == "validate_inputs") c->validate_inputs = value != 0;
-    else if (n == "fold_small_b8k") {
-        c->fold_small_b8k = value != 0;
-        drop_graph(c);
-    }
     else if (n == "spin_wait") {
         c->spin_wait = value != 0;
         drop_graph(c);

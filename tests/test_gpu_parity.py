@@ -471,10 +471,10 @@ def test_compare_and_transpose(cfg):
 # BASELINE.json configs[1..3] at FULL size (the stand-ins fitted to the SuiteSparse figures), the
 # nlpkkt one at a size the oracle finishes in seconds (its full size: test_nlpkkt_full_size_properties below).
 # The sequence bench.py TIMES is the replayed one (a hipGraph specialised to the classes / counts of the previous
-# identical call, with the under-filled NUM_B8K class folded into NUM_B2K on the scircuit stand-in): the eager
-# result and the output of the replayed sequence are both compared with the oracle.
+# identical call): the eager result and the output of the replayed sequence are both compared with the oracle, and
+# both must have put the same rows into the same classes.
 @pytest.mark.parametrize("kind,scale,expect", [
-    ("scircuit", 1.0, [("num", "g16"), ("num", "wave512"), ("num", "block2k"), ("num", "block8k")]),
+    ("scircuit", 1.0, [("num", "g16"), ("num", "wave512"), ("num", "block2k")]),
     ("mac_econ", 1.0, [("num", "g16"), ("num", "wave128")]),
     ("cant", 1.0, [("sym", "numeric_first"), ("num", "nfcopy")]),
     ("webbase", 1.0, [("num", "global"), ("num", "block8k"), ("num", "direct"), ("sym", "block16k")]),
@@ -519,19 +519,13 @@ def test_suitesparse_standins_full_parity(cfg, kind, scale, expect):
     st2 = cfg.last_stats()
     assert st2["replayed"] and st2["graph_replays"] >= replays0 + 3
     same_as_oracle("replayed")
-    if kind == "scircuit":
-        # two NUM_B8K rows in the eager call; the replayed sequence runs them in NUM_B2K at a load of 0.85
-        assert st["num_bin_rows"]["block8k"] > 0 and st2["b8k_folded"]
-        assert st2["num_bin_rows"]["block8k"] == 0
-        assert st2["num_bin_rows"]["block2k"] == st["num_bin_rows"]["block2k"] + st["num_bin_rows"]["block8k"]
-    else:
-        assert not st2["b8k_folded"] or st["num_bin_rows"]["block8k"] * 8 < cfg.sm
+    assert st2["num_bin_rows"] == st["num_bin_rows"] and st2["sym_bin_rows"] == st["sym_bin_rows"]
 
 
-def test_under_filled_b8k_class_is_folded_at_load_085(cfg):
-    """A handful of rows with 1366..1740 distinct columns (NUM_B8K by the 2/3 rule) next to many NUM_B2K rows:
-    the replayed sequence classifies them into NUM_B2K (2 Ki table, load up to 0.85).  Checked against the oracle
-    eagerly, replayed, and with the fold switched off; a row beyond 1740 keeps the class alive."""
+def test_workgroup_classes_take_rows_up_to_load_085(cfg):
+    """NUM_B2K / NUM_B8K size their tables for a load of 0.85 (double hashing keeps the probing short): rows of
+    1366..1740 distinct columns -- NUM_B8K by the reference's 2/3 rule, 61 KiB of LDS -- are NUM_B2K rows (30 KiB), a
+    row just beyond 1740 is the first NUM_B8K one; eager and replayed, same classes, same result."""
     rng = np.random.default_rng(17)
     kb, n = 4000, 3_000_000
     B = fast_random_csr(kb, n, 12, 18, jitter=False)
@@ -543,37 +537,20 @@ def test_under_filled_b8k_class_is_folded_at_load_085(cfg):
         col = np.concatenate([np.sort(rng.choice(kb, size=k, replace=False)) for k in lens]).astype(np.uint32)
         return po.HostCSR(lens.size, kb, ro, col, (0.5 + rng.random(col.size)) * rng.choice([-1.0, 1.0], size=col.size))
 
-    A = a_with([115, 120, 128, 135, 140, 145])         # ~1380 .. ~1740 distinct columns per heavy row
+    A = a_with([115, 120, 128, 135, 140, 145, 160, 300])     # ~1380 .. ~1740, then ~1920 and ~3600 distinct columns
     R, _ = po.spgemm(A, B)
     heavy = np.diff(R.row_offsets.astype(np.int64))[400:]
-    assert heavy.min() > 1365 and heavy.max() <= 1740, heavy
+    assert heavy[:6].min() > 1365 and heavy[:6].max() <= 1740 and heavy[6] > 1740 and heavy[7] > 3481, heavy
     dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR()
     sa.MultiplyspECK(dA, dB, dC, cfg)
     st = cfg.last_stats()
-    assert st["num_bin_rows"]["block8k"] == 6 and not st["b8k_folded"]
+    assert st["num_bin_rows"]["block8k"] == 2 and st["num_bin_rows"]["block2k"] == 406
     _assert_matches_oracle(dC, A, B)
     for _ in range(4):
         sa.MultiplyspECK(dA, dB, dC, cfg)
     st2 = cfg.last_stats()
-    assert st2["replayed"] and st2["b8k_folded"] and st2["num_bin_rows"]["block8k"] == 0
-    assert st2["num_bin_rows"]["block2k"] == st["num_bin_rows"]["block2k"] + 6
+    assert st2["replayed"] and st2["num_bin_rows"] == st["num_bin_rows"]
     _assert_matches_oracle(dC, A, B)
-    cfg.set_option("fold_small_b8k", 0)
-    try:
-        for _ in range(4):
-            sa.MultiplyspECK(dA, dB, dC, cfg)
-        st3 = cfg.last_stats()
-        assert st3["replayed"] and not st3["b8k_folded"] and st3["num_bin_rows"]["block8k"] == 6
-        _assert_matches_oracle(dC, A, B)
-    finally:
-        cfg.set_option("fold_small_b8k", 1)
-    A2 = a_with([115, 120, 128, 135, 140, 160])         # one row beyond the stretched table: no fold
-    dA2, dC2 = sa.dCSR.from_host(to_sa(A2)), sa.dCSR()
-    for _ in range(4):
-        sa.MultiplyspECK(dA2, dB, dC2, cfg)
-    st4 = cfg.last_stats()
-    assert st4["replayed"] and not st4["b8k_folded"] and st4["num_bin_rows"]["block8k"] == 6
-    _assert_matches_oracle(dC2, A2, B)
 
 
 def test_nlpkkt_full_size_properties_and_sampled_blocks(cfg):
