@@ -367,7 +367,8 @@ def verify_last_output(env, job, A, mode):
     scfg, sC = job.last
     r0, r1 = job.bounds
     st = scfg.last_stats()
-    info = {"mode": mode, "checked": "output of the last timed step", "replayed": st["replayed"]}
+    info = {"mode": mode, "checked": "output of the last timed step", "replayed": st["replayed"],
+            "nf_direct": st["nf_direct"]}
     try:
         if mode == "oracle":
             got = sC.to_host()

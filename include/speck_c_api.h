@@ -75,7 +75,8 @@ typedef struct speck_stats {
     int32_t graph_captures;
     float sym_phase_ms, num_phase_ms;            /* fork-to-join span of the symbolic / numeric launches (pipeline stream) */
     int32_t replayed;                            /* 1: the last multiply was served by the replayed hipGraph */
-    int32_t reserved0_;
+    int32_t nf_direct;                           /* 1: that sequence wrote the numeric-first rows straight to C at the row
+                                                  *    offsets of the previous identical call (verified) */
     int32_t pool_fallbacks;                      /* scratch-pool classes switched off because the pool did not fit */
     int32_t reserved_;
     uint64_t scratch_pool_bytes;                 /* numeric-first / global-key-set pool currently allocated */

@@ -29,7 +29,8 @@ void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_r
 void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
-                 DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u);
+                 DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
+                 const u32* pred_off = nullptr);
 
 // Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
 // and two product pools (expanded by column bucket; reduced and sorted).
@@ -67,6 +68,13 @@ struct RowWork {
     u32* nf_col;
     void* nf_val;
     u64 nf_cap;             // entries the pool holds (a slot never ends beyond it)
+    // Replayed sequence only: the numeric-first kernel writes a finished row STRAIGHT to its place in
+    // C -- at the row offset of the previous identical call (pred_off, the config's own copy) -- when the row's fresh
+    // nnz is what that call found; the scan of this call recomputes every offset and rejects the replay if one
+    // differs.  No scratch slot, no copy kernel.  All null on the eager path.
+    const u32* nf_pred_off;
+    u32* nf_direct_col;
+    void* nf_direct_val;
     uint2* w_sl;            // per A entry: (start, length) of its B row INSIDE the current column window
                             //   (multi-window rows, row_groups.hpp WindowCursors); a row's entries belong to its workgroup
     u32 xcd_aware;          // class lists are walked in per-XCD contiguous slices (row_groups.hpp)

@@ -578,8 +578,9 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
     u32* scratch = stage + 2 * THREADS;
     RowMeta<T> meta{stage, stage + THREADS, m_av, scratch + THREADS / 64 + 2};
     static_assert(THREADS >= kNumD1Cols / 32, "bitmap + prefix fit the staging area");
-    u32* __restrict__ o_col = w.nf_col;
-    T* __restrict__ o_val = static_cast<T*>(w.nf_val);
+    const bool direct = w.nf_pred_off != nullptr;  // replayed sequence: rows go straight to C (RowWork)
+    u32* __restrict__ o_col = direct ? w.nf_direct_col : w.nf_col;
+    T* __restrict__ o_val = static_cast<T*>(direct ? w.nf_direct_val : w.nf_val);
     const RowSlice rs = row_slice(w.st->sym.count[SYM_NF], blockIdx.x, gridDim.x, 1u, 0u, (w.xcd_aware & 2u) != 0);
     const RowRec* recs = w.recs + w.st->sym.offset[SYM_NF];
     RowRec next{};
@@ -590,11 +591,17 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
     for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
         const RowRec rec = next;  // fetched while the previous row was being processed
         if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
-        const u64 slot = w.nf_off[rec.row];
+        u64 slot = 0;
+        u32 slot_len = 0;
+        if (direct) {
+            slot = w.nf_pred_off[rec.row];
+            slot_len = w.nf_pred_off[rec.row + 1] - (u32)slot;
+        } else
+            slot = w.nf_off[rec.row];
         const u32 wbase = rec.cmin, ncols = rec.cmax - rec.cmin + 1u, nwords = (ncols + 31) >> 5;
         // a replayed sequence met a wider row than its window was sized for, or a slot past the pool it was
         // captured with: eager re-run
-        if (ncols > WCOLS || slot + nf_slot_entries(rec.cmin, rec.cmax, rec.ops) > w.nf_cap) {
+        if (ncols > WCOLS || (!direct && slot + nf_slot_entries(rec.cmin, rec.cmax, rec.ops) > w.nf_cap)) {
             if (threadIdx.x == 0) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
             continue;
         }
@@ -622,16 +629,24 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
         }
         __syncthreads();
         const u32 total = bitmap_prefix(g, bm, pref, nwords, scratch);
+        // direct placement: only a row that still has the nnz its place in C was made for is written (the window is
+        // cleaned either way); any other row voids the replay
+        const bool place = !direct || total == slot_len;
         for (u32 d = threadIdx.x; d < ncols; d += THREADS) {
             const u32 word = bm[d >> 5];
             if (word & (1u << (d & 31))) {
                 const u32 r = pref[d >> 5] + __popc(word & ((1u << (d & 31)) - 1u));
-                o_col[slot + r] = wbase + d;
-                o_val[slot + r] = (T)vals[d];
+                if (place) {
+                    o_col[slot + r] = wbase + d;
+                    o_val[slot + r] = (T)vals[d];
+                }
                 vals[d] = 0;
             }
         }
-        if (threadIdx.x == 0) counts[rec.row] = total;
+        if (threadIdx.x == 0) {
+            counts[rec.row] = total;
+            if (!place) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
+        }
         __syncthreads();  // bitmap and prefix are dead: the next row stages its A entries over them
     }
 }

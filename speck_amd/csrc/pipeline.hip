@@ -105,6 +105,16 @@ struct speck_config {
     u64 nf_cap_entries = 0;
     size_t nf_pool_max_bytes = 0;  // 0: half of the free device memory at allocation time
     int pool_fallbacks = 0;        // times a scratch-pool class was switched off because the pool did not fit
+    // direct placement of the numeric-first rows by a replayed sequence: the row offsets of the last eager call
+    // (the config's own copy -- C.row_offsets is the caller's to overwrite), and the C buffers of the capture
+    u32* d_pred_off = nullptr;
+    size_t pred_cap = 0;
+    bool pred_valid = false;
+    bool nf_direct = true;           // option nf_direct
+    bool capture_direct = false;     // set while a sequence with direct placement is being captured
+    u32* capture_c_col = nullptr;
+    void* capture_c_val = nullptr;
+    bool graph_direct = false;       // the captured sequence places the numeric-first rows directly
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
@@ -250,6 +260,9 @@ RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill)
     w.nf_col = static_cast<u32*>(c->nfpool);
     w.nf_val = c->nfpool ? static_cast<unsigned char*>(c->nfpool) + Carver::need(c->nf_cap_entries, 4) : nullptr;
     w.nf_cap = c->nfpool ? c->nf_cap_entries : 0;
+    w.nf_pred_off = c->capture_direct ? c->d_pred_off : nullptr;
+    w.nf_direct_col = c->capture_direct ? c->capture_c_col : nullptr;
+    w.nf_direct_val = c->capture_direct ? c->capture_c_val : nullptr;
     w.w_sl = sc.w_sl;
     w.xcd_aware = c->xcd_aware;
     return w;
@@ -496,7 +509,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     }
     launch_scan(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                 classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
-                host_mirror, expect_g, expect_g_rows);
+                host_mirror, expect_g, expect_g_rows, c->capture_direct ? c->d_pred_off : nullptr);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -597,15 +610,28 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     // (The replayed sequence classifies exactly like the eager one.  Round 2 re-classified an under-filled NUM_B8K
     //  class into NUM_B2K at a load of 0.85 here; since the workgroup classes take rows up to that load in every
     //  call -- device_common.hpp, SPECK_LOAD_PCT -- there is nothing left to fold.)
-    const u32 num_mask = c->last_num_mask;
+    u32 num_mask = c->last_num_mask;
     const u32* num_counts = c->last_num_counts;
+    // Numeric-first rows: the eager call wrote them to scratch slots and copied them after the scan (nothing else
+    // knows where a row goes before the scan).  The replayed sequence knows where they WENT: it writes each row
+    // straight to the offset the previous identical call gave it, provided its fresh nnz is the same, and the scan
+    // checks every fresh offset against that prediction -- no slot, no copy launch.
+    c->graph_direct = c->nf_direct && c->pred_valid && (num_mask >> NUM_NFCOPY & 1u);
+    c->capture_direct = c->graph_direct;
+    c->capture_c_col = C->col_ids;
+    c->capture_c_val = C->data;
+    const u32 launch_mask = c->graph_direct ? (num_mask & ~(1u << NUM_NFCOPY)) : num_mask;
+    struct Reset {
+        speck_config* c;
+        ~Reset() { c->capture_direct = false; }
+    } reset{c};
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
                            num_mask, true, nullptr, c->last_sym_counts, nullptr,
                            c->last_g_products, c->last_num_counts[NUM_G], 3u, c->nf_cap_entries);
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
-                             num_mask, num_counts, nullptr);
+                             launch_mask, num_counts, nullptr);
     // no copy node: the last kernel mirrors the (final) statistics block into pinned host memory, then stores
     // the completion ticket
     if (rc == SPECK_OK) launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
@@ -706,6 +732,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 ++c->graph_replays;
                 publish_counts(c);
                 c->last.replayed = 1;
+                c->last.nf_direct = c->graph_direct ? 1 : 0;
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -918,6 +945,26 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     std::memcpy(c->last_num_counts, c->h_stats->num.count, sizeof(c->last_num_counts));
     c->last_key = make_key<T>(c, A, B, C, s);
     c->last_key_valid = true;
+    // ... and where every row went (the config's own copy of the offsets: the numeric-first rows of a replayed
+    // sequence are placed by it)
+    c->pred_valid = false;
+    if (c->nf_direct && (num_mask >> NUM_NFCOPY & 1u)) {
+        if (c->pred_cap < size_t(m) + 1) {
+            if (c->d_pred_off) (void)hipFree(c->d_pred_off);
+            c->d_pred_off = nullptr;
+            c->pred_cap = 0;
+            drop_graph(c);
+            if (hipMalloc(reinterpret_cast<void**>(&c->d_pred_off), (size_t(m) + 1) * sizeof(u32)) == hipSuccess)
+                c->pred_cap = size_t(m) + 1;
+            else
+                (void)hipGetLastError();
+        }
+        if (c->d_pred_off) {
+            HIP_TRY(hipMemcpyAsync(c->d_pred_off, sc.offsets, (size_t(m) + 1) * sizeof(u32), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            c->pred_valid = true;
+        }
+    }
 
     rc = finish_complete();
     if (rc != SPECK_OK) return rc;
@@ -1059,6 +1106,7 @@ int speck_config_destroy(speck_config* c)
     if (c->arena) (void)hipFree(c->arena);
     if (c->gpool) (void)hipFree(c->gpool);
     if (c->nfpool) (void)hipFree(c->nfpool);
+    if (c->d_pred_off) (void)hipFree(c->d_pred_off);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->h_ticket) (void)hipHostFree(c->h_ticket);
@@ -1115,6 +1163,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->last_key_valid = false;
     }
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
+    else if (n == "nf_direct") {
+        c->nf_direct = value != 0;
+        drop_graph(c);
+    }
     else if (n == "sym_w128") {
         c->cp.sym_w128 = value != 0;
         drop_graph(c);

@@ -680,7 +680,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
     const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
     RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz, u64 expect_g, u32 expect_g_rows,
-    DeviceStats* __restrict__ host_mirror)
+    DeviceStats* __restrict__ host_mirror, const u32* __restrict__ pred_off)
 {
     constexpr int NW = kScanThreads / 64;
     __shared__ Fold s_fold;
@@ -735,6 +735,9 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     for (int i = 0; i < ITEMS; ++i) {
         off[i] = run;
         if (base + i < m && !miss) offsets_out[base + i] = run;
+        // rows the numeric-first kernel has already placed by the previous call's offsets: the fresh ones must agree
+        // (checked for EVERY row: a shift anywhere before such a row moves it)
+        if (pred_off && base + i < m && pred_off[base + i] != run) st->capacity_miss = 1;
         run += c[i];
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && !miss) offsets_out[m] = (u32)nnz_c;
@@ -887,7 +890,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
-                 DeviceStats* host_mirror, u64 expect_g, u32 expect_g_rows)
+                 DeviceStats* host_mirror, u64 expect_g, u32 expect_g_rows, const u32* pred_off)
 {
     const u32 tiles = scan_tiles(m);
     auto go = [&](auto items) {
@@ -897,7 +900,7 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
                            partials, cp, vsize);
         hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, st,
                            partials, tiles, (const u8*)num_cls, a_ro, row_ops,
-                           row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, expect_g_rows, host_mirror);
+                           row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, expect_g_rows, host_mirror, pred_off);
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;

@@ -913,3 +913,59 @@ def test_replay_with_grown_global_key_sets_does_not_touch_the_old_pool(cfg):
     _assert_matches_oracle(dC, A2, B)
     st = cfg.last_stats()
     assert st["numeric_reruns"] == misses + 1 and st["sym_bin_rows"]["global_hash"] == rows
+
+
+def test_direct_placement_of_numeric_first_rows_is_verified_per_row(cfg):
+    """A replayed sequence writes numeric-first rows straight to C at the offsets of the previous identical call.
+    Two rows of A swap their column ids in place (same row lengths, same nnz(A), same nnz(C) -- the nnz of the two
+    C rows swap): the total-nnz check passes, the per-row checks must reject the replay, and the eager re-run gives
+    the right answer; with the option off the same sequence copies through the scratch slots."""
+    import ctypes as C_
+    A = to_po(sa.gen_matrix("cant", 0.05, 3, signed=True))
+    R, _ = po.spgemm(A, A)
+    lens_a = np.diff(A.row_offsets.astype(np.int64))
+    lens_c = np.diff(R.row_offsets.astype(np.int64))
+    i = j = None
+    for cand in range(A.rows - 1):                      # two rows, same length in A, different nnz in C
+        same = np.where((lens_a == lens_a[cand]) & (lens_c != lens_c[cand]))[0]
+        if same.size:
+            i, j = cand, int(same[0])
+            break
+    assert i is not None
+    dA, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR()
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dA, dC, cfg)
+    st = cfg.last_stats()
+    assert st["replayed"] and st["nf_direct"] and st["sym_bin_rows"]["numeric_first"] > A.rows // 2
+    _assert_matches_oracle(dC, A, A)
+    # swap the column ids (and values) of rows i and j of A -- as the left factor only: B is a separate copy
+    dB = sa.dCSR.from_host(to_sa(A))
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["nf_direct"]
+    A2 = po.HostCSR(A.rows, A.cols, A.row_offsets.copy(), A.col_ids.copy(), A.data.copy())
+    si, sj = slice(A.row_offsets[i], A.row_offsets[i + 1]), slice(A.row_offsets[j], A.row_offsets[j + 1])
+    A2.col_ids[si], A2.col_ids[sj] = A.col_ids[sj], A.col_ids[si]
+    A2.data[si], A2.data[sj] = A.data[sj], A.data[si]
+    R2, _ = po.spgemm(A2, A)
+    assert R2.nnz == R.nnz and (np.diff(R2.row_offsets.astype(np.int64)) != lens_c).sum() == 2
+    L = _lib.load()
+    assert L.speck_dcsr_update(C_.byref(dA._c), None, np.ascontiguousarray(A2.col_ids).ctypes.data,
+                               np.ascontiguousarray(A2.data).ctypes.data, 8) == 0
+    misses = cfg.last_stats()["numeric_reruns"]
+    sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["numeric_reruns"] == misses + 1
+    _assert_matches_oracle(dC, A2, A)
+    for _ in range(3):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["nf_direct"]
+    _assert_matches_oracle(dC, A2, A)
+    cfg.set_option("nf_direct", 0)
+    try:
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        st = cfg.last_stats()
+        assert st["replayed"] and not st["nf_direct"]
+        _assert_matches_oracle(dC, A2, A)
+    finally:
+        cfg.set_option("nf_direct", 1)
