@@ -218,6 +218,19 @@ __global__ __launch_bounds__(256) void rebase_offsets_kernel(uint32_t* __restric
 
 uint64_t segment_bytes(uint64_t rows, uint64_t nnz, size_t vsize) { return rows * 4 + nnz * 4 + nnz * vsize + 64; }
 
+// all ranks of a host-staged communicator (generation counter: reusable)
+int shm_barrier(speck_comm* c)
+{
+    ShmControl* k = c->control();
+    const uint32_t bg = k->bar_gen.load();
+    if (k->bar_count.fetch_add(1) + 1 == (uint32_t)c->nranks) {
+        k->bar_count.store(0);
+        k->bar_gen.fetch_add(1);
+    } else if (!spin_until([&] { return k->bar_gen.load() != bg; }))
+        return SPECK_ERR_COMM;
+    return SPECK_OK;
+}
+
 int exchange_sizes(speck_comm* c, uint64_t rows, uint64_t nnz, std::vector<uint64_t>& all_rows, std::vector<uint64_t>& all_nnz)
 {
     all_rows.assign(c->nranks, 0);
@@ -251,13 +264,7 @@ int exchange_sizes(speck_comm* c, uint64_t rows, uint64_t nnz, std::vector<uint6
         all_nnz[p] = k->sizes[p][1].load();
     }
     // nobody starts the next exchange of sizes before everyone has read this one
-    const uint32_t bg = k->bar_gen.load();
-    if (k->bar_count.fetch_add(1) + 1 == (uint32_t)c->nranks) {
-        k->bar_count.store(0);
-        k->bar_gen.fetch_add(1);
-    } else if (!spin_until([&] { return k->bar_gen.load() != bg; }))
-        return SPECK_ERR_COMM;
-    return SPECK_OK;
+    return shm_barrier(c);
 }
 
 }  // namespace
@@ -421,6 +428,9 @@ int speck_gather_plan_create(speck_comm* c, int root, uint64_t rows_local, uint6
                                                   segment_bytes(all_rows[r], all_nnz[r], value_size), false))
                         return SPECK_ERR_COMM;
         }
+        // every segment exists and is mapped by both sides before anyone moves on (its owner unlinks the name
+        // when the plan goes)
+        if (shm_barrier(c) != SPECK_OK) return SPECK_ERR_COMM;
     }
     *out = p;
     return SPECK_OK;
@@ -547,6 +557,14 @@ int speck_gather_plan_destroy(speck_gather_plan* p)
     if (!p) return SPECK_ERR_INVALID;
     (void)hipSetDevice(p->comm->device);
     for (int s = 0; s < p->slots; ++s) (void)speck_gather_wait(p, s, nullptr);
+    // host-staged transport: my segments stay until the root has taken what I put there
+    if (p->comm->transport == SPECK_TRANSPORT_HOSTMEM && p->comm->nranks > 1 && p->comm->rank != p->root) {
+        ShmControl* k = p->comm->control();
+        for (int s = 0; s < p->slots; ++s)
+            if (p->gen[s])
+                (void)spin_until([&] { return k->taken[p->comm->rank][s].load(std::memory_order_acquire) ==
+                                              ((p->id << 32) | p->gen[s]); }, 30);
+    }
     for (auto& o : p->out) (void)speck_dcsr_free(&o);
     for (auto& e : p->done) (void)hipEventDestroy(e);
     for (auto& m : p->mine) unmap_segment(m);
