@@ -60,6 +60,9 @@ static inline void row_chunking(u32 m, u32* rows_per_block, u32* blocks)
 // --------------------------------------------------------------------------------
 constexpr u32 kAnRowPathMax = 8;  // rows per lane up to this many entries (sub-chunk maximum)
 constexpr int kAnThreads = 512;  // 8 waves x 32 rows = one kChunk of rows per pass of the block
+constexpr u32 kAnCoopMax = 64;        // ... at most this many per workgroup (the others stay with their wave)
+constexpr u32 kAnCoopRowLen = 256, kAnCoopEntries = 2048;  // sub-chunks (32 rows) with more entries than this, one row
+                                                            //   holding more than that, are walked by the whole workgroup
 __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     const u32* __restrict__ a_ro, const u32* __restrict__ a_col, const u32* __restrict__ b_ro,
     const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* __restrict__ row_ops,
@@ -103,6 +106,143 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
 #pragma unroll
     for (int c = 0; c < SYM_CLASSES; ++c) hist[c] = 0;
 
+    // The entry-parallel walk of one sub-chunk: entries [e_first, e_end) in steps of e_step, 64 x U per tile, per-row
+    // reductions into the LDS arrays of the sub-chunk (ro_ = its A row offsets).  A wave alone: e_first = e_begin +
+    // lane, e_step = 64 U; the whole workgroup on one sub-chunk: e_first = e_begin + wid * 64 U + lane, e_step = NW * 64 U.
+    auto walk_entries = [&](u32 e_first, u32 e_end, u32 e_step, u32 nrows, const u32* ro_, u64* ops_, u32* mx_, u32* cmin_,
+                            u32* cmax_) {
+        for (u32 t0 = e_first - lane; t0 < e_end; t0 += e_step) {  // (a tile at a time: uniform for the wave)
+            const u32 e0 = t0 + lane;
+            u32 bs[U], be[U], first[U], last[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u32 e = e0 + u * 64;
+                ok[u] = e < e_end;
+                u32 k = ok[u] ? a_col[e] : 0u;
+                if (k >= b_rows) {
+                    bad_col = true;
+                    k = 0;
+                }
+                // B.rowptr[k], B.rowptr[k+1] as ONE 8-byte gather (4-byte aligned): the random
+                // gathers of this kernel are bound by addresses per cycle, not by bytes
+                const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
+                bs[u] = ok[u] ? pr.x : 0u;
+                be[u] = ok[u] ? pr.y : 0u;
+                // hand the B-row bounds to the symbolic / numeric kernels
+                if (ok[u] && b_sl) b_sl[e - e_base] = make_uint2(bs[u], be[u] - bs[u]);
+            }
+            AN_MARK(1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool has = ok[u] && be[u] > bs[u];
+                first[u] = has ? b_col[bs[u]] : 0xFFFFFFFFu;
+                last[u] = has ? b_col[be[u] - 1] : 0u;
+            }
+            AN_MARK(2);
+            // local row of each entry: largest r with ro_[r] <= e; the U searches advance in lock
+            // step (independent LDS reads)
+            u32 lo[U], hi[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                lo[u] = 0;
+                hi[u] = nrows;
+            }
+#pragma unroll
+            for (int step = 0; step < 5; ++step) {  // 2^5 = R
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const u32 mid = (lo[u] + hi[u]) >> 1;
+                    const bool act = hi[u] - lo[u] > 1;
+                    const bool le = ro_[mid] <= e0 + u * 64;
+                    lo[u] = (act && le) ? mid : lo[u];
+                    hi[u] = (act && !le) ? mid : hi[u];
+                }
+            }
+            AN_MARK(3);
+            // The lanes of a row are contiguous: reduce every run of equal rows inside its 16-lane DPP row first
+            // (segmented scan, pure VALU) and let the LAST lane of the run issue the LDS atomics.  With all
+            // entries of a long row adding to the same LDS word the atomics serialised (27 lanes per address
+            // on the nlpkkt stand-in: most of that kernel's 2.3 ms, 81 % of its LDS cycles were conflicts).
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u32 len = be[u] - bs[u];
+                const bool live = ok[u] && len;
+                const u32 key = ok[u] ? lo[u] : 0xFFFFFFFFu;  // entries with an empty B row stay inside their run
+                u32 v_sum = live ? len : 0u, v_mx = v_sum, v_min = first[u], v_max = live ? last[u] : 0u;
+#define SPECK_SEG_STEP(S_)                                                                        \
+                {                                                                                 \
+                    const bool same = dpp_move<kDppRowShr + S_>(0xFFFFFFFEu, key) == key;         \
+                    const u32 t_sum = dpp_move<kDppRowShr + S_>(0u, v_sum);                       \
+                    const u32 t_mx = dpp_move<kDppRowShr + S_>(0u, v_mx);                         \
+                    const u32 t_min = dpp_move<kDppRowShr + S_>(0xFFFFFFFFu, v_min);              \
+                    const u32 t_max = dpp_move<kDppRowShr + S_>(0u, v_max);                       \
+                    v_sum += same ? t_sum : 0u;                                                   \
+                    v_mx = same ? max(v_mx, t_mx) : v_mx;                                         \
+                    v_min = same ? min(v_min, t_min) : v_min;                                     \
+                    v_max = same ? max(v_max, t_max) : v_max;                                     \
+                }
+                SPECK_SEG_STEP(1)
+                SPECK_SEG_STEP(2)
+                SPECK_SEG_STEP(4)
+                SPECK_SEG_STEP(8)
+#undef SPECK_SEG_STEP
+                const bool tail = dpp_move<kDppRowShl + 1>(0xFFFFFFFEu, key) != key;  // lane 15 of a row: no source
+                if (tail && v_sum != 0u) {  // (a run of empty B rows only adds nothing; lanes past the tile hold 0)
+                    atomicAdd(&ops_[key], (u64)v_sum);
+                    atomicMax(&mx_[key], v_mx);
+                    atomicMin(&cmin_[key], v_min);
+                    atomicMax(&cmax_[key], v_max);
+                }
+            }
+        }
+    };
+    // Rows of a sub-chunk from their LDS accumulators to the output arrays, class and block statistics (one lane
+    // per row, executed by a whole wave: the class histogram is ballots).
+    auto finish_rows = [&](u32 row0, u32 nrows, const u32* ro_, const u64* ops_, const u32* mx_, const u32* cmin_,
+                           const u32* cmax_) {
+        u8 cls = SYM_NONE;
+        if (lane < nrows) {
+            const u32 row = row0 + lane;
+            const u64 ops = ops_[lane];
+            const u32 ops32 = ops > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)ops;
+            const u32 len_a = ro_[lane + 1] - ro_[lane];
+            const u32 cmin = cmin_[lane], cmax = cmax_[lane];
+            if (row_ops) row_ops[row] = ops32;
+            if (row_max_ops) row_max_ops[row] = mx_[lane];
+            if (row_col_min) row_col_min[row] = cmin;
+            if (row_col_max) row_col_max[row] = cmax;
+            my_products += ops;
+            my_max = max(my_max, ops32);
+            if (sym_cls) {
+                cls = classify_symbolic(len_a, ops32, cmin, cmax, cp);
+                sym_cls[row] = cls;
+                if (cls == SYM_NF) {
+                    my_nf += nf_slot_entries(cmin, cmax, ops32);  // scratch slot: nnz <= min(column range, products)
+                    my_nfr = max(my_nfr, cmax - cmin + 1);
+                }
+                if (cls == SYM_GH) my_nf += gh_table_slots(ops32);  // ... = the row's key set in global memory
+                if (cls == SYM_NONE) {
+                    // empty row, or a single A entry: the C row is a scaled copy of one B row
+                    counts[row] = ops32;
+                } else if (cp.want_bytes) {
+                    atomicAdd(&s_bytes[cls], symbolic_row_bytes(len_a, ops32));
+                }
+            }
+        }
+        if (sym_cls) {
+#pragma unroll
+            for (int c = 0; c < SYM_CLASSES; ++c) hist[c] += __popcll(__ballot(cls == c));
+        }
+    };
+
+    // Sub-chunks with a HUB row (power-law inputs: thousands of entries in one row) are not walked by
+    // the wave that meets them -- its chain of dependent gathers would be the lifetime of the kernel -- but put on
+    // a list and walked by ALL waves of the workgroup together afterwards (webbase stand-in: 170 -> 90 us; uniformly long rows stay with their waves: every sub-chunk of the cant stand-in on the list cost it 30 us).
+    __shared__ u32 s_coop[kAnCoopMax];
+    __shared__ u32 s_ncoop;
+    if (t == 0) s_ncoop = 0;
+    __syncthreads();
     for (u32 row0 = row_begin + wid * R; row0 < row_end; row0 += NW * R) {
         const u32 nrows = min(R, row_end - row0);
         wave_lds_fence();
@@ -122,6 +262,15 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
         // would run at a fraction of its lanes (webbase stand-in: 172 -> ~60 us for this kernel).
         const u32 my_len = lane < nrows ? s_ro[lane + 1] - s_ro[lane] : 0u;
         const u32 max_len = wave_reduce_max(my_len);
+        if (max_len > kAnCoopRowLen && e_end - e_begin > kAnCoopEntries) {  // (uniform) a hub row: later, by the whole workgroup -- if the list has room
+            u32 at = 0;
+            if (lane == 0) at = atomicAdd(&s_ncoop, 1u);
+            at = (u32)__builtin_amdgcn_readfirstlane((int)at);
+            if (at < kAnCoopMax) {
+                if (lane == 0) s_coop[at] = row0;
+                continue;
+            }
+        }
         if (max_len <= kAnRowPathMax) {
             const u32 e_lo = lane < nrows ? s_ro[lane] : 0u;
             u64 r_ops = 0;
@@ -161,125 +310,34 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
                 s_cmax[lane] = r_max;
             }
         } else
-        for (u32 e0 = e_begin + lane; e0 < e_end; e0 += 64 * U) {
-            u32 bs[U], be[U], first[U], last[U];
-            bool ok[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const u32 e = e0 + u * 64;
-                ok[u] = e < e_end;
-                u32 k = ok[u] ? a_col[e] : 0u;
-                if (k >= b_rows) {
-                    bad_col = true;
-                    k = 0;
-                }
-                // B.rowptr[k], B.rowptr[k+1] as ONE 8-byte gather (4-byte aligned): the random
-                // gathers of this kernel are bound by addresses per cycle, not by bytes
-                const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
-                bs[u] = ok[u] ? pr.x : 0u;
-                be[u] = ok[u] ? pr.y : 0u;
-                // hand the B-row bounds to the symbolic / numeric kernels
-                if (ok[u] && b_sl) b_sl[e - e_base] = make_uint2(bs[u], be[u] - bs[u]);
-            }
-            AN_MARK(1);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool has = ok[u] && be[u] > bs[u];
-                first[u] = has ? b_col[bs[u]] : 0xFFFFFFFFu;
-                last[u] = has ? b_col[be[u] - 1] : 0u;
-            }
-            AN_MARK(2);
-            // local row of each entry: largest r with s_ro[r] <= e; the U searches advance in lock
-            // step (independent LDS reads)
-            u32 lo[U], hi[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                lo[u] = 0;
-                hi[u] = nrows;
-            }
-#pragma unroll
-            for (int step = 0; step < 5; ++step) {  // 2^5 = R
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const u32 mid = (lo[u] + hi[u]) >> 1;
-                    const bool act = hi[u] - lo[u] > 1;
-                    const bool le = s_ro[mid] <= e0 + u * 64;
-                    lo[u] = (act && le) ? mid : lo[u];
-                    hi[u] = (act && !le) ? mid : hi[u];
-                }
-            }
-            AN_MARK(3);
-            // The lanes of a row are contiguous: reduce every run of equal rows inside its 16-lane DPP row first
-            // (segmented scan, pure VALU) and let the LAST lane of the run issue the LDS atomics.  With all
-            // entries of a long row adding to the same LDS word the atomics serialised (27 lanes per address
-            // on the nlpkkt stand-in: most of that kernel's 2.3 ms, 81 % of its LDS cycles were conflicts).
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const u32 len = be[u] - bs[u];
-                const bool live = ok[u] && len;
-                const u32 key = ok[u] ? lo[u] : 0xFFFFFFFFu;  // entries with an empty B row stay inside their run
-                u32 v_sum = live ? len : 0u, v_mx = v_sum, v_min = first[u], v_max = live ? last[u] : 0u;
-#define SPECK_SEG_STEP(S_)                                                                        \
-                {                                                                                 \
-                    const bool same = dpp_move<kDppRowShr + S_>(0xFFFFFFFEu, key) == key;         \
-                    const u32 t_sum = dpp_move<kDppRowShr + S_>(0u, v_sum);                       \
-                    const u32 t_mx = dpp_move<kDppRowShr + S_>(0u, v_mx);                         \
-                    const u32 t_min = dpp_move<kDppRowShr + S_>(0xFFFFFFFFu, v_min);              \
-                    const u32 t_max = dpp_move<kDppRowShr + S_>(0u, v_max);                       \
-                    v_sum += same ? t_sum : 0u;                                                   \
-                    v_mx = same ? max(v_mx, t_mx) : v_mx;                                         \
-                    v_min = same ? min(v_min, t_min) : v_min;                                     \
-                    v_max = same ? max(v_max, t_max) : v_max;                                     \
-                }
-                SPECK_SEG_STEP(1)
-                SPECK_SEG_STEP(2)
-                SPECK_SEG_STEP(4)
-                SPECK_SEG_STEP(8)
-#undef SPECK_SEG_STEP
-                const bool tail = dpp_move<kDppRowShl + 1>(0xFFFFFFFEu, key) != key;  // lane 15 of a row: no source
-                if (tail && v_sum != 0u) {  // (a run of empty B rows only adds nothing; lanes past the tile hold 0)
-                    atomicAdd(&s_ops[key], (u64)v_sum);
-                    atomicMax(&s_mx[key], v_mx);
-                    atomicMin(&s_cmin[key], v_min);
-                    atomicMax(&s_cmax[key], v_max);
-                }
-            }
-        }
+            walk_entries(e_begin + lane, e_end, 64 * U, nrows, s_ro, s_ops, s_mx, s_cmin, s_cmax);
         wave_lds_fence();
         AN_MARK(4);
-        u8 cls = SYM_NONE;
-        if (lane < nrows) {
-            const u32 row = row0 + lane;
-            const u64 ops = s_ops[lane];
-            const u32 ops32 = ops > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)ops;
-            const u32 len_a = s_ro[lane + 1] - s_ro[lane];
-            const u32 cmin = s_cmin[lane], cmax = s_cmax[lane];
-            if (row_ops) row_ops[row] = ops32;
-            if (row_max_ops) row_max_ops[row] = s_mx[lane];
-            if (row_col_min) row_col_min[row] = cmin;
-            if (row_col_max) row_col_max[row] = cmax;
-            my_products += ops;
-            my_max = max(my_max, ops32);
-            if (sym_cls) {
-                cls = classify_symbolic(len_a, ops32, cmin, cmax, cp);
-                sym_cls[row] = cls;
-                if (cls == SYM_NF) {
-                    my_nf += nf_slot_entries(cmin, cmax, ops32);  // scratch slot: nnz <= min(column range, products)
-                    my_nfr = max(my_nfr, cmax - cmin + 1);
-                }
-                if (cls == SYM_GH) my_nf += gh_table_slots(ops32);  // ... = the row's key set in global memory
-                if (cls == SYM_NONE) {
-                    // empty row, or a single A entry: the C row is a scaled copy of one B row
-                    counts[row] = ops32;
-                } else if (cp.want_bytes) {
-                    atomicAdd(&s_bytes[cls], symbolic_row_bytes(len_a, ops32));
-                }
+        finish_rows(row0, nrows, s_ro, s_ops, s_mx, s_cmin, s_cmax);
+    }
+    // the listed sub-chunks, one after the other, by all waves (wave 0's staging arrays; workgroup barriers)
+    __syncthreads();
+    const u32 ncoop = min(s_ncoop, kAnCoopMax);
+    for (u32 i = 0; i < ncoop; ++i) {
+        const u32 row0 = s_coop[i];
+        const u32 nrows = min(R, row_end - row0);
+        u32* ro0 = s_ro_all[0];
+        if (wid == 0) {
+            if (lane <= nrows) ro0[lane] = a_ro[row0 + lane];
+            if (lane == 0 && nrows == R) ro0[R] = a_ro[row0 + R];
+            if (lane < R) {
+                s_ops_all[0][lane] = 0;
+                s_mx_all[0][lane] = 0;
+                s_cmin_all[0][lane] = 0xFFFFFFFFu;
+                s_cmax_all[0][lane] = 0;
             }
         }
-        if (sym_cls) {
-#pragma unroll
-            for (int c = 0; c < SYM_CLASSES; ++c) hist[c] += __popcll(__ballot(cls == c));
-        }
+        __syncthreads();
+        walk_entries(ro0[0] + wid * 64 * U + lane, ro0[nrows], NW * 64 * U, nrows, ro0, s_ops_all[0], s_mx_all[0],
+                     s_cmin_all[0], s_cmax_all[0]);
+        __syncthreads();
+        if (wid == 0) finish_rows(row0, nrows, ro0, s_ops_all[0], s_mx_all[0], s_cmin_all[0], s_cmax_all[0]);
+        __syncthreads();
     }
     AN_MARK(5);
     my_products = wave_reduce_add(my_products);

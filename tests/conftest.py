@@ -3,6 +3,7 @@ import subprocess
 import sys
 
 import numpy as np
+import torch  # noqa: F401  FIRST: torch and libspeck_amd.so each link a HIP runtime, the first one loaded serves the process
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
