@@ -40,4 +40,5 @@ for w in $WORKLOADS; do
   python scripts/make_counters.py $w $OUT/${ROUND}_pmc_${w}_counters.csv $OUT/traffic.json $OUT/counters.json $CSVS
   tail -1 $OUT/${ROUND}_bench_${w}_under_rocprof.log | cut -c1-300
 done
+rm -rf gpurun_out/_p_*
 ls -la $OUT
