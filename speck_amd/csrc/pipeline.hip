@@ -1455,6 +1455,6 @@ const char* speck_status_string(int status)
     return "unknown";
 }
 
-const char* speck_version(void) { return "speck_amd 0.2 (gfx950)"; }
+const char* speck_version(void) { return "speck_amd 0.3 (gfx950)"; }
 
 }  // extern "C"
