@@ -70,10 +70,13 @@ enum NumClass : u8 {
     NUM_NONE = 0xFF
 };
 
-constexpr u32 kSymG8Cap = 32, kSymG8MaxOps = 25;
-constexpr u32 kSymG16Cap = 64, kSymG16MaxOps = 51;
-constexpr u32 kSymW128Cap = 128, kSymW128MaxOps = 102;
-constexpr u32 kSymW256Cap = 256, kSymW256MaxOps = 204;
+// Key sets of the sub-wave symbolic classes: TWICE the slots the 4/5 rule of the reference (Multiply.cu:263) would give
+// them -- a key costs 4 bytes, the LDS of these launches is nowhere near the limit, and at a load <= 0.4 the probing
+// loops (whose length is the longest chain of the wave) mostly do not start (mac_econ stand-in -2.5 %).
+constexpr u32 kSymG8Cap = 64, kSymG8MaxOps = 25;
+constexpr u32 kSymG16Cap = 128, kSymG16MaxOps = 51;
+constexpr u32 kSymW128Cap = 256, kSymW128MaxOps = 102;
+constexpr u32 kSymW256Cap = 512, kSymW256MaxOps = 204;
 constexpr u32 kSymW1KCap = 1024, kSymW1KMaxOps = 819;
 constexpr u32 kSymB4KCap = 4096, kSymB4KMaxOps = 3276;
 constexpr u32 kSymB16KCap = 16384, kSymB16KMaxOps = 13107;
