@@ -294,53 +294,39 @@ int speck_comm_unique_id(int transport, void* id128)
 int speck_comm_init(int device, int nranks, int rank, int transport, const void* id128, speck_comm** out)
 {
     if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks || nranks > kMaxRanks) return SPECK_ERR_INVALID;
+    if (transport != SPECK_TRANSPORT_RCCL && transport != SPECK_TRANSPORT_HOSTMEM) return SPECK_ERR_INVALID;
     COMM_HIP(hipSetDevice(device));
     auto* c = new speck_comm();
     c->nranks = nranks;
     c->rank = rank;
     c->transport = transport;
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
-        return SPECK_ERR_HIP;
-    }
+    auto fail = [&](int code) {
+        (void)speck_comm_destroy(c);  // releases whatever exists so far
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(SPECK_ERR_HIP);
     if (transport == SPECK_TRANSPORT_RCCL) {
-        if (!rccl()) {
-            delete c;
-            return SPECK_ERR_COMM;
-        }
+        if (!rccl()) return fail(SPECK_ERR_COMM);
         ncclUniqueId id;
         std::memcpy(&id, id128, sizeof(id));
-        if (rccl()->CommInitRank(&c->nccl, nranks, id, rank) != ncclSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&c->d_sizes), (2 + 2 * size_t(nranks)) * 8) != hipSuccess) {
-            (void)hipStreamDestroy(c->stream);
-            delete c;
-            return SPECK_ERR_COMM;
+        if (rccl()->CommInitRank(&c->nccl, nranks, id, rank) != ncclSuccess) {
+            c->nccl = nullptr;
+            return fail(SPECK_ERR_COMM);
         }
-    } else if (transport == SPECK_TRANSPORT_HOSTMEM) {
-        if (std::memcmp(id128, kShmMagic, 8) != 0) {
-            delete c;
-            return SPECK_ERR_INVALID;
-        }
+        if (hipMalloc(reinterpret_cast<void**>(&c->d_sizes), (2 + 2 * size_t(nranks)) * 8) != hipSuccess)
+            return fail(SPECK_ERR_OOM);
+    } else {
+        if (std::memcmp(id128, kShmMagic, 8) != 0) return fail(SPECK_ERR_INVALID);
         uint64_t token;
         std::memcpy(&token, static_cast<const char*>(id128) + 8, 8);
         char buf[64];
         std::snprintf(buf, sizeof(buf), "/speck_%016llx", (unsigned long long)token);
         c->shm_token = buf;
-        if (!map_segment(c->ctl, c->shm_token + "_ctl", sizeof(ShmControl), rank == 0)) {
-            delete c;
-            return SPECK_ERR_COMM;
-        }
+        if (!map_segment(c->ctl, c->shm_token + "_ctl", sizeof(ShmControl), rank == 0)) return fail(SPECK_ERR_COMM);
         ShmControl* k = c->control();  // a fresh segment is zero-filled: every counter starts at 0
         k->arrived.fetch_add(1);
-        if (!spin_until([&] { return k->arrived.load() >= (uint32_t)nranks; })) {
-            unmap_segment(c->ctl);
-            delete c;
-            return SPECK_ERR_COMM;
-        }
-    } else {
-        delete c;
-        return SPECK_ERR_INVALID;
+        if (!spin_until([&] { return k->arrived.load() >= (uint32_t)nranks; })) return fail(SPECK_ERR_COMM);
     }
     *out = c;
     return SPECK_OK;
@@ -368,15 +354,30 @@ int speck_comm_info(const speck_comm* c, int* nranks, int* rank, int* transport)
     return SPECK_OK;
 }
 
+static int fill_plan(speck_gather_plan* p, speck_comm* c, int root, uint64_t rows_local, uint64_t cols,
+                     uint64_t nnz_local, size_t value_size, int slots);
+
 int speck_gather_plan_create(speck_comm* c, int root, uint64_t rows_local, uint64_t cols, uint64_t nnz_local,
                              size_t value_size, int slots, speck_gather_plan** out)
 {
     if (!c || !out || root < 0 || root >= c->nranks || slots < 1 || slots > kMaxSlots ||
         (value_size != 4 && value_size != 8))
         return SPECK_ERR_INVALID;
+    auto* p = new speck_gather_plan();
+    const int rc = fill_plan(p, c, root, rows_local, cols, nnz_local, value_size, slots);
+    if (rc != SPECK_OK) {
+        (void)speck_gather_plan_destroy(p);  // whatever was allocated so far
+        return rc;
+    }
+    *out = p;
+    return SPECK_OK;
+}
+
+static int fill_plan(speck_gather_plan* p, speck_comm* c, int root, uint64_t rows_local, uint64_t cols,
+                     uint64_t nnz_local, size_t value_size, int slots)
+{
     COMM_HIP(hipSetDevice(c->device));
     static std::atomic<uint64_t> next_id{1};
-    auto* p = new speck_gather_plan();
     p->comm = c;
     p->root = root;
     p->slots = slots;
@@ -384,19 +385,17 @@ int speck_gather_plan_create(speck_comm* c, int root, uint64_t rows_local, uint6
     p->cols = cols;
     p->id = next_id++;
     std::vector<uint64_t> all_rows, all_nnz;
-    int rc = exchange_sizes(c, rows_local, nnz_local, all_rows, all_nnz);
-    if (rc != SPECK_OK) {
-        delete p;
-        return rc;
-    }
-    if (!speck::gather_layout(all_rows.data(), all_nnz.data(), c->nranks, &p->lay)) {
-        delete p;
-        return SPECK_ERR_NNZ_OVERFLOW;  // the concatenation does not fit u32 row offsets
-    }
-    p->done.resize(slots);
     p->pending.assign(slots, 0);
     p->gen.assign(slots, 0);
-    for (auto& e : p->done) COMM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int rc = exchange_sizes(c, rows_local, nnz_local, all_rows, all_nnz);
+    if (rc != SPECK_OK) return rc;
+    // the concatenation must fit the u32 row offsets of the dCSR layout
+    if (!speck::gather_layout(all_rows.data(), all_nnz.data(), c->nranks, &p->lay)) return SPECK_ERR_NNZ_OVERFLOW;
+    for (int i = 0; i < slots; ++i) {
+        hipEvent_t e = nullptr;
+        COMM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->done.push_back(e);
+    }
     const bool is_root = c->rank == root;
     if (is_root) {
         p->out.resize(slots);
@@ -432,7 +431,6 @@ int speck_gather_plan_create(speck_comm* c, int root, uint64_t rows_local, uint6
         // when the plan goes)
         if (shm_barrier(c) != SPECK_OK) return SPECK_ERR_COMM;
     }
-    *out = p;
     return SPECK_OK;
 }
 
@@ -555,12 +553,17 @@ int speck_gather_plan_layout(const speck_gather_plan* p, uint64_t* row_displs, u
 int speck_gather_plan_destroy(speck_gather_plan* p)
 {
     if (!p) return SPECK_ERR_INVALID;
+    if (!p->comm) {  // never got as far as a communicator
+        delete p;
+        return SPECK_OK;
+    }
     (void)hipSetDevice(p->comm->device);
-    for (int s = 0; s < p->slots; ++s) (void)speck_gather_wait(p, s, nullptr);
+    for (int s = 0; s < (int)p->done.size() && s < (int)p->pending.size(); ++s) (void)speck_gather_wait(p, s, nullptr);
     // host-staged transport: my segments stay until the root has taken what I put there
-    if (p->comm->transport == SPECK_TRANSPORT_HOSTMEM && p->comm->nranks > 1 && p->comm->rank != p->root) {
+    if (p->comm->transport == SPECK_TRANSPORT_HOSTMEM && p->comm->nranks > 1 && p->comm->rank != p->root &&
+        !p->mine.empty()) {
         ShmControl* k = p->comm->control();
-        for (int s = 0; s < p->slots; ++s)
+        for (int s = 0; s < (int)p->mine.size(); ++s)
             if (p->gen[s])
                 (void)spin_until([&] { return k->taken[p->comm->rank][s].load(std::memory_order_acquire) ==
                                               ((p->id << 32) | p->gen[s]); }, 30);
