@@ -969,3 +969,22 @@ def test_direct_placement_of_numeric_first_rows_is_verified_per_row(cfg):
         _assert_matches_oracle(dC, A2, A)
     finally:
         cfg.set_option("nf_direct", 1)
+
+
+@pytest.mark.parametrize("kind,scale", [("scircuit", 0.3), ("mac_econ", 0.3), ("cant", 0.1), ("webbase", 0.1),
+                                         ("nlpkkt", 0.002)])
+def test_plain_relative_1e12_on_cancellation_free_standins(cfg, kind, scale):
+    """north_star's wording is "within 1e-12 relative": with positive values no cancellation is possible and the
+    plain form |c - c_ref| <= 1e-12 |c_ref| must hold for every entry of every stand-in (the signed ones are held to
+    the rigorous bound 1e-12 * sum|a*b| instead) -- eager and replayed."""
+    A = to_po(sa.gen_matrix(kind, scale, 7, signed=False))
+    assert (A.data > 0).all()
+    dA, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR()
+    R, _ = po.spgemm(A, A)
+    for call in range(4):
+        sa.MultiplyspECK(dA, dA, dC, cfg)
+        if call in (0, 3):
+            got = dC.to_host()
+            assert (got.row_offsets == R.row_offsets).all() and (got.col_ids == R.col_ids).all()
+            assert np.max(np.abs(got.data - R.data) / np.abs(R.data)) <= TOL64
+    assert cfg.last_stats()["replayed"]
