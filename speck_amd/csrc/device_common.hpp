@@ -114,6 +114,7 @@ __host__ __device__ inline u32 table_bits(u32 nnz, u32 pct)
     return bits;
 }
 constexpr u32 kNumG8Cap = 32, kNumG8MaxNnz = max_nnz_of(32, SPECK_LOAD_TINY_PCT);
+constexpr u32 kNumEscMaxOps = 32, kNumEscMaxLen = 8;  // NUM_G8 = the register-resident class (esc.hpp)
 constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = max_nnz_of(64, SPECK_LOAD_TINY_PCT);
 constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = max_nnz_of(128, SPECK_LOAD_TINY_PCT);
 constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = max_nnz_of(512, SPECK_LOAD_TINY_PCT);
@@ -173,7 +174,8 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
 {
     if (ops == 0 || len_a <= 1) return SYM_NONE;
     if (is_numeric_first(len_a, ops, cmin, cmax, p)) return SYM_NF;
-    if (p.sym_g8 && ops <= kSymG8MaxOps) return SYM_G8;
+    // at most 32 products from at most 8 entries of A: sorted in registers (esc.hpp)
+    if (p.sym_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return SYM_G8;
     if (ops <= kSymG16MaxOps) return SYM_G16;
     if (p.sym_w128 && ops <= kSymW128MaxOps) return SYM_W128;
     if (ops <= kSymW256MaxOps) return SYM_W256;
@@ -200,7 +202,9 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     if (nnz == 0) return NUM_NONE;
     if (len_a == 1) return NUM_DIRECT;
     if (is_numeric_first(len_a, ops, cmin, cmax, p)) return NUM_NFCOPY;
-    if (p.num_g8 && nnz <= kNumG8MaxNnz) return NUM_G8;
+    // at most 32 products from at most 8 entries of A: expand / sort / compress in registers (esc.hpp), whatever
+    // the nnz; the hash classes take the rest by nnz
+    if (p.num_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return NUM_G8;
     if (nnz <= kNumG16MaxNnz) return NUM_G16;
     if (nnz <= kNumW128MaxNnz) return NUM_W128;
     const u64 range = u64(cmax) - u64(cmin) + 1;

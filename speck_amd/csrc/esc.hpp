@@ -1,0 +1,116 @@
+// esc.hpp -- expand / sort / compress in registers for rows with at most 32 products (8 lanes x 4 products).
+//
+// The hash classes pay a fixed price per row -- clear a table, stage the A row, insert with compare-and-swap,
+// compact, rank-sort, emit: ~410 of the ~600 VALU wave-instructions an 8-row wave-iteration of the small-row
+// launch issues, and that launch is bound by VALU issue (70 % of all issue slots on the mac_econ stand-in,
+// DESIGN.md 6).  A row whose products fit the registers of its lane group needs none of it:
+//   expand    lane <-> product (4 per lane), owner of a product from a bit mask of where the entries' products end
+//   sort      the products as packed keys (column << 5 | product number: columns are < 2^27, Multiply.cu:57-66)
+//             with a bitonic network over 8 lanes x 4 registers -- min / max only, DPP moves inside the group
+//   compress  equal columns are neighbours: segmented sum in sorted order (deterministic: by product number),
+//             the last element of every run carries the entry, its rank is the number of runs before it
+// No LDS atomics, no probing loops, no table.  The values ride in LDS by product number (32 x 8 B per group).
+// (Role of the reference's multi-row hash blocks for tiny rows, include/GPU/spECK_HashSpGEMM.cuh:591-738.)
+#pragma once
+#include "device_common.hpp"
+
+namespace speck {
+
+constexpr u32 kEscLanes = 8, kEscPerLane = 4, kEscProducts = kEscLanes * kEscPerLane;  // 32
+constexpr u32 kEscInvalid = 0xFFFFFFFFu;
+
+constexpr int kDppQuadXor1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;   // quad_perm [2,3,0,1]
+constexpr int kDppQuadMirror = 0x1B; // quad_perm [3,2,1,0]
+constexpr int kDppRowHalfMirror = 0x141;
+
+// OR over the 8 lanes of a group, result in every lane
+__device__ __forceinline__ u32 esc_group_or(u32 v)
+{
+    v |= dpp_move<kDppQuadXor1>(0u, v);
+    v |= dpp_move<kDppQuadXor2>(0u, v);
+    v |= dpp_move<kDppRowHalfMirror>(0u, v);
+    return v;
+}
+
+// compare-exchange with the same register of a partner lane: the lower lane of the pair keeps the minimum
+template <int CTRL>
+__device__ __forceinline__ void esc_cx_lane(u32& x, u32 src, bool lower)
+{
+    const u32 p = dpp_move<CTRL>(0u, src);
+    const u32 mn = min(x, p), mx = max(x, p);
+    x = lower ? mn : mx;
+}
+__device__ __forceinline__ void esc_cx(u32& lo, u32& hi)
+{
+    const u32 a = min(lo, hi), b = max(lo, hi);
+    lo = a;
+    hi = b;
+}
+
+// Ascending bitonic sort of the 32 elements of an 8-lane group, element i = lane * 4 + register ("flip" form:
+// every compare-exchange gives the lower index the minimum).  `gl` = lane inside the group.
+__device__ __forceinline__ void esc_sort32(u32 (&x)[4], u32 gl)
+{
+    const bool l0 = (gl & 1u) == 0, l1 = (gl & 2u) == 0, l2 = (gl & 4u) == 0;
+    // k = 1, 2: inside the lane
+    esc_cx(x[0], x[1]);
+    esc_cx(x[2], x[3]);
+    esc_cx(x[0], x[3]);
+    esc_cx(x[1], x[2]);
+    esc_cx(x[0], x[1]);
+    esc_cx(x[2], x[3]);
+    // k = 3: flip over 8 elements = partner lane ^ 1, register 3 - r; then distances 2, 1 inside the lane
+    {
+        const u32 y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3];
+        esc_cx_lane<kDppQuadXor1>(x[0], y3, l0);
+        esc_cx_lane<kDppQuadXor1>(x[1], y2, l0);
+        esc_cx_lane<kDppQuadXor1>(x[2], y1, l0);
+        esc_cx_lane<kDppQuadXor1>(x[3], y0, l0);
+    }
+    esc_cx(x[0], x[2]);
+    esc_cx(x[1], x[3]);
+    esc_cx(x[0], x[1]);
+    esc_cx(x[2], x[3]);
+    // k = 4: flip over 16 = lane ^ 3, register 3 - r; distance 4 = lane ^ 1; then 2, 1
+    {
+        const u32 y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3];
+        esc_cx_lane<kDppQuadMirror>(x[0], y3, l1);
+        esc_cx_lane<kDppQuadMirror>(x[1], y2, l1);
+        esc_cx_lane<kDppQuadMirror>(x[2], y1, l1);
+        esc_cx_lane<kDppQuadMirror>(x[3], y0, l1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) esc_cx_lane<kDppQuadXor1>(x[r], x[r], l0);
+    esc_cx(x[0], x[2]);
+    esc_cx(x[1], x[3]);
+    esc_cx(x[0], x[1]);
+    esc_cx(x[2], x[3]);
+    // k = 5: flip over 32 = lane ^ 7, register 3 - r; distance 8 = lane ^ 2; 4 = lane ^ 1; then 2, 1
+    {
+        const u32 y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3];
+        esc_cx_lane<kDppRowHalfMirror>(x[0], y3, l2);
+        esc_cx_lane<kDppRowHalfMirror>(x[1], y2, l2);
+        esc_cx_lane<kDppRowHalfMirror>(x[2], y1, l2);
+        esc_cx_lane<kDppRowHalfMirror>(x[3], y0, l2);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) esc_cx_lane<kDppQuadXor2>(x[r], x[r], l1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) esc_cx_lane<kDppQuadXor1>(x[r], x[r], l0);
+    esc_cx(x[0], x[2]);
+    esc_cx(x[1], x[3]);
+    esc_cx(x[0], x[1]);
+    esc_cx(x[2], x[3]);
+}
+
+// move a double one lane up / down inside the 16-lane DPP row (lanes without a source get `fill`)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double fill, double v)
+{
+    const u64 f = __double_as_longlong(fill), x = __double_as_longlong(v);
+    const u32 lo = dpp_move<CTRL>((u32)f, (u32)x), hi = dpp_move<CTRL>((u32)(f >> 32), (u32)(x >> 32));
+    return __longlong_as_double((u64(hi) << 32) | lo);
+}
+
+}  // namespace speck

@@ -28,6 +28,7 @@
 #include "device_common.hpp"
 #include "launch.hpp"
 #include "row_groups.hpp"
+#include "esc.hpp"
 
 namespace speck {
 
@@ -444,6 +445,143 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     }
 }
 
+// ------------------------------------------------------------------ NUM_G8: expand / sort / compress (esc.hpp)
+// Rows with at most 32 products and 8 entries of A: 8 lanes per row, 4 products per lane, nothing but registers, DPP
+// and 32 values in LDS.  LDS per group: B-row offsets and a_ik of the (non-empty) entries | the products by number.
+template <typename T>
+constexpr u32 num_esc_group_lds()
+{
+    return kEscLanes * (4u + (u32)sizeof(Acc<T>)) + kEscProducts * (u32)sizeof(Acc<T>);
+}
+
+template <typename T, int THREADS>
+__device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
+                                             u32* __restrict__ c_col, T* __restrict__ c_val, u32 bidx, u32 nblk,
+                                             ClassHint hint = kNoHint)
+{
+    using G = SubWave<kEscLanes>;
+    constexpr u32 NG = THREADS / kEscLanes;
+    const G g;
+    const u32 gid = threadIdx.x / kEscLanes;
+    unsigned char* mine = smem + gid * num_esc_group_lds<T>();
+    Acc<T>* s_vals = reinterpret_cast<Acc<T>*>(mine);               // [32] products by number
+    Acc<T>* s_av = s_vals + kEscProducts;                           // [8]  a_ik of the j-th non-empty entry
+    u32* s_off = reinterpret_cast<u32*>(s_av + kEscLanes);          // [8]  its B-row start minus its first product number
+    const ListHead head = open_list<false>(w, NUM_G8, hint, bidx, nblk, NG, gid, (w.xcd_aware & 1u) != 0);
+    if (head.miss) return;
+    const RowRec* recs = head.recs;
+    u32 idx = head.rs.idx;
+    const u32 stride = head.rs.stride, count = head.rs.end;
+    RowRec next = head.next;
+    const u32 gl = g.lane;
+    while (idx < count) {
+        const RowRec rec = next;  // fetched while the previous row was being processed
+        if (idx + stride < count) next = recs[idx + stride];
+        // ---- expand: my entry of A, where its products end
+        const bool have = rec.a0 + gl < rec.a1;
+        uint2 sl = make_uint2(0u, 0u);
+        Acc<T> av = 0;
+        if (have) {
+            sl = src.b_sl[rec.a0 + gl];
+            av = (Acc<T>)src.a_val[rec.a0 + gl];
+        }
+        u32 total;
+        const u32 incl = g.inclusive_scan(sl.y, &total, nullptr);
+        const bool nonempty = sl.y != 0;
+        const u32 before = (u32)__popcll(g.ballot(nonempty) & ((1ull << gl) - 1ull));  // non-empty entries before mine
+        if (nonempty) {
+            s_off[before] = sl.x - (incl - sl.y);
+            s_av[before] = av;
+        }
+        // bit k: a (non-empty) entry's products end at k -- the owner of product p is the number of set bits <= p
+        const u32 ends = esc_group_or((nonempty && incl < 32u) ? (1u << incl) : 0u);
+        wave_lds_fence();
+        u32 key[kEscPerLane];
+#pragma unroll
+        for (u32 u = 0; u < kEscPerLane; ++u) {
+            const u32 p = u * kEscLanes + gl;
+            key[u] = kEscInvalid;
+            if (p < total) {
+                const u32 j = (u32)__popc(ends & ((2u << p) - 1u));
+                const u32 ib = s_off[j] + p;
+                const u32 c = src.b_col[ib];
+                const T bv = src.b_val[ib];
+                const T prod = (T)s_av[j] * bv;  // rounded product, added later (no FMA across the add)
+                s_vals[p] = (Acc<T>)prod;
+                key[u] = (c << 5) | p;
+            }
+        }
+        wave_lds_fence();
+        // ---- sort by (column, product number)
+        esc_sort32(key, gl);
+        // ---- compress: sums of the runs of equal columns, in sorted order
+        u32 col[kEscPerLane];
+        Acc<T> sum[kEscPerLane];
+#pragma unroll
+        for (u32 r = 0; r < kEscPerLane; ++r) {
+            col[r] = key[r] == kEscInvalid ? kEscInvalid : key[r] >> 5;
+            sum[r] = key[r] == kEscInvalid ? Acc<T>(0) : s_vals[key[r] & 31u];
+        }
+        bool lead[kEscPerLane];  // element r continues the run of element 0 of this lane
+        lead[0] = true;
+#pragma unroll
+        for (u32 r = 1; r < kEscPerLane; ++r) {
+            const bool same = col[r] == col[r - 1] && col[r] != kEscInvalid;
+            lead[r] = lead[r - 1] && same;
+            sum[r] += same ? sum[r - 1] : Acc<T>(0);
+        }
+        // across the lanes: what the lanes before me contribute to the run my element 0 continues
+        const u32 prev_col = dpp_move<kDppRowShr + 1>(kEscInvalid, col[kEscPerLane - 1]);
+        const bool cont = gl != 0 && col[0] != kEscInvalid && prev_col == col[0];
+        Acc<T> chain = sum[kEscPerLane - 1];                // running sum of the run that ends this lane
+        bool stop = !(lead[kEscPerLane - 1] && cont);       // ... which does not reach back into the lane before
+#pragma unroll
+        for (u32 d = 1; d < kEscLanes; d <<= 1) {
+            Acc<T> t;
+            bool ts;
+            if (d == 1) {
+                t = dpp_move_f64<kDppRowShr + 1>(0.0, chain);
+                ts = dpp_move<kDppRowShr + 1>(1u, (u32)stop) != 0;
+            } else if (d == 2) {
+                t = dpp_move_f64<kDppRowShr + 2>(0.0, chain);
+                ts = dpp_move<kDppRowShr + 2>(1u, (u32)stop) != 0;
+            } else {
+                t = dpp_move_f64<kDppRowShr + 4>(0.0, chain);
+                ts = dpp_move<kDppRowShr + 4>(1u, (u32)stop) != 0;
+            }
+            const bool in_group = gl >= d;  // (the DPP row is 16 lanes: two groups)
+            if (!stop && in_group) chain += t;
+            stop = stop || !in_group || ts;
+        }
+        // (the move first, for ALL lanes: a DPP read from a lane the branch has switched off returns the fill value)
+        const Acc<T> from_prev = dpp_move_f64<kDppRowShr + 1>(0.0, chain);
+        const Acc<T> carry = cont ? from_prev : Acc<T>(0);
+#pragma unroll
+        for (u32 r = 0; r < kEscPerLane; ++r) sum[r] += lead[r] ? carry : Acc<T>(0);
+        // the last element of a run carries the entry; its rank = runs that end before it
+        const u32 next_col = dpp_move<kDppRowShl + 1>(kEscInvalid, col[0]);
+        bool tail[kEscPerLane];
+        u32 ntail = 0;
+#pragma unroll
+        for (u32 r = 0; r < kEscPerLane; ++r) {
+            const u32 after = r + 1 < kEscPerLane ? col[r + 1] : (gl == kEscLanes - 1 ? kEscInvalid : next_col);
+            tail[r] = col[r] != kEscInvalid && after != col[r];
+            ntail += tail[r] ? 1u : 0u;
+        }
+        u32 all;
+        u32 pos = rec.base + g.inclusive_scan(ntail, &all, nullptr) - ntail;
+#pragma unroll
+        for (u32 r = 0; r < kEscPerLane; ++r)
+            if (tail[r]) {
+                c_col[pos] = col[r];
+                c_val[pos] = (T)sum[r];
+                ++pos;
+            }
+        wave_lds_fence();  // the next row overwrites the staging and the products
+        idx += stride;
+    }
+}
+
 // ------------------------------------------------------------------ NUM_D1/D2
 template <typename T, u32 WCOLS, int THREADS>
 constexpr u32 num_dense_lds()
@@ -709,6 +847,15 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
     num_dense_body<T, WCOLS, THREADS>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void num_esc_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                      u32* __restrict__ c_col, T* __restrict__ c_val)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    src.rebase(a_ro);
+    num_esc_body<T, 256>(smem, src, w, c_col, c_val, blockIdx.x, gridDim.x);
+}
+
 constexpr u32 kW256W1 = 256;   // 256 Ki columns per sort window
 constexpr u32 kW512W1 = 768;   // 768 Ki columns per sort window (its level-1 pairs fill the 6 KiB table exactly)
 constexpr u32 kB2KW1 = 1024;   // 1 Mi columns per sort window
@@ -743,8 +890,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
         num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
             smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else if (b < cg.first[7])
-        num_hash_body<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        num_esc_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
     else
         num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
 }
@@ -767,8 +913,7 @@ __global__ __launch_bounds__(TT) void num_tiny_kernel(ProductSrc<T> src, const u
         num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, TT>(
             smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else if (b < cg.first[7])
-        num_hash_body<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, TT>(
-            smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        num_esc_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
     else
         num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
 }
@@ -1206,7 +1351,7 @@ u32 numeric_lds_bytes_t(int cls)
 {
     switch (cls) {
         case NUM_DIRECT: return num_direct_lds<T, 256>();
-        case NUM_G8: return 32 * num_group_lds<SubWave<8>, T, kNumG8Cap, 256>();
+        case NUM_G8: return 32 * num_esc_group_lds<T>();
         case NUM_G16: return 16 * num_group_lds<SubWave<16>, T, kNumG16Cap, 256>();
         case NUM_W128: return 8 * num_group_lds<SubWave<32>, T, kNumW128Cap, 256>();
         case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, 256>();
@@ -1329,8 +1474,8 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             break;
         }
         case NUM_G8:
-            launch_num_hash<SubWave<8>, T, kNumG8Cap, 0, kNumG8MaxNnz, SORT_RANK, 256>(
-                s, cls, count, A, B, w, c_col, c_val, cu_count);
+            hipLaunchKernelGGL((num_esc_kernel<T>), dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B, w,
+                               c_col, c_val);
             break;
         case NUM_G16:
             launch_num_hash<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
