@@ -114,7 +114,8 @@ __host__ __device__ inline u32 table_bits(u32 nnz, u32 pct)
     return bits;
 }
 constexpr u32 kNumG8Cap = 32, kNumG8MaxNnz = max_nnz_of(32, SPECK_LOAD_TINY_PCT);
-constexpr u32 kNumEscMaxOps = 32, kNumEscMaxLen = 8;  // NUM_G8 = the register-resident class (esc.hpp)
+constexpr u32 kNumEscMaxOps = 32, kNumEscMaxLen = 8;  // NUM_G8 / SYM_G8 = the register-resident classes (esc.hpp)
+constexpr u32 kNumEsc16MaxOps = 64, kNumEsc16MaxLen = 16;  // NUM_G16 / SYM_G16: 16 lanes; columns < 2^26 (ClassifyParams::esc16)
 constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = max_nnz_of(64, SPECK_LOAD_TINY_PCT);
 constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = max_nnz_of(128, SPECK_LOAD_TINY_PCT);
 constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = max_nnz_of(512, SPECK_LOAD_TINY_PCT);
@@ -133,6 +134,7 @@ struct ClassifyParams {
     u32 num_dense_ratio;    // use D1 when range <= kNumD1Cols and range <= ratio * nnz
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
     u32 num_w256;           // rows of 86..170 nnz: 32 lanes per row (else they join NUM_W512)
+    u32 esc16;              // cols(B) <= 2^26: the 16-lane register class may pack (column, product number) into 32 bits
     u32 num_g8;             // rows of <= kNumG8MaxNnz entries: 8 lanes per row (else they join NUM_G16)
     u32 sym_g8;             // rows of <= kSymG8MaxOps products: 8 lanes per row (else they join SYM_G16)
     u32 sym_w128;           // rows of 52..102 products: 16 lanes per row (else they join SYM_W256)
@@ -176,7 +178,7 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
     if (is_numeric_first(len_a, ops, cmin, cmax, p)) return SYM_NF;
     // at most 32 products from at most 8 entries of A: sorted in registers (esc.hpp)
     if (p.sym_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return SYM_G8;
-    if (ops <= kSymG16MaxOps) return SYM_G16;
+    if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return SYM_G16;  // 16 lanes, 64 products
     if (p.sym_w128 && ops <= kSymW128MaxOps) return SYM_W128;
     if (ops <= kSymW256MaxOps) return SYM_W256;
     const u64 range = u64(cmax) - u64(cmin) + 1;
@@ -205,7 +207,7 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     // at most 32 products from at most 8 entries of A: expand / sort / compress in registers (esc.hpp), whatever
     // the nnz; the hash classes take the rest by nnz
     if (p.num_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return NUM_G8;
-    if (nnz <= kNumG16MaxNnz) return NUM_G16;
+    if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return NUM_G16;
     if (nnz <= kNumW128MaxNnz) return NUM_W128;
     const u64 range = u64(cmax) - u64(cmin) + 1;
     if (range <= kNumD1Cols && range <= u64(p.num_dense_ratio) * nnz) return NUM_D1;

@@ -16,8 +16,12 @@
 
 namespace speck {
 
+// Two widths: 8 lanes (32 products, key = column << 5 | product) and 16 lanes (64 products, key = column << 6 |
+// product -- columns must then be < 2^26: ClassifyParams::esc16).
 constexpr u32 kEscLanes = 8, kEscPerLane = 4, kEscProducts = kEscLanes * kEscPerLane;  // 32
 constexpr u32 kEscInvalid = 0xFFFFFFFFu;
+constexpr int kDppRowMirror = 0x140;
+constexpr int kDppRowShl4 = 0x104, kDppRowShr4 = 0x114;
 
 constexpr int kDppQuadXor1 = 0xB1;   // quad_perm [1,0,3,2]
 constexpr int kDppQuadXor2 = 0x4E;   // quad_perm [2,3,0,1]
@@ -31,6 +35,21 @@ __device__ __forceinline__ u32 esc_group_or(u32 v)
     v |= dpp_move<kDppQuadXor2>(0u, v);
     v |= dpp_move<kDppRowHalfMirror>(0u, v);
     return v;
+}
+
+// OR over the 16 lanes of a DPP row
+__device__ __forceinline__ u32 esc_row_or(u32 v)
+{
+    v = esc_group_or(v);
+    v |= dpp_move<kDppRowMirror>(0u, v);
+    return v;
+}
+// the value of lane ^ 4 (two bank-masked row shifts: quads 0 / 2 read the quad above, quads 1 / 3 the quad below)
+__device__ __forceinline__ u32 esc_xor4(u32 v)
+{
+    u32 t = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, kDppRowShl4, 0xF, 0x5, false);
+    t = (u32)__builtin_amdgcn_update_dpp((int)t, (int)v, kDppRowShr4, 0xF, 0xA, false);
+    return t;
 }
 
 // compare-exchange with the same register of a partner lane: the lower lane of the pair keeps the minimum
@@ -102,6 +121,40 @@ __device__ __forceinline__ void esc_sort32(u32 (&x)[4], u32 gl)
     esc_cx(x[1], x[3]);
     esc_cx(x[0], x[1]);
     esc_cx(x[2], x[3]);
+}
+
+// ... and of the 64 elements of a 16-lane group (one DPP row)
+__device__ __forceinline__ void esc_sort64(u32 (&x)[4], u32 gl)
+{
+    const bool l0 = (gl & 1u) == 0, l1 = (gl & 2u) == 0, l2 = (gl & 4u) == 0, l3 = (gl & 8u) == 0;
+    esc_sort32(x, gl);  // every half of 8 lanes ascending (the k = 1 .. 5 stages never leave the half)
+    // k = 6: flip over 64 = lane ^ 15, register 3 - r; distances 32 .. 4 = lane ^ 4, ^ 2, ^ 1; then 2, 1 inside the lane
+    {
+        const u32 y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3];
+        esc_cx_lane<kDppRowMirror>(x[0], y3, l3);
+        esc_cx_lane<kDppRowMirror>(x[1], y2, l3);
+        esc_cx_lane<kDppRowMirror>(x[2], y1, l3);
+        esc_cx_lane<kDppRowMirror>(x[3], y0, l3);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const u32 p = esc_xor4(x[r]);
+        const u32 mn = min(x[r], p), mx = max(x[r], p);
+        x[r] = l2 ? mn : mx;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) esc_cx_lane<kDppQuadXor2>(x[r], x[r], l1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) esc_cx_lane<kDppQuadXor1>(x[r], x[r], l0);
+    esc_cx(x[0], x[2]);
+    esc_cx(x[1], x[3]);
+    esc_cx(x[0], x[1]);
+    esc_cx(x[2], x[3]);
+}
+template <u32 L>
+__device__ __forceinline__ void esc_sort(u32 (&x)[4], u32 gl)
+{
+    if constexpr (L == 8) esc_sort32(x, gl); else esc_sort64(x, gl);
 }
 
 // move a double one lane up / down inside the 16-lane DPP row (lanes without a source get `fill`)

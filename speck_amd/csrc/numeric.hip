@@ -445,29 +445,32 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     }
 }
 
-// ------------------------------------------------------------------ NUM_G8: expand / sort / compress (esc.hpp)
-// Rows with at most 32 products and 8 entries of A: 8 lanes per row, 4 products per lane, nothing but registers, DPP
-// and 32 values in LDS.  LDS per group: B-row offsets and a_ik of the (non-empty) entries | the products by number.
-template <typename T>
+// ------------------------------------------------------------------ NUM_G8 / NUM_G16: expand / sort / compress (esc.hpp)
+// Rows with at most 4 L products and L entries of A (L = 8 or 16 lanes per row): 4 products per lane, nothing but
+// registers, DPP and 4 L values in LDS.  LDS per group: the products by number | a_ik and B-row offsets of the
+// (non-empty) entries.
+template <typename T, u32 L>
 constexpr u32 num_esc_group_lds()
 {
-    return kEscLanes * (4u + (u32)sizeof(Acc<T>)) + kEscProducts * (u32)sizeof(Acc<T>);
+    return 4u * L * (u32)sizeof(Acc<T>) + L * (4u + (u32)sizeof(Acc<T>));
 }
 
-template <typename T, int THREADS>
+template <typename T, u32 L, int THREADS>
 __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
-                                             u32* __restrict__ c_col, T* __restrict__ c_val, u32 bidx, u32 nblk,
-                                             ClassHint hint = kNoHint)
+                                             u32* __restrict__ c_col, T* __restrict__ c_val, int cls, u32 bidx,
+                                             u32 nblk, ClassHint hint = kNoHint)
 {
-    using G = SubWave<kEscLanes>;
-    constexpr u32 NG = THREADS / kEscLanes;
+    static_assert(L == 8 || L == 16, "8 or 16 lanes per row");
+    using G = SubWave<L>;
+    using Mask = typename std::conditional<L == 8, u32, u64>::type;
+    constexpr u32 NG = THREADS / L, PER = kEscPerLane, NP = PER * L, TAG = L == 8 ? 5u : 6u;
     const G g;
-    const u32 gid = threadIdx.x / kEscLanes;
-    unsigned char* mine = smem + gid * num_esc_group_lds<T>();
-    Acc<T>* s_vals = reinterpret_cast<Acc<T>*>(mine);               // [32] products by number
-    Acc<T>* s_av = s_vals + kEscProducts;                           // [8]  a_ik of the j-th non-empty entry
-    u32* s_off = reinterpret_cast<u32*>(s_av + kEscLanes);          // [8]  its B-row start minus its first product number
-    const ListHead head = open_list<false>(w, NUM_G8, hint, bidx, nblk, NG, gid, (w.xcd_aware & 1u) != 0);
+    const u32 gid = threadIdx.x / L;
+    unsigned char* mine = smem + gid * num_esc_group_lds<T, L>();
+    Acc<T>* s_vals = reinterpret_cast<Acc<T>*>(mine);     // [4 L] products by number
+    Acc<T>* s_av = s_vals + NP;                           // [L]   a_ik of the j-th non-empty entry
+    u32* s_off = reinterpret_cast<u32*>(s_av + L);        // [L]   its B-row start minus its first product number
+    const ListHead head = open_list<false>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 1u) != 0);
     if (head.miss) return;
     const RowRec* recs = head.recs;
     u32 idx = head.rs.idx;
@@ -494,49 +497,58 @@ __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductS
             s_av[before] = av;
         }
         // bit k: a (non-empty) entry's products end at k -- the owner of product p is the number of set bits <= p
-        const u32 ends = esc_group_or((nonempty && incl < 32u) ? (1u << incl) : 0u);
+        Mask ends;
+        if constexpr (L == 8) {
+            ends = esc_group_or((nonempty && incl < 32u) ? (1u << incl) : 0u);
+        } else {
+            const u64 bit = (nonempty && incl < 64u) ? (1ull << incl) : 0ull;
+            ends = (u64(esc_row_or((u32)(bit >> 32))) << 32) | esc_row_or((u32)bit);
+        }
         wave_lds_fence();
-        u32 key[kEscPerLane];
+        u32 key[PER];
 #pragma unroll
-        for (u32 u = 0; u < kEscPerLane; ++u) {
-            const u32 p = u * kEscLanes + gl;
+        for (u32 u = 0; u < PER; ++u) {
+            const u32 p = u * L + gl;
             key[u] = kEscInvalid;
             if (p < total) {
-                const u32 j = (u32)__popc(ends & ((2u << p) - 1u));
+                u32 j;
+                if constexpr (L == 8) j = (u32)__popc(ends & ((2u << p) - 1u));
+                else j = (u32)__popcll(ends & ((2ull << p) - 1ull));
                 const u32 ib = s_off[j] + p;
                 const u32 c = src.b_col[ib];
                 const T bv = src.b_val[ib];
                 const T prod = (T)s_av[j] * bv;  // rounded product, added later (no FMA across the add)
                 s_vals[p] = (Acc<T>)prod;
-                key[u] = (c << 5) | p;
+                key[u] = (c << TAG) | p;
             }
         }
         wave_lds_fence();
         // ---- sort by (column, product number)
-        esc_sort32(key, gl);
+        esc_sort<L>(key, gl);
         // ---- compress: sums of the runs of equal columns, in sorted order
-        u32 col[kEscPerLane];
-        Acc<T> sum[kEscPerLane];
+        u32 col[PER];
+        Acc<T> sum[PER];
 #pragma unroll
-        for (u32 r = 0; r < kEscPerLane; ++r) {
-            col[r] = key[r] == kEscInvalid ? kEscInvalid : key[r] >> 5;
-            sum[r] = key[r] == kEscInvalid ? Acc<T>(0) : s_vals[key[r] & 31u];
+        for (u32 r = 0; r < PER; ++r) {
+            col[r] = key[r] == kEscInvalid ? kEscInvalid : key[r] >> TAG;
+            sum[r] = key[r] == kEscInvalid ? Acc<T>(0) : s_vals[key[r] & (NP - 1u)];
         }
-        bool lead[kEscPerLane];  // element r continues the run of element 0 of this lane
+        bool lead[PER];  // element r continues the run of element 0 of this lane
         lead[0] = true;
 #pragma unroll
-        for (u32 r = 1; r < kEscPerLane; ++r) {
+        for (u32 r = 1; r < PER; ++r) {
             const bool same = col[r] == col[r - 1] && col[r] != kEscInvalid;
             lead[r] = lead[r - 1] && same;
             sum[r] += same ? sum[r - 1] : Acc<T>(0);
         }
         // across the lanes: what the lanes before me contribute to the run my element 0 continues
-        const u32 prev_col = dpp_move<kDppRowShr + 1>(kEscInvalid, col[kEscPerLane - 1]);
+        const u32 prev_col = dpp_move<kDppRowShr + 1>(kEscInvalid, col[PER - 1]);
         const bool cont = gl != 0 && col[0] != kEscInvalid && prev_col == col[0];
-        Acc<T> chain = sum[kEscPerLane - 1];                // running sum of the run that ends this lane
-        bool stop = !(lead[kEscPerLane - 1] && cont);       // ... which does not reach back into the lane before
+        Acc<T> chain = sum[PER - 1];             // running sum of the run that ends this lane
+        bool stop = !(lead[PER - 1] && cont);    // ... which does not reach back into the lane before
 #pragma unroll
-        for (u32 d = 1; d < kEscLanes; d <<= 1) {
+        for (u32 d = 1; d < L; d <<= 1) {
+            // (the moves first, for ALL lanes: a DPP read from a lane a branch has switched off returns the fill value)
             Acc<T> t;
             bool ts;
             if (d == 1) {
@@ -545,33 +557,35 @@ __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductS
             } else if (d == 2) {
                 t = dpp_move_f64<kDppRowShr + 2>(0.0, chain);
                 ts = dpp_move<kDppRowShr + 2>(1u, (u32)stop) != 0;
-            } else {
+            } else if (d == 4) {
                 t = dpp_move_f64<kDppRowShr + 4>(0.0, chain);
                 ts = dpp_move<kDppRowShr + 4>(1u, (u32)stop) != 0;
+            } else {
+                t = dpp_move_f64<kDppRowShr + 8>(0.0, chain);
+                ts = dpp_move<kDppRowShr + 8>(1u, (u32)stop) != 0;
             }
-            const bool in_group = gl >= d;  // (the DPP row is 16 lanes: two groups)
+            const bool in_group = gl >= d;  // (the DPP row is 16 lanes: two groups of 8)
             if (!stop && in_group) chain += t;
             stop = stop || !in_group || ts;
         }
-        // (the move first, for ALL lanes: a DPP read from a lane the branch has switched off returns the fill value)
         const Acc<T> from_prev = dpp_move_f64<kDppRowShr + 1>(0.0, chain);
         const Acc<T> carry = cont ? from_prev : Acc<T>(0);
 #pragma unroll
-        for (u32 r = 0; r < kEscPerLane; ++r) sum[r] += lead[r] ? carry : Acc<T>(0);
+        for (u32 r = 0; r < PER; ++r) sum[r] += lead[r] ? carry : Acc<T>(0);
         // the last element of a run carries the entry; its rank = runs that end before it
         const u32 next_col = dpp_move<kDppRowShl + 1>(kEscInvalid, col[0]);
-        bool tail[kEscPerLane];
+        bool tail[PER];
         u32 ntail = 0;
 #pragma unroll
-        for (u32 r = 0; r < kEscPerLane; ++r) {
-            const u32 after = r + 1 < kEscPerLane ? col[r + 1] : (gl == kEscLanes - 1 ? kEscInvalid : next_col);
+        for (u32 r = 0; r < PER; ++r) {
+            const u32 after = r + 1 < PER ? col[r + 1] : (gl == L - 1 ? kEscInvalid : next_col);
             tail[r] = col[r] != kEscInvalid && after != col[r];
             ntail += tail[r] ? 1u : 0u;
         }
         u32 all;
         u32 pos = rec.base + g.inclusive_scan(ntail, &all, nullptr) - ntail;
 #pragma unroll
-        for (u32 r = 0; r < kEscPerLane; ++r)
+        for (u32 r = 0; r < PER; ++r)
             if (tail[r]) {
                 c_col[pos] = col[r];
                 c_val[pos] = (T)sum[r];
@@ -847,13 +861,13 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
     num_dense_body<T, WCOLS, THREADS>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
 }
 
-template <typename T>
+template <typename T, u32 L>
 __global__ __launch_bounds__(256) void num_esc_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
-                                                      u32* __restrict__ c_col, T* __restrict__ c_val)
+                                                      u32* __restrict__ c_col, T* __restrict__ c_val, int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
-    num_esc_body<T, 256>(smem, src, w, c_col, c_val, blockIdx.x, gridDim.x);
+    num_esc_body<T, L, 256>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
 }
 
 constexpr u32 kW256W1 = 256;   // 256 Ki columns per sort window
@@ -887,10 +901,9 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
         num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
             smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
     else if (b < cg.first[6])
-        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+        num_esc_body<T, 16, 256>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else if (b < cg.first[7])
-        num_esc_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
     else
         num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
 }
@@ -910,10 +923,9 @@ __global__ __launch_bounds__(TT) void num_tiny_kernel(ProductSrc<T> src, const u
         num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, TT>(
             smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
     else if (b < cg.first[6])
-        num_hash_body<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, TT>(
-            smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+        num_esc_body<T, 16, TT>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else if (b < cg.first[7])
-        num_esc_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        num_esc_body<T, 8, TT>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
     else
         num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
 }
@@ -1351,8 +1363,8 @@ u32 numeric_lds_bytes_t(int cls)
 {
     switch (cls) {
         case NUM_DIRECT: return num_direct_lds<T, 256>();
-        case NUM_G8: return 32 * num_esc_group_lds<T>();
-        case NUM_G16: return 16 * num_group_lds<SubWave<16>, T, kNumG16Cap, 256>();
+        case NUM_G8: return 32 * num_esc_group_lds<T, 8>();
+        case NUM_G16: return 16 * num_esc_group_lds<T, 16>();
         case NUM_W128: return 8 * num_group_lds<SubWave<32>, T, kNumW128Cap, 256>();
         case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, 256>();
         case NUM_W256: return 8 * num_group_lds<SubWave<32>, T, kNumW256Cap, 256>();
@@ -1474,12 +1486,12 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             break;
         }
         case NUM_G8:
-            hipLaunchKernelGGL((num_esc_kernel<T>), dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B, w,
-                               c_col, c_val);
+            hipLaunchKernelGGL((num_esc_kernel<T, 8>), dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B,
+                               w, c_col, c_val, cls);
             break;
         case NUM_G16:
-            launch_num_hash<SubWave<16>, T, kNumG16Cap, 0, kNumG16MaxNnz, SORT_RANK, 256>(
-                s, cls, count, A, B, w, c_col, c_val, cu_count);
+            hipLaunchKernelGGL((num_esc_kernel<T, 16>), dim3(grid_for(count, lds, 256, cu_count, 16)), dim3(256), lds, s, A, B,
+                               w, c_col, c_val, cls);
             break;
         case NUM_W128:
             launch_num_hash<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(

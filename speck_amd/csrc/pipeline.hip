@@ -435,6 +435,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     ClassifyParams cp = c->cp;
     cp.sym_allowed = sym_mask;
     cp.num_allowed = num_mask;
+    cp.esc16 = (c->cp.esc16 && B->cols <= (1ull << 26)) ? 1u : 0u;  // (column << 6 | product number) fits 32 bits
     const bool timed = c->profile_kernels && tm;
     if (parts & 1u) {
         if (timed) {
@@ -1079,7 +1080,8 @@ int speck_config_create(int device, speck_config** out)
     c->cp.nf_min_ops = 512;   // numeric-first for narrow rows with at least this many products (0 = off; 256 costs the
                               // scircuit stand-in 5 %, 1024 leaves the boundary rows of the cant one a launch of their own)
     c->cp.gh_per_window = 8192;  // global key set for rows with fewer products per 1 Mi-column bitmap window (0 = off)
-    c->cp.num_g8 = 1;      // rows of <= 21 entries: 8 lanes per row
+    c->cp.esc16 = 1;       // rows of <= 64 products from <= 16 entries: 16 lanes per row, in registers (esc.hpp)
+    c->cp.num_g8 = 1;      // rows of <= 32 products from <= 8 entries: 8 lanes per row, in registers
     c->cp.sym_g8 = 1;      // rows of <= 25 products: 8 lanes per row
     c->cp.sym_w128 = 1;    // rows of 52..102 products: 16 lanes per row
     c->cp.num_w256 = 1;    // rows of 86..170 entries: 32 lanes per row
@@ -1174,6 +1176,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "sym_g8") {
         c->cp.sym_g8 = value != 0;
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
+    else if (n == "esc16") {
+        c->cp.esc16 = value != 0;
         drop_graph(c);
         c->last_key_valid = false;
     }

@@ -67,21 +67,24 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
     }
 }
 
-// SYM_G8: rows with at most 32 products from at most 8 entries of A (esc.hpp) -- the products' columns are sorted
-// in the registers of the row's 8 lanes, the row's nnz is the number of places where the column changes.  No key
-// set, no compare-and-swap, no probing loop.  LDS per group: the B-row offsets of the (non-empty) entries.
-constexpr u32 sym_esc_group_lds() { return kEscLanes * 4u; }
+// SYM_G8 / SYM_G16: rows with at most 4 L products from at most L entries of A (esc.hpp; L = 8 / 16 lanes per row)
+// -- the products' columns are sorted in the registers of the row's lanes, the row's nnz is the number of places
+// where the column changes.  No key set, no compare-and-swap, no probing loop.  LDS per group: the B-row offsets
+// of the (non-empty) entries.
+template <u32 L>
+constexpr u32 sym_esc_group_lds() { return L * 4u; }
 
-template <int THREADS>
+template <u32 L, int THREADS>
 __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductSrc<float>& src, const RowWork& w,
-                                             u32* __restrict__ counts, u32 bidx, u32 nblk, ClassHint hint = kNoHint)
+                                             u32* __restrict__ counts, int cls, u32 bidx, u32 nblk,
+                                             ClassHint hint = kNoHint)
 {
-    using G = SubWave<kEscLanes>;
-    constexpr u32 NG = THREADS / kEscLanes;
+    using G = SubWave<L>;
+    constexpr u32 NG = THREADS / L, PER = kEscPerLane;
     const G g;
-    const u32 gid = threadIdx.x / kEscLanes;
-    u32* s_off = reinterpret_cast<u32*>(smem + gid * sym_esc_group_lds());
-    const ListHead head = open_list<true>(w, SYM_G8, hint, bidx, nblk, NG, gid, (w.xcd_aware & 1u) != 0);
+    const u32 gid = threadIdx.x / L;
+    u32* s_off = reinterpret_cast<u32*>(smem + gid * sym_esc_group_lds<L>());
+    const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 1u) != 0);
     const RowRec* recs = head.recs;
     u32 idx = head.rs.idx;
     const u32 stride = head.rs.stride, count = head.rs.end;
@@ -97,20 +100,26 @@ __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductS
         const bool nonempty = sl.y != 0;
         const u32 before = (u32)__popcll(g.ballot(nonempty) & ((1ull << gl) - 1ull));
         if (nonempty) s_off[before] = sl.x - (incl - sl.y);
-        const u32 ends = esc_group_or((nonempty && incl < 32u) ? (1u << incl) : 0u);
-        wave_lds_fence();
-        u32 col[kEscPerLane];
-#pragma unroll
-        for (u32 u = 0; u < kEscPerLane; ++u) {
-            const u32 p = u * kEscLanes + gl;
-            col[u] = kEscInvalid;
-            if (p < total) col[u] = src.b_col[s_off[(u32)__popc(ends & ((2u << p) - 1u))] + p];
+        u64 ends;
+        if constexpr (L == 8) {
+            ends = esc_group_or((nonempty && incl < 32u) ? (1u << incl) : 0u);
+        } else {
+            const u64 bit = (nonempty && incl < 64u) ? (1ull << incl) : 0ull;
+            ends = (u64(esc_row_or((u32)(bit >> 32))) << 32) | esc_row_or((u32)bit);
         }
-        esc_sort32(col, gl);
-        const u32 prev_col = dpp_move<kDppRowShr + 1>(kEscInvalid, col[kEscPerLane - 1]);
+        wave_lds_fence();
+        u32 col[PER];
+#pragma unroll
+        for (u32 u = 0; u < PER; ++u) {
+            const u32 p = u * L + gl;
+            col[u] = kEscInvalid;
+            if (p < total) col[u] = src.b_col[s_off[(u32)__popcll(ends & ((2ull << p) - 1ull))] + p];
+        }
+        esc_sort<L>(col, gl);
+        const u32 prev_col = dpp_move<kDppRowShr + 1>(kEscInvalid, col[PER - 1]);
         u32 heads = 0;
 #pragma unroll
-        for (u32 r = 0; r < kEscPerLane; ++r) {
+        for (u32 r = 0; r < PER; ++r) {
             const u32 before_col = r ? col[r - 1] : (gl ? prev_col : kEscInvalid);
             heads += (col[r] != kEscInvalid && col[r] != before_col) ? 1u : 0u;
         }
@@ -291,12 +300,13 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> s
     sym_bitmap_body<WORDS, THREADS>(smem, src, w, counts, cls, blockIdx.x, gridDim.x);
 }
 
+template <u32 L>
 __global__ __launch_bounds__(256) void sym_esc_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
-                                                      u32* __restrict__ counts)
+                                                      u32* __restrict__ counts, int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
-    sym_esc_body<256>(smem, src, w, counts, blockIdx.x, gridDim.x);
+    sym_esc_body<L, 256>(smem, src, w, counts, cls, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
@@ -317,16 +327,16 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     else if (b < cg.first[5])
         sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
     else if (b < cg.first[6])
-        sym_hash_body<SubWave<16>, kSymG16Cap, 256>(smem, src, w, counts, SYM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+        sym_esc_body<16, 256>(smem, src, w, counts, SYM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else
-        sym_esc_body<256>(smem, src, w, counts, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        sym_esc_body<8, 256>(smem, src, w, counts, SYM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
 }
 
 u32 symbolic_lds_bytes(int cls)
 {
     switch (cls) {
-        case SYM_G8: return 32 * sym_esc_group_lds();
-        case SYM_G16: return 16 * sym_group_lds<SubWave<16>, kSymG16Cap, 256>();
+        case SYM_G8: return 32 * sym_esc_group_lds<8>();
+        case SYM_G16: return 16 * sym_esc_group_lds<16>();
         case SYM_W128: return 16 * sym_group_lds<SubWave<16>, kSymW128Cap, 256>();
         case SYM_W256: return 8 * sym_group_lds<SubWave<32>, kSymW256Cap, 256>();
         case SYM_W1K: return 4 * sym_group_lds<SubWave<64>, kSymW1KCap, 256>();
@@ -422,10 +432,13 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
         case SYM_G8:
-            hipLaunchKernelGGL(sym_esc_kernel, dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B, w,
-                               counts);
+            hipLaunchKernelGGL(sym_esc_kernel<8>, dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B, w,
+                               counts, cls);
             break;
-        case SYM_G16: launch_sym_hash<SubWave<16>, kSymG16Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
+        case SYM_G16:
+            hipLaunchKernelGGL(sym_esc_kernel<16>, dim3(grid_for(count, lds, 256, cu_count, 16)), dim3(256), lds, s, A, B, w,
+                               counts, cls);
+            break;
         case SYM_W128: launch_sym_hash<SubWave<16>, kSymW128Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_W256: launch_sym_hash<SubWave<32>, kSymW256Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_W1K: launch_sym_hash<SubWave<64>, kSymW1KCap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
