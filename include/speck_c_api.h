@@ -78,7 +78,8 @@ typedef struct speck_stats {
     int32_t nf_direct;                           /* 1: that sequence wrote the numeric-first rows straight to C at the row
                                                   *    offsets of the previous identical call (verified) */
     int32_t pool_fallbacks;                      /* scratch-pool classes switched off because the pool did not fit */
-    int32_t reserved_;
+    int32_t esc_fused;                           /* 1: that sequence finished the rows of the register classes (<= 64
+                                                  *    products) in its symbolic phase, at those offsets */
     uint64_t scratch_pool_bytes;                 /* numeric-first / global-key-set pool currently allocated */
 } speck_stats;
 

@@ -288,7 +288,7 @@ class spECKConfig:
             kernel_events_valid=bool(s.kernel_events_valid), numeric_reruns=int(s.numeric_reruns),
             graph_replays=int(s.graph_replays), graph_captures=int(s.graph_captures),
             sym_phase_ms=float(s.sym_phase_ms), num_phase_ms=float(s.num_phase_ms),
-            replayed=bool(s.replayed), nf_direct=bool(s.nf_direct), pool_fallbacks=int(s.pool_fallbacks),
+            replayed=bool(s.replayed), nf_direct=bool(s.nf_direct), esc_fused=bool(s.esc_fused), pool_fallbacks=int(s.pool_fallbacks),
             scratch_pool_bytes=int(s.scratch_pool_bytes))
 
 

@@ -135,6 +135,8 @@ struct ClassifyParams {
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
     u32 num_w256;           // rows of 86..170 nnz: 32 lanes per row (else they join NUM_W512)
     u32 esc16;              // cols(B) <= 2^26: the 16-lane register class may pack (column, product number) into 32 bits
+    u32 esc_fused;          // replayed sequence with direct placement: the rows of the register classes are finished
+                            //   in the symbolic phase (esc_rows.hpp) -- the numeric phase only accounts for them
     u32 num_g8;             // rows of <= kNumG8MaxNnz entries: 8 lanes per row (else they join NUM_G16)
     u32 sym_g8;             // rows of <= kSymG8MaxOps products: 8 lanes per row (else they join SYM_G16)
     u32 sym_w128;           // rows of 52..102 products: 16 lanes per row (else they join SYM_W256)
@@ -206,8 +208,9 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     if (is_numeric_first(len_a, ops, cmin, cmax, p)) return NUM_NFCOPY;
     // at most 32 products from at most 8 entries of A: expand / sort / compress in registers (esc.hpp), whatever
     // the nnz; the hash classes take the rest by nnz
-    if (p.num_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return NUM_G8;
-    if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return NUM_G16;
+    // (num_g8 and sym_g8 are switched together: a fused row must be a register-class row in BOTH phases)
+    if (p.num_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G8;
+    if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G16;
     if (nnz <= kNumW128MaxNnz) return NUM_W128;
     const u64 range = u64(cmax) - u64(cmin) + 1;
     if (range <= kNumD1Cols && range <= u64(p.num_dense_ratio) * nnz) return NUM_D1;

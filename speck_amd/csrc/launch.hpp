@@ -103,7 +103,8 @@ constexpr u32 kNumLightMask = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512
 // `exact`: counts_hint holds the exact rows of EVERY class (the kernels then get ClassHints).
 void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, const u32* a_ro,
                            const uint2* b_sl, const u32* b_col, const RowWork& w,
-                           u32* counts, int cu_count, bool exact = false);
+                           u32* counts, int cu_count, bool exact = false, u32 fused_vsize = 0,
+                           const void* a_val = nullptr, const void* b_val = nullptr);
 template <typename T>
 void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const CsrView<T>& A,
                           const CsrView<T>& B, const RowWork& w, u32* c_col, T* c_val, int cu_count,

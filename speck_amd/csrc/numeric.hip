@@ -28,7 +28,7 @@
 #include "device_common.hpp"
 #include "launch.hpp"
 #include "row_groups.hpp"
-#include "esc.hpp"
+#include "esc_rows.hpp"
 
 namespace speck {
 
@@ -131,12 +131,7 @@ __device__ __forceinline__ void num_direct_body(unsigned char* smem, const Produ
     }
 }
 
-// LDS accumulator cell.  fp32 rows accumulate in fp64 cells too: ds_add_f32 is ~10x slower than
-// ds_add_f64 on gfx950 (192 vs 20.6 cycles per wave instruction, scripts/ubench/lds_atomics.hip).
-// The product a*b is still rounded to T first (as the reference does); the sum is rounded to T
-// once, when the row is written.
-template <typename T>
-using Acc = double;
+// (Acc<T>, the LDS accumulator cell: esc_rows.hpp)
 
 // ------------------------------------------------------------------ sorting back-ends
 // Rank sort for tiny tables.  The occupied slots are first COMPACTED (ballots) into `ckeys` with their
@@ -445,156 +440,7 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     }
 }
 
-// ------------------------------------------------------------------ NUM_G8 / NUM_G16: expand / sort / compress (esc.hpp)
-// Rows with at most 4 L products and L entries of A (L = 8 or 16 lanes per row): 4 products per lane, nothing but
-// registers, DPP and 4 L values in LDS.  LDS per group: the products by number | a_ik and B-row offsets of the
-// (non-empty) entries.
-template <typename T, u32 L>
-constexpr u32 num_esc_group_lds()
-{
-    return 4u * L * (u32)sizeof(Acc<T>) + L * (4u + (u32)sizeof(Acc<T>));
-}
-
-template <typename T, u32 L, int THREADS>
-__device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
-                                             u32* __restrict__ c_col, T* __restrict__ c_val, int cls, u32 bidx,
-                                             u32 nblk, ClassHint hint = kNoHint)
-{
-    static_assert(L == 8 || L == 16, "8 or 16 lanes per row");
-    using G = SubWave<L>;
-    using Mask = typename std::conditional<L == 8, u32, u64>::type;
-    constexpr u32 NG = THREADS / L, PER = kEscPerLane, NP = PER * L, TAG = L == 8 ? 5u : 6u;
-    const G g;
-    const u32 gid = threadIdx.x / L;
-    unsigned char* mine = smem + gid * num_esc_group_lds<T, L>();
-    Acc<T>* s_vals = reinterpret_cast<Acc<T>*>(mine);     // [4 L] products by number
-    Acc<T>* s_av = s_vals + NP;                           // [L]   a_ik of the j-th non-empty entry
-    u32* s_off = reinterpret_cast<u32*>(s_av + L);        // [L]   its B-row start minus its first product number
-    const ListHead head = open_list<false>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 1u) != 0);
-    if (head.miss) return;
-    const RowRec* recs = head.recs;
-    u32 idx = head.rs.idx;
-    const u32 stride = head.rs.stride, count = head.rs.end;
-    RowRec next = head.next;
-    const u32 gl = g.lane;
-    while (idx < count) {
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + stride < count) next = recs[idx + stride];
-        // ---- expand: my entry of A, where its products end
-        const bool have = rec.a0 + gl < rec.a1;
-        uint2 sl = make_uint2(0u, 0u);
-        Acc<T> av = 0;
-        if (have) {
-            sl = src.b_sl[rec.a0 + gl];
-            av = (Acc<T>)src.a_val[rec.a0 + gl];
-        }
-        u32 total;
-        const u32 incl = g.inclusive_scan(sl.y, &total, nullptr);
-        const bool nonempty = sl.y != 0;
-        const u32 before = (u32)__popcll(g.ballot(nonempty) & ((1ull << gl) - 1ull));  // non-empty entries before mine
-        if (nonempty) {
-            s_off[before] = sl.x - (incl - sl.y);
-            s_av[before] = av;
-        }
-        // bit k: a (non-empty) entry's products end at k -- the owner of product p is the number of set bits <= p
-        Mask ends;
-        if constexpr (L == 8) {
-            ends = esc_group_or((nonempty && incl < 32u) ? (1u << incl) : 0u);
-        } else {
-            const u64 bit = (nonempty && incl < 64u) ? (1ull << incl) : 0ull;
-            ends = (u64(esc_row_or((u32)(bit >> 32))) << 32) | esc_row_or((u32)bit);
-        }
-        wave_lds_fence();
-        u32 key[PER];
-#pragma unroll
-        for (u32 u = 0; u < PER; ++u) {
-            const u32 p = u * L + gl;
-            key[u] = kEscInvalid;
-            if (p < total) {
-                u32 j;
-                if constexpr (L == 8) j = (u32)__popc(ends & ((2u << p) - 1u));
-                else j = (u32)__popcll(ends & ((2ull << p) - 1ull));
-                const u32 ib = s_off[j] + p;
-                const u32 c = src.b_col[ib];
-                const T bv = src.b_val[ib];
-                const T prod = (T)s_av[j] * bv;  // rounded product, added later (no FMA across the add)
-                s_vals[p] = (Acc<T>)prod;
-                key[u] = (c << TAG) | p;
-            }
-        }
-        wave_lds_fence();
-        // ---- sort by (column, product number)
-        esc_sort<L>(key, gl);
-        // ---- compress: sums of the runs of equal columns, in sorted order
-        u32 col[PER];
-        Acc<T> sum[PER];
-#pragma unroll
-        for (u32 r = 0; r < PER; ++r) {
-            col[r] = key[r] == kEscInvalid ? kEscInvalid : key[r] >> TAG;
-            sum[r] = key[r] == kEscInvalid ? Acc<T>(0) : s_vals[key[r] & (NP - 1u)];
-        }
-        bool lead[PER];  // element r continues the run of element 0 of this lane
-        lead[0] = true;
-#pragma unroll
-        for (u32 r = 1; r < PER; ++r) {
-            const bool same = col[r] == col[r - 1] && col[r] != kEscInvalid;
-            lead[r] = lead[r - 1] && same;
-            sum[r] += same ? sum[r - 1] : Acc<T>(0);
-        }
-        // across the lanes: what the lanes before me contribute to the run my element 0 continues
-        const u32 prev_col = dpp_move<kDppRowShr + 1>(kEscInvalid, col[PER - 1]);
-        const bool cont = gl != 0 && col[0] != kEscInvalid && prev_col == col[0];
-        Acc<T> chain = sum[PER - 1];             // running sum of the run that ends this lane
-        bool stop = !(lead[PER - 1] && cont);    // ... which does not reach back into the lane before
-#pragma unroll
-        for (u32 d = 1; d < L; d <<= 1) {
-            // (the moves first, for ALL lanes: a DPP read from a lane a branch has switched off returns the fill value)
-            Acc<T> t;
-            bool ts;
-            if (d == 1) {
-                t = dpp_move_f64<kDppRowShr + 1>(0.0, chain);
-                ts = dpp_move<kDppRowShr + 1>(1u, (u32)stop) != 0;
-            } else if (d == 2) {
-                t = dpp_move_f64<kDppRowShr + 2>(0.0, chain);
-                ts = dpp_move<kDppRowShr + 2>(1u, (u32)stop) != 0;
-            } else if (d == 4) {
-                t = dpp_move_f64<kDppRowShr + 4>(0.0, chain);
-                ts = dpp_move<kDppRowShr + 4>(1u, (u32)stop) != 0;
-            } else {
-                t = dpp_move_f64<kDppRowShr + 8>(0.0, chain);
-                ts = dpp_move<kDppRowShr + 8>(1u, (u32)stop) != 0;
-            }
-            const bool in_group = gl >= d;  // (the DPP row is 16 lanes: two groups of 8)
-            if (!stop && in_group) chain += t;
-            stop = stop || !in_group || ts;
-        }
-        const Acc<T> from_prev = dpp_move_f64<kDppRowShr + 1>(0.0, chain);
-        const Acc<T> carry = cont ? from_prev : Acc<T>(0);
-#pragma unroll
-        for (u32 r = 0; r < PER; ++r) sum[r] += lead[r] ? carry : Acc<T>(0);
-        // the last element of a run carries the entry; its rank = runs that end before it
-        const u32 next_col = dpp_move<kDppRowShl + 1>(kEscInvalid, col[0]);
-        bool tail[PER];
-        u32 ntail = 0;
-#pragma unroll
-        for (u32 r = 0; r < PER; ++r) {
-            const u32 after = r + 1 < PER ? col[r + 1] : (gl == L - 1 ? kEscInvalid : next_col);
-            tail[r] = col[r] != kEscInvalid && after != col[r];
-            ntail += tail[r] ? 1u : 0u;
-        }
-        u32 all;
-        u32 pos = rec.base + g.inclusive_scan(ntail, &all, nullptr) - ntail;
-#pragma unroll
-        for (u32 r = 0; r < PER; ++r)
-            if (tail[r]) {
-                c_col[pos] = col[r];
-                c_val[pos] = (T)sum[r];
-                ++pos;
-            }
-        wave_lds_fence();  // the next row overwrites the staging and the products
-        idx += stride;
-    }
-}
+// (NUM_G8 / NUM_G16, expand / sort / compress in registers: num_esc_body in esc_rows.hpp)
 
 // ------------------------------------------------------------------ NUM_D1/D2
 template <typename T, u32 WCOLS, int THREADS>

@@ -82,9 +82,12 @@ struct speck_config {
     float fork_min_us = 60.f;  // estimated duration from which a class launch gets its own stream
     bool merge_light = true;  // all 256-thread classes of a phase in one launch
     bool split_light = true;  // ... in two back-to-back launches, by LDS / register need
-    u32 xcd_aware = 2;        // class lists walked in per-XCD contiguous slices: bit 0 sub-wave classes,
-                              //   bit 1 dense-window / bitmap classes, bit 2 workgroup hash classes (measured:
-                              //   +3.5 % on the cant stand-in for bit 1; bits 0 and 2 lose to load imbalance)
+    u32 xcd_aware = 10;       // class lists walked in per-XCD contiguous slices: bit 0 sub-wave hash classes,
+                              //   bit 1 dense-window / bitmap classes, bit 2 workgroup hash classes, bit 3 the
+                              //   register classes (measured: +3.5 % on the cant stand-in for bit 1, -9 % time of
+                              //   the small-row launch on the mac_econ stand-in for bit 3 -- that launch is bound by
+                              //   its gathers of B rows since it sorts in registers; bits 0 and 2 lose to load
+                              //   imbalance)
     u32 last_sym_counts[kMaxClasses] = {}, last_num_counts[kMaxClasses] = {};
 
     // captured launch sequence of the last repeated call
@@ -112,9 +115,13 @@ struct speck_config {
     bool pred_valid = false;
     bool nf_direct = true;           // option nf_direct
     bool capture_direct = false;     // set while a sequence with direct placement is being captured
+    bool esc_fused = true;           // option esc_fused: such a sequence finishes the rows of the register classes in
+                                     //   its symbolic phase
+    bool capture_fused = false;      // set while a sequence that does so is being captured
     u32* capture_c_col = nullptr;
     void* capture_c_val = nullptr;
     bool graph_direct = false;       // the captured sequence places the numeric-first rows directly
+    bool graph_fused = false;        // ... and finishes the rows of the register classes in its symbolic phase
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
@@ -436,6 +443,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     cp.sym_allowed = sym_mask;
     cp.num_allowed = num_mask;
     cp.esc16 = (c->cp.esc16 && B->cols <= (1ull << 26)) ? 1u : 0u;  // (column << 6 | product number) fits 32 bits
+    cp.esc_fused = c->capture_fused ? 1u : 0u;
     const bool timed = c->profile_kernels && tm;
     if (parts & 1u) {
         if (timed) {
@@ -487,7 +495,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                                  const u32 part = cls == kLightBig ? sym_big : ~sym_big;
                                  launch_symbolic_light(ks, hint, sym_mask & kSymLightMask & part, A->row_offsets,
                                                        sc.b_sl, B->col_ids, w, c_ro, c->sm,
-                                                       sym_hint != nullptr);
+                                                       sym_hint != nullptr, c->capture_fused ? vsize : 0u, A->data,
+                                                       B->data);
                              } else if (cls == SYM_NF) {
                                  // the numeric dense-window kernel, in the symbolic phase (numeric.hip)
                                  if (vsize == 8) {
@@ -612,24 +621,37 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     //  class into NUM_B2K at a load of 0.85 here; since the workgroup classes take rows up to that load in every
     //  call -- device_common.hpp, SPECK_LOAD_PCT -- there is nothing left to fold.)
     u32 num_mask = c->last_num_mask;
-    const u32* num_counts = c->last_num_counts;
+    u32 num_counts[kMaxClasses];
+    std::memcpy(num_counts, c->last_num_counts, sizeof(num_counts));
     // Numeric-first rows: the eager call wrote them to scratch slots and copied them after the scan (nothing else
     // knows where a row goes before the scan).  The replayed sequence knows where they WENT: it writes each row
     // straight to the offset the previous identical call gave it, provided its fresh nnz is the same, and the scan
     // checks every fresh offset against that prediction -- no slot, no copy launch.
+    // The same knowledge lets the rows of the register classes (NUM_G8 / NUM_G16: products sorted in registers,
+    // nothing sized by the nnz) be finished in the SYMBOLIC phase: one walk of the row instead of two.  The numeric
+    // phase then accounts for them as rows that are already in place.
+    constexpr u32 kEscNum = (1u << NUM_G8) | (1u << NUM_G16);
+    c->capture_fused = c->esc_fused && c->nf_direct && c->pred_valid && (num_mask & kEscNum) != 0 &&
+                       c->cp.sym_g8 == c->cp.num_g8;
+    if (c->capture_fused) {
+        num_counts[NUM_NFCOPY] += num_counts[NUM_G8] + num_counts[NUM_G16];
+        num_counts[NUM_G8] = num_counts[NUM_G16] = 0;
+        num_mask = (num_mask & ~kEscNum) | (1u << NUM_NFCOPY);
+    }
     c->graph_direct = c->nf_direct && c->pred_valid && (num_mask >> NUM_NFCOPY & 1u);
+    c->graph_fused = c->capture_fused;
     c->capture_direct = c->graph_direct;
     c->capture_c_col = C->col_ids;
     c->capture_c_val = C->data;
     const u32 launch_mask = c->graph_direct ? (num_mask & ~(1u << NUM_NFCOPY)) : num_mask;
     struct Reset {
         speck_config* c;
-        ~Reset() { c->capture_direct = false; }
+        ~Reset() { c->capture_direct = c->capture_fused = false; }
     } reset{c};
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
                            num_mask, true, nullptr, c->last_sym_counts, nullptr,
-                           c->last_g_products, c->last_num_counts[NUM_G], 3u, c->nf_cap_entries);
+                           c->last_g_products, num_counts[NUM_G], 3u, c->nf_cap_entries);
     if (rc == SPECK_OK)
         rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
                              launch_mask, num_counts, nullptr);
@@ -734,6 +756,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 publish_counts(c);
                 c->last.replayed = 1;
                 c->last.nf_direct = c->graph_direct ? 1 : 0;
+                c->last.esc_fused = c->graph_fused ? 1 : 0;
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -949,7 +972,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // ... and where every row went (the config's own copy of the offsets: the numeric-first rows of a replayed
     // sequence are placed by it)
     c->pred_valid = false;
-    if (c->nf_direct && (num_mask >> NUM_NFCOPY & 1u)) {
+    const u32 placed_mask = (1u << NUM_NFCOPY) | (c->esc_fused ? (1u << NUM_G8) | (1u << NUM_G16) : 0u);
+    if (c->nf_direct && (num_mask & placed_mask)) {
         if (c->pred_cap < size_t(m) + 1) {
             if (c->d_pred_off) (void)hipFree(c->d_pred_off);
             c->d_pred_off = nullptr;
@@ -1165,6 +1189,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->last_key_valid = false;
     }
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
+    else if (n == "esc_fused") {
+        c->esc_fused = value != 0;
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
     else if (n == "nf_direct") {
         c->nf_direct = value != 0;
         drop_graph(c);

@@ -836,6 +836,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     for (int i = 0; i < ITEMS; ++i) {
         const u64 row = base + i;
         if (cls[i] == NUM_NONE) continue;
+        if (cls[i] == NUM_NFCOPY && pred_off) continue;  // already in place: no launch reads that list
         const u32 k = cls[i];
         const u32 pos = class_offset(s_fold, k) + s_fold.prefix[k] + before.get(k) + used.get(k);
         used.add(k);

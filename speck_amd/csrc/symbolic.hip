@@ -17,6 +17,7 @@
 #include "launch.hpp"
 #include "row_groups.hpp"
 #include "esc.hpp"
+#include "esc_rows.hpp"
 
 namespace speck {
 
@@ -84,7 +85,7 @@ __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductS
     const G g;
     const u32 gid = threadIdx.x / L;
     u32* s_off = reinterpret_cast<u32*>(smem + gid * sym_esc_group_lds<L>());
-    const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 1u) != 0);
+    const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
     const RowRec* recs = head.recs;
     u32 idx = head.rs.idx;
     const u32 stride = head.rs.stride, count = head.rs.end;
@@ -332,6 +333,35 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
         sym_esc_body<8, 256>(smem, src, w, counts, SYM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
 }
 
+// The light launch of a REPLAYED sequence: the rows of the two register classes are finished here -- products
+// expanded, sorted, summed and written to the place the previous identical call gave the row in C (num_esc_body,
+// FUSED) -- instead of being counted now and walked again in the numeric phase.  The other classes count as above.
+template <typename T>
+__global__ __launch_bounds__(256) void sym_light_fused_kernel(ProductSrc<T> nsrc, const u32* a_ro, RowWork w,
+                                                              u32* __restrict__ counts, ClassGrid cg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    nsrc.rebase(a_ro);
+    const ProductSrc<float> src{nsrc.b_sl, nullptr, nsrc.b_col, nullptr, nsrc.w_sl};
+    const u32 b = blockIdx.x;
+    if (b < cg.first[1])
+        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], cg.hint[0]);
+    else if (b < cg.first[2])
+        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], cg.hint[1]);
+    else if (b < cg.first[3])
+        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], cg.hint[2]);
+    else if (b < cg.first[4])
+        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.hint[3]);
+    else if (b < cg.first[5])
+        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
+    else if (b < cg.first[6])
+        num_esc_body<T, 16, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G16,
+                                       b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5], counts);
+    else
+        num_esc_body<T, 8, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G8,
+                                      b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6], counts);
+}
+
 u32 symbolic_lds_bytes(int cls)
 {
     switch (cls) {
@@ -396,15 +426,24 @@ static void launch_sym_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
                        dim3(THREADS), lds, s, A, B, w, counts, cls);
 }
 
+// `fused_vsize` (8 / 4, replayed sequence with direct placement only; 0 = off): the rows of SYM_G8 / SYM_G16 are
+// finished by this launch (sym_light_fused_kernel); a_val / b_val are then the values of A and B.
 void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, const u32* a_ro,
                            const uint2* b_sl, const u32* b_col, const RowWork& w,
-                           u32* counts, int cu_count, bool exact)
+                           u32* counts, int cu_count, bool exact, u32 fused_vsize, const void* a_val,
+                           const void* b_val)
 {
     static const int slots[7] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_W128, SYM_G16, SYM_G8};
     static const u32 rows_per_block[7] = {1, 1, 4, 8, 16, 16, 32};
+    const bool fused = fused_vsize != 0 && (mask & ((1u << SYM_G8) | (1u << SYM_G16))) != 0;
+    auto class_lds = [&](int cls) -> u32 {
+        if (fused && cls == SYM_G8) return 32 * (fused_vsize == 8 ? num_esc_group_lds<double, 8>() : num_esc_group_lds<float, 8>());
+        if (fused && cls == SYM_G16) return 16 * (fused_vsize == 8 ? num_esc_group_lds<double, 16>() : num_esc_group_lds<float, 16>());
+        return symbolic_lds_bytes(cls);
+    };
     u32 lds = 0;
     for (int k = 0; k < 7; ++k)
-        if (mask >> slots[k] & 1u) lds = lds > symbolic_lds_bytes(slots[k]) ? lds : symbolic_lds_bytes(slots[k]);
+        if (mask >> slots[k] & 1u) lds = lds > class_lds(slots[k]) ? lds : class_lds(slots[k]);
     ClassGrid cg{};
     for (int k = 0; k < 7; ++k) {
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
@@ -417,6 +456,16 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
         u32 off = 0;  // class lists follow each other in class order (publish_bins)
         for (int c = 0; c < slots[k]; ++c) off += counts_hint[c];
         cg.hint[k] = ClassHint{off, counts_hint[slots[k]]};
+    }
+    if (fused && fused_vsize == 8) {
+        const ProductSrc<double> nsrc{b_sl, static_cast<const double*>(a_val), b_col, static_cast<const double*>(b_val), w.w_sl};
+        hipLaunchKernelGGL((sym_light_fused_kernel<double>), dim3(cg.first[7]), dim3(256), lds, s, nsrc, a_ro, w, counts, cg);
+        return;
+    }
+    if (fused) {
+        const ProductSrc<float> nsrc{b_sl, static_cast<const float*>(a_val), b_col, static_cast<const float*>(b_val), w.w_sl};
+        hipLaunchKernelGGL((sym_light_fused_kernel<float>), dim3(cg.first[7]), dim3(256), lds, s, nsrc, a_ro, w, counts, cg);
+        return;
     }
     const ProductSrc<float> src{b_sl, nullptr, b_col, nullptr, w.w_sl};
     hipLaunchKernelGGL(sym_light_kernel, dim3(cg.first[7]), dim3(256), lds, s, src, a_ro, w, counts, cg);

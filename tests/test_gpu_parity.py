@@ -519,7 +519,11 @@ def test_suitesparse_standins_full_parity(cfg, kind, scale, expect):
     st2 = cfg.last_stats()
     assert st2["replayed"] and st2["graph_replays"] >= replays0 + 3
     same_as_oracle("replayed")
-    assert st2["num_bin_rows"] == st["num_bin_rows"] and st2["sym_bin_rows"] == st["sym_bin_rows"]
+    want = dict(st["num_bin_rows"])
+    if st2["esc_fused"]:  # the rows of the register classes were finished in the symbolic phase: "already in place"
+        want["nfcopy"] += want["g8"] + want["g16"]
+        want["g8"] = want["g16"] = 0
+    assert st2["num_bin_rows"] == want and st2["sym_bin_rows"] == st["sym_bin_rows"]
 
 
 def test_workgroup_classes_take_rows_up_to_load_085(cfg):
@@ -969,6 +973,77 @@ def test_direct_placement_of_numeric_first_rows_is_verified_per_row(cfg):
         _assert_matches_oracle(dC, A2, A)
     finally:
         cfg.set_option("nf_direct", 1)
+
+
+def test_register_class_rows_are_finished_in_the_symbolic_phase_of_a_replay(cfg):
+    """A replayed sequence finishes the rows of the register classes (<= 64 products) in its symbolic phase, at
+    the offsets of the previous identical call.  Same checks as for the numeric-first rows: the replayed output is
+    the oracle's; two such rows of A swapping their column ids in place (same lengths, same total nnz) must be
+    caught per row; with the option off the replay runs the two-phase path."""
+    import ctypes as C_
+    A = to_po(sa.gen_matrix("mac_econ", 0.1, 5, signed=True))
+    R, _ = po.spgemm(A, A)
+    lens_a = np.diff(A.row_offsets.astype(np.int64))
+    lens_c = np.diff(R.row_offsets.astype(np.int64))
+    i = j = None
+    for cand in range(A.rows - 1):
+        if not 2 <= lens_a[cand] <= 8:
+            continue
+        same = np.where((lens_a == lens_a[cand]) & (lens_c != lens_c[cand]) & (lens_c <= 32) & (lens_c > 0))[0]
+        if same.size and 0 < lens_c[cand] <= 32:
+            i, j = cand, int(same[0])
+            break
+    assert i is not None
+    dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(A)), sa.dCSR()
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    st = cfg.last_stats()
+    assert st["replayed"] and st["esc_fused"] and st["nf_direct"]
+    assert st["num_bin_rows"]["nfcopy"] > A.rows // 2 and st["num_bin_rows"]["g8"] == 0 == st["num_bin_rows"]["g16"]
+    _assert_matches_oracle(dC, A, A)
+    A2 = po.HostCSR(A.rows, A.cols, A.row_offsets.copy(), A.col_ids.copy(), A.data.copy())
+    si, sj = slice(A.row_offsets[i], A.row_offsets[i + 1]), slice(A.row_offsets[j], A.row_offsets[j + 1])
+    A2.col_ids[si], A2.col_ids[sj] = A.col_ids[sj], A.col_ids[si]
+    A2.data[si], A2.data[sj] = A.data[sj], A.data[si]
+    R2, _ = po.spgemm(A2, A)
+    assert R2.nnz == R.nnz and (np.diff(R2.row_offsets.astype(np.int64)) != lens_c).sum() == 2
+    L = _lib.load()
+    assert L.speck_dcsr_update(C_.byref(dA._c), None, np.ascontiguousarray(A2.col_ids).ctypes.data,
+                               np.ascontiguousarray(A2.data).ctypes.data, 8) == 0
+    misses = cfg.last_stats()["numeric_reruns"]
+    sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["numeric_reruns"] == misses + 1
+    _assert_matches_oracle(dC, A2, A)
+    for _ in range(3):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["esc_fused"]
+    _assert_matches_oracle(dC, A2, A)
+    # values only (same structure): the replay stays valid and the fresh values arrive
+    A3 = po.HostCSR(A2.rows, A2.cols, A2.row_offsets, A2.col_ids, A2.data * 1.5)
+    assert L.speck_dcsr_update(C_.byref(dA._c), None, None, np.ascontiguousarray(A3.data).ctypes.data, 8) == 0
+    misses = cfg.last_stats()["numeric_reruns"]
+    sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["numeric_reruns"] == misses and cfg.last_stats()["esc_fused"]
+    _assert_matches_oracle(dC, A3, A)
+    cfg.set_option("esc_fused", 0)
+    try:
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        st = cfg.last_stats()
+        assert st["replayed"] and not st["esc_fused"] and st["num_bin_rows"]["g8"] > 0
+        _assert_matches_oracle(dC, A3, A)
+    finally:
+        cfg.set_option("esc_fused", 1)
+    # fp32 instantiation of the fused launch
+    Af = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float32))
+    dAf, dCf = sa.dCSR.from_host(to_sa(Af)), sa.dCSR()
+    for _ in range(4):
+        sa.MultiplyspECK(dAf, dAf, dCf, cfg)
+    assert cfg.last_stats()["esc_fused"]
+    Rf, abf = po.spgemm(Af, Af)
+    got = dCf.to_host()
+    assert got.nnz == Rf.nnz and (got.row_offsets == Rf.row_offsets).all() and (got.col_ids == Rf.col_ids).all()
+    assert (np.abs(got.data.astype(np.float64) - Rf.data.astype(np.float64)) <= TOL32 * abf + 1e-30).all()
 
 
 @pytest.mark.parametrize("kind,scale", [("scircuit", 0.3), ("mac_econ", 0.3), ("cant", 0.1), ("webbase", 0.1),
