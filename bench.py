@@ -56,7 +56,7 @@ LDS_ATOMIC_PEAK_GWPS = 256 * 2.4 / 20.6
 SUITESPARSE_FILES = {"scircuit": "scircuit", "webbase": "webbase-1M", "mac_econ": "mac_econ_fwd500",
                      "cant": "cant", "nlpkkt": "nlpkkt160"}
 # numeric launches as bench.py names them -> key in profiles/traffic.json (scripts/make_traffic.py)
-TRAFFIC_KEYS = {"light": "num_light", "tiny": "num_tiny", "block8k": "num_block8k", "dense16k": "num_dense16k",
+TRAFFIC_KEYS = {"light": "num_light", "tiny": "num_tiny", "fused_light": "sym_light_fused", "block8k": "num_block8k", "dense16k": "num_dense16k",
                 "global": "num_global", "numeric_first": "num_numeric_first"}
 
 
@@ -232,8 +232,10 @@ class Job:
 
 
 def profile_prepass(job, split, merged, prof_steps=5):
-    """Untimed eager steps with HIP events around every launch, each recorded on the stream the
-    launch runs on (algorithmic bytes per class, per-launch ms), then with events around the phases only."""
+    """Untimed steps with HIP events, each recorded on the stream the launch runs on.  One eager call collects the
+    algorithmic bytes per class; then the launches of the REPLAYED sequence -- the one the timed region replays as
+    a graph -- run uncaptured (library option profile_replay) with events around every launch, then with events
+    around the phases only."""
     cfg = job.cfg
     cfg.profile_kernels(1)
     cfg.set_option("collect_bytes", 1)   # per-class algorithmic bytes: one call is enough
@@ -241,16 +243,23 @@ def profile_prepass(job, split, merged, prof_steps=5):
     torch.cuda.synchronize()
     st = cfg.last_stats()
     cfg.set_option("collect_bytes", 0)
-    # the 256-thread numeric classes run as TWO launches: "light" (num_light_kernel: the big-LDS
-    # classes) and "tiny" (num_tiny_kernel); the other classes launch separately
+    cfg.profile_kernels(0)
+    job.step()                           # (an eager call without the byte model: what the replay is specialised to)
+    cfg.set_option("profile_replay", 1)
+    cfg.profile_kernels(1)
+    # the 256-thread numeric classes run as ONE launch ("light": num_light_kernel), or with option split_light=1
+    # as two ("light": the big-LDS classes, "tiny": num_tiny_kernel); the other classes launch separately
     LIGHT, TINY = ("dense4k", "block2k", "wave512", "wave256"), ("wave128", "g16", "g8", "direct")
     if not split:
         LIGHT, TINY = LIGHT + TINY, ()
-    kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny"]}
+    SYM_LIGHT = ("bitmap256k", "block4k", "wave1k", "wave256", "wave128", "g16", "g8")
+    kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny", "numeric_first", "fused_light"]}
     sym_ms = num_ms = 0.0
+    fused = False
     for _ in range(prof_steps):
         job.step()
         s = cfg.last_stats()
+        fused = s["esc_fused"]
         for k in NUM_CLASS_NAMES:
             kernel_ms[k] += s["num_bin_ms"][k] / prof_steps
         kernel_ms["light"] += s["num_light_ms"] / prof_steps
@@ -258,25 +267,35 @@ def profile_prepass(job, split, merged, prof_steps=5):
         # numeric-first rows: their NUMERIC kernel runs inside the symbolic phase; it is
         # accounted as a numeric launch, the symbolic phase is what remains
         nf = s["sym_bin_ms"]["numeric_first"] if s["sym_bin_rows"]["numeric_first"] else 0.0
-        kernel_ms["numeric_first"] = kernel_ms.get("numeric_first", 0.0) + nf / prof_steps
+        kernel_ms["numeric_first"] += nf / prof_steps
+        # ... and so is the symbolic light launch of a sequence that finishes the rows of the register classes
+        # in it: it moves their numeric bytes, plus the symbolic bytes of its other classes
+        if fused:
+            kernel_ms["fused_light"] += (s["sym_light_ms"] + s["sym_tiny_ms"]) / prof_steps
     # the phases, timed WITHOUT an event between their class launches (mode 2: one event pair per phase; an
     # event record between two launches of a phase costs each a few us the replayed sequence does not pay)
     cfg.profile_kernels(2)
-    nf_ms = kernel_ms.get("numeric_first", 0.0)
+    in_sym_ms = kernel_ms["numeric_first"] + kernel_ms["fused_light"]
     for _ in range(prof_steps):
         job.step()
         s = cfg.last_stats()
-        sym_ms += (s["analysis_ms"] + s["scan_ms"] + max(s["sym_phase_ms"] - nf_ms, 0.0)) / prof_steps
-        num_ms += (s["num_phase_ms"] + nf_ms) / prof_steps
+        sym_ms += (s["analysis_ms"] + s["scan_ms"] + max(s["sym_phase_ms"] - in_sym_ms, 0.0)) / prof_steps
+        num_ms += (s["num_phase_ms"] + in_sym_ms) / prof_steps
     kernel_bytes = dict(st["num_bin_bytes"])
     # the algorithmic bytes of the numeric-first rows belong to the launch that computes them; the
     # copy of the finished rows into C is extra traffic outside the model (listed by time only)
     kernel_bytes["numeric_first"] = kernel_bytes.pop("nfcopy")
+    if fused:
+        kernel_bytes["fused_light"] = (kernel_bytes.pop("g8") + kernel_bytes.pop("g16") +
+                                       sum(st["sym_bin_bytes"][k] for k in SYM_LIGHT if k not in ("g8", "g16")))
+        kernel_bytes["g8"] = kernel_bytes["g16"] = 0
     if merged:
         kernel_bytes["light"] = sum(kernel_bytes.pop(k) for k in LIGHT)
         kernel_bytes["tiny"] = sum(kernel_bytes.pop(k) for k in TINY)
     cfg.profile_kernels(0)
+    cfg.set_option("profile_replay", 0)
     st["num_bin_bytes"] = kernel_bytes
+    st["esc_fused"] = fused
     return st, kernel_ms, sym_ms, num_ms
 
 
@@ -348,7 +367,8 @@ def roofline_block(workload, st, kernel_ms, num_ms):
         if traffic is not None else None,
         "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": dom["ms"],
         "selected_by": "longest numeric launch (HIP events on the launch's own stream)",
-        "timed_with": "HIP events, profiled pre-pass (eager) of the same process",
+        "timed_with": "HIP events around every launch of the replayed sequence, run uncaptured on the pipeline's own "
+                      "streams (library option profile_replay) in an untimed pre-pass of the same process",
         "largest": {"kernel": f"numeric:{big['name']}", "bytes": big["bytes"], "ms": big["ms"], "frac": big["frac"]},
         "numeric_phase_frac": round(total_bytes / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
         "ceilings": dom["ceilings"],
@@ -368,7 +388,7 @@ def verify_last_output(env, job, A, mode):
     r0, r1 = job.bounds
     st = scfg.last_stats()
     info = {"mode": mode, "checked": "output of the last timed step", "replayed": st["replayed"],
-            "nf_direct": st["nf_direct"]}
+            "nf_direct": st["nf_direct"], "esc_fused": st["esc_fused"]}
     try:
         if mode == "oracle":
             got = sC.to_host()
@@ -396,7 +416,7 @@ def measure(env, A, steps, warmup, gather, profile, verify=None, eager=False):
     out = {}
     if profile:
         merged = not any(n == "merge_light" and v == "0" for n, v in env.opts)
-        split = not any(n == "split_light" and v == "0" for n, v in env.opts)
+        split = any(n == "split_light" and v == "1" for n, v in env.opts)
         st, kernel_ms, sym_ms, num_ms = profile_prepass(job, split, merged)
         out.update(st=st, kernel_ms=kernel_ms, sym_ms=sym_ms, num_ms=num_ms)
     else:
@@ -529,9 +549,11 @@ def main():
             "parity": "oracle- and rocSPARSE-pinned (reference ships no golden vectors): indices bit-exact, "
                       "|c - c_ref| <= 1e-12 * sum|a*b| per entry",
             "phases_ms": dict(head["phases_ms"],
-                              note="untimed profiled pre-pass (eager), one HIP event pair per phase; symbolic = "
-                                   "analysis + binning + symbolic launches + scan, numeric = the numeric-first launch "
-                                   "(it runs in the symbolic phase) + fork to join of the numeric launches"),
+                              note="untimed profiled pre-pass (the launches of the replayed sequence, uncaptured), one "
+                                   "HIP event pair per phase; symbolic = analysis + binning + symbolic launches + scan, "
+                                   "numeric = the launches of the symbolic phase that finish rows (numeric-first rows; "
+                                   "the light launch when it finishes the register-class rows) + fork to join of the "
+                                   "numeric launches"),
             "roofline": head["roofline"],
             "kernels_ms": head["kernels_ms"],
             "rows_per_class": head["rows_per_class"],

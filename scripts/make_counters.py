@@ -16,7 +16,8 @@ import sys
 
 KEYS = [
     (r"nf_dense_kernel", "num_numeric_first"), (r"nf_copy_kernel", "num_nfcopy"),
-    (r"num_light_kernel", "num_light"), (r"num_tiny_kernel", "num_tiny"), (r"sym_light_kernel", "sym_light"),
+    (r"num_light_kernel", "num_light"), (r"num_tiny_kernel", "num_tiny"),
+    (r"sym_light_fused_kernel", "sym_light_fused"), (r"sym_light_kernel", "sym_light"),
     (r"num_hash_kernel<Block<512>", "num_block8k"), (r"num_hash_kernel<Block<256>", "num_block2k"),
     (r"num_dense_kernel<\w+, 16384u", "num_dense16k"),
     (r"num_spill_scatter_kernel", "num_global_scatter"), (r"num_spill_count_kernel", "num_global_count"),

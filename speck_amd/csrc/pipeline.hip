@@ -71,6 +71,8 @@ struct speck_config {
     ClassifyParams cp{};
     int profile_kernels = 0;  // 1: HIP events around every launch; 2: around the phases only (no event between
                               //    the class launches of a phase: their spans are what a replayed sequence sees)
+    bool profile_replay = false;  // option profile_replay: a profiled call that COULD be replayed runs the launches
+                                  //    of the replayed sequence (uncaptured) instead of the eager path
     std::vector<hipEvent_t> kev;   // kernel event pool (timing)
     std::vector<hipStream_t> aux;  // one stream per kernel class: classes run concurrently
     std::vector<hipEvent_t> aux_done;
@@ -81,7 +83,9 @@ struct speck_config {
     float split_min_us = 10.f; // both parts of a light launch must be at least this long to be launched apart
     float fork_min_us = 60.f;  // estimated duration from which a class launch gets its own stream
     bool merge_light = true;  // all 256-thread classes of a phase in one launch
-    bool split_light = true;  // ... in two back-to-back launches, by LDS / register need
+    bool split_light = false; // ... in two back-to-back launches, by LDS / register need (since the register classes
+                              //   sort without LDS tables the small rows are bound by their gathers, and ONE launch
+                              //   overlaps them with the latency-bound wave / workgroup rows: -5 % on every stand-in)
     u32 xcd_aware = 10;       // class lists walked in per-XCD contiguous slices: bit 0 sub-wave hash classes,
                               //   bit 1 dense-window / bitmap classes, bit 2 workgroup hash classes, bit 3 the
                               //   register classes (measured: +3.5 % on the cant stand-in for bit 1, -9 % time of
@@ -610,19 +614,22 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
     return k;
 }
 
-// Capture front + back + stats read-back into one graph, specialised to `key` and to the
-// classes that were non-empty when the same inputs were last multiplied eagerly.
-template <typename T>
-int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
-                  const speck_dcsr* C, const Scratch& sc, const GraphKey& key)
+// What a replayed launch sequence is specialised to: the classes that were non-empty when the same inputs were last
+// multiplied eagerly, and what the previous identical call lets it skip.
+struct ReplayPlan {
+    u32 num_mask, launch_mask;
+    u32 num_counts[kMaxClasses];
+    bool direct, fused;
+};
+
+ReplayPlan plan_replay(const speck_config* c)
 {
-    drop_graph(c);
     // (The replayed sequence classifies exactly like the eager one.  Round 2 re-classified an under-filled NUM_B8K
     //  class into NUM_B2K at a load of 0.85 here; since the workgroup classes take rows up to that load in every
     //  call -- device_common.hpp, SPECK_LOAD_PCT -- there is nothing left to fold.)
-    u32 num_mask = c->last_num_mask;
-    u32 num_counts[kMaxClasses];
-    std::memcpy(num_counts, c->last_num_counts, sizeof(num_counts));
+    ReplayPlan p;
+    p.num_mask = c->last_num_mask;
+    std::memcpy(p.num_counts, c->last_num_counts, sizeof(p.num_counts));
     // Numeric-first rows: the eager call wrote them to scratch slots and copied them after the scan (nothing else
     // knows where a row goes before the scan).  The replayed sequence knows where they WENT: it writes each row
     // straight to the offset the previous identical call gave it, provided its fresh nnz is the same, and the scan
@@ -631,37 +638,68 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     // nothing sized by the nnz) be finished in the SYMBOLIC phase: one walk of the row instead of two.  The numeric
     // phase then accounts for them as rows that are already in place.
     constexpr u32 kEscNum = (1u << NUM_G8) | (1u << NUM_G16);
-    c->capture_fused = c->esc_fused && c->nf_direct && c->pred_valid && (num_mask & kEscNum) != 0 &&
-                       c->cp.sym_g8 == c->cp.num_g8;
-    if (c->capture_fused) {
-        num_counts[NUM_NFCOPY] += num_counts[NUM_G8] + num_counts[NUM_G16];
-        num_counts[NUM_G8] = num_counts[NUM_G16] = 0;
-        num_mask = (num_mask & ~kEscNum) | (1u << NUM_NFCOPY);
+    p.fused = c->esc_fused && c->nf_direct && c->pred_valid && (p.num_mask & kEscNum) != 0 &&
+              c->cp.sym_g8 == c->cp.num_g8;
+    if (p.fused) {
+        p.num_counts[NUM_NFCOPY] += p.num_counts[NUM_G8] + p.num_counts[NUM_G16];
+        p.num_counts[NUM_G8] = p.num_counts[NUM_G16] = 0;
+        p.num_mask = (p.num_mask & ~kEscNum) | (1u << NUM_NFCOPY);
     }
-    c->graph_direct = c->nf_direct && c->pred_valid && (num_mask >> NUM_NFCOPY & 1u);
-    c->graph_fused = c->capture_fused;
-    c->capture_direct = c->graph_direct;
+    p.direct = c->nf_direct && c->pred_valid && (p.num_mask >> NUM_NFCOPY & 1u);
+    p.launch_mask = p.direct ? (p.num_mask & ~(1u << NUM_NFCOPY)) : p.num_mask;
+    return p;
+}
+
+// front + back + ticket of a replayed sequence, into a stream under capture -- or, with `tm`, straight onto the
+// stream with HIP events around the launches (speck_config_profile_kernels + option profile_replay: the launches
+// the replay consists of, timed one by one)
+template <typename T>
+int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B, const speck_dcsr* C,
+                   const Scratch& sc, const ReplayPlan& p, Timing* tm, size_t* ev_num_end)
+{
+    c->capture_fused = p.fused;
+    c->capture_direct = p.direct;
     c->capture_c_col = C->col_ids;
     c->capture_c_val = C->data;
-    const u32 launch_mask = c->graph_direct ? (num_mask & ~(1u << NUM_NFCOPY)) : num_mask;
     struct Reset {
         speck_config* c;
         ~Reset() { c->capture_direct = c->capture_fused = false; }
     } reset{c};
-    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
-                           num_mask, true, nullptr, c->last_sym_counts, nullptr,
-                           c->last_g_products, num_counts[NUM_G], 3u, c->nf_cap_entries);
-    if (rc == SPECK_OK)
-        rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
-                             launch_mask, num_counts, nullptr);
+                           p.num_mask, true, tm, c->last_sym_counts, nullptr,
+                           c->last_g_products, p.num_counts[NUM_G], 3u, c->nf_cap_entries);
+    if (rc != SPECK_OK) return rc;
+    if (tm) {
+        tm->ev_num = tm->ev;
+        (void)hipEventRecord(kernel_event(c, tm->ev++), s);
+    }
+    rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
+                         p.launch_mask, p.num_counts, tm);
+    if (rc != SPECK_OK) return rc;
+    if (tm) {
+        *ev_num_end = tm->ev;
+        (void)hipEventRecord(kernel_event(c, tm->ev++), s);
+    }
     // no copy node: the last kernel mirrors the (final) statistics block into pinned host memory, then stores
     // the completion ticket
-    if (rc == SPECK_OK) launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
-    hipError_t e = rc == SPECK_OK ? hipSuccess : hipErrorUnknown;
+    launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
+    return SPECK_OK;
+}
+
+// Capture the sequence into one graph, specialised to `key`.
+template <typename T>
+int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
+                  const speck_dcsr* C, const Scratch& sc, const GraphKey& key)
+{
+    drop_graph(c);
+    const ReplayPlan plan = plan_replay(c);
+    c->graph_direct = plan.direct;
+    c->graph_fused = plan.fused;
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    const int rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, nullptr, nullptr);
     hipGraph_t g = nullptr;
     hipError_t e2 = hipStreamEndCapture(s, &g);
-    if (rc != SPECK_OK || e != hipSuccess || e2 != hipSuccess || !g) {
+    if (rc != SPECK_OK || e2 != hipSuccess || !g) {
         if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
         return SPECK_ERR_HIP;
@@ -678,6 +716,33 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     c->graph_valid = true;
     ++c->graph_captures;
     return SPECK_OK;
+}
+
+// per-launch / per-phase times of the last call from its events (speck_stats)
+void publish_kernel_times(speck_config* c, const Timing& tm, size_t ev_num_end)
+{
+    auto ms = [&](size_t a) {
+        float v = 0.f;
+        (void)hipEventElapsedTime(&v, c->kev[a], c->kev[a + 1]);
+        return v;
+    };
+    (void)hipEventElapsedTime(&c->last.analysis_ms, c->kev[tm.ev_analysis], c->kev[tm.ev_analysis_end]);
+    c->last.scan_ms = ms(tm.ev_scan);
+    // phases: end of the analysis launches -> start of the scan (all symbolic branches joined);
+    // before the first numeric launch -> after the last join
+    (void)hipEventElapsedTime(&c->last.sym_phase_ms, c->kev[tm.ev_analysis_end], c->kev[tm.ev_scan]);
+    (void)hipEventElapsedTime(&c->last.num_phase_ms, c->kev[tm.ev_num], c->kev[ev_num_end]);
+    for (const auto& ct : tm.sym) {
+        if (ct.cls == kLightBig) c->last.sym_light_ms = ms(ct.ev);
+        else if (ct.cls == kLightTiny) c->last.sym_tiny_ms = ms(ct.ev);
+        else c->last.sym_bin_ms[ct.cls] = ms(ct.ev);
+    }
+    for (const auto& ct : tm.num) {
+        if (ct.cls == kLightBig) c->last.num_light_ms = ms(ct.ev);
+        else if (ct.cls == kLightTiny) c->last.num_tiny_ms = ms(ct.ev);
+        else c->last.num_bin_ms[ct.cls] = ms(ct.ev);
+    }
+    c->last.kernel_events_valid = 1;
 }
 
 template <typename T>
@@ -727,6 +792,27 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // captured launch sequence.  The device checks the two assumptions baked into it (nnz(C)
     // unchanged, no row in a class that was pruned); on a miss the eager path below re-runs.
     const bool c_ready = C->rows == A->rows && C->row_offsets && C->col_ids && C->data && C->nnz > 0;
+    if (c->use_graph && c_ready && c->profile_kernels && c->profile_replay && !t->measureAll) {
+        // the launches a replay of this call consists of, straight onto the stream with events around them
+        const GraphKey key = make_key<T>(c, A, B, C, s);
+        if (c->last_key_valid && c->last_key == key) {
+            const ReplayPlan plan = plan_replay(c);
+            Timing tm;
+            size_t ev_num_end = 0;
+            rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, &tm, &ev_num_end);
+            if (rc != SPECK_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(s));
+            c->ticket_expected = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE);
+            if (!c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
+                publish_counts(c);
+                publish_kernel_times(c, tm, ev_num_end);
+                c->last.replayed = 0;  // (not served by the graph: graph_replays does not count it)
+                c->last.nf_direct = plan.direct ? 1 : 0;
+                c->last.esc_fused = plan.fused ? 1 : 0;
+                return finish_complete();
+            }
+        }
+    }
     if (c->use_graph && c_ready && !c->profile_kernels && !t->measureAll) {
         const GraphKey key = make_key<T>(c, A, B, C, s);
         bool have = c->graph_valid && c->graph_key == key;
@@ -996,33 +1082,12 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     if (c->profile_kernels) {
         HIP_TRY(hipStreamSynchronize(s));
-        auto ms = [&](size_t a) {
-            float v = 0.f;
-            (void)hipEventElapsedTime(&v, c->kev[a], c->kev[a + 1]);
-            return v;
-        };
         auto span = [&](size_t a, size_t b) {
             float v = 0.f;
             (void)hipEventElapsedTime(&v, c->kev[a], c->kev[b]);
             return v;
         };
-        c->last.analysis_ms = span(tm.ev_analysis, tm.ev_analysis_end);
-        c->last.scan_ms = ms(tm.ev_scan);
-        // phases: end of the analysis launches -> start of the scan (all symbolic branches joined);
-        // before the first numeric launch -> after the last join
-        (void)hipEventElapsedTime(&c->last.sym_phase_ms, c->kev[tm.ev_analysis_end], c->kev[tm.ev_scan]);
-        (void)hipEventElapsedTime(&c->last.num_phase_ms, c->kev[tm.ev_num], c->kev[ev_num_end]);
-        for (const auto& ct : tm.sym) {
-            if (ct.cls == kLightBig) c->last.sym_light_ms = ms(ct.ev);
-            else if (ct.cls == kLightTiny) c->last.sym_tiny_ms = ms(ct.ev);
-            else c->last.sym_bin_ms[ct.cls] = ms(ct.ev);
-        }
-        for (const auto& ct : tm.num) {
-            if (ct.cls == kLightBig) c->last.num_light_ms = ms(ct.ev);
-            else if (ct.cls == kLightTiny) c->last.num_tiny_ms = ms(ct.ev);
-            else c->last.num_bin_ms[ct.cls] = ms(ct.ev);
-        }
-        c->last.kernel_events_valid = 1;
+        publish_kernel_times(c, tm, ev_num_end);
         if (t->measureAll) {
             // the reference's eleven stage fields (Timings.h:7-18, filled at Multiply.cu:227-1073) from
             // the kernel events: stages that are fused here report under the field of their role
@@ -1189,6 +1254,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->last_key_valid = false;
     }
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
+    else if (n == "profile_replay") c->profile_replay = value != 0;
     else if (n == "esc_fused") {
         c->esc_fused = value != 0;
         drop_graph(c);
