@@ -81,6 +81,11 @@ typedef struct speck_stats {
     int32_t esc_fused;                           /* 1: that sequence finished the rows of the register classes (<= 64
                                                   *    products) in its symbolic phase, at those offsets */
     uint64_t scratch_pool_bytes;                 /* numeric-first / global-key-set pool currently allocated */
+    int32_t pred_stages;                         /* that sequence's integer stages verified the previous identical call's
+                                                  *    decisions instead of folding them again: bit 0 the row-offset scan +
+                                                  *    numeric binning (one kernel), bit 1 the symbolic binning (inside the
+                                                  *    analysis kernel) -- DESIGN.md 4.3 */
+    int32_t reserved_;
 } speck_stats;
 
 typedef struct speck_config speck_config; /* opaque; reference: spECKConfig, include/spECKConfig.h:8-53 */

@@ -36,7 +36,8 @@ class CStats(C.Structure):
                 ("graph_replays", C.c_int32), ("graph_captures", C.c_int32),
                 ("sym_phase_ms", C.c_float), ("num_phase_ms", C.c_float),
                 ("replayed", C.c_int32), ("nf_direct", C.c_int32), ("pool_fallbacks", C.c_int32),
-                ("esc_fused", C.c_int32), ("scratch_pool_bytes", C.c_uint64)]
+                ("esc_fused", C.c_int32), ("scratch_pool_bytes", C.c_uint64),
+                ("pred_stages", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # every symbol include/speck_c_api.h declares, with its ctypes signature

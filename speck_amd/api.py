@@ -289,7 +289,7 @@ class spECKConfig:
             graph_replays=int(s.graph_replays), graph_captures=int(s.graph_captures),
             sym_phase_ms=float(s.sym_phase_ms), num_phase_ms=float(s.num_phase_ms),
             replayed=bool(s.replayed), nf_direct=bool(s.nf_direct), esc_fused=bool(s.esc_fused), pool_fallbacks=int(s.pool_fallbacks),
-            scratch_pool_bytes=int(s.scratch_pool_bytes))
+            scratch_pool_bytes=int(s.scratch_pool_bytes), pred_stages=int(s.pred_stages))
 
 
 _NO_TIMINGS = CTimings()  # scratch for calls that do not ask for stage times

@@ -30,7 +30,25 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
                  DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
-                 const u32* pred_off = nullptr);
+                 const u32* pred_off = nullptr, u32* pred_off_out = nullptr, u32* pred_tile_out = nullptr,
+                 bool pred_fold_esc = false);
+
+// What a call leaves behind for a replay of the SAME call to verify instead of recompute (pipeline.hip: Prediction):
+// per scan tile the position of its rows in every numeric class list, how many there are, and the products of its
+// NUM_G rows.  Layout of one tile: pos[kMaxClasses] | count[kMaxClasses] | g_ops (lo, hi).
+constexpr u32 kPredTileWords = 2 * kMaxClasses + 2;
+// ... and per analysis block the same for the symbolic class lists (+ the scratch entries of its numeric-first rows)
+constexpr u32 kPredBlockWords = 2 * kMaxClasses + 2;
+
+// The scan of a replayed sequence whose every row offset is predicted (pred_off) and whose tile tables are known
+// (pred_tile): ONE kernel, no fold over the tiles -- each tile scans its rows from its predicted base, compares
+// every fresh offset and its class histogram with the prediction (capacity_miss on any difference; nothing is then
+// written by that tile) and writes the row records at the predicted list positions.  The statistics the numeric
+// kernels and the host read are those of the predicted call (pred_stats), valid if no tile objects.
+void launch_scan_predicted(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro,
+                           const u32* row_ops, const u32* row_col_min, const u32* row_col_max, RowRec* recs,
+                           DeviceStats* st, const ClassifyParams& cp, const u32* pred_off, const u32* pred_tile,
+                           const DeviceStats* pred_stats);
 
 // Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
 // and two product pools (expanded by column bucket; reduced and sorted).

@@ -46,6 +46,21 @@ struct GraphKey {
     }
 };
 
+// What an eager call leaves behind for a replay of the SAME call (same buffers, same sizes) to verify instead of
+// recompute: the row offsets of C, per scan tile / analysis block where its rows go in the class lists (launch.hpp,
+// kPredTileWords), and the final statistics block.  One device allocation, carved.  The config keeps two: `pred`,
+// rewritten by every eager call, and `gpred`, the snapshot a captured sequence owns -- an eager call on OTHER
+// buffers in between must not change what that sequence compares against (and writes by).
+struct Prediction {
+    void* buf = nullptr;
+    size_t bytes = 0;
+    u32* off = nullptr;        // [rows + 1]
+    u32* num_tile = nullptr;   // [scan_tiles(rows)][kPredTileWords]
+    u32* sym_block = nullptr;  // [analysis_blocks(rows)][kPredBlockWords]
+    DeviceStats* stats = nullptr;
+    u32 rows = 0;
+};
+
 struct speck_config {
     int device = 0;
     int sm = 0;                 // compute units
@@ -114,9 +129,12 @@ struct speck_config {
     int pool_fallbacks = 0;        // times a scratch-pool class was switched off because the pool did not fit
     // direct placement of the numeric-first rows by a replayed sequence: the row offsets of the last eager call
     // (the config's own copy -- C.row_offsets is the caller's to overwrite), and the C buffers of the capture
-    u32* d_pred_off = nullptr;
-    size_t pred_cap = 0;
-    bool pred_valid = false;
+    Prediction pred, gpred;
+    bool pred_valid = false;         // pred.off holds the offsets of the last eager call
+    bool pred_tiles_valid = false;   // ... and pred.num_tile its tile tables,
+    bool pred_fold_esc = false;      //     in the shape of a sequence that finishes the register-class rows early
+    bool pred_scan = true;           // option pred_scan: a replayed sequence scans with launch_scan_predicted
+    bool capture_pred_scan = false;  // set while such a sequence is being enqueued
     bool nf_direct = true;           // option nf_direct
     bool capture_direct = false;     // set while a sequence with direct placement is being captured
     bool esc_fused = true;           // option esc_fused: such a sequence finishes the rows of the register classes in
@@ -126,6 +144,7 @@ struct speck_config {
     void* capture_c_val = nullptr;
     bool graph_direct = false;       // the captured sequence places the numeric-first rows directly
     bool graph_fused = false;        // ... and finishes the rows of the register classes in its symbolic phase
+    bool graph_pred_scan = false;    // ... and scans with the predicted kernel
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
@@ -232,6 +251,31 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
     return s;
 }
 
+// (re)allocate and carve a Prediction for `m` rows; false if the device has no room (the replay then predicts less)
+bool ensure_pred(Prediction& p, u32 m)
+{
+    const size_t need = Carver::need(size_t(m) + 1, 4) + Carver::need(size_t(scan_tiles(m)) * kPredTileWords, 4) +
+                        Carver::need(size_t(analysis_blocks(m)) * kPredBlockWords, 4) +
+                        Carver::need(1, sizeof(DeviceStats));
+    if (need > p.bytes) {
+        if (p.buf) (void)hipFree(p.buf);
+        p = Prediction{};
+        if (hipMalloc(&p.buf, need) != hipSuccess) {
+            (void)hipGetLastError();
+            p.buf = nullptr;
+            return false;
+        }
+        p.bytes = need;
+    }
+    Carver cv(p.buf);
+    p.off = cv.take<u32>(size_t(m) + 1);
+    p.num_tile = cv.take<u32>(size_t(scan_tiles(m)) * kPredTileWords);
+    p.sym_block = cv.take<u32>(size_t(analysis_blocks(m)) * kPredBlockWords);
+    p.stats = cv.take<DeviceStats>(1);
+    p.rows = m;
+    return true;
+}
+
 // scratch pool of the numeric-first rows: `entries` column ids followed by `entries` values
 int ensure_nfpool(speck_config* c, u64 entries, size_t vsize)
 {
@@ -271,7 +315,7 @@ RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill)
     w.nf_col = static_cast<u32*>(c->nfpool);
     w.nf_val = c->nfpool ? static_cast<unsigned char*>(c->nfpool) + Carver::need(c->nf_cap_entries, 4) : nullptr;
     w.nf_cap = c->nfpool ? c->nf_cap_entries : 0;
-    w.nf_pred_off = c->capture_direct ? c->d_pred_off : nullptr;
+    w.nf_pred_off = c->capture_direct ? c->gpred.off : nullptr;
     w.nf_direct_col = c->capture_direct ? c->capture_c_col : nullptr;
     w.nf_direct_val = c->capture_direct ? c->capture_c_val : nullptr;
     w.w_sl = sc.w_sl;
@@ -439,7 +483,9 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                   const Scratch& sc, u32* offsets_out, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
                   bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr,
                   DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
-                  u32 parts = 3 /* 1: analysis + binning, 2: symbolic launches + scan */, u64 expect_nf = ~0ull)
+                  u32 parts = 3 /* 1: analysis + binning, 2: symbolic launches + scan */, u64 expect_nf = ~0ull,
+                  const Prediction* pred_out = nullptr /* eager: what this call leaves for a replay */,
+                  bool pred_fold_esc = false)
 {
     const u32 m = (u32)A->rows;
     u32* const c_ro = sc.counts;  // the symbolic kernels count into scratch; the scan writes offsets_out
@@ -521,9 +567,14 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         tm->ev_scan = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
-    launch_scan(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
-                classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
-                host_mirror, expect_g, expect_g_rows, c->capture_direct ? c->d_pred_off : nullptr);
+    if (c->capture_pred_scan)
+        launch_scan_predicted(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
+                              sc.recs, c->d_stats, cp, c->gpred.off, c->gpred.num_tile, c->gpred.stats);
+    else
+        launch_scan(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
+                    classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
+                    host_mirror, expect_g, expect_g_rows, c->capture_direct ? c->gpred.off : nullptr,
+                    pred_out ? pred_out->off : nullptr, pred_out ? pred_out->num_tile : nullptr, pred_fold_esc);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -619,8 +670,33 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
 struct ReplayPlan {
     u32 num_mask, launch_mask;
     u32 num_counts[kMaxClasses];
-    bool direct, fused;
+    bool direct, fused, pred_scan;
 };
+
+// The config's prediction (of the last eager call = this call: same key) becomes the sequence's own: device copy of
+// the arrays, and the statistics block of that call in the shape the sequence classifies in.
+int snapshot_prediction(speck_config* c, hipStream_t s, const ReplayPlan& p)
+{
+    if (!c->pred_valid) return SPECK_OK;
+    if (!ensure_pred(c->gpred, c->pred.rows)) return SPECK_ERR_OOM;
+    HIP_TRY(hipMemcpyAsync(c->gpred.buf, c->pred.buf, std::min(c->pred.bytes, c->gpred.bytes), hipMemcpyDeviceToDevice, s));
+    DeviceStats ps = *c->h_stats;
+    ps.capacity_miss = 0;
+    std::memcpy(ps.num.count, p.num_counts, sizeof(ps.num.count));
+    u32 run = 0;
+    for (int k = 0; k < kMaxClasses; ++k) {
+        ps.num.offset[k] = run;
+        run += ps.num.count[k];
+    }
+    ps.num.offset[kMaxClasses] = run;
+    if (p.fused) {
+        ps.num.bytes[NUM_NFCOPY] += ps.num.bytes[NUM_G8] + ps.num.bytes[NUM_G16];
+        ps.num.bytes[NUM_G8] = ps.num.bytes[NUM_G16] = 0;
+    }
+    HIP_TRY(hipMemcpyAsync(c->gpred.stats, &ps, sizeof(ps), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (`ps` is on the stack)
+    return SPECK_OK;
+}
 
 ReplayPlan plan_replay(const speck_config* c)
 {
@@ -647,6 +723,11 @@ ReplayPlan plan_replay(const speck_config* c)
     }
     p.direct = c->nf_direct && c->pred_valid && (p.num_mask >> NUM_NFCOPY & 1u);
     p.launch_mask = p.direct ? (p.num_mask & ~(1u << NUM_NFCOPY)) : p.num_mask;
+    // Every row offset predicted, every tile table known (in the shape this sequence classifies in): the scan is one
+    // kernel that verifies instead of two that fold (launch_scan_predicted).  Rows waiting for the copy launch need
+    // their records: not with those.
+    p.pred_scan = c->pred_scan && c->pred_valid && c->pred_tiles_valid && c->pred_fold_esc == p.fused &&
+                  (p.direct || !(p.num_mask >> NUM_NFCOPY & 1u));
     return p;
 }
 
@@ -659,11 +740,12 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
 {
     c->capture_fused = p.fused;
     c->capture_direct = p.direct;
+    c->capture_pred_scan = p.pred_scan;
     c->capture_c_col = C->col_ids;
     c->capture_c_val = C->data;
     struct Reset {
         speck_config* c;
-        ~Reset() { c->capture_direct = c->capture_fused = false; }
+        ~Reset() { c->capture_direct = c->capture_fused = c->capture_pred_scan = false; }
     } reset{c};
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
                            p.num_mask, true, tm, c->last_sym_counts, nullptr,
@@ -692,9 +774,14 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                   const speck_dcsr* C, const Scratch& sc, const GraphKey& key)
 {
     drop_graph(c);
-    const ReplayPlan plan = plan_replay(c);
+    ReplayPlan plan = plan_replay(c);
+    if (snapshot_prediction(c, s, plan) != SPECK_OK) {  // no room for the sequence's own copy: predict nothing
+        c->pred_valid = c->pred_tiles_valid = false;
+        plan = plan_replay(c);
+    }
     c->graph_direct = plan.direct;
     c->graph_fused = plan.fused;
+    c->graph_pred_scan = plan.pred_scan;
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     const int rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, nullptr, nullptr);
     hipGraph_t g = nullptr;
@@ -796,7 +883,11 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         // the launches a replay of this call consists of, straight onto the stream with events around them
         const GraphKey key = make_key<T>(c, A, B, C, s);
         if (c->last_key_valid && c->last_key == key) {
-            const ReplayPlan plan = plan_replay(c);
+            ReplayPlan plan = plan_replay(c);
+            if (snapshot_prediction(c, s, plan) != SPECK_OK) {
+                c->pred_valid = c->pred_tiles_valid = false;
+                plan = plan_replay(c);
+            }
             Timing tm;
             size_t ev_num_end = 0;
             rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, &tm, &ev_num_end);
@@ -809,6 +900,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->last.replayed = 0;  // (not served by the graph: graph_replays does not count it)
                 c->last.nf_direct = plan.direct ? 1 : 0;
                 c->last.esc_fused = plan.fused ? 1 : 0;
+                c->last.pred_stages = (plan.pred_scan ? 1 : 0);
                 return finish_complete();
             }
         }
@@ -843,6 +935,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->last.replayed = 1;
                 c->last.nf_direct = c->graph_direct ? 1 : 0;
                 c->last.esc_fused = c->graph_fused ? 1 : 0;
+                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0);
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -870,11 +963,18 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     Timing tm;
     u32 sym_now[kMaxClasses];
     const u32* sym_known = nullptr;  // rows per symbolic class, once a read-back of this call has them
+    // what this call leaves behind for a replay of itself (Prediction): its row offsets and tile tables, written by
+    // the scan kernel next to its other outputs.  No room on the device: the replay predicts nothing.
+    c->pred_valid = c->pred_tiles_valid = false;
+    const bool keep_pred = (c->nf_direct || c->pred_scan) && c->use_graph && ensure_pred(c->pred, m);
+    // (the shape of the tile tables: will that replay finish the register-class rows in its symbolic phase?)
+    const bool fold_esc = keep_pred && c->esc_fused && c->nf_direct && c->cp.sym_g8 == c->cp.num_g8;
     auto front = [&](u32 parts) {
         // (the offsets go to scratch: C.row_offsets -- possibly the caller's reused buffer -- is written only once
         //  nothing can fail any more)
         return enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm,
-                             parts == 2u ? sym_known : nullptr, nullptr, ~0ull, ~0u, parts);
+                             parts == 2u ? sym_known : nullptr, nullptr, ~0ull, ~0u, parts, ~0ull,
+                             keep_pred ? &c->pred : nullptr, fold_esc);
     };
     // analysis + binning, then the input check: B's rows strictly ascending and in range (one coalesced pass;
     // A's column ids are checked -- and clamped -- by the analysis itself).  The check sits behind the analysis
@@ -1055,27 +1155,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     std::memcpy(c->last_num_counts, c->h_stats->num.count, sizeof(c->last_num_counts));
     c->last_key = make_key<T>(c, A, B, C, s);
     c->last_key_valid = true;
-    // ... and where every row went (the config's own copy of the offsets: the numeric-first rows of a replayed
-    // sequence are placed by it)
-    c->pred_valid = false;
-    const u32 placed_mask = (1u << NUM_NFCOPY) | (c->esc_fused ? (1u << NUM_G8) | (1u << NUM_G16) : 0u);
-    if (c->nf_direct && (num_mask & placed_mask)) {
-        if (c->pred_cap < size_t(m) + 1) {
-            if (c->d_pred_off) (void)hipFree(c->d_pred_off);
-            c->d_pred_off = nullptr;
-            c->pred_cap = 0;
-            drop_graph(c);
-            if (hipMalloc(reinterpret_cast<void**>(&c->d_pred_off), (size_t(m) + 1) * sizeof(u32)) == hipSuccess)
-                c->pred_cap = size_t(m) + 1;
-            else
-                (void)hipGetLastError();
-        }
-        if (c->d_pred_off) {
-            HIP_TRY(hipMemcpyAsync(c->d_pred_off, sc.offsets, (size_t(m) + 1) * sizeof(u32), hipMemcpyDeviceToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            c->pred_valid = true;
-        }
-    }
+    // ... and where every row went: the scan kernel wrote the prediction (offsets, tile tables) as it went
+    c->pred_valid = c->pred_tiles_valid = keep_pred;
+    c->pred_fold_esc = fold_esc;
 
     rc = finish_complete();
     if (rc != SPECK_OK) return rc;
@@ -1197,7 +1279,8 @@ int speck_config_destroy(speck_config* c)
     if (c->arena) (void)hipFree(c->arena);
     if (c->gpool) (void)hipFree(c->gpool);
     if (c->nfpool) (void)hipFree(c->nfpool);
-    if (c->d_pred_off) (void)hipFree(c->d_pred_off);
+    if (c->pred.buf) (void)hipFree(c->pred.buf);
+    if (c->gpred.buf) (void)hipFree(c->gpred.buf);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->h_ticket) (void)hipHostFree(c->h_ticket);
@@ -1255,6 +1338,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
     else if (n == "profile_replay") c->profile_replay = value != 0;
+    else if (n == "pred_scan") {
+        c->pred_scan = value != 0;
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
     else if (n == "esc_fused") {
         c->esc_fused = value != 0;
         drop_graph(c);

@@ -738,7 +738,8 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     const u32* __restrict__ a_ro, const u32* __restrict__ row_ops,
     const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
     RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz, u64 expect_g, u32 expect_g_rows,
-    DeviceStats* __restrict__ host_mirror, const u32* __restrict__ pred_off)
+    DeviceStats* __restrict__ host_mirror, const u32* __restrict__ pred_off, u32* __restrict__ pred_off_out,
+    u32* __restrict__ pred_tile_out, bool pred_fold_esc)
 {
     constexpr int NW = kScanThreads / 64;
     __shared__ Fold s_fold;
@@ -783,6 +784,28 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
             for (u32 i = 0; i < sizeof(DeviceStats) / 8; ++i) dst[i] = src[i];
         }
     }
+    // what a replay of this call may take for granted and verify (launch.hpp, kPredTileWords): where my tile's rows
+    // of every class go, how many there are -- in the shape the REPLAY classifies (its register-class rows are
+    // finished in the symbolic phase and count as rows already in place: pred_fold_esc)
+    if (pred_tile_out && threadIdx.x < kMaxClasses) {
+        const PartialArrays pa(parts, nb);
+        auto shaped = [&](auto&& get, u32 k) -> u32 {
+            if (!pred_fold_esc) return get(k);
+            if (k == NUM_G8 || k == NUM_G16) return 0u;
+            return k == NUM_NFCOPY ? get(NUM_NFCOPY) + get(NUM_G8) + get(NUM_G16) : get(k);
+        };
+        const u32 k = threadIdx.x;
+        u32 pos = shaped([&](u32 q) { return s_fold.prefix[q]; }, k);
+        for (u32 q = 0; q < k; ++q) pos += shaped([&](u32 r) { return s_fold.total[r]; }, q);
+        u32* out = pred_tile_out + size_t(blockIdx.x) * kPredTileWords;
+        out[k] = pos;
+        out[kMaxClasses + k] = shaped([&](u32 q) { return pa.count[q * pa.cap + blockIdx.x]; }, k);
+        if (k == 0) {
+            const u64 g = pa.g_ops[blockIdx.x];
+            out[2 * kMaxClasses] = (u32)g;
+            out[2 * kMaxClasses + 1] = (u32)(g >> 32);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) tsum += c[i];
     u32 total;
@@ -792,13 +815,19 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         off[i] = run;
-        if (base + i < m && !miss) offsets_out[base + i] = run;
+        if (base + i < m && !miss) {
+            offsets_out[base + i] = run;
+            if (pred_off_out) pred_off_out[base + i] = run;  // the config's own copy: C.row_offsets is the caller's
+        }
         // rows the numeric-first kernel has already placed by the previous call's offsets: the fresh ones must agree
         // (checked for EVERY row: a shift anywhere before such a row moves it)
         if (pred_off && base + i < m && pred_off[base + i] != run) st->capacity_miss = 1;
         run += c[i];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && !miss) offsets_out[m] = (u32)nnz_c;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && !miss) {
+        offsets_out[m] = (u32)nnz_c;
+        if (pred_off_out) pred_off_out[m] = (u32)nnz_c;
+    }
     if (!num_cls) return;
 
     // class of my rows, packed per-thread histogram, exclusive scan over the threads
@@ -839,6 +868,146 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
         if (cls[i] == NUM_NFCOPY && pred_off) continue;  // already in place: no launch reads that list
         const u32 k = cls[i];
         const u32 pos = class_offset(s_fold, k) + s_fold.prefix[k] + before.get(k) + used.get(k);
+        used.add(k);
+        RowRec r;
+        r.row = (u32)row;
+        r.a0 = a_ro[row];
+        r.a1 = a_ro[row + 1];
+        r.base = off[i];
+        r.cmin = row_col_min[row];
+        r.cmax = row_col_max[row];
+        r.ops = row_ops[row];
+        r.nnz = c[i];
+        recs[pos] = r;
+    }
+}
+
+// The scan of a replayed sequence with every row offset and every tile table predicted (launch.hpp,
+// launch_scan_predicted): no count kernel, no fold.
+template <int ITEMS>
+__global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
+    const u32* counts, u32* offsets_out /* may alias counts */, u32 m, DeviceStats* __restrict__ st,
+    const u32* __restrict__ a_ro, const u32* __restrict__ row_ops, const u32* __restrict__ row_col_min,
+    const u32* __restrict__ row_col_max, RowRec* __restrict__ recs, ClassifyParams cp,
+    const u32* __restrict__ pred_off, const u32* __restrict__ pred_tile, const DeviceStats* __restrict__ pred_stats)
+{
+    constexpr int NW = kScanThreads / 64;
+    __shared__ u32 s_scan[NW + 1];
+    __shared__ u64 s_wave[NW][3];
+    __shared__ u64 s_g[NW];
+    __shared__ u32 s_pos[kMaxClasses];
+    __shared__ u32 s_bad;
+    const u32 lane = lane_id(), wid = threadIdx.x >> 6;
+    const u64 tile0 = u64(blockIdx.x) * (kScanThreads * ITEMS);
+    const u64 base = tile0 + u64(threadIdx.x) * ITEMS;
+    const u32* tab = pred_tile + size_t(blockIdx.x) * kPredTileWords;
+    if (threadIdx.x == 0) s_bad = 0;
+    if (threadIdx.x < kMaxClasses) s_pos[threadIdx.x] = tab[threadIdx.x];
+    u32 c[ITEMS], po[ITEMS + 1];
+    u8 cls[ITEMS];
+    u32 tsum = 0;
+    u64 g_ops = 0;
+    PackedCounts mine;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const u64 row = base + i;
+        c[i] = row < m ? counts[row] : 0;
+        po[i] = row < m ? pred_off[row] : 0;
+        cls[i] = NUM_NONE;
+        if (row < m) {
+            const u32 ops = row_ops[row];
+            cls[i] = classify_numeric(a_ro[row + 1] - a_ro[row], ops, c[i], row_col_min[row], row_col_max[row], cp);
+            if (cls[i] == NUM_G) g_ops += ops;
+            if (cls[i] != NUM_NONE) mine.add(cls[i]);
+        }
+        tsum += c[i];
+    }
+    po[ITEMS] = base < m ? pred_off[base + ITEMS <= m ? base + ITEMS : m] : 0;  // where my last row ends
+    const u32 tile_base = pred_off[tile0];  // (tile0 < m: the grid has no empty tile)
+    // the statistics of the predicted call: what the numeric kernels (class lists) and the host read
+    if (blockIdx.x == 0) {
+        constexpr u32 kWords = sizeof(BinTable) / 4;
+        const u32* src = reinterpret_cast<const u32*>(&pred_stats->num);
+        u32* dst = reinterpret_cast<u32*>(&st->num);
+        for (u32 i = threadIdx.x; i < kWords; i += kScanThreads) dst[i] = src[i];
+        if (threadIdx.x == 0) {
+            st->nnz_c = pred_stats->nnz_c;
+            st->max_row_nnz_c = pred_stats->max_row_nnz_c;
+            st->g_products = pred_stats->g_products;
+        }
+    }
+    u32 total;
+    const u32 excl = block_exclusive_scan<kScanThreads>(tsum, s_scan, &total);
+    u32 run = tile_base + excl;
+    bool bad = false;
+    u32 off[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        off[i] = run;
+        if (base + i < m && po[i] != run) bad = true;
+        run += c[i];
+    }
+    if (base < m && po[ITEMS] != run) bad = true;  // (rows past m add nothing: the last row of C ends at pred_off[m])
+    // class histogram of the tile and the products of its NUM_G rows against the prediction
+    PackedCounts incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 ta = __shfl_up(incl.a, o, 64), tb = __shfl_up(incl.b, o, 64), tc = __shfl_up(incl.c, o, 64);
+        if (lane >= (u32)o) {
+            incl.a += ta;
+            incl.b += tb;
+            incl.c += tc;
+        }
+    }
+    g_ops = wave_reduce_add(g_ops);
+    if (lane == 63) {
+        s_wave[wid][0] = incl.a;
+        s_wave[wid][1] = incl.b;
+        s_wave[wid][2] = incl.c;
+    }
+    if (lane == 0) s_g[wid] = g_ops;
+    if (__ballot(bad) != 0 && lane == 0) s_bad = 1;
+    __syncthreads();
+    if (threadIdx.x < kMaxClasses) {
+        PackedCounts all;
+        for (int w = 0; w < NW; ++w) {
+            all.a += s_wave[w][0];
+            all.b += s_wave[w][1];
+            all.c += s_wave[w][2];
+        }
+        if (all.get(threadIdx.x) != tab[kMaxClasses + threadIdx.x]) s_bad = 1;
+        if (threadIdx.x == 0) {
+            u64 g = 0;
+            for (int w = 0; w < NW; ++w) g += s_g[w];
+            if (g != ((u64(tab[2 * kMaxClasses + 1]) << 32) | tab[2 * kMaxClasses])) s_bad = 1;
+        }
+    }
+    __syncthreads();
+    if (s_bad) {  // (uniform) this tile is not what it was: nothing of it is written, the eager path re-runs the call
+        if (threadIdx.x == 0) st->capacity_miss = 1;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (base + i < m) offsets_out[base + i] = off[i];  // (= the prediction = what the previous call left there)
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) offsets_out[m] = pred_off[m];
+    PackedCounts before;  // rows of each class in the threads before mine (exclusive)
+    before.a = incl.a - mine.a;
+    before.b = incl.b - mine.b;
+    before.c = incl.c - mine.c;
+    for (u32 w = 0; w < wid; ++w) {
+        before.a += s_wave[w][0];
+        before.b += s_wave[w][1];
+        before.c += s_wave[w][2];
+    }
+    PackedCounts used;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const u64 row = base + i;
+        if (cls[i] == NUM_NONE) continue;
+        if (cls[i] == NUM_NFCOPY) continue;  // already in place (direct placement): no launch reads that list
+        const u32 k = cls[i];
+        const u32 pos = s_pos[k] + before.get(k) + used.get(k);
         used.add(k);
         RowRec r;
         r.row = (u32)row;
@@ -949,7 +1118,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
-                 DeviceStats* host_mirror, u64 expect_g, u32 expect_g_rows, const u32* pred_off)
+                 DeviceStats* host_mirror, u64 expect_g, u32 expect_g_rows, const u32* pred_off, u32* pred_off_out,
+                 u32* pred_tile_out, bool pred_fold_esc)
 {
     const u32 tiles = scan_tiles(m);
     auto go = [&](auto items) {
@@ -959,7 +1129,26 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
                            partials, cp, vsize);
         hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, st,
                            partials, tiles, (const u8*)num_cls, a_ro, row_ops,
-                           row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, expect_g_rows, host_mirror, pred_off);
+                           row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, expect_g_rows, host_mirror, pred_off,
+                           pred_off_out, num_cls ? pred_tile_out : nullptr, pred_fold_esc);
+    };
+    switch (scan_items(m)) {
+        case 2: go(std::integral_constant<int, 2>{}); break;
+        case 8: go(std::integral_constant<int, 8>{}); break;
+        default: go(std::integral_constant<int, 32>{}); break;
+    }
+}
+
+void launch_scan_predicted(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro,
+                           const u32* row_ops, const u32* row_col_min, const u32* row_col_max, RowRec* recs,
+                           DeviceStats* st, const ClassifyParams& cp, const u32* pred_off, const u32* pred_tile,
+                           const DeviceStats* pred_stats)
+{
+    const u32 tiles = scan_tiles(m);
+    auto go = [&](auto items) {
+        constexpr int I = decltype(items)::value;
+        hipLaunchKernelGGL(num_apply_pred_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, st,
+                           a_ro, row_ops, row_col_min, row_col_max, recs, cp, pred_off, pred_tile, pred_stats);
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;

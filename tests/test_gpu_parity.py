@@ -1046,6 +1046,41 @@ def test_register_class_rows_are_finished_in_the_symbolic_phase_of_a_replay(cfg)
     assert (np.abs(got.data.astype(np.float64) - Rf.data.astype(np.float64)) <= TOL32 * abf + 1e-30).all()
 
 
+def test_a_captured_sequence_owns_its_prediction(cfg):
+    """A replayed sequence verifies (and places rows by) what the previous identical call decided.  That prediction
+    belongs to the sequence: an eager multiply of OTHER matrices on the same config in between -- more rows, other
+    offsets -- must not change what the sequence of the first problem compares against or writes by."""
+    A = to_po(sa.gen_matrix("mac_econ", 0.05, 7, signed=True))
+    Bg = to_po(sa.gen_matrix("cant", 0.08, 8, signed=True))   # numeric-first rows, other sizes
+    dA, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR()
+    dB, dD = sa.dCSR.from_host(to_sa(Bg)), sa.dCSR()
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dA, dC, cfg)
+    st = cfg.last_stats()
+    assert st["replayed"] and st["pred_stages"] & 1
+    replays = st["graph_replays"]
+    sa.MultiplyspECK(dB, dB, dD, cfg)                          # eager, other buffers: rewrites the config's prediction
+    _assert_matches_oracle(dD, Bg, Bg)
+    junk = np.full(dC.nnz, 0xFFFFFFF0, dtype=np.uint32)
+    assert _lib.load().speck_dcsr_update(ctypes.byref(dC._c), None, junk.ctypes.data,
+                                         np.full(dC.nnz, np.nan).ctypes.data, 8) == 0
+    sa.MultiplyspECK(dA, dA, dC, cfg)                          # the captured sequence of the first problem, again
+    st = cfg.last_stats()
+    assert st["graph_replays"] == replays + 1 and st["replayed"]
+    _assert_matches_oracle(dC, A, A)
+    _assert_matches_oracle(dD, Bg, Bg)                         # ... which wrote nothing into the other problem's C
+    # the option off: same answers through the two-kernel scan
+    cfg.set_option("pred_scan", 0)
+    try:
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dA, dC, cfg)
+        st = cfg.last_stats()
+        assert st["replayed"] and not st["pred_stages"] & 1
+        _assert_matches_oracle(dC, A, A)
+    finally:
+        cfg.set_option("pred_scan", 1)
+
+
 @pytest.mark.parametrize("kind,scale", [("scircuit", 0.3), ("mac_econ", 0.3), ("cant", 0.1), ("webbase", 0.1),
                                          ("nlpkkt", 0.002)])
 def test_plain_relative_1e12_on_cancellation_free_standins(cfg, kind, scale):
