@@ -135,6 +135,9 @@ struct speck_config {
     bool pred_fold_esc = false;      //     in the shape of a sequence that finishes the register-class rows early
     bool pred_scan = true;           // option pred_scan: a replayed sequence scans with launch_scan_predicted
     bool capture_pred_scan = false;  // set while such a sequence is being enqueued
+    bool pred_sym = true;            // option pred_sym: ... and bins its rows for the symbolic phase inside the analysis
+                                     //   kernel, at the list positions of the previous identical call (no scatter kernel)
+    bool capture_pred_sym = false;
     bool nf_direct = true;           // option nf_direct
     bool capture_direct = false;     // set while a sequence with direct placement is being captured
     bool esc_fused = true;           // option esc_fused: such a sequence finishes the rows of the register classes in
@@ -145,6 +148,7 @@ struct speck_config {
     bool graph_direct = false;       // the captured sequence places the numeric-first rows directly
     bool graph_fused = false;        // ... and finishes the rows of the register classes in its symbolic phase
     bool graph_pred_scan = false;    // ... and scans with the predicted kernel
+    bool graph_pred_sym = false;     // ... and has no scatter kernel
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
@@ -507,7 +511,9 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         }
         launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
                         sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
-                        c->d_stats, cp, sc.b_sl, between, sc.nf_off, expect_nf, (u32)B->rows);
+                        c->d_stats, cp, sc.b_sl, between, sc.nf_off, expect_nf, (u32)B->rows,
+                        pred_out ? pred_out->sym_block : nullptr, c->capture_pred_sym ? c->gpred.sym_block : nullptr,
+                        c->gpred.stats);
         if (timed) {
             tm->ev_analysis_end = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -569,7 +575,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     }
     if (c->capture_pred_scan)
         launch_scan_predicted(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
-                              sc.recs, c->d_stats, cp, c->gpred.off, c->gpred.num_tile, c->gpred.stats);
+                              sc.recs, c->d_stats, cp, c->gpred.off, c->gpred.num_tile, c->gpred.stats,
+                              c->capture_pred_sym ? sc.partials : nullptr);
     else
         launch_scan(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                     classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
@@ -670,7 +677,7 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
 struct ReplayPlan {
     u32 num_mask, launch_mask;
     u32 num_counts[kMaxClasses];
-    bool direct, fused, pred_scan;
+    bool direct, fused, pred_scan, pred_sym;
 };
 
 // The config's prediction (of the last eager call = this call: same key) becomes the sequence's own: device copy of
@@ -728,6 +735,11 @@ ReplayPlan plan_replay(const speck_config* c)
     // their records: not with those.
     p.pred_scan = c->pred_scan && c->pred_valid && c->pred_tiles_valid && c->pred_fold_esc == p.fused &&
                   (p.direct || !(p.num_mask >> NUM_NFCOPY & 1u));
+    // ... and so is the symbolic binning, inside the analysis kernel (no scatter kernel, its totals folded by the
+    // predicted scan).  Rows that need a scratch slot from the scatter's prefix (global key sets; numeric-first rows
+    // that are not placed directly) keep the scatter kernel.
+    p.pred_sym = c->pred_sym && p.pred_scan && !(c->last_sym_mask >> SYM_GH & 1u) &&
+                 (!(c->last_sym_mask >> SYM_NF & 1u) || p.direct);
     return p;
 }
 
@@ -741,11 +753,12 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
     c->capture_fused = p.fused;
     c->capture_direct = p.direct;
     c->capture_pred_scan = p.pred_scan;
+    c->capture_pred_sym = p.pred_sym;
     c->capture_c_col = C->col_ids;
     c->capture_c_val = C->data;
     struct Reset {
         speck_config* c;
-        ~Reset() { c->capture_direct = c->capture_fused = c->capture_pred_scan = false; }
+        ~Reset() { c->capture_direct = c->capture_fused = c->capture_pred_scan = c->capture_pred_sym = false; }
     } reset{c};
     int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
                            p.num_mask, true, tm, c->last_sym_counts, nullptr,
@@ -782,6 +795,7 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     c->graph_direct = plan.direct;
     c->graph_fused = plan.fused;
     c->graph_pred_scan = plan.pred_scan;
+    c->graph_pred_sym = plan.pred_sym;
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     const int rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, nullptr, nullptr);
     hipGraph_t g = nullptr;
@@ -900,7 +914,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->last.replayed = 0;  // (not served by the graph: graph_replays does not count it)
                 c->last.nf_direct = plan.direct ? 1 : 0;
                 c->last.esc_fused = plan.fused ? 1 : 0;
-                c->last.pred_stages = (plan.pred_scan ? 1 : 0);
+                c->last.pred_stages = (plan.pred_scan ? 1 : 0) | (plan.pred_sym ? 2 : 0);
                 return finish_complete();
             }
         }
@@ -935,7 +949,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->last.replayed = 1;
                 c->last.nf_direct = c->graph_direct ? 1 : 0;
                 c->last.esc_fused = c->graph_fused ? 1 : 0;
-                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0);
+                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0) | (c->graph_pred_sym ? 2 : 0);
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -1338,6 +1352,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
     else if (n == "profile_replay") c->profile_replay = value != 0;
+    else if (n == "pred_sym") {
+        c->pred_sym = value != 0;
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
     else if (n == "pred_scan") {
         c->pred_scan = value != 0;
         drop_graph(c);

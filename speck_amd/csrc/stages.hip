@@ -68,7 +68,8 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* __restrict__ row_ops,
     u32* __restrict__ row_max_ops, u32* __restrict__ row_col_min, u32* __restrict__ row_col_max,
     u8* __restrict__ sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
-    ClassifyParams cp, uint2* __restrict__ b_sl, DeviceStats* __restrict__ st, u32 b_rows)
+    ClassifyParams cp, uint2* __restrict__ b_sl, DeviceStats* __restrict__ st, u32 b_rows,
+    const u32* __restrict__ pred_block, const DeviceStats* __restrict__ pred_stats, RowRec* __restrict__ recs)
 {
     constexpr int NW = kAnThreads / 64;
     constexpr int U = 4;   // entries per lane and tile: 256 entries cover most 32-row sub-chunks in ONE
@@ -79,8 +80,20 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     static_assert(kChunk / 64 == 4, "sym_scatter_kernel sums four per-wave counters");
     // the statistics block of this call starts from zero (no memset node in the launch sequence;
     // nothing reads or writes it before the scatter kernel that follows)
-    if (blockIdx.x == 0)
+    // (a replayed sequence whose symbolic binning is PREDICTED -- pred_block, below -- has no scatter kernel: its
+    //  blocks raise the flags of the statistics block themselves, so block 0 must not wipe them.  They are zero
+    //  when such a sequence starts: it only ever follows a call that completed -- or it finds a flag of a failed one,
+    //  stops, and the eager path, which starts from zero, re-runs.  Block 0 then writes what the symbolic kernels
+    //  read: the class table of the predicted call, which every block checks its own share of.)
+    if (blockIdx.x == 0 && !pred_block)
         for (u32 i = threadIdx.x; i < sizeof(DeviceStats) / 4; i += kAnThreads) reinterpret_cast<u32*>(st)[i] = 0;
+    if (blockIdx.x == 0 && pred_block) {
+        constexpr u32 kWords = sizeof(BinTable) / 4;
+        const u32* src = reinterpret_cast<const u32*>(&pred_stats->sym);
+        u32* dst = reinterpret_cast<u32*>(&st->sym);
+        for (u32 i = threadIdx.x; i < kWords; i += kAnThreads) dst[i] = src[i];
+        if (threadIdx.x == 0) st->nf_entries = pred_stats->nf_entries;
+    }
     const u32 e_base = a_ro[0];  // A may be a row-range view with absolute offsets
     __shared__ u32 s_ro_all[NW][R + 1];
     __shared__ u64 s_ops_all[NW][R];
@@ -378,6 +391,76 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
         pa.count[t * pa.cap + blockIdx.x] = h;
         if (cp.want_bytes) pa.bytes[t * pa.cap + blockIdx.x] = s_bytes[t];
     }
+    if (!pred_block) return;
+
+    // ---- predicted symbolic binning (replayed sequence): the scatter kernel's work for my rows, at the list
+    // positions the previous identical call gave this block -- if my rows are, class by class, as many as then.
+    __shared__ u32 s_wcnt[SYM_CLASSES][kChunk / 64];
+    __shared__ u32 s_run[SYM_CLASSES];
+    __shared__ u32 s_bad;
+    const u32* tab = pred_block + size_t(blockIdx.x) * kPredBlockWords;
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+    if (t < SYM_CLASSES) {
+        u32 h = 0;
+        for (int w = 0; w < NW; ++w) h += s_hist[w][t];
+        if (h != tab[kMaxClasses + t]) s_bad = 1;
+        s_run[t] = tab[t];
+    }
+    if (t == 0) {
+        u64 nf = 0;
+        u32 nfr = 0;
+        for (int w = 0; w < NW; ++w) {
+            nf += s_nf[w];
+            nfr = max(nfr, s_nfr[w]);
+        }
+        if (nf != ((u64(tab[2 * kMaxClasses + 1]) << 32) | tab[2 * kMaxClasses])) s_bad = 1;
+        if (nfr == 0xFFFFFFFFu) {  // a column id of A >= rows(B)
+            st->a_invalid = 1;
+            s_bad = 1;
+        }
+    }
+    __threadfence_block();  // my rows' classes and bounds (global, written by the waves of this block) before the reads below
+    __syncthreads();
+    if (s_bad) {  // (uniform) not the rows of the predicted call: nothing is written, the eager path re-runs
+        if (t == 0) st->capacity_miss = 1;
+        return;
+    }
+    for (u32 row0 = row_begin; row0 < row_end; row0 += kChunk) {
+        const u32 row = row0 + t;
+        const u32 c = (t < kChunk && row < row_end) ? sym_cls[row] : 0xFFu;
+        u32 my_rank = 0;
+        if (t < kChunk) {
+#pragma unroll
+            for (u32 b = 0; b < SYM_CLASSES; ++b) {
+                const u64 mask = __ballot(c == b);
+                if (lane == 0) s_wcnt[b][wid] = __popcll(mask);
+                if (c == b) my_rank = __popcll(mask & lanemask_lt());
+            }
+        }
+        __syncthreads();
+        if (c < SYM_CLASSES) {
+            u32 pos = s_run[c] + my_rank;
+            for (u32 w = 0; w < wid; ++w) pos += s_wcnt[c][w];
+            RowRec r;
+            r.row = row;
+            r.a0 = a_ro[row];
+            r.a1 = a_ro[row + 1];
+            r.base = 0;
+            r.cmin = row_col_min[row];
+            r.cmax = row_col_max[row];
+            r.ops = row_ops[row];
+            r.nnz = 0;
+            recs[pos] = r;
+        }
+        __syncthreads();
+        if (t < SYM_CLASSES) {
+            u32 add = 0;
+            for (int w = 0; w < kChunk / 64; ++w) add += s_wcnt[t][w];
+            s_run[t] += add;
+        }
+        __syncthreads();
+    }
 }
 
 // --------------------------------------------------------------------------------
@@ -520,7 +603,7 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
     BlockPartial* __restrict__ parts, u32 nb, const u32* __restrict__ a_ro,
     const u32* __restrict__ row_ops, const u32* __restrict__ row_col_min,
     const u32* __restrict__ row_col_max, RowRec* __restrict__ recs, ClassifyParams cp,
-    u64* __restrict__ nf_off, u64 expect_nf)
+    u64* __restrict__ nf_off, u64 expect_nf, u32* __restrict__ pred_block_out)
 {
     constexpr int NW = kChunk / 64;
     __shared__ Fold s_fold;
@@ -562,6 +645,19 @@ __global__ __launch_bounds__(kChunk) void sym_scatter_kernel(
     if (!cls) return;
     if (threadIdx.x == 0) s_nfrun = s_fold.g_prefix;
     if (threadIdx.x < SYM_CLASSES) s_run[threadIdx.x] = class_offset(s_fold, threadIdx.x) + s_fold.prefix[threadIdx.x];
+    // what a replay of this call may take for granted and verify (launch.hpp, kPredBlockWords)
+    if (pred_block_out && threadIdx.x < kMaxClasses) {
+        const PartialArrays pa(parts, nb);
+        u32* out = pred_block_out + size_t(blockIdx.x) * kPredBlockWords;
+        const u32 k = threadIdx.x;
+        out[k] = k < SYM_CLASSES ? class_offset(s_fold, k) + s_fold.prefix[k] : 0u;
+        out[kMaxClasses + k] = pa.count[k * pa.cap + blockIdx.x];
+        if (k == 0) {
+            const u64 g = pa.g_ops[blockIdx.x];
+            out[2 * kMaxClasses] = (u32)g;
+            out[2 * kMaxClasses + 1] = (u32)(g >> 32);
+        }
+    }
     __syncthreads();
     for (u32 row0 = row_begin; row0 < row_end; row0 += kChunk) {
         const u32 row = row0 + threadIdx.x;
@@ -889,7 +985,8 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
     const u32* counts, u32* offsets_out /* may alias counts */, u32 m, DeviceStats* __restrict__ st,
     const u32* __restrict__ a_ro, const u32* __restrict__ row_ops, const u32* __restrict__ row_col_min,
     const u32* __restrict__ row_col_max, RowRec* __restrict__ recs, ClassifyParams cp,
-    const u32* __restrict__ pred_off, const u32* __restrict__ pred_tile, const DeviceStats* __restrict__ pred_stats)
+    const u32* __restrict__ pred_off, const u32* __restrict__ pred_tile, const DeviceStats* __restrict__ pred_stats,
+    BlockPartial* __restrict__ an_parts, u32 an_blocks)
 {
     constexpr int NW = kScanThreads / 64;
     __shared__ u32 s_scan[NW + 1];
@@ -934,6 +1031,40 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
             st->nnz_c = pred_stats->nnz_c;
             st->max_row_nnz_c = pred_stats->max_row_nnz_c;
             st->g_products = pred_stats->g_products;
+        }
+        // the sequence had no scatter kernel (predicted symbolic binning): the totals of the analysis are folded here
+        if (an_parts) {
+            __shared__ u64 s_ap[NW];
+            __shared__ u32 s_am[NW], s_ar[NW];
+            const PartialArrays pa(an_parts, an_blocks);
+            u64 p = 0;
+            u32 mx = 0, ar = 0;
+            for (u32 b = threadIdx.x; b < an_blocks; b += kScanThreads) {
+                p += pa.products[b];
+                mx = max(mx, pa.max_val[b]);
+                ar = max(ar, pa.aux_max[b]);
+            }
+            p = wave_reduce_add(p);
+            mx = wave_reduce_max(mx);
+            ar = wave_reduce_max(ar);
+            if (lane == 0) {
+                s_ap[wid] = p;
+                s_am[wid] = mx;
+                s_ar[wid] = ar;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u64 tp = 0;
+                u32 tm = 0, tr = 0;
+                for (int w = 0; w < NW; ++w) {
+                    tp += s_ap[w];
+                    tm = max(tm, s_am[w]);
+                    tr = max(tr, s_ar[w]);
+                }
+                st->sum_products = tp;
+                st->max_row_ops = tm;
+                st->nf_max_range = tr == 0xFFFFFFFFu ? 0u : tr;
+            }
         }
     }
     u32 total;
@@ -1100,19 +1231,28 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* b_col, u32 m, u64 /*nnz_a*/, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
-                     uint2* b_sl, hipEvent_t between, u64* nf_off, u64 expect_nf, u32 b_rows)
+                     uint2* b_sl, hipEvent_t between, u64* nf_off, u64 expect_nf, u32 b_rows, u32* pred_block_out,
+                     const u32* pred_block, const DeviceStats* pred_stats)
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
+    if (pred_block && sym_cls) {  // replayed sequence, symbolic binning predicted: no scatter kernel
+        hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kAnThreads), 0, s, a_ro, a_col, b_ro, b_col, m,
+                           rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
+                           partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs);
+        if (between) (void)hipEventRecord(between, s);
+        return;
+    }
     hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kAnThreads), 0, s, a_ro, a_col, b_ro, b_col, m,
                        rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                       partials, cp, b_sl, st, b_rows);
+                       partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
+                       (RowRec*)nullptr);
     if (between) (void)hipEventRecord(between, s);  // analysis | binning (Timings::countProducts / loadBalanceCounting)
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,
                        (const u8*)sym_cls, m, rows_per_block, st, partials, blocks, a_ro,
                        (const u32*)row_ops, (const u32*)row_col_min, (const u32*)row_col_max, recs, cp, nf_off,
-                       expect_nf);
+                       expect_nf, sym_cls ? pred_block_out : nullptr);
 }
 
 void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro, const u32* row_ops,
@@ -1142,13 +1282,14 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
 void launch_scan_predicted(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro,
                            const u32* row_ops, const u32* row_col_min, const u32* row_col_max, RowRec* recs,
                            DeviceStats* st, const ClassifyParams& cp, const u32* pred_off, const u32* pred_tile,
-                           const DeviceStats* pred_stats)
+                           const DeviceStats* pred_stats, BlockPartial* analysis_partials)
 {
     const u32 tiles = scan_tiles(m);
     auto go = [&](auto items) {
         constexpr int I = decltype(items)::value;
         hipLaunchKernelGGL(num_apply_pred_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, st,
-                           a_ro, row_ops, row_col_min, row_col_max, recs, cp, pred_off, pred_tile, pred_stats);
+                           a_ro, row_ops, row_col_min, row_col_max, recs, cp, pred_off, pred_tile, pred_stats,
+                           analysis_partials, analysis_partials ? analysis_blocks(m) : 0u);
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;

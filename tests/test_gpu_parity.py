@@ -524,6 +524,9 @@ def test_suitesparse_standins_full_parity(cfg, kind, scale, expect):
         want["nfcopy"] += want["g8"] + want["g16"]
         want["g8"] = want["g16"] = 0
     assert st2["num_bin_rows"] == want and st2["sym_bin_rows"] == st["sym_bin_rows"]
+    # the statistics of a sequence whose integer stages verify the previous call instead of folding again
+    for k in ("sum_products", "max_row_ops", "nnz_c", "max_row_nnz_c"):
+        assert st2[k] == st[k], (k, st2[k], st[k], st2["pred_stages"])
 
 
 def test_workgroup_classes_take_rows_up_to_load_085(cfg):
@@ -1057,7 +1060,7 @@ def test_a_captured_sequence_owns_its_prediction(cfg):
     for _ in range(4):
         sa.MultiplyspECK(dA, dA, dC, cfg)
     st = cfg.last_stats()
-    assert st["replayed"] and st["pred_stages"] & 1
+    assert st["replayed"] and st["pred_stages"] == 3
     replays = st["graph_replays"]
     sa.MultiplyspECK(dB, dB, dD, cfg)                          # eager, other buffers: rewrites the config's prediction
     _assert_matches_oracle(dD, Bg, Bg)
@@ -1070,15 +1073,16 @@ def test_a_captured_sequence_owns_its_prediction(cfg):
     _assert_matches_oracle(dC, A, A)
     _assert_matches_oracle(dD, Bg, Bg)                         # ... which wrote nothing into the other problem's C
     # the option off: same answers through the two-kernel scan
-    cfg.set_option("pred_scan", 0)
-    try:
-        for _ in range(4):
-            sa.MultiplyspECK(dA, dA, dC, cfg)
-        st = cfg.last_stats()
-        assert st["replayed"] and not st["pred_stages"] & 1
-        _assert_matches_oracle(dC, A, A)
-    finally:
-        cfg.set_option("pred_scan", 1)
+    for opt, want in (("pred_sym", 1), ("pred_scan", 0)):
+        cfg.set_option(opt, 0)
+        try:
+            for _ in range(4):
+                sa.MultiplyspECK(dA, dA, dC, cfg)
+            st = cfg.last_stats()
+            assert st["replayed"] and st["pred_stages"] == want
+            _assert_matches_oracle(dC, A, A)
+        finally:
+            cfg.set_option(opt, 1)
 
 
 @pytest.mark.parametrize("kind,scale", [("scircuit", 0.3), ("mac_econ", 0.3), ("cant", 0.1), ("webbase", 0.1),
