@@ -733,7 +733,8 @@ ReplayPlan plan_replay(const speck_config* c)
     // Every row offset predicted, every tile table known (in the shape this sequence classifies in): the scan is one
     // kernel that verifies instead of two that fold (launch_scan_predicted).  Rows waiting for the copy launch need
     // their records: not with those.
-    p.pred_scan = c->pred_scan && c->pred_valid && c->pred_tiles_valid && c->pred_fold_esc == p.fused &&
+    const bool shape_ok = c->pred_fold_esc == p.fused || !(c->last_num_mask & kEscNum);  // (no such rows: one shape)
+    p.pred_scan = c->pred_scan && c->pred_valid && c->pred_tiles_valid && shape_ok &&
                   (p.direct || !(p.num_mask >> NUM_NFCOPY & 1u));
     // ... and so is the symbolic binning, inside the analysis kernel (no scatter kernel, its totals folded by the
     // predicted scan).  Rows that need a scratch slot from the scatter's prefix (global key sets; numeric-first rows
