@@ -257,12 +257,14 @@ __device__ __forceinline__ void emit_narrow_sorted(const G& g, const u32* keys, 
 
 // Two-level bitmap sort (see the header comment).  S: LDS scratch of max(2*W1, 2*NMAX) words;
 // it may alias the table (slots are loaded into registers first).
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX>
-__device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, const u32* keys, const Acc<T>* vals, u32* S,
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, bool STAGE = G::kIsBlock>
+__device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, u32* keys, Acc<T>* vals, u32* S,
                                                    u32* scan_scratch, u32 cap_row, u32 cmin, u32 cmax,
                                                    u32 base, u32* __restrict__ c_col,
                                                    T* __restrict__ c_val, int cls = 0)
 {
+    u32* const st_keys = keys;       // staging of the sorted window (STAGE): the table's own arrays
+    Acc<T>* const st_vals = vals;
     constexpr u32 OWN = CAP / G::SIZE;
     constexpr u64 kWindowCols = u64(W1) * 1024;
     PHASE_BEGIN(cls);
@@ -326,15 +328,46 @@ __device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, const u32* keys, c
         PHASE_MARK(7);
         const u32 total = bitmap_prefix<G, 2>(g, &mx[0].x, &mx[0].y, nocc, scan_scratch);
         PHASE_MARK(8);
+        if constexpr (!STAGE) {
 #pragma unroll
-        for (u32 j = 0; j < OWN; ++j) {
-            if (j * G::SIZE >= cap_row) continue;
-            const u32 d = k[j] - wbase;
-            if (k[j] != kEmptyKey && d < ncols) {
-                const uint2 e = mx[brank[j]];
-                const u32 r = emitted + e.y + __popc(e.x & ((1u << (d & 31)) - 1u));
-                c_col[base + r] = k[j];
-                c_val[base + r] = (T)v[j];
+            for (u32 j = 0; j < OWN; ++j) {
+                if (j * G::SIZE >= cap_row) continue;
+                const u32 d = k[j] - wbase;
+                if (k[j] != kEmptyKey && d < ncols) {
+                    const uint2 e = mx[brank[j]];
+                    const u32 r = emitted + e.y + __popc(e.x & ((1u << (d & 31)) - 1u));
+                    c_col[base + r] = k[j];
+                    c_val[base + r] = (T)v[j];
+                }
+            }
+        } else {
+            // Every lane holds slots of the HASH order: their ranks are scattered over the row, and 2 x OWN store
+            // instructions that each touch 64 different lines were the longest step of the sort for the workgroup
+            // classes (16 slots per lane: 8.6 k of a row's 42 k cycles).  The sorted window is put together in LDS
+            // first -- the table is dead (its slots are in registers, the masks are read before the barrier) -- and
+            // leaves with coalesced stores.
+            u32 r[OWN];
+#pragma unroll
+            for (u32 j = 0; j < OWN; ++j) {
+                r[j] = 0xFFFFFFFFu;
+                if (j * G::SIZE >= cap_row) continue;
+                const u32 d = k[j] - wbase;
+                if (k[j] != kEmptyKey && d < ncols) {
+                    const uint2 e = mx[brank[j]];
+                    r[j] = e.y + __popc(e.x & ((1u << (d & 31)) - 1u));
+                }
+            }
+            g.sync();  // the masks are dead
+#pragma unroll
+            for (u32 j = 0; j < OWN; ++j)
+                if (r[j] != 0xFFFFFFFFu) {
+                    st_keys[r[j]] = k[j];
+                    st_vals[r[j]] = v[j];
+                }
+            g.sync();
+            for (u32 i = g.lane; i < total; i += G::SIZE) {
+                c_col[base + emitted + i] = st_keys[i];
+                c_val[base + emitted + i] = (T)st_vals[i];
             }
         }
         emitted += total;
