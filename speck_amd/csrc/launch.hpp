@@ -5,6 +5,7 @@
 namespace speck {
 
 u32 analysis_blocks(u32 m);
+void set_analysis_wide_rows(u32 avg_len);  // analysis: 64 rows per wave when nnz(A) / rows(A) <= avg_len (0: never)
 u32 scan_tiles(u32 m);
 
 // analysis (+ stats fold + ordered scatter of the symbolic row records when sym_cls != nullptr)

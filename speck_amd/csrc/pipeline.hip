@@ -1353,6 +1353,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
     else if (n == "profile_replay") c->profile_replay = value != 0;
+    else if (n == "analysis_wide_rows") {
+        set_analysis_wide_rows((u32)value);
+        drop_graph(c);
+        c->last_key_valid = false;
+    }
     else if (n == "pred_sym") {
         c->pred_sym = value != 0;
         drop_graph(c);

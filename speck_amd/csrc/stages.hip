@@ -59,11 +59,15 @@ static inline void row_chunking(u32 m, u32* rows_per_block, u32* blocks)
 // [first/last col of the B row] + 17 m written (+ 8 nnzA for b_start / b_len).
 // --------------------------------------------------------------------------------
 constexpr u32 kAnRowPathMax = 8;  // rows per lane up to this many entries (sub-chunk maximum)
-constexpr int kAnThreads = 512;  // 8 waves x 32 rows = one kChunk of rows per pass of the block
+// Two shapes, one kChunk of rows per pass of a block either way: 8 waves x 32 rows (the default) and 4 waves x 64 rows
+// for inputs of short rows -- there a lane per row is the common path, 32 rows leave half a wave idle, and at 91 VGPRs
+// (5 waves per SIMD) the 8 x 32 shape needs more wave slots than the chip has for ~200 k rows: two rounds of
+// workgroups, each as long as its chain of dependent gathers (scircuit / mac_econ stand-ins).
 constexpr u32 kAnCoopMax = 64;        // ... at most this many per workgroup (the others stay with their wave)
 constexpr u32 kAnCoopRowLen = 256, kAnCoopEntries = 2048;  // sub-chunks (32 rows) with more entries than this, one row
                                                             //   holding more than that, are walked by the whole workgroup
-__global__ __launch_bounds__(kAnThreads) void analysis_kernel(
+template <int NW, u32 R>
+__global__ __launch_bounds__(NW * 64) void analysis_kernel(
     const u32* __restrict__ a_ro, const u32* __restrict__ a_col, const u32* __restrict__ b_ro,
     const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* __restrict__ row_ops,
     u32* __restrict__ row_max_ops, u32* __restrict__ row_col_min, u32* __restrict__ row_col_max,
@@ -71,10 +75,10 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
     ClassifyParams cp, uint2* __restrict__ b_sl, DeviceStats* __restrict__ st, u32 b_rows,
     const u32* __restrict__ pred_block, const DeviceStats* __restrict__ pred_stats, RowRec* __restrict__ recs)
 {
-    constexpr int NW = kAnThreads / 64;
+    constexpr int kAnThreads = NW * 64;
     constexpr int U = 4;   // entries per lane and tile: 256 entries cover most 32-row sub-chunks in ONE
                            //   round of the dependent chain A.col -> B.rowptr -> B.col
-    constexpr u32 R = 32;  // rows per sub-chunk (one per lane when they are finalised): the kernel
+    // R = rows per sub-chunk (one per lane when they are finalised): the kernel
                            //   lasts as long as its slowest wave, so the waves are kept short and many
     static_assert(NW * R == kChunk, "one pass of a block covers one kChunk of rows");
     static_assert(kChunk / 64 == 4, "sym_scatter_kernel sums four per-wave counters");
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
                 hi[u] = nrows;
             }
 #pragma unroll
-            for (int step = 0; step < 5; ++step) {  // 2^5 = R
+            for (int step = 0; step < (R == 32 ? 5 : 6); ++step) {  // 2^steps = R
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const u32 mid = (lo[u] + hi[u]) >> 1;
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(kAnThreads) void analysis_kernel(
         // would run at a fraction of its lanes (webbase stand-in: 172 -> ~60 us for this kernel).
         const u32 my_len = lane < nrows ? s_ro[lane + 1] - s_ro[lane] : 0u;
         const u32 max_len = wave_reduce_max(my_len);
-        if (max_len > kAnCoopRowLen && e_end - e_begin > kAnCoopEntries) {  // (uniform) a hub row: later, by the whole workgroup -- if the list has room
+        if (max_len > kAnCoopRowLen && e_end - e_begin > kAnCoopEntries * (R / 32)) {  // (uniform) a hub row: later, by the whole workgroup -- if the list has room
             u32 at = 0;
             if (lane == 0) at = atomicAdd(&s_ncoop, 1u);
             at = (u32)__builtin_amdgcn_readfirstlane((int)at);
@@ -1219,6 +1223,9 @@ void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceS
 // --------------------------------------------------------------------------------
 // host launchers
 // --------------------------------------------------------------------------------
+static u32 g_an_wide_rows = 16;
+void set_analysis_wide_rows(u32 avg_len) { g_an_wide_rows = avg_len; }
+
 u32 analysis_blocks(u32 m)
 {
     u32 r, b;
@@ -1228,7 +1235,7 @@ u32 analysis_blocks(u32 m)
 u32 scan_tiles(u32 m) { return cdiv(m ? m : 1, kScanThreads * scan_items(m)); }
 
 void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32* b_ro,
-                     const u32* b_col, u32 m, u64 /*nnz_a*/, u32* row_ops, u32* row_max_ops,
+                     const u32* b_col, u32 m, u64 nnz_a, u32* row_ops, u32* row_max_ops,
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
                      uint2* b_sl, hipEvent_t between, u64* nf_off, u64 expect_nf, u32 b_rows, u32* pred_block_out,
@@ -1236,17 +1243,30 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
+    // 64 rows per wave for short rows (g_an_wide_rows: average entries per row up to which; 0 = never)
+    const bool wide = g_an_wide_rows && m && nnz_a / m <= g_an_wide_rows;
     if (pred_block && sym_cls) {  // replayed sequence, symbolic binning predicted: no scatter kernel
-        hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kAnThreads), 0, s, a_ro, a_col, b_ro, b_col, m,
-                           rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                           partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs);
+        if (wide)
+            hipLaunchKernelGGL((analysis_kernel<4, 64>), dim3(blocks), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
+                               rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
+                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs);
+        else
+            hipLaunchKernelGGL((analysis_kernel<8, 32>), dim3(blocks), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
+                               rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
+                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs);
         if (between) (void)hipEventRecord(between, s);
         return;
     }
-    hipLaunchKernelGGL(analysis_kernel, dim3(blocks), dim3(kAnThreads), 0, s, a_ro, a_col, b_ro, b_col, m,
-                       rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                       partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
-                       (RowRec*)nullptr);
+    if (wide)
+        hipLaunchKernelGGL((analysis_kernel<4, 64>), dim3(blocks), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
+                           rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
+                           partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
+                           (RowRec*)nullptr);
+    else
+        hipLaunchKernelGGL((analysis_kernel<8, 32>), dim3(blocks), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
+                           rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
+                           partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
+                           (RowRec*)nullptr);
     if (between) (void)hipEventRecord(between, s);  // analysis | binning (Timings::countProducts / loadBalanceCounting)
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,
