@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
 // expanded, sorted, summed and written to the place the previous identical call gave the row in C (num_esc_body,
 // FUSED) -- instead of being counted now and walked again in the numeric phase.  The other classes count as above.
 template <typename T>
-__global__ __launch_bounds__(256) void sym_light_fused_kernel(ProductSrc<T> nsrc, const u32* a_ro, RowWork w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void sym_light_fused_kernel(ProductSrc<T> nsrc, const u32* a_ro, RowWork w,
                                                               u32* __restrict__ counts, ClassGrid cg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
