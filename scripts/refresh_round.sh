@@ -7,10 +7,10 @@ export PYTHONPATH=$PWD
 OUT=gpurun_out/profiles
 mkdir -p $OUT
 bash scripts/collect_counters.sh $ROUND "scircuit mac_econ cant webbase" > $OUT/collect.log 2>&1
+cp $OUT/counters.json $OUT/traffic.json profiles/   # the bench lines read the ceilings of THIS round's passes
 for w in scircuit mac_econ cant webbase uniform; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline --no-config5 --no-configs 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_$w.json
 done
-cp $OUT/counters.json $OUT/traffic.json profiles/   # the default line reads the ceilings of THIS round's passes
 timeout 900 python bench.py 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_default.json
 timeout 300 python scripts/multiwindow_time.py 2>&1 | grep windows > $OUT/${ROUND}_multiwindow_now.txt
 python - <<'PY'
