@@ -1,16 +1,16 @@
 // extras.hip -- the two side utilities the reference driver uses around the hot path:
 //   * spECK::Compare   (reference source/GPU/Compare.cu:11-82) -- made strict: offsets and
 //     column ids bit-exact, values by relative tolerance
-//   * transpose for non-square A (reference source/GPU/Transpose.cu:10-117; the driver
-//     actually calls cuSPARSE csr2csc, source/DataLoader.cpp:65-69).  Order preserving:
-//     a STABLE device radix sort of (column, position) pairs -- rocPRIM, the one library
-//     call in this backend, used outside the timed path only.
+//   * transpose for non-square A (reference source/GPU/Transpose.cu:10-117: a column histogram with global
+//     atomics, a scan, an unordered placement and an O(n^2) rank per output row; the driver actually calls
+//     cuSPARSE csr2csc, source/DataLoader.cpp:65-69).  Here: a STABLE least-significant-digit radix sort of
+//     (column, position) pairs, hand-written for wave64 (8-bit digits, ranks from ballots, no atomics on the
+//     ordered path) -- the CSR order is by row, so a stable sort by column IS the transpose, rows ascending
+//     inside every output row, whatever the length of that row (hub columns included).  Outside the timed path.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
 #include <string.h>
-
-#include <rocprim/rocprim.hpp>
 
 #include <cmath>
 #include <cstdio>
@@ -112,6 +112,135 @@ __global__ void offsets_from_sorted_kernel(const u32* __restrict__ keys, u32 nnz
     }
 }
 
+// ---- stable LSD radix sort of (key, payload) pairs, 8 bits per pass ------------------------------------------
+// kRadixBlocks workgroups each own a contiguous slice of the input, walked in tiles of 256 x kRadixItems elements;
+// element order inside a tile: wave w owns elements [w, w+1) x 64 x kRadixItems, step s of a wave holds 64
+// consecutive ones (lane = position) -- so "earlier in the input" = (lower wave, lower step, lower lane).
+//   radix_hist_kernel     per workgroup: digit histogram of its slice            -> hist[digit][workgroup]
+//   radix_scan_kernel     one workgroup: exclusive scan of hist in (digit, workgroup) order = where the keys of
+//                         (digit, workgroup) start in the output
+//   radix_scatter_kernel  per tile: the rank of a key among the equal digits before it = running count of its
+//                         wave (LDS, advanced by one leader lane per digit and step) + lanes before it in the step
+//                         (ballots: the lanes holding MY digit) + the counts of the waves before mine
+constexpr int kRadixThreads = 256, kRadixItems = 8, kRadixBlocks = 1024;
+constexpr u32 kRadixTile = kRadixThreads * kRadixItems;
+
+__device__ __forceinline__ u32 slice_begin(u32 n, u32 b)
+{
+    // slices are whole tiles (the last one takes the remainder)
+    const u32 tiles = (n + kRadixTile - 1) / kRadixTile;
+    const u32 per = (tiles + kRadixBlocks - 1) / kRadixBlocks;
+    const u64 t0 = u64(b) * per;
+    return (u32)(t0 * kRadixTile < n ? t0 * kRadixTile : n);
+}
+
+__global__ __launch_bounds__(kRadixThreads) void radix_hist_kernel(const u32* __restrict__ keys, u32 n, u32 shift,
+                                                                  u32* __restrict__ hist)
+{
+    __shared__ u32 s_cnt[256];
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 lo = slice_begin(n, blockIdx.x), hi = slice_begin(n, blockIdx.x + 1);
+    for (u32 i = lo + threadIdx.x; i < hi; i += kRadixThreads) atomicAdd(&s_cnt[(keys[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    hist[threadIdx.x * kRadixBlocks + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void radix_scan_kernel(u32* __restrict__ hist)
+{
+    __shared__ u32 s_scan[1024 / 64 + 1];
+    constexpr u32 per = 256 * kRadixBlocks / 1024;
+    u32* mine = hist + threadIdx.x * per;
+    u32 sum = 0;
+    for (u32 i = 0; i < per; ++i) sum += mine[i];
+    u32 total;
+    u32 run = block_exclusive_scan<1024>(sum, s_scan, &total);
+    for (u32 i = 0; i < per; ++i) {
+        const u32 v = mine[i];
+        mine[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(kRadixThreads) void radix_scatter_kernel(const u32* __restrict__ keys_in,
+                                                                     const u32* __restrict__ vals_in, u32 n, u32 shift,
+                                                                     const u32* __restrict__ hist,
+                                                                     u32* __restrict__ keys_out,
+                                                                     u32* __restrict__ vals_out)
+{
+    constexpr int NW = kRadixThreads / 64;
+    __shared__ u32 s_base[256];        // where the next key of each digit goes (this workgroup's share of the output)
+    __shared__ u32 s_wave[NW][256];    // keys of each digit seen by each wave in the current tile
+    const u32 lane = lane_id(), wid = threadIdx.x >> 6;
+    s_base[threadIdx.x] = hist[threadIdx.x * kRadixBlocks + blockIdx.x];
+    const u32 lo = slice_begin(n, blockIdx.x), hi = slice_begin(n, blockIdx.x + 1);
+    for (u32 t0 = lo; t0 < hi; t0 += kRadixTile) {
+        for (int w = 0; w < NW; ++w) s_wave[w][threadIdx.x] = 0;
+        __syncthreads();
+        u32 key[kRadixItems], val[kRadixItems], rank[kRadixItems];
+#pragma unroll
+        for (int it = 0; it < kRadixItems; ++it) {
+            const u32 i = t0 + (wid * kRadixItems + it) * 64 + lane;
+            const bool ok = i < hi;
+            key[it] = ok ? keys_in[i] : 0u;
+            val[it] = ok ? vals_in[i] : 0u;
+            const u32 d = (key[it] >> shift) & 255u;
+            // the lanes of this step that hold my digit (lanes past the end match nobody)
+            u64 peers = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const u64 m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            const u32 before = s_wave[wid][d];  // (LDS operations of one wave complete in order)
+            rank[it] = before + (u32)__popcll(peers & lanemask_lt());
+            if (ok && (peers & lanemask_lt()) == 0) s_wave[wid][d] = before + (u32)__popcll(peers);
+            wave_lds_fence();
+        }
+        __syncthreads();
+        // digit threadIdx.x: exclusive prefix over the waves, then the tile's total moves the base
+        {
+            u32 run = s_base[threadIdx.x];
+            for (int w = 0; w < NW; ++w) {
+                const u32 c = s_wave[w][threadIdx.x];
+                s_wave[w][threadIdx.x] = run;
+                run += c;
+            }
+            s_base[threadIdx.x] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kRadixItems; ++it) {
+            const u32 i = t0 + (wid * kRadixItems + it) * 64 + lane;
+            if (i < hi) {
+                const u32 pos = s_wave[wid][(key[it] >> shift) & 255u] + rank[it];
+                keys_out[pos] = key[it];
+                vals_out[pos] = val[it];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// sorts (keys, vals) by the low `bits` bits of the keys; a/b are ping-pong buffers (the input is in a, the result
+// in the returned index: 0 = a, 1 = b)
+int radix_sort_pairs(u32* keys_a, u32* vals_a, u32* keys_b, u32* vals_b, u32 n, unsigned bits, u32* hist)
+{
+    int cur = 0;
+    for (unsigned shift = 0; shift < bits; shift += 8) {
+        const u32* ki = cur ? keys_b : keys_a;
+        const u32* vi = cur ? vals_b : vals_a;
+        u32* ko = cur ? keys_a : keys_b;
+        u32* vo = cur ? vals_a : vals_b;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(kRadixBlocks), dim3(kRadixThreads), 0, 0, ki, n, shift, hist);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, 0, hist);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(kRadixBlocks), dim3(kRadixThreads), 0, 0, ki, vi, n, shift,
+                           (const u32*)hist, ko, vo);
+        cur ^= 1;
+    }
+    return cur;
+}
+
 template <typename T>
 int compare_impl(const speck_dcsr* ref, const speck_dcsr* cmp, const speck_dcsr* scale, int compare_data,
                  double rel_tol, uint64_t* h_structure, uint64_t* h_values)
@@ -159,36 +288,35 @@ int transpose_impl(const speck_dcsr* A, speck_dcsr* At)
     }
     u32 base = 0;
     HIP_TRY(hipMemcpy(&base, A->row_offsets, 4, hipMemcpyDeviceToHost));
-    u32 *row_of = nullptr, *perm_in = nullptr, *perm_out = nullptr, *keys_out = nullptr;
+    u32 *row_of = nullptr, *perm_a = nullptr, *perm_b = nullptr, *keys_a = nullptr, *keys_b = nullptr, *hist = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&row_of), size_t(nnz) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&perm_in), size_t(nnz) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&perm_out), size_t(nnz) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&keys_out), size_t(nnz) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&perm_a), size_t(nnz) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&perm_b), size_t(nnz) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&keys_a), size_t(nnz) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&keys_b), size_t(nnz) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hist), size_t(256) * kRadixBlocks * 4));
     u32 blocks = (rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, 0, A->row_offsets,
                        rows, base, row_of);
-    hipLaunchKernelGGL(iota_kernel, dim3(2048), dim3(256), 0, 0, perm_in, nnz);
-    const u32* keys_in = A->col_ids + base;
+    hipLaunchKernelGGL(iota_kernel, dim3(2048), dim3(256), 0, 0, perm_a, nnz);
+    HIP_TRY(hipMemcpyAsync(keys_a, A->col_ids + base, size_t(nnz) * 4, hipMemcpyDeviceToDevice, 0));
     unsigned end_bit = 1;
     while (end_bit < 32 && (1ull << end_bit) < (cols ? cols : 1)) ++end_bit;
-    size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, perm_in, perm_out, nnz, 0,
-                                      end_bit, (hipStream_t)0));
-    void* tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, perm_in, perm_out, nnz, 0,
-                                      end_bit, (hipStream_t)0));
+    const int res = radix_sort_pairs(keys_a, perm_a, keys_b, perm_b, nnz, end_bit, hist);
+    const u32* keys_out = res ? keys_b : keys_a;
+    const u32* perm_out = res ? perm_b : perm_a;
     hipLaunchKernelGGL(transpose_gather_kernel<T>, dim3(2048), dim3(256), 0, 0, perm_out, row_of,
                        static_cast<const T*>(A->data) + base, nnz, At->col_ids, static_cast<T*>(At->data));
     hipLaunchKernelGGL(offsets_from_sorted_kernel, dim3(2048), dim3(256), 0, 0, keys_out, nnz, cols,
                        At->row_offsets);
     HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(tmp);
     (void)hipFree(row_of);
-    (void)hipFree(perm_in);
-    (void)hipFree(perm_out);
-    (void)hipFree(keys_out);
+    (void)hipFree(perm_a);
+    (void)hipFree(perm_b);
+    (void)hipFree(keys_a);
+    (void)hipFree(keys_b);
+    (void)hipFree(hist);
     return SPECK_OK;
 }
 

@@ -468,6 +468,49 @@ def test_compare_and_transpose(cfg):
     assert sa.compare_bounded(dC1, dC2, dS, cfg, tol=1e-8) == (0, 0)
 
 
+def test_transpose_is_a_stable_sort_by_column_at_size(cfg):
+    """The transpose is a hand-written stable radix sort of (column, position): rows ascending inside every output
+    row whatever its length.  Power-law input (webbase stand-in, > 3 M entries: every workgroup walks several
+    tiles) there and back, a rectangular input with > 2^24 columns (four digit passes), an empty matrix, and a row
+    range of a larger matrix (absolute offsets)."""
+    import scipy.sparse as sp
+    A = to_po(sa.gen_matrix("webbase", 1.0, 3, signed=True))
+    T = sa.transpose(sa.dCSR.from_host(to_sa(A)), cfg).to_host()
+    R = sp.csr_matrix((A.data, A.col_ids.astype(np.int64), A.row_offsets.astype(np.int64)),
+                      shape=(A.rows, A.cols)).T.tocsr()
+    R.sort_indices()
+    assert T.rows == A.cols and T.cols == A.rows and T.nnz == A.nnz
+    assert (T.row_offsets == R.indptr).all() and (T.col_ids == R.indices).all() and (T.data == R.data).all()
+    # ... and back: the hub ROWS of the stand-in are hub columns of its transpose -- output rows of thousands of entries
+    dT = sa.dCSR.from_host(to_sa(po.HostCSR(T.rows, T.cols, T.row_offsets, T.col_ids, T.data)))
+    B2 = sa.transpose(dT, cfg).to_host()
+    assert np.diff(B2.row_offsets.astype(np.int64)).max() > 2000
+    assert (B2.row_offsets == A.row_offsets).all() and (B2.col_ids == A.col_ids).all() and (B2.data == A.data).all()
+    rng = np.random.default_rng(5)
+    rows, cols, per = 20000, (1 << 25) + 12345, 9
+    col = np.sort(rng.integers(0, cols, size=(rows, per), dtype=np.int64), axis=1)
+    col[:, 1:][col[:, 1:] == col[:, :-1]] += 1                        # (near enough to strictly ascending)
+    col = np.sort(np.minimum(col, cols - 1), axis=1)
+    keep = np.ones_like(col, dtype=bool)
+    keep[:, 1:] = col[:, 1:] != col[:, :-1]
+    ro = np.zeros(rows + 1, dtype=np.int64)
+    ro[1:] = np.cumsum(keep.sum(axis=1))
+    W = po.HostCSR(rows, cols, ro.astype(np.uint32), col[keep].astype(np.uint32), rng.random(int(ro[-1])) + 0.5)
+    Tw = sa.transpose(sa.dCSR.from_host(to_sa(W)), cfg).to_host()
+    Rw = po.transpose(W)
+    assert (Tw.row_offsets == Rw.row_offsets).all() and (Tw.col_ids == Rw.col_ids).all() and (Tw.data == Rw.data).all()
+    E = po.HostCSR(5, 7, np.zeros(6, dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.zeros(0))
+    Te = sa.transpose(sa.dCSR.from_host(to_sa(E)), cfg).to_host()
+    assert Te.rows == 7 and Te.nnz == 0 and (Te.row_offsets == 0).all()
+    dA = sa.dCSR.from_host(to_sa(A))
+    r0, r1 = A.rows // 3, A.rows // 3 + 50000
+    Tv = sa.transpose(dA.row_view(r0, r1), cfg).to_host()
+    e0, e1 = int(A.row_offsets[r0]), int(A.row_offsets[r1])
+    Rv = po.transpose(po.HostCSR(r1 - r0, A.cols, (A.row_offsets[r0:r1 + 1] - A.row_offsets[r0]).astype(np.uint32),
+                                 A.col_ids[e0:e1].copy(), A.data[e0:e1].copy()))
+    assert (Tv.row_offsets == Rv.row_offsets).all() and (Tv.col_ids == Rv.col_ids).all() and (Tv.data == Rv.data).all()
+
+
 # BASELINE.json configs[1..3] at FULL size (the stand-ins fitted to the SuiteSparse figures), the
 # nlpkkt one at a size the oracle finishes in seconds (its full size: test_nlpkkt_full_size_properties below).
 # The sequence bench.py TIMES is the replayed one (a hipGraph specialised to the classes / counts of the previous
