@@ -367,8 +367,10 @@ def roofline_block(workload, st, kernel_ms, num_ms):
         if traffic is not None else None,
         "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": dom["ms"],
         "selected_by": "longest numeric launch (HIP events on the launch's own stream)",
-        "timed_with": "HIP events around every launch of the replayed sequence, run uncaptured on the pipeline's own "
-                      "streams (library option profile_replay) in an untimed pre-pass of the same process",
+        "timed_with": "HIP events of the launches of the replayed sequence, run uncaptured on the pipeline's own streams "
+                      "(library option profile_replay) in an untimed pre-pass of the same process; the light launches "
+                      "and the numeric-first launch carry their own begin / end stamps (hipExtLaunchKernelGGL), the other "
+                      "launches are bracketed by two event records",
         "largest": {"kernel": f"numeric:{big['name']}", "bytes": big["bytes"], "ms": big["ms"], "frac": big["frac"]},
         "numeric_phase_frac": round(total_bytes / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
         "ceilings": dom["ceilings"],

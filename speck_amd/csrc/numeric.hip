@@ -1286,7 +1286,8 @@ void set_tiny_threads(int t) { g_tiny_threads = (t == 64 || t == 128) ? t : 256;
 
 template <typename T>
 void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const CsrView<T>& Av,
-                          const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count, bool exact)
+                          const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count, bool exact,
+                          hipEvent_t e0, hipEvent_t e1)
 {
     static const int slots[8] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W256, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
     static const u32 rows_per_block[8] = {1, 1, 4, 8, 8, 16, 32, 256};
@@ -1311,7 +1312,10 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
         const u32 rpb = rows_per_block[k] >= div ? rows_per_block[k] / div : 1u;
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, threads, cu_count, rpb) : 0u);
     }
-    if (cg.first[8] == 0) return;
+    if (cg.first[8] == 0) {
+        if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);  // (nothing to time: an empty interval)
+        return;
+    }
     for (int k = 0; k < 8; ++k) {
         cg.hint[k] = kNoHint;
         if (!exact) continue;
@@ -1321,30 +1325,33 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
     }
     const ProductSrc<T> src{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
     if (!tiny_only)
-        hipLaunchKernelGGL((num_light_kernel<T>), dim3(cg.first[8]), dim3(256), lds, s, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_light_kernel<T>), dim3(cg.first[8]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else if (threads == 64)
-        hipLaunchKernelGGL((num_tiny_kernel<T, 64>), dim3(cg.first[8]), dim3(64), lds, s, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 64>), dim3(cg.first[8]), dim3(64), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else if (threads == 128)
-        hipLaunchKernelGGL((num_tiny_kernel<T, 128>), dim3(cg.first[8]), dim3(128), lds, s, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 128>), dim3(cg.first[8]), dim3(128), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else
-        hipLaunchKernelGGL((num_tiny_kernel<T, 256>), dim3(cg.first[8]), dim3(256), lds, s, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 256>), dim3(cg.first[8]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
 }
 
 template <typename T>
 void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& Av, const CsrView<T>& Bv, const RowWork& w,
-                          u32* counts, int cu_count, u32 wcols)
+                          u32* counts, int cu_count, u32 wcols, hipEvent_t e0, hipEvent_t e1)
 {
-    if (count == 0) return;
+    if (count == 0) {
+        if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);
+        return;
+    }
     const ProductSrc<T> src{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
     wcols = wcols < 256u ? 256u : (wcols > kNumD1Cols ? kNumD1Cols : (wcols + 255u) & ~255u);
     const u32 lds = (wcols + 256) * (u32)sizeof(Acc<T>) + wcols +
                     (2 * 256 + 256 / 64 + 2 + win_words<Block<256>>() + 3) / 4 * 16;
     set_dyn_lds((nf_dense_kernel<T, 256>), lds);
-    hipLaunchKernelGGL((nf_dense_kernel<T, 256>), dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s,
+    SPECK_LAUNCH_TIMED((nf_dense_kernel<T, 256>), dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, e0, e1,
                        src, Av.row_offsets, w, counts, wcols);
 }
 
@@ -1468,13 +1475,15 @@ extern "C" int speck_debug_phase_clocks(unsigned long long* out)
 namespace speck {
 
 template void launch_numeric_light<double>(hipStream_t, const u32*, u32, const CsrView<double>&,
-                                           const CsrView<double>&, const RowWork&, u32*, double*, int, bool);
+                                           const CsrView<double>&, const RowWork&, u32*, double*, int, bool,
+                                           hipEvent_t, hipEvent_t);
 template void launch_numeric_light<float>(hipStream_t, const u32*, u32, const CsrView<float>&,
-                                          const CsrView<float>&, const RowWork&, u32*, float*, int, bool);
+                                          const CsrView<float>&, const RowWork&, u32*, float*, int, bool, hipEvent_t,
+                                          hipEvent_t);
 template void launch_numeric_first<double>(hipStream_t, u32, const CsrView<double>&, const CsrView<double>&,
-                                           const RowWork&, u32*, int, u32);
+                                           const RowWork&, u32*, int, u32, hipEvent_t, hipEvent_t);
 template void launch_numeric_first<float>(hipStream_t, u32, const CsrView<float>&, const CsrView<float>&,
-                                          const RowWork&, u32*, int, u32);
+                                          const RowWork&, u32*, int, u32, hipEvent_t, hipEvent_t);
 template void launch_numeric<double>(hipStream_t, int, u32, const CsrView<double>&,
                                      const CsrView<double>&, const RowWork&, u32*, double*, int);
 template void launch_numeric<float>(hipStream_t, int, u32, const CsrView<float>&,

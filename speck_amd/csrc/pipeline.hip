@@ -388,7 +388,7 @@ constexpr int kLightBig = -1, kLightTiny = -2;
 template <typename LaunchFn>
 int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u32 mask, u32 big_mask,
                 u32 tiny_mask, const u32* counts, const float* ns_per_row, size_t* ev_idx,
-                std::vector<ClassTiming>* timing, LaunchFn&& launch)
+                std::vector<ClassTiming>* timing, int exact_cls, LaunchFn&& launch)
 {
     bool forked = false;
     size_t used = 0;
@@ -446,10 +446,14 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
             ++used;
         }
         const bool timed = c->profile_kernels == 1 && timing;
-        if (timed) (void)hipEventRecord(kernel_event(c, *ev_idx), ks);
-        launch(ks, cls);
+        // the light launches and the numeric-first one stamp their events themselves, with the kernel's own begin and
+        // end (launch.hpp, SPECK_LAUNCH_TIMED); the others are bracketed by two event records
+        const bool exact = timed && (cls == kLightBig || cls == kLightTiny || cls == exact_cls);
+        hipEvent_t e0 = timed ? kernel_event(c, *ev_idx) : nullptr, e1 = timed ? kernel_event(c, *ev_idx + 1) : nullptr;
+        if (timed && !exact) (void)hipEventRecord(e0, ks);
+        launch(ks, cls, exact ? e0 : nullptr, exact ? e1 : nullptr);
         if (timed) {
-            (void)hipEventRecord(kernel_event(c, *ev_idx + 1), ks);
+            if (!exact) (void)hipEventRecord(e1, ks);
             timing->push_back({cls, *ev_idx});
             *ev_idx += 2;
         }
@@ -546,23 +550,24 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     const u32 sym_big = split_sym ? (1u << SYM_BM1) : kSymLightMask;
     int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 7 : (int)SYM_CLASSES, sym_mask,
                          kSymLightMask & sym_big, kSymLightMask & ~sym_big, sym_hint, kSymNsPerRow,
-                         tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr, [&](hipStream_t ks, int cls) {
+                         tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr, (int)SYM_NF,
+                         [&](hipStream_t ks, int cls, hipEvent_t e0, hipEvent_t e1) {
                              if (cls == kLightBig || cls == kLightTiny) {
                                  const u32 part = cls == kLightBig ? sym_big : ~sym_big;
                                  launch_symbolic_light(ks, hint, sym_mask & kSymLightMask & part, A->row_offsets,
                                                        sc.b_sl, B->col_ids, w, c_ro, c->sm,
                                                        sym_hint != nullptr, c->capture_fused ? vsize : 0u, A->data,
-                                                       B->data);
+                                                       B->data, e0, e1);
                              } else if (cls == SYM_NF) {
                                  // the numeric dense-window kernel, in the symbolic phase (numeric.hip)
                                  if (vsize == 8) {
                                      CsrView<double> Av{A->row_offsets, A->col_ids, static_cast<const double*>(A->data), m, (u32)A->cols};
                                      CsrView<double> Bv{B->row_offsets, B->col_ids, static_cast<const double*>(B->data), (u32)B->rows, (u32)B->cols};
-                                     launch_numeric_first<double>(ks, hint[cls], Av, Bv, w, c_ro, c->sm, c->nf_wcols);
+                                     launch_numeric_first<double>(ks, hint[cls], Av, Bv, w, c_ro, c->sm, c->nf_wcols, e0, e1);
                                  } else {
                                      CsrView<float> Av{A->row_offsets, A->col_ids, static_cast<const float*>(A->data), m, (u32)A->cols};
                                      CsrView<float> Bv{B->row_offsets, B->col_ids, static_cast<const float*>(B->data), (u32)B->rows, (u32)B->cols};
-                                     launch_numeric_first<float>(ks, hint[cls], Av, Bv, w, c_ro, c->sm, c->nf_wcols);
+                                     launch_numeric_first<float>(ks, hint[cls], Av, Bv, w, c_ro, c->sm, c->nf_wcols, e0, e1);
                                  }
                              } else
                                  launch_symbolic(ks, cls, hint[cls], A->row_offsets, sc.b_sl,
@@ -618,11 +623,12 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     const u32 num_big = split_num ? kBigPart : kNumLightMask;
     return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 6 : (int)NUM_CLASSES, num_mask,
                        kNumLightMask & num_big, kNumLightMask & ~num_big, counts, kNumNsPerRow,
-                       tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr, [&](hipStream_t ks, int cls) {
+                       tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr, -100,
+                       [&](hipStream_t ks, int cls, hipEvent_t e0, hipEvent_t e1) {
                            if (cls == kLightBig || cls == kLightTiny) {
                                const u32 part = cls == kLightBig ? num_big : ~num_big;
                                launch_numeric_light<T>(ks, hint, num_mask & kNumLightMask & part, Av, Bv, w, c_col,
-                                                       c_val, c->sm, counts != nullptr);
+                                                       c_val, c->sm, counts != nullptr, e0, e1);
                            } else
                                launch_numeric<T>(ks, cls, hint[cls], Av, Bv, w, c_col, c_val, c->sm);
                        });

@@ -431,7 +431,7 @@ static void launch_sym_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
 void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, const u32* a_ro,
                            const uint2* b_sl, const u32* b_col, const RowWork& w,
                            u32* counts, int cu_count, bool exact, u32 fused_vsize, const void* a_val,
-                           const void* b_val)
+                           const void* b_val, hipEvent_t e0, hipEvent_t e1)
 {
     static const int slots[7] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_W128, SYM_G16, SYM_G8};
     static const u32 rows_per_block[7] = {1, 1, 4, 8, 16, 16, 32};
@@ -449,7 +449,10 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
     }
-    if (cg.first[7] == 0) return;
+    if (cg.first[7] == 0) {
+        if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);  // (nothing to time: an empty interval)
+        return;
+    }
     for (int k = 0; k < 7; ++k) {
         cg.hint[k] = kNoHint;
         if (!exact) continue;
@@ -459,16 +462,16 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
     }
     if (fused && fused_vsize == 8) {
         const ProductSrc<double> nsrc{b_sl, static_cast<const double*>(a_val), b_col, static_cast<const double*>(b_val), w.w_sl};
-        hipLaunchKernelGGL((sym_light_fused_kernel<double>), dim3(cg.first[7]), dim3(256), lds, s, nsrc, a_ro, w, counts, cg);
+        SPECK_LAUNCH_TIMED((sym_light_fused_kernel<double>), dim3(cg.first[7]), dim3(256), lds, s, e0, e1, nsrc, a_ro, w, counts, cg);
         return;
     }
     if (fused) {
         const ProductSrc<float> nsrc{b_sl, static_cast<const float*>(a_val), b_col, static_cast<const float*>(b_val), w.w_sl};
-        hipLaunchKernelGGL((sym_light_fused_kernel<float>), dim3(cg.first[7]), dim3(256), lds, s, nsrc, a_ro, w, counts, cg);
+        SPECK_LAUNCH_TIMED((sym_light_fused_kernel<float>), dim3(cg.first[7]), dim3(256), lds, s, e0, e1, nsrc, a_ro, w, counts, cg);
         return;
     }
     const ProductSrc<float> src{b_sl, nullptr, b_col, nullptr, w.w_sl};
-    hipLaunchKernelGGL(sym_light_kernel, dim3(cg.first[7]), dim3(256), lds, s, src, a_ro, w, counts, cg);
+    SPECK_LAUNCH_TIMED(sym_light_kernel, dim3(cg.first[7]), dim3(256), lds, s, e0, e1, src, a_ro, w, counts, cg);
 }
 
 void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const uint2* b_sl,
