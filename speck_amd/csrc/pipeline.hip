@@ -634,8 +634,36 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
                        });
 }
 
+// Wait for everything enqueued on `s` behind a done_kernel (launch_done): the host spins on the ticket that kernel
+// stores into pinned memory (bounded by TIME -- work that is still running after kSpinBudget is long enough for the
+// wake-up latency of the blocking call not to matter -- then the blocking synchronisation).
+int wait_ticket(speck_config* c, hipStream_t s)
+{
+    if (c->spin_wait) {
+        const u32 want = ++c->ticket_expected;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        while (!(seen = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE) == want)) {
+            for (int i = 0; i < 64; ++i) cpu_relax();
+            if (std::chrono::steady_clock::now() - t0 > kSpinBudget) break;
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    c->ticket_expected = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE);
+    return SPECK_OK;
+}
+
+// The statistics block of the call so far, on the host.  With the ticket: done_kernel mirrors the block into pinned
+// memory and the host spins (a copy + blocking synchronisation costs 10-20 us of wake-up latency, and the eager path
+// reads back twice).
 int read_stats(speck_config* c, hipStream_t s)
 {
+    if (c->spin_wait) {
+        launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
+        return wait_ticket(c, s);
+    }
     HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SPECK_OK;
@@ -933,23 +961,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             have = capture_graph<T>(c, s, A, B, C, sc, key) == SPECK_OK;
         if (have) {
             HIP_TRY(hipGraphLaunch(c->graph_exec, s));
-            if (c->spin_wait) {
-                // the last node of the sequence stores a ticket into pinned memory: spin on it (bounded),
-                // then fall back to the blocking synchronisation
-                // (bounded by TIME: a multiply that is still running after kSpinBudget is long enough for the
-                //  wake-up latency of the blocking call not to matter)
-                const u32 want = ++c->ticket_expected;
-                const auto t0 = std::chrono::steady_clock::now();
-                bool seen = false;
-                while (!(seen = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE) == want)) {
-                    for (int i = 0; i < 64; ++i) cpu_relax();
-                    if (std::chrono::steady_clock::now() - t0 > kSpinBudget) break;
-                }
-                if (!seen) HIP_TRY(hipStreamSynchronize(s));
-            } else {
-                HIP_TRY(hipStreamSynchronize(s));
-            }
-            c->ticket_expected = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE);
+            // the last node of the sequence stores a ticket into pinned memory
+            rc = wait_ticket(c, s);
+            if (rc != SPECK_OK) return rc;
             if (!c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 ++c->graph_replays;
                 publish_counts(c);
@@ -1163,7 +1177,13 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // The reference may return before its kernels finish when measureCompleteTime is off
     // (Multiply.cu:1082-1085) and relies on blocking streams to order later copies.  The
     // pipeline streams here are non-blocking, so the call always returns with C complete.
-    HIP_TRY(hipStreamSynchronize(s));
+    if (c->spin_wait && !c->profile_kernels) {
+        launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
+        rc = wait_ticket(c, s);
+        if (rc != SPECK_OK) return rc;
+    } else {
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     t->spGEMMNumeric = st.lap();
     t->sorting = 0.f;  // sorting is fused into the numeric kernels
     t->cleanup = 0.f;  // nothing to free: the arena persists
