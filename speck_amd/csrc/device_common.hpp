@@ -260,7 +260,9 @@ struct DeviceStats {
     u32 b_invalid;           // a row of B is not strictly ascending / holds a column >= cols (eager path)
     u32 nf_max_range;        // widest column range among the SYM_NF rows (sizes the LDS window of their kernel)
     u32 a_invalid;           // a column id of A is >= rows(B) (the analysis clamps it, so nothing reads out of bounds)
-    u32 pad_;
+    u32 b_bad_epoch;         // LAST word, never zeroed by the analysis kernel: the validation blocks of that kernel store
+                             //   the call's epoch here when a row of B is not strictly ascending / in range (they run
+                             //   next to the block that zeroes the rest, so the verdict is a value no other call wrote)
 };
 static_assert(sizeof(DeviceStats) % 8 == 0, "mirrored to the host in 8-byte words");
 

@@ -17,15 +17,12 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
                      uint2* b_sl, hipEvent_t between = nullptr, u64* nf_off = nullptr,
                      u64 expect_nf = ~0ull, u32 b_rows = ~0u, u32* pred_block_out = nullptr,
-                     const u32* pred_block = nullptr, const DeviceStats* pred_stats = nullptr);
+                     const u32* pred_block = nullptr, const DeviceStats* pred_stats = nullptr, u32 b_cols = 0,
+                     u64 b_nnz = 0, u32 validate_epoch = 0 /* != 0: also check B's rows (DeviceStats::b_bad_epoch) */);
 
 // completion ticket of a replayed launch sequence (pinned host word the host spins on)
 // (the kernel also copies the statistics block into its pinned mirror, before the ticket)
 void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceStats* st, DeviceStats* host_mirror);
-
-// strictly ascending, in-range column ids in every row of B (sets DeviceStats::b_invalid)
-void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st,
-                       u64 b_nnz);
 
 // exclusive scan of the row counts into offsets_out (may alias counts; + numeric classification, stats fold,
 // ordered scatter of the numeric row records when num_cls != nullptr).  offsets_out is left as it was when a

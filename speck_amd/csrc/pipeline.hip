@@ -93,6 +93,8 @@ struct speck_config {
     std::vector<hipEvent_t> aux_done;
     hipEvent_t fork = nullptr;
     bool validate_inputs = true;  // eager path: B's rows strictly ascending and in range
+    u32 epoch_counter = 0, check_epoch = 0;  // ... reported as the call's epoch (DeviceStats::b_bad_epoch); set while
+                                             //   an eager call that checks is in flight
     bool concurrent_classes = true;
     u32 max_side_streams = 12;
     float split_min_us = 10.f; // both parts of a light launch must be at least this long to be launched apart
@@ -517,7 +519,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                         sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
                         c->d_stats, cp, sc.b_sl, between, sc.nf_off, expect_nf, (u32)B->rows,
                         pred_out ? pred_out->sym_block : nullptr, c->capture_pred_sym ? c->gpred.sym_block : nullptr,
-                        c->gpred.stats);
+                        c->gpred.stats, (u32)B->cols, B->nnz, c->check_epoch);
         if (timed) {
             tm->ev_analysis_end = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -662,10 +664,14 @@ int read_stats(speck_config* c, hipStream_t s)
 {
     if (c->spin_wait) {
         launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
-        return wait_ticket(c, s);
+        const int rc = wait_ticket(c, s);
+        if (rc != SPECK_OK) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
     }
-    HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // the input check of this (eager) call reports with the call's epoch
+    if (c->check_epoch && c->h_stats->b_bad_epoch == c->check_epoch) c->h_stats->b_invalid = 1;
     return SPECK_OK;
 }
 
@@ -1011,13 +1017,16 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                              parts == 2u ? sym_known : nullptr, nullptr, ~0ull, ~0u, parts, ~0ull,
                              keep_pred ? &c->pred : nullptr, fold_esc);
     };
-    // analysis + binning, then the input check: B's rows strictly ascending and in range (one coalesced pass;
-    // A's column ids are checked -- and clamped -- by the analysis itself).  The check sits behind the analysis
-    // because block 0 of the analysis kernel is what zeroes the statistics block it reports into.
+    // analysis + binning, and in the same launch the input check: B's rows strictly ascending and in range (one
+    // coalesced pass by extra workgroups of the analysis kernel; A's column ids are checked -- and clamped -- by the
+    // analysis itself).  The verdict is the call's epoch in a word block 0 of that kernel does not zero.
+    c->check_epoch = c->validate_inputs ? (++c->epoch_counter ? c->epoch_counter : ++c->epoch_counter) : 0u;
+    struct EpochOff {
+        speck_config* c;
+        ~EpochOff() { c->check_epoch = 0; }
+    } epoch_off{c};
     rc = front(1u);
     if (rc != SPECK_OK) return fail(rc);
-    if (c->validate_inputs)
-        launch_validate_b(s, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, c->d_stats, B->nnz);
     if (c->cp.nf_min_ops || c->cp.gh_per_window) {
         // numeric-first rows (and the global key sets of SYM_GH rows) need their scratch pool before the
         // symbolic phase: one more read-back -- which also stops an invalid input before any kernel walks B's rows

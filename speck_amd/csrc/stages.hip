@@ -66,6 +66,30 @@ constexpr u32 kAnRowPathMax = 8;  // rows per lane up to this many entries (sub-
 constexpr u32 kAnCoopMax = 64;        // ... at most this many per workgroup (the others stay with their wave)
 constexpr u32 kAnCoopRowLen = 256, kAnCoopEntries = 2048;  // sub-chunks (32 rows) with more entries than this, one row
                                                             //   holding more than that, are walked by the whole workgroup
+// Input check (eager path; the long comment is further down): workgroup `vb` of `nvb` walks its share of B's
+// entries -- col[e] < col[e + 1] unless e + 1 starts a row, looked up (binary search in the row offsets) only for the
+// pairs that are NOT ascending, i.e. almost never -- and stores the call's epoch on a violation.
+__device__ __forceinline__ void validate_b_slice(const u32* __restrict__ b_ro, const u32* __restrict__ b_col, u32 b_rows,
+                                                 u32 b_cols, u32 vb, u32 nvb, u32 epoch, DeviceStats* __restrict__ st)
+{
+    const u32 e_first = b_ro[0], e_last = b_ro[b_rows];
+    bool bad = e_last < e_first;
+    for (u64 i = u64(vb) * blockDim.x + threadIdx.x; e_first + i < e_last; i += u64(nvb) * blockDim.x) {
+        const u32 e = e_first + (u32)i;
+        const u32 c = b_col[e];
+        if (c >= b_cols) bad = true;
+        if (e + 1 < e_last && b_col[e + 1] <= c) {
+            u32 lo = 0, hi = b_rows;  // first row whose offset is >= e + 1
+            while (lo < hi) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                if (b_ro[mid] < e + 1) lo = mid + 1; else hi = mid;
+            }
+            if (b_ro[lo] != e + 1) bad = true;
+        }
+    }
+    if (__ballot(bad) != 0 && lane_id() == 0) st->b_bad_epoch = epoch;  // plain store: every writer stores the same value
+}
+
 template <int NW, u32 R>
 __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     const u32* __restrict__ a_ro, const u32* __restrict__ a_col, const u32* __restrict__ b_ro,
@@ -73,8 +97,15 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     u32* __restrict__ row_max_ops, u32* __restrict__ row_col_min, u32* __restrict__ row_col_max,
     u8* __restrict__ sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
     ClassifyParams cp, uint2* __restrict__ b_sl, DeviceStats* __restrict__ st, u32 b_rows,
-    const u32* __restrict__ pred_block, const DeviceStats* __restrict__ pred_stats, RowRec* __restrict__ recs)
+    const u32* __restrict__ pred_block, const DeviceStats* __restrict__ pred_stats, RowRec* __restrict__ recs,
+    u32 an_blocks, u32 b_cols, u32 validate_epoch)
 {
+    // workgroups behind the analysis grid (eager path): the input check of B, next to the analysis instead of in a
+    // launch of its own behind it
+    if (blockIdx.x >= an_blocks) {
+        validate_b_slice(b_ro, b_col, b_rows, b_cols, blockIdx.x - an_blocks, gridDim.x - an_blocks, validate_epoch, st);
+        return;
+    }
     constexpr int kAnThreads = NW * 64;
     constexpr int U = 4;   // entries per lane and tile: 256 entries cover most 32-row sub-chunks in ONE
                            //   round of the dependent chain A.col -> B.rowptr -> B.col
@@ -90,7 +121,7 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     //  stops, and the eager path, which starts from zero, re-runs.  Block 0 then writes what the symbolic kernels
     //  read: the class table of the predicted call, which every block checks its own share of.)
     if (blockIdx.x == 0 && !pred_block)
-        for (u32 i = threadIdx.x; i < sizeof(DeviceStats) / 4; i += kAnThreads) reinterpret_cast<u32*>(st)[i] = 0;
+        for (u32 i = threadIdx.x; i < sizeof(DeviceStats) / 4 - 1; i += kAnThreads) reinterpret_cast<u32*>(st)[i] = 0;  // (all but b_bad_epoch)
     if (blockIdx.x == 0 && pred_block) {
         constexpr u32 kWords = sizeof(BinTable) / 4;
         const u32* src = reinterpret_cast<const u32*>(&pred_stats->sym);
@@ -373,7 +404,7 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
         for (int c = 0; c < SYM_CLASSES; ++c) s_hist[wid][c] = hist[c];
     }
     __syncthreads();
-    const PartialArrays pa(partials, gridDim.x);
+    const PartialArrays pa(partials, an_blocks);
     if (t == 0) {
         u64 p = 0, nf = 0;
         u32 mxv = 0, nfr = 0;
@@ -1161,40 +1192,9 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
 // Input precondition (undocumented upstream): the column ids of every row of B are
 // strictly ascending (the min/max column range of the analysis, the scaled-copy rows and the bitmap
 // sorts rely on it; the reference's loader guarantees it and silently computes garbage otherwise).
-// One coalesced pass over B.col_ids, eager path only (a replayed sequence runs on unchanged inputs).
+// One coalesced pass over B.col_ids, eager path only (a replayed sequence runs on unchanged inputs): validate_b_slice,
+// run by extra workgroups of the analysis launch (above).
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__ b_ro, const u32* __restrict__ b_col,
-                                                         u32 b_rows, u32 b_cols, DeviceStats* __restrict__ st)
-{
-    // a thread per entry: col[e] < col[e + 1] unless e + 1 starts a row -- looked up (binary search in the
-    // row offsets) only for the pairs that are NOT ascending, i.e. almost never
-    const u32 e_first = b_ro[0], e_last = b_ro[b_rows];
-    bool bad = e_last < e_first;
-    for (u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; e_first + i < e_last; i += u64(gridDim.x) * blockDim.x) {
-        const u32 e = e_first + (u32)i;
-        const u32 c = b_col[e];
-        if (c >= b_cols) bad = true;
-        if (e + 1 < e_last && b_col[e + 1] <= c) {
-            u32 lo = 0, hi = b_rows;  // first row whose offset is >= e + 1
-            while (lo < hi) {
-                const u32 mid = lo + ((hi - lo) >> 1);
-                if (b_ro[mid] < e + 1) lo = mid + 1; else hi = mid;
-            }
-            if (b_ro[lo] != e + 1) bad = true;
-        }
-    }
-    if (__ballot(bad) != 0 && lane_id() == 0) st->b_invalid = 1;  // plain store: every writer stores the same value
-}
-
-void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, DeviceStats* st,
-                       u64 b_nnz)
-{
-    if (b_rows == 0) return;
-    u32 blocks = cdiv(b_nnz ? b_nnz : 1, 256 * 4);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(validate_b_kernel, dim3(blocks), dim3(256), 0, s, b_ro, b_col, b_rows, b_cols, st);
-}
-
 // Last node of a replayed launch sequence: a ticket in pinned host memory the host spins on (a blocking
 // stream synchronisation costs ~10-20 us of wake-up latency: a tenth of a 200 us multiply).
 // The same wave first copies the (final) statistics block into the pinned mirror with system-scope stores, so
@@ -1239,8 +1239,14 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
                      uint2* b_sl, hipEvent_t between, u64* nf_off, u64 expect_nf, u32 b_rows, u32* pred_block_out,
-                     const u32* pred_block, const DeviceStats* pred_stats)
+                     const u32* pred_block, const DeviceStats* pred_stats, u32 b_cols, u64 b_nnz, u32 validate_epoch)
 {
+    // eager path with the input check on: workgroups behind the analysis grid walk B's entries (validate_b_slice)
+    auto vblocks = [&](u32 threads) -> u32 {
+        if (!validate_epoch || b_rows == 0 || b_rows == ~0u) return 0u;
+        const u32 want = cdiv(b_nnz ? b_nnz : 1, threads * 4);
+        return want > 2048u ? 2048u : want;
+    };
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
     // 64 rows per wave for short rows (g_an_wide_rows: average entries per row up to which; 0 = never)
@@ -1249,24 +1255,24 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
         if (wide)
             hipLaunchKernelGGL((analysis_kernel<4, 64>), dim3(blocks), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
                                rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs);
+                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u);
         else
             hipLaunchKernelGGL((analysis_kernel<8, 32>), dim3(blocks), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
                                rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs);
+                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u);
         if (between) (void)hipEventRecord(between, s);
         return;
     }
     if (wide)
-        hipLaunchKernelGGL((analysis_kernel<4, 64>), dim3(blocks), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
+        hipLaunchKernelGGL((analysis_kernel<4, 64>), dim3(blocks + vblocks(256)), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
                            rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                            partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
-                           (RowRec*)nullptr);
+                           (RowRec*)nullptr, blocks, b_cols, validate_epoch);
     else
-        hipLaunchKernelGGL((analysis_kernel<8, 32>), dim3(blocks), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
+        hipLaunchKernelGGL((analysis_kernel<8, 32>), dim3(blocks + vblocks(512)), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
                            rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                            partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
-                           (RowRec*)nullptr);
+                           (RowRec*)nullptr, blocks, b_cols, validate_epoch);
     if (between) (void)hipEventRecord(between, s);  // analysis | binning (Timings::countProducts / loadBalanceCounting)
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,
