@@ -172,6 +172,9 @@ struct speck_comm {
     ncclComm_t nccl = nullptr;
     hipStream_t stream = nullptr;
     uint64_t* d_sizes = nullptr;  // RCCL: 2 (mine) + 2 * nranks (everyone's)
+    uint64_t* h_sizes = nullptr;  // ... and their PINNED host mirror: asynchronous copies never touch pageable memory
+                                  //   (the runtime locks such pages behind the caller's back; a later copy of other
+                                  //   pageable memory then faulted on the GPU -- found with the replay stress)
     std::string shm_token;
     Segment ctl;
     uint64_t sizes_gen = 0;
@@ -241,11 +244,12 @@ int exchange_sizes(speck_comm* c, uint64_t rows, uint64_t nnz, std::vector<uint6
         return SPECK_OK;
     }
     if (c->transport == SPECK_TRANSPORT_RCCL) {
-        const uint64_t h[2] = {rows, nnz};
-        COMM_HIP(hipMemcpyAsync(c->d_sizes, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        c->h_sizes[0] = rows;
+        c->h_sizes[1] = nnz;
+        COMM_HIP(hipMemcpyAsync(c->d_sizes, c->h_sizes, 16, hipMemcpyHostToDevice, c->stream));
         COMM_NCCL(rccl()->AllGather(c->d_sizes, c->d_sizes + 2, 2, ncclUint64, c->nccl, c->stream));
-        std::vector<uint64_t> all(2 * c->nranks);
-        COMM_HIP(hipMemcpyAsync(all.data(), c->d_sizes + 2, all.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        uint64_t* all = c->h_sizes + 2;
+        COMM_HIP(hipMemcpyAsync(all, c->d_sizes + 2, size_t(2 * c->nranks) * 8, hipMemcpyDeviceToHost, c->stream));
         COMM_HIP(hipStreamSynchronize(c->stream));
         for (int p = 0; p < c->nranks; ++p) {
             all_rows[p] = all[2 * p];
@@ -314,7 +318,9 @@ int speck_comm_init(int device, int nranks, int rank, int transport, const void*
             c->nccl = nullptr;
             return fail(SPECK_ERR_COMM);
         }
-        if (hipMalloc(reinterpret_cast<void**>(&c->d_sizes), (2 + 2 * size_t(nranks)) * 8) != hipSuccess)
+        if (hipMalloc(reinterpret_cast<void**>(&c->d_sizes), (2 + 2 * size_t(nranks)) * 8) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&c->h_sizes), (2 + 2 * size_t(nranks)) * 8, hipHostMallocDefault) !=
+                hipSuccess)
             return fail(SPECK_ERR_OOM);
     } else {
         if (std::memcmp(id128, kShmMagic, 8) != 0) return fail(SPECK_ERR_INVALID);
@@ -339,6 +345,7 @@ int speck_comm_destroy(speck_comm* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
     if (c->d_sizes) (void)hipFree(c->d_sizes);
+    if (c->h_sizes) (void)hipHostFree(c->h_sizes);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     unmap_segment(c->ctl);
     delete c;
@@ -521,13 +528,14 @@ int speck_gather_wait(speck_gather_plan* p, int slot, speck_dcsr* full_view)
             if (!spin_until([&] { return k->ready[r][slot].load(std::memory_order_acquire) == tag; })) return SPECK_ERR_COMM;
             const char* base = static_cast<const char*>(p->theirs[slot][r].p);
             const uint64_t rows = p->lay.rows[r], nnz = p->lay.nnz[r], r0 = p->lay.r_off[r], n0 = p->lay.n_off[r];
-            if (rows) COMM_HIP(hipMemcpyAsync(o.row_offsets + r0, base, rows * 4, hipMemcpyHostToDevice, c->stream));
+            // (blocking copies: the source is pageable shared memory that is unmapped later -- see h_sizes)
+            if (rows) COMM_HIP(hipMemcpy(o.row_offsets + r0, base, rows * 4, hipMemcpyHostToDevice));
             if (nnz) {
-                COMM_HIP(hipMemcpyAsync(o.col_ids + n0, base + rows * 4, nnz * 4, hipMemcpyHostToDevice, c->stream));
-                COMM_HIP(hipMemcpyAsync(static_cast<char*>(o.data) + n0 * p->vsize, base + rows * 4 + nnz * 4,
-                                        nnz * p->vsize, hipMemcpyHostToDevice, c->stream));
+                COMM_HIP(hipMemcpy(o.col_ids + n0, base + rows * 4, nnz * 4, hipMemcpyHostToDevice));
+                COMM_HIP(hipMemcpy(static_cast<char*>(o.data) + n0 * p->vsize, base + rows * 4 + nnz * 4,
+                                   nnz * p->vsize, hipMemcpyHostToDevice));
             }
-            COMM_HIP(hipStreamSynchronize(c->stream));  // the segment may be refilled once it is marked taken
+            // the segment may be refilled once it is marked taken
             k->taken[r][slot].store(tag, std::memory_order_release);
         }
         hipLaunchKernelGGL(rebase_offsets_kernel, dim3(256), dim3(256), 0, c->stream, o.row_offsets, p->d_off,

@@ -740,8 +740,11 @@ int snapshot_prediction(speck_config* c, hipStream_t s, const ReplayPlan& p)
         ps.num.bytes[NUM_NFCOPY] += ps.num.bytes[NUM_G8] + ps.num.bytes[NUM_G16];
         ps.num.bytes[NUM_G8] = ps.num.bytes[NUM_G16] = 0;
     }
-    HIP_TRY(hipMemcpyAsync(c->gpred.stats, &ps, sizeof(ps), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // (`ps` is on the stack)
+    // (a BLOCKING copy, behind the device-to-device one: `ps` is on the stack, and an asynchronous copy from pageable
+    //  memory makes the runtime lock those pages behind the caller's back -- a later copy of other pageable memory,
+    //  e.g. the caller downloading C, then ended in a GPU memory fault during the next replay: found by the stress run)
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(c->gpred.stats, &ps, sizeof(ps), hipMemcpyHostToDevice));
     return SPECK_OK;
 }
 

@@ -1092,6 +1092,19 @@ def test_register_class_rows_are_finished_in_the_symbolic_phase_of_a_replay(cfg)
     assert (np.abs(got.data.astype(np.float64) - Rf.data.astype(np.float64)) <= TOL32 * abf + 1e-30).all()
 
 
+def test_randomised_sequence_of_problems_on_one_config():
+    """tests/tools/stress_gpu.py, the first 45 cases of seed 9001: random shapes / row-length laws / precisions, three
+    calls each (eager, capture + replay, replay) with C downloaded after every call, all on ONE config.  Case 42 of
+    this seed -- a 2 942-row problem behind a 312-row one -- ended in a GPU memory fault in round 3 (an asynchronous
+    copy from stack memory at capture time; `snapshot_prediction`), which no single-problem test saw."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "stress_gpu.py")
+    r = subprocess.run([sys.executable, tool, "45", "9001"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "failures: 0" in r.stdout
+
+
 def test_a_captured_sequence_owns_its_prediction(cfg):
     """A replayed sequence verifies (and places rows by) what the previous identical call decided.  That prediction
     belongs to the sequence: an eager multiply of OTHER matrices on the same config in between -- more rows, other

@@ -1,7 +1,7 @@
 """Randomised parity stress of the HIP path against the oracle (run by hand on a GPU box):
 power-law / uniform / clustered row lengths, empty rows and columns, rectangular shapes, fp32 and fp64,
 repeated calls (graph replay) with changing values.
-usage: python tests/tools/stress_gpu.py [cases] [seed] [option=value ...]"""
+usage: python tests/tools/stress_gpu.py [cases] [seed] [option=value ...]   (first=N: only multiply cases >= N)"""
 import os
 import sys
 
@@ -50,8 +50,12 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     cfg = sa.spECKConfig.initialize(0)
+    first = 0
     for opt in sys.argv[3:]:   # library options name=value, e.g. nf_min_ops=1 num_global_passes=1000000 xcd_aware=7
         name, value = opt.split("=")
+        if name == "first":
+            first = int(value)
+            continue
         cfg.set_option(name, int(value))
     bad = 0
     for it in range(cases):
@@ -63,6 +67,8 @@ def main():
         kb = rng.choice(["uniform", "powerlaw", "sparse_empty", "dense_band"])
         A = rand_csr(rng, m, k, int(rng.choice([1, 3, 10, 40])), ka, dtype)
         B = rand_csr(rng, k, n, int(rng.choice([1, 3, 10, 40, 150])), kb, dtype)
+        if it < first:
+            continue
         R, ab = po.spgemm(A, B)
         dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR(dtype)
         ok = True
