@@ -61,6 +61,14 @@ struct Prediction {
     u32 rows = 0;
 };
 
+// What a replayed launch sequence is specialised to: the classes that were non-empty when the same inputs were last
+// multiplied eagerly, and what the previous identical call lets it skip.
+struct ReplayPlan {
+    u32 num_mask, launch_mask;
+    u32 num_counts[kMaxClasses];
+    bool direct, fused, pred_scan, pred_sym;
+};
+
 struct speck_config {
     int device = 0;
     int sm = 0;                 // compute units
@@ -132,6 +140,7 @@ struct speck_config {
     // direct placement of the numeric-first rows by a replayed sequence: the row offsets of the last eager call
     // (the config's own copy -- C.row_offsets is the caller's to overwrite), and the C buffers of the capture
     Prediction pred, gpred;
+    DeviceStats last_eager_stats{};  // final statistics block of the last eager call (what `pred` goes with)
     bool pred_valid = false;         // pred.off holds the offsets of the last eager call
     bool pred_tiles_valid = false;   // ... and pred.num_tile its tile tables,
     bool pred_fold_esc = false;      //     in the shape of a sequence that finishes the register-class rows early
@@ -151,6 +160,9 @@ struct speck_config {
     bool graph_fused = false;        // ... and finishes the rows of the register classes in its symbolic phase
     bool graph_pred_scan = false;    // ... and scans with the predicted kernel
     bool graph_pred_sym = false;     // ... and has no scatter kernel
+    ReplayPlan graph_plan{};
+    bool exec_dirty = false;         // other launches went onto the pipeline stream since graph_exec was last launched
+    bool replay_uncaptured = false;  // option replay_uncaptured (debugging): enqueue the sequence instead of launching its graph
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
@@ -712,13 +724,6 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
     return k;
 }
 
-// What a replayed launch sequence is specialised to: the classes that were non-empty when the same inputs were last
-// multiplied eagerly, and what the previous identical call lets it skip.
-struct ReplayPlan {
-    u32 num_mask, launch_mask;
-    u32 num_counts[kMaxClasses];
-    bool direct, fused, pred_scan, pred_sym;
-};
 
 // The config's prediction (of the last eager call = this call: same key) becomes the sequence's own: device copy of
 // the arrays, and the statistics block of that call in the shape the sequence classifies in.
@@ -727,7 +732,9 @@ int snapshot_prediction(speck_config* c, hipStream_t s, const ReplayPlan& p)
     if (!c->pred_valid) return SPECK_OK;
     if (!ensure_pred(c->gpred, c->pred.rows)) return SPECK_ERR_OOM;
     HIP_TRY(hipMemcpyAsync(c->gpred.buf, c->pred.buf, std::min(c->pred.bytes, c->gpred.bytes), hipMemcpyDeviceToDevice, s));
-    DeviceStats ps = *c->h_stats;
+    // (the statistics of THAT call, kept by the eager path: the pinned mirror holds whatever ran last -- a replay of
+    //  another problem on this config, for instance)
+    DeviceStats ps = c->last_eager_stats;
     ps.capacity_miss = 0;
     std::memcpy(ps.num.count, p.num_counts, sizeof(ps.num.count));
     u32 run = 0;
@@ -836,6 +843,7 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         c->pred_valid = c->pred_tiles_valid = false;
         plan = plan_replay(c);
     }
+    c->graph_plan = plan;
     c->graph_direct = plan.direct;
     c->graph_fused = plan.fused;
     c->graph_pred_scan = plan.pred_scan;
@@ -859,6 +867,7 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     c->graph_exec = ge;
     c->graph_key = key;
     c->graph_valid = true;
+    c->exec_dirty = false;
     ++c->graph_captures;
     return SPECK_OK;
 }
@@ -941,6 +950,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         // the launches a replay of this call consists of, straight onto the stream with events around them
         const GraphKey key = make_key<T>(c, A, B, C, s);
         if (c->last_key_valid && c->last_key == key) {
+            c->exec_dirty = true;
+            if (c->graph_valid && !(c->graph_key == key)) drop_graph(c);  // (its copy of the prediction is rewritten below)
             ReplayPlan plan = plan_replay(c);
             if (snapshot_prediction(c, s, plan) != SPECK_OK) {
                 c->pred_valid = c->pred_tiles_valid = false;
@@ -969,7 +980,30 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         if (!have && c->last_key_valid && c->last_key == key)
             have = capture_graph<T>(c, s, A, B, C, sc, key) == SPECK_OK;
         if (have) {
-            HIP_TRY(hipGraphLaunch(c->graph_exec, s));
+            // Launching the SAME executable graph again after other launches went onto the same stream in between
+            // (an eager multiply of another problem on this config) ended in GPU memory faults on this runtime --
+            // gone with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, i.e. the runtime's pre-recorded launch packets; found by
+            // the interleaved stress (tests/tools/stress_gpu.py interleave=K).  So: an executable that has seen other
+            // work on the pipeline stream since its last launch is instantiated afresh from the captured graph (a few
+            // hundred us, once per switch between problems); on a CALLER's stream, whose traffic the library cannot
+            // see, the launches of the sequence are enqueued one by one instead (option replay_uncaptured does the same
+            // everywhere: +1..6 % per multiply).
+            if (c->replay_uncaptured || c->use_user_stream) {
+                rc = enqueue_replay<T>(c, s, A, B, C, sc, c->graph_plan, nullptr, nullptr);
+                if (rc != SPECK_OK) return rc;
+            } else {
+                if (c->exec_dirty) {
+                    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+                    c->graph_exec = nullptr;
+                    if (hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) != hipSuccess) {
+                        (void)hipGetLastError();
+                        drop_graph(c);
+                        return SPECK_ERR_HIP;
+                    }
+                    c->exec_dirty = false;
+                }
+                HIP_TRY(hipGraphLaunch(c->graph_exec, s));
+            }
             // the last node of the sequence stores a ticket into pinned memory
             rc = wait_ticket(c, s);
             if (rc != SPECK_OK) return rc;
@@ -988,6 +1022,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     }
 
     // ------------------------------------------------------------------ eager path
+    c->exec_dirty = true;  // (a captured sequence of another problem must not be launched again as it is)
     // INIT: C.row_offsets reuse rule (Multiply.cu:156-165)
     u32* c_ro = nullptr;
     bool own_ro = false;
@@ -1211,6 +1246,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // ... and where every row went: the scan kernel wrote the prediction (offsets, tile tables) as it went
     c->pred_valid = c->pred_tiles_valid = keep_pred;
     c->pred_fold_esc = fold_esc;
+    c->last_eager_stats = *c->h_stats;
 
     rc = finish_complete();
     if (rc != SPECK_OK) return rc;
@@ -1291,6 +1327,9 @@ int speck_config_create(int device, speck_config** out)
     }
     HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(DeviceStats)));
+    // (b_bad_epoch is the one word no kernel zeroes: recycled memory of a destroyed config must not hold an epoch
+    //  this config is going to use)
+    HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stats), sizeof(DeviceStats), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_stats_dev), c->h_stats, 0));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_ticket), sizeof(u32)));
@@ -1391,6 +1430,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
     else if (n == "profile_replay") c->profile_replay = value != 0;
+    else if (n == "replay_uncaptured") c->replay_uncaptured = value != 0;
     else if (n == "analysis_wide_rows") {
         set_analysis_wide_rows((u32)value);
         drop_graph(c);
@@ -1528,6 +1568,7 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     if (rc != SPECK_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = main_stream(c);
+    c->exec_dirty = true;  // (stage entry point: launches on the pipeline stream)
     const u32 m = (u32)A->rows;
     if (m == 0 || A->nnz == 0 || B->nnz == 0) {
         if (h_sum_products) *h_sum_products = 0;
@@ -1569,6 +1610,7 @@ int speck_symbolic(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     if (rc != SPECK_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = main_stream(c);
+    c->exec_dirty = true;  // (stage entry point: launches on the pipeline stream)
     const u32 m = (u32)A->rows;
     if (A->nnz == 0 || B->nnz == 0) {
         HIP_TRY(hipMemsetAsync(d_row_offsets, 0, (size_t(m) + 1) * 4, s));

@@ -1105,6 +1105,20 @@ def test_randomised_sequence_of_problems_on_one_config():
     assert "failures: 0" in r.stdout
 
 
+def test_randomised_problems_taking_turns_on_one_config():
+    """tests/tools/stress_gpu.py interleave=4: four random problems alive on ONE config, a random one multiplied (and
+    downloaded, and compared with the oracle) at every step, problems replaced now and then.  A captured sequence, the
+    config's prediction and its scratch are shared between them: in round 3 the capture of problem B took the
+    statistics block of 'the last eager call' from the pinned mirror, which a replay of problem A had rewritten in
+    between (GPU memory fault / endless kernel; `last_eager_stats` since)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "stress_gpu.py")
+    r = subprocess.run([sys.executable, tool, "150", "777", "interleave=4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "failures: 0" in r.stdout and "replayed=1" in r.stdout
+
+
 def test_a_captured_sequence_owns_its_prediction(cfg):
     """A replayed sequence verifies (and places rows by) what the previous identical call decided.  That prediction
     belongs to the sequence: an eager multiply of OTHER matrices on the same config in between -- more rows, other

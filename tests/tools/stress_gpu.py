@@ -1,7 +1,9 @@
 """Randomised parity stress of the HIP path against the oracle (run by hand on a GPU box):
 power-law / uniform / clustered row lengths, empty rows and columns, rectangular shapes, fp32 and fp64,
 repeated calls (graph replay) with changing values.
-usage: python tests/tools/stress_gpu.py [cases] [seed] [option=value ...]   (first=N: only multiply cases >= N)"""
+usage: python tests/tools/stress_gpu.py [cases] [seed] [option=value ...]   (first=N: only multiply cases >= N;
+       interleave=K: keep K problems alive on the one config and multiply a random one of them each step -- captured
+       sequences, predictions and scratch of several problems taking turns)"""
 import os
 import sys
 
@@ -45,18 +47,77 @@ def to_sa(h):
     return sa.HostCSR(h.rows, h.cols, h.row_offsets, h.col_ids, h.data)
 
 
+def random_problem(rng):
+    dtype = np.float64 if rng.random() < 0.8 else np.float32
+    m = int(rng.integers(1, 3000))
+    k = int(rng.integers(1, 3000))
+    n = int(rng.choice([50, 1000, 20000, 300000, 3000000]))
+    ka = rng.choice(["uniform", "powerlaw", "sparse_empty", "dense_band"])
+    kb = rng.choice(["uniform", "powerlaw", "sparse_empty", "dense_band"])
+    A = rand_csr(rng, m, k, int(rng.choice([1, 3, 10, 40])), ka, dtype)
+    B = rand_csr(rng, k, n, int(rng.choice([1, 3, 10, 40, 150])), kb, dtype)
+    return dict(A=A, B=B, R=None, ab=None, dtype=dtype, dA=None, dB=None, dC=None,
+                name=f"{m}x{k}x{n} {ka}/{kb} {dtype.__name__}", calls=0)
+
+
+def materialise(p):
+    if p["dA"] is None:
+        p["R"], p["ab"] = po.spgemm(p["A"], p["B"])
+        p["dA"], p["dB"], p["dC"] = sa.dCSR.from_host(to_sa(p["A"])), sa.dCSR.from_host(to_sa(p["B"])), sa.dCSR(p["dtype"])
+
+
+def interleaved(cfg, rng, steps, alive):
+    probs = [random_problem(rng) for _ in range(alive)]
+    bad = 0
+    for it in range(steps):
+        j = int(rng.integers(0, alive))
+        if rng.random() < 0.08:          # now and then a problem is replaced by a new one (buffers freed, reused)
+            probs[j] = random_problem(rng)
+        p = probs[j]
+        if it < int(os.environ.get("STRESS_SKIP_BEFORE", "0")):   # fast-forward to a step of a long run (same draws)
+            p["calls"] += 1
+            continue
+        materialise(p)
+        if os.environ.get("STRESS_VERBOSE"):
+            print(f"     step {it}: problem {j} call {p['calls'] + 1} {p['name']}", flush=True)
+        if it == int(os.environ.get("STRESS_UNCAPTURED_AT", "-1")):   # this step: the launches of the replay, uncaptured
+            cfg.set_option("profile_replay", 1)
+            cfg.profile_kernels(1)
+        sa.MultiplyspECK(p["dA"], p["dB"], p["dC"], cfg)
+        p["calls"] += 1
+        got = p["dC"].to_host()
+        R, ab = p["R"], p["ab"]
+        tol = 1e-12 if p["dtype"] == np.float64 else 2e-5
+        ok = got.nnz == R.nnz and (got.row_offsets == R.row_offsets).all() and (got.col_ids == R.col_ids).all() and \
+            bool((np.abs(got.data.astype(np.float64) - R.data.astype(np.float64)) <= tol * ab + 1e-300).all())
+        st = cfg.last_stats()
+        bad += 0 if ok else 1
+        print(f"{it:4d} {'ok ' if ok else 'BAD'} problem {j} call {p['calls']} replayed={int(st['replayed'])} "
+              f"pred={st['pred_stages']} {p['name']} nnzC={R.nnz}", flush=True)
+        if os.environ.get("STRESS_VERBOSE"):
+            print("       sym", {k: v for k, v in st["sym_bin_rows"].items() if v}, "num",
+                  {k: v for k, v in st["num_bin_rows"].items() if v}, "pool", st["scratch_pool_bytes"], flush=True)
+    print("failures:", bad)
+    sys.exit(1 if bad else 0)
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     cfg = sa.spECKConfig.initialize(0)
-    first = 0
+    first, alive = 0, 0
     for opt in sys.argv[3:]:   # library options name=value, e.g. nf_min_ops=1 num_global_passes=1000000 xcd_aware=7
         name, value = opt.split("=")
         if name == "first":
             first = int(value)
             continue
+        if name == "interleave":
+            alive = int(value)
+            continue
         cfg.set_option(name, int(value))
+    if alive:
+        return interleaved(cfg, rng, cases, alive)
     bad = 0
     for it in range(cases):
         dtype = np.float64 if rng.random() < 0.8 else np.float32
