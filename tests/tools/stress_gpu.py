@@ -115,6 +115,10 @@ def main():
         if name == "interleave":
             alive = int(value)
             continue
+        if name == "user_stream":     # run the pipeline on a stream of the caller (torch's current one)
+            if int(value):
+                cfg.set_stream(torch.cuda.current_stream().cuda_stream)
+            continue
         cfg.set_option(name, int(value))
     if alive:
         return interleaved(cfg, rng, cases, alive)
