@@ -78,6 +78,30 @@ def interleaved(cfg, rng, steps, alive):
             p["calls"] += 1
             continue
         materialise(p)
+        if rng.random() < 0.1:           # new VALUES under the same pointers and structure: a replay stays valid
+            import ctypes
+            from speck_amd import _lib
+            A = p["A"]
+            newv = (A.data * (0.5 + rng.random(A.data.size))).astype(A.data.dtype)
+            p["A"] = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, newv)
+            assert _lib.load().speck_dcsr_update(ctypes.byref(p["dA"]._c), None, None, np.ascontiguousarray(newv).ctypes.data,
+                                                 newv.dtype.itemsize) == 0
+            p["R"], p["ab"] = po.spgemm(p["A"], p["B"])
+        if rng.random() < 0.06 and p["A"].nnz:   # new STRUCTURE under the same pointers (same row lengths of A): a
+            import ctypes                          #   replay must notice -- whatever it predicted -- and re-run eagerly
+            from speck_amd import _lib
+            A = p["A"]
+            ro = A.row_offsets.astype(np.int64)
+            col = A.col_ids.copy()
+            rows = rng.choice(A.rows, size=max(1, A.rows // 20), replace=False)
+            for r in rows:
+                n = int(ro[r + 1] - ro[r])
+                if n:
+                    col[ro[r]:ro[r + 1]] = np.sort(rng.choice(A.cols, size=n, replace=False)).astype(np.uint32)
+            p["A"] = po.HostCSR(A.rows, A.cols, A.row_offsets, col, A.data)
+            assert _lib.load().speck_dcsr_update(ctypes.byref(p["dA"]._c), None, np.ascontiguousarray(col).ctypes.data,
+                                                 None, A.data.dtype.itemsize) == 0
+            p["R"], p["ab"] = po.spgemm(p["A"], p["B"])
         if os.environ.get("STRESS_VERBOSE"):
             print(f"     step {it}: problem {j} call {p['calls'] + 1} {p['name']}", flush=True)
         if it == int(os.environ.get("STRESS_UNCAPTURED_AT", "-1")):   # this step: the launches of the replay, uncaptured
