@@ -49,7 +49,7 @@ __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductS
     Acc<T>* s_av = s_vals + NP;                           // [L]   a_ik of the j-th non-empty entry
     u32* s_off = reinterpret_cast<u32*>(s_av + L);        // [L]   its B-row start minus its first product number
     const ListHead head = open_list<FUSED>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
-    if (!FUSED && head.miss) return;
+    if (head.miss) return;  // (FUSED too: the records of a block whose rows changed are not written by a predicted binning)
     const RowRec* recs = head.recs;
     u32 idx = head.rs.idx;
     const u32 stride = head.rs.stride, count = head.rs.end;

@@ -47,6 +47,9 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
     u32* scratch = tab + CAP + 2 * G::SIZE;
     RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr, scratch + sym_scratch_words<G, THREADS>()};
     const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
+    // (a replayed sequence that an earlier kernel has declared void: with predicted binning the records of a block
+    //  whose rows changed are NOT written -- nothing may walk them)
+    if (head.miss) return;
     const RowRec* recs = head.recs;
     u32 idx = head.rs.idx;
     const u32 stride = head.rs.stride, count = head.rs.end;
@@ -86,6 +89,9 @@ __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductS
     const u32 gid = threadIdx.x / L;
     u32* s_off = reinterpret_cast<u32*>(smem + gid * sym_esc_group_lds<L>());
     const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
+    // (a replayed sequence that an earlier kernel has declared void: with predicted binning the records of a block
+    //  whose rows changed are NOT written -- nothing may walk them)
+    if (head.miss) return;
     const RowRec* recs = head.recs;
     u32 idx = head.rs.idx;
     const u32 stride = head.rs.stride, count = head.rs.end;
@@ -143,6 +149,9 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
     RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr, scratch + THREADS / 64 + 2};
     constexpr u64 kWindowCols = u64(WORDS) * 32;
     const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
+    // (a replayed sequence that an earlier kernel has declared void: with predicted binning the records of a block
+    //  whose rows changed are NOT written -- nothing may walk them)
+    if (head.miss) return;
     const RowSlice rs = head.rs;
     const RowRec* recs = head.recs;
     RowRec next = head.next;

@@ -1119,6 +1119,19 @@ def test_randomised_problems_taking_turns_on_one_config():
     assert "failures: 0" in r.stdout and "replayed=1" in r.stdout
 
 
+def test_randomised_structure_changes_under_the_same_pointers():
+    """The same tool, seed 202 with two problems: besides new values, now and then a twentieth of A's rows get new
+    column ids IN PLACE (same row lengths).  A replay must notice whatever it predicted and the eager path re-run.  In
+    round 3 the symbolic kernels of a sequence with predicted binning walked the records of a block whose rows had
+    changed -- which that block, rightly, had not written -- and never came back (step 177 of this seed)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "stress_gpu.py")
+    r = subprocess.run([sys.executable, tool, "400", "202", "interleave=2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "failures: 0" in r.stdout and "replayed=1" in r.stdout
+
+
 def test_a_captured_sequence_owns_its_prediction(cfg):
     """A replayed sequence verifies (and places rows by) what the previous identical call decided.  That prediction
     belongs to the sequence: an eager multiply of OTHER matrices on the same config in between -- more rows, other
