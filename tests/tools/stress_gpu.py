@@ -102,6 +102,20 @@ def interleaved(cfg, rng, steps, alive):
             assert _lib.load().speck_dcsr_update(ctypes.byref(p["dA"]._c), None, np.ascontiguousarray(col).ctypes.data,
                                                  None, A.data.dtype.itemsize) == 0
             p["R"], p["ab"] = po.spgemm(p["A"], p["B"])
+        if rng.random() < 0.04 and p["B"].nnz:   # ... and the same for rows of B
+            import ctypes
+            from speck_amd import _lib
+            B = p["B"]
+            ro = B.row_offsets.astype(np.int64)
+            col = B.col_ids.copy()
+            for r in rng.choice(B.rows, size=max(1, B.rows // 20), replace=False):
+                n = int(ro[r + 1] - ro[r])
+                if n:
+                    col[ro[r]:ro[r + 1]] = np.sort(rng.choice(B.cols, size=n, replace=False)).astype(np.uint32)
+            p["B"] = po.HostCSR(B.rows, B.cols, B.row_offsets, col, B.data)
+            assert _lib.load().speck_dcsr_update(ctypes.byref(p["dB"]._c), None, np.ascontiguousarray(col).ctypes.data,
+                                                 None, B.data.dtype.itemsize) == 0
+            p["R"], p["ab"] = po.spgemm(p["A"], p["B"])
         if os.environ.get("STRESS_VERBOSE"):
             print(f"     step {it}: problem {j} call {p['calls'] + 1} {p['name']}", flush=True)
         if it == int(os.environ.get("STRESS_UNCAPTURED_AT", "-1")):   # this step: the launches of the replay, uncaptured
