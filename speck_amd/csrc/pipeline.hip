@@ -67,6 +67,13 @@ struct ReplayPlan {
     u32 num_mask, launch_mask;
     u32 num_counts[kMaxClasses];
     bool direct, fused, pred_scan, pred_sym;
+    // ... and everything else of "the last eager call" the launches are sized from: a sequence that is enqueued anew at
+    // every call (caller's stream, replay_uncaptured, profile_replay) must not pick up what a multiply of ANOTHER
+    // problem left in the config since (a captured graph has it baked in)
+    u32 sym_mask;
+    u32 sym_counts[kMaxClasses];
+    u64 g_products, nf_cap_entries;
+    u32 nf_wcols;
 };
 
 struct speck_config {
@@ -763,6 +770,11 @@ ReplayPlan plan_replay(const speck_config* c)
     ReplayPlan p;
     p.num_mask = c->last_num_mask;
     std::memcpy(p.num_counts, c->last_num_counts, sizeof(p.num_counts));
+    p.sym_mask = c->last_sym_mask;
+    std::memcpy(p.sym_counts, c->last_sym_counts, sizeof(p.sym_counts));
+    p.g_products = c->last_g_products;
+    p.nf_cap_entries = c->nf_cap_entries;
+    p.nf_wcols = c->nf_wcols;
     // Numeric-first rows: the eager call wrote them to scratch slots and copied them after the scan (nothing else
     // knows where a row goes before the scan).  The replayed sequence knows where they WENT: it writes each row
     // straight to the offset the previous identical call gave it, provided its fresh nnz is the same, and the scan
@@ -809,11 +821,17 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
     c->capture_c_val = C->data;
     struct Reset {
         speck_config* c;
-        ~Reset() { c->capture_direct = c->capture_fused = c->capture_pred_scan = c->capture_pred_sym = false; }
-    } reset{c};
-    int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, c->last_sym_mask,
-                           p.num_mask, true, tm, c->last_sym_counts, nullptr,
-                           c->last_g_products, p.num_counts[NUM_G], 3u, c->nf_cap_entries);
+        u32 wcols;
+        ~Reset()
+        {
+            c->capture_direct = c->capture_fused = c->capture_pred_scan = c->capture_pred_sym = false;
+            c->nf_wcols = wcols;
+        }
+    } reset{c, c->nf_wcols};
+    c->nf_wcols = p.nf_wcols;
+    int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, p.sym_mask,
+                           p.num_mask, true, tm, p.sym_counts, nullptr,
+                           p.g_products, p.num_counts[NUM_G], 3u, p.nf_cap_entries);
     if (rc != SPECK_OK) return rc;
     if (tm) {
         tm->ev_num = tm->ev;
@@ -848,6 +866,14 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     c->graph_fused = plan.fused;
     c->graph_pred_scan = plan.pred_scan;
     c->graph_pred_sym = plan.pred_sym;
+    if (c->use_user_stream || c->replay_uncaptured) {
+        // the launches of this sequence are enqueued one by one at every call (multiply_impl): only the plan and the
+        // sequence's copy of the prediction are kept -- a caller's stream is never put into capture mode
+        c->graph_key = key;
+        c->graph_valid = true;
+        ++c->graph_captures;
+        return SPECK_OK;
+    }
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     const int rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, nullptr, nullptr);
     hipGraph_t g = nullptr;
@@ -1409,6 +1435,7 @@ int speck_config_set_stream(speck_config* c, void* hip_stream)
     if (!c) return SPECK_ERR_INVALID;
     c->user_stream = static_cast<hipStream_t>(hip_stream);
     c->use_user_stream = hip_stream != nullptr;
+    drop_graph(c);  // (a sequence is tied to the stream it was made for, and to HOW it is replayed there)
     return SPECK_OK;
 }
 
@@ -1430,7 +1457,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
     else if (n == "profile_replay") c->profile_replay = value != 0;
-    else if (n == "replay_uncaptured") c->replay_uncaptured = value != 0;
+    else if (n == "replay_uncaptured") {
+        c->replay_uncaptured = value != 0;
+        drop_graph(c);
+    }
     else if (n == "analysis_wide_rows") {
         set_analysis_wide_rows((u32)value);
         drop_graph(c);
