@@ -784,7 +784,7 @@ ReplayPlan plan_replay(const speck_config* c)
     // phase then accounts for them as rows that are already in place.
     constexpr u32 kEscNum = (1u << NUM_G8) | (1u << NUM_G16);
     p.fused = c->esc_fused && c->nf_direct && c->pred_valid && (p.num_mask & kEscNum) != 0 &&
-              c->cp.sym_g8 == c->cp.num_g8;
+              c->cp.sym_g8 == c->cp.num_g8 && c->merge_light;  // (the fused body lives in the merged light launch)
     if (p.fused) {
         p.num_counts[NUM_NFCOPY] += p.num_counts[NUM_G8] + p.num_counts[NUM_G16];
         p.num_counts[NUM_G8] = p.num_counts[NUM_G16] = 0;
@@ -1073,7 +1073,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     c->pred_valid = c->pred_tiles_valid = false;
     const bool keep_pred = (c->nf_direct || c->pred_scan) && c->use_graph && ensure_pred(c->pred, m);
     // (the shape of the tile tables: will that replay finish the register-class rows in its symbolic phase?)
-    const bool fold_esc = keep_pred && c->esc_fused && c->nf_direct && c->cp.sym_g8 == c->cp.num_g8;
+    const bool fold_esc = keep_pred && c->esc_fused && c->nf_direct && c->cp.sym_g8 == c->cp.num_g8 && c->merge_light;
     auto front = [&](u32 parts) {
         // (the offsets go to scratch: C.row_offsets -- possibly the caller's reused buffer -- is written only once
         //  nothing can fail any more)
