@@ -49,8 +49,9 @@ def to_sa(h):
 
 def random_problem(rng):
     dtype = np.float64 if rng.random() < 0.8 else np.float32
-    m = int(rng.integers(1, 3000))
-    k = int(rng.integers(1, 3000))
+    scale = int(os.environ.get("STRESS_SCALE", "1"))   # rows of A and B up to 3000 x scale
+    m = int(rng.integers(1, 3000 * scale))
+    k = int(rng.integers(1, 3000 * scale))
     n = int(rng.choice([50, 1000, 20000, 300000, 3000000]))
     ka = rng.choice(["uniform", "powerlaw", "sparse_empty", "dense_band"])
     kb = rng.choice(["uniform", "powerlaw", "sparse_empty", "dense_band"])
