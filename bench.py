@@ -123,8 +123,47 @@ class Env:
         # RCCL communicator and take the library's host-staged transport -- same plan / displacement code
         self.exchange = args.exchange
         self.comm = None
+        self.exchange_note = None
         if self.world > 1 and self.exchange == "native":
-            self.comm = NativeComm(self.local_rank, TRANSPORT_HOSTMEM if self.shared_gpu else TRANSPORT_RCCL)
+            # The library's RCCL transport has only ever met ranks that share one GPU in this build environment (no
+            # multi-GPU box): it is brought up and SELF-TESTED here -- a tiny gatherv whose result rank 0 checks -- and
+            # if any rank fails, all ranks fall back to the torch.distributed exchange together (and the line says so).
+            ok, why = 1, ""
+            try:
+                if os.environ.get("SPECK_BENCH_FAIL_NATIVE") == "1":   # (test hook: the bring-up fails on every rank --
+                    raise RuntimeError("forced by SPECK_BENCH_FAIL_NATIVE")  #  a failure of ONE rank inside a collective
+                                                                             #  cannot be recovered from: the others wait)
+                self.comm = NativeComm(self.local_rank, TRANSPORT_HOSTMEM if self.shared_gpu else TRANSPORT_RCCL)
+                rows = 3 + self.rank
+                ro = np.arange(rows + 1, dtype=np.uint32) * 2
+                col = np.tile(np.array([1, 5], dtype=np.uint32), rows)
+                val = np.full(2 * rows, float(self.rank + 1))
+                shard = sa.dCSR.from_host(sa.HostCSR(rows, 8, ro, col, val))
+                full = self.comm.gatherv(shard, 8, root=0)
+                if self.rank == 0:
+                    h = full.to_host()
+                    want_rows = sum(3 + r for r in range(self.world))
+                    want_val = np.concatenate([np.full(2 * (3 + r), float(r + 1)) for r in range(self.world)])
+                    good = (h.rows == want_rows and h.nnz == 2 * want_rows and
+                            (h.row_offsets == np.arange(want_rows + 1, dtype=np.uint32) * 2).all() and
+                            (h.col_ids == np.tile(np.array([1, 5], dtype=np.uint32), want_rows)).all() and
+                            (h.data == want_val).all())
+                    if not good:
+                        ok, why = 0, "self-test gatherv returned a wrong matrix"
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.int64, device=self.dev if not self.shared_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if self.comm is not None:
+                    try:
+                        self.comm.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                self.comm = None
+                self.exchange = "torch"
+                self.exchange_note = "native exchange failed its self-test on some rank (" + (why or "another rank") + \
+                                     "): fell back to torch.distributed"
 
     def new_config(self):
         cfg = sa.spECKConfig.initialize(self.local_rank)
@@ -541,6 +580,7 @@ def main():
                 "workload": wl_name, "rows": A.rows, "nnzA": A.nnz, "products": res["P"],
                 "nnzC": res["nnzC"], "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",
                 "gather": bool(n_gpus > 1 and not args.no_gather),
+                "exchange_note": env.exchange_note,
                 "exchange": (f"pipelined gatherv to rank 0 ({env.exchange}: " +
                              ("speck_gather_* of the C ABI, " + ("host-staged transport" if env.shared_gpu else "RCCL")
                               if env.exchange == "native" else "torch.distributed") + ")")

@@ -100,6 +100,25 @@ def test_bench_two_ranks_share_the_gpu():
     assert c5["verified"] is True
 
 
+def test_bench_falls_back_to_the_torch_exchange_when_the_native_one_fails_its_self_test():
+    """bench.py brings the library's exchange up with a tiny self-checked gatherv; if that fails (here: forced on every
+    rank) all ranks switch to the torch.distributed exchange together, and the line says so."""
+    import json
+    import sys
+    env = dict(os.environ, SPECK_BENCH_SHARED_GPU="1", SPECK_BENCH_FAIL_NATIVE="1")
+    port = 29000 + os.getpid() % 300
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--scale", "0.1", "--no-config5", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["value"] > 0
+    assert "torch" in d["config"]["exchange"] and "fell back" in d["config"]["exchange_note"]
+
+
 def test_bench_strong_scaling_mode_two_ranks_share_the_gpu():
     """`--workload nlpkkt --scaling strong`: the same matrix at every N, sharded by products."""
     import json
