@@ -1005,6 +1005,17 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         bool have = c->graph_valid && c->graph_key == key;
         if (!have && c->last_key_valid && c->last_key == key)
             have = capture_graph<T>(c, s, A, B, C, sc, key) == SPECK_OK;
+        if (have && c->exec_dirty && !(c->replay_uncaptured || c->use_user_stream)) {
+            // (see below) a fresh executable for a graph that other launches have passed; no executable: eager path
+            if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+            c->graph_exec = nullptr;
+            if (hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                drop_graph(c);
+                have = false;
+            }
+            c->exec_dirty = false;
+        }
         if (have) {
             // Launching the SAME executable graph again after other launches went onto the same stream in between
             // (an eager multiply of another problem on this config) ended in GPU memory faults on this runtime --
@@ -1018,16 +1029,6 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 rc = enqueue_replay<T>(c, s, A, B, C, sc, c->graph_plan, nullptr, nullptr);
                 if (rc != SPECK_OK) return rc;
             } else {
-                if (c->exec_dirty) {
-                    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-                    c->graph_exec = nullptr;
-                    if (hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) != hipSuccess) {
-                        (void)hipGetLastError();
-                        drop_graph(c);
-                        return SPECK_ERR_HIP;
-                    }
-                    c->exec_dirty = false;
-                }
                 HIP_TRY(hipGraphLaunch(c->graph_exec, s));
             }
             // the last node of the sequence stores a ticket into pinned memory
