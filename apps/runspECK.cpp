@@ -343,7 +343,8 @@ int main(int argc, char* argv[])
                 speck_timings tm{};
                 int rc = speck_multiply_f64(cfgs[slot].handle, &mine, &b, &out[slot], &tm);
                 if (rc != SPECK_OK) throw std::runtime_error(speck_status_string(rc));
-                if (!plan && speck_gather_plan_create(comm, 0, out[slot].rows, b.cols, out[slot].nnz, 8, 2, &plan) != SPECK_OK)
+                // (mine.rows, not out[slot].rows: a shard without products comes back with nnz = 0 and no row count)
+                if (!plan && speck_gather_plan_create(comm, 0, mine.rows, b.cols, out[slot].nnz, 8, 2, &plan) != SPECK_OK)
                     throw std::runtime_error("gather plan failed");
                 if (speck_gather_start(plan, slot, &out[slot]) != SPECK_OK) throw std::runtime_error("gather start failed");
             }

@@ -49,6 +49,7 @@ from speck_amd.api import NUM_CLASS_NAMES  # noqa: E402
 from speck_amd.sharding import GatherPlan, NativeComm, NativeGatherPlan, TRANSPORT_HOSTMEM, TRANSPORT_RCCL  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+XGMI_LINK_GBS = 153.0  # one xGMI link, per direction (7 links per GPU, point to point)
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XCDs
 # LDS atomic issue ceiling, wave-instructions per second for the whole chip: ds_add_f64 takes 20.6 cycles per
 # wave-instruction and CU (scripts/ubench/lds_atomics.hip); 256 CUs at 2.4 GHz
@@ -72,7 +73,7 @@ def shard_tensors(dC):
     n, rows = dC.nnz, dC.rows
     ro = torch.as_tensor(_DevArray(dC._c.row_offsets, rows + 1, "<i4"), device="cuda")
     col = torch.as_tensor(_DevArray(dC._c.col_ids, max(n, 1), "<i4"), device="cuda")[:n]
-    val = torch.as_tensor(_DevArray(dC._c.data, max(n, 1), "<f8"), device="cuda")[:n]
+    val = torch.as_tensor(_DevArray(dC._c.data, max(n, 1), "<f4" if dC.dtype == np.float32 else "<f8"), device="cuda")[:n]
     return ro, col, val
 
 
@@ -116,7 +117,10 @@ class Env:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
         else:
             torch.cuda.set_device(0)
-        assert self.world == args.gpus or self.world == 1, "launch with torch.distributed.run for --gpus > 1"
+        # (main() re-launches itself as N ranks when --gpus N arrives without a launcher: a line never claims fewer
+        #  GPUs than it was asked for)
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
         self.dev = torch.device("cuda", self.local_rank)
         self.opts = [o.split("=") for o in args.opt]
         # the exchange itself: the library's own RCCL gatherv (C ABI); ranks that share one GPU cannot form an
@@ -201,7 +205,7 @@ class Job:
         self.t_col = torch.from_numpy(A.col_ids.view(np.int32)).to(dev)
         self.t_val = torch.from_numpy(A.data).to(dev)
         self.dA = sa.dCSR.from_device(A.rows, A.cols, A.nnz, self.t_ro.data_ptr(), self.t_col.data_ptr(),
-                                      self.t_val.data_ptr(), keep=(self.t_ro, self.t_col, self.t_val),
+                                      self.t_val.data_ptr(), dtype=A.data.dtype, keep=(self.t_ro, self.t_col, self.t_val),
                                       host_row_offsets=A.row_offsets)
         self.cfg = env.new_config()
         if env.world > 1:
@@ -212,9 +216,9 @@ class Job:
         self.gather = gather and env.world > 1
         # N > 1: two output matrices (each with its own config: a captured launch sequence is tied to
         # the buffers it writes) alternate, so that a shard can be sent while the next one is computed
-        self.slots = [(self.cfg, sa.dCSR())]
+        self.slots = [(self.cfg, sa.dCSR(A.data.dtype))]
         if self.gather:
-            self.slots.append((env.new_config(), sa.dCSR()))
+            self.slots.append((env.new_config(), sa.dCSR(A.data.dtype)))
         self.plan = None
         self.n_step = 0
         self.last = None  # (config, output matrix) of the last step
@@ -235,7 +239,8 @@ class Job:
         if self.gather and exchange:
             if self.env.comm is not None:
                 if self.plan is None:
-                    self.plan = NativeGatherPlan(self.env.comm, sC.rows, sC.cols, sC.nnz, 8, root=0,
+                    self.plan = NativeGatherPlan(self.env.comm, self.mine.rows, self.dA.cols, sC.nnz,
+                                                 self.A.data.dtype.itemsize, root=0,
                                                  slots=len(self.slots))
                 self.plan.start(slot, sC)
             else:
@@ -368,7 +373,12 @@ def ceilings_for(counters, workload, launch_name, ms):
     return out or None
 
 
-def roofline_block(workload, st, kernel_ms, num_ms):
+def b_num_bytes(rows, nnz_a, products, nnz_c, vsize=8):
+    """the algorithmic bytes of the numeric phase of one multiply."""
+    return 4 * (rows + 1) + (4 + vsize) * nnz_a + 8 * nnz_a + (4 + vsize) * products + 4 * (rows + 1) + (4 + vsize) * nnz_c
+
+
+def roofline_block(workload, st, kernel_ms, num_ms, b_num=None):
     """Every numeric launch with its algorithmic bytes, duration and fraction of the HBM peak; the
     headline `kernel` is the launch with the LONGEST duration (it bounds the phase), `largest` the one
     that moves the most algorithmic bytes."""
@@ -411,7 +421,12 @@ def roofline_block(workload, st, kernel_ms, num_ms):
                       "and the numeric-first launch carry their own begin / end stamps (hipExtLaunchKernelGGL), the other "
                       "launches are bracketed by two event records",
         "largest": {"kernel": f"numeric:{big['name']}", "bytes": big["bytes"], "ms": big["ms"], "frac": big["frac"]},
-        "numeric_phase_frac": round(total_bytes / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+        # the PHASE by SURVEY 8(d)'s B_num alone (the north star's ">= 40 % on the numeric phase"); the launches above may
+        # carry more: a fused light launch also moves the symbolic bytes of the classes it only counts
+        "numeric_phase_frac": round((b_num if b_num else total_bytes) / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+        "numeric_phase_bytes": int(b_num if b_num else total_bytes),
+        "numeric_phase_ms": round(num_ms, 5),
+        "numeric_phase_frac_by_launch_bytes": round(total_bytes / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
         "ceilings": dom["ceilings"],
         "ceilings_source": ((csrc or "profiles/counters.json") + ": separate rocprofv3 --pmc passes of the same command "
                             "(counts per launch) over the duration measured in this run; peaks: HBM 8 TB/s, L2 34.5 TB/s "
@@ -475,6 +490,16 @@ def measure(env, A, steps, warmup, gather, profile, verify=None, eager=False):
         bad = 0 if out["verify"]["ok"] else 1
         out["verify"]["ok_all_ranks"] = env.sum_over_ranks(bad)[0] == 0
     out["P"], out["nnzC"] = env.sum_over_ranks(P_local, nnzc_local)
+    # the floor the exchange puts under a step at N > 1: every peer -> root transfer rides ONE xGMI link, so a step
+    # cannot be shorter than the largest peer shard (row counts + column ids + values) over that link's peak
+    out["exchange_floor_ms"] = None
+    if env.world > 1:
+        mine_bytes = 4 * (job.bounds[1] - job.bounds[0]) + 12 * nnzc_local
+        t = torch.zeros(env.world, dtype=torch.int64, device=env.dev if not env.shared_gpu else "cpu")
+        t[env.rank] = mine_bytes
+        dist.all_reduce(t)
+        peers = [int(x) for i, x in enumerate(t.tolist()) if i != 0]
+        out["exchange_floor_ms"] = round(max(peers) / XGMI_LINK_GBS / 1e9 * 1e3, 4) if peers else 0.0
     out["elapsed"] = elapsed
     out["ms_per_step"] = elapsed * 1e3 / steps
     out["gflops"] = 2.0 * out["P"] / (elapsed / steps) / 1e9
@@ -501,13 +526,18 @@ def measure(env, A, steps, warmup, gather, profile, verify=None, eager=False):
 def config_entry(env, workload, wl_name, data_label, A, res, steps):
     """One single-GPU configuration as an object of `configs` (and the body of the headline)."""
     st = res["st"]
-    roof = roofline_block(workload, st, res["kernel_ms"], res["num_ms"])
+    vsize = 4 if A.data.dtype == np.float32 else 8
+    # (the committed counter passes are fp64 runs: an fp32 leg finds none under its own key)
+    roof = roofline_block(workload if vsize == 8 else workload + "_f32", st, res["kernel_ms"], res["num_ms"], b_num_bytes(A.rows, A.nnz, res["P"], res["nnzC"], vsize))
+    eager_ms = res["eager_ms_per_step"]
     return {
-        "workload": wl_name, "name": workload, "data": data_label, "rows": A.rows, "nnzA": A.nnz,
+        "workload": wl_name, "name": workload, "data": data_label, "dtype": "f32" if vsize == 4 else "f64",
+        "rows": A.rows, "nnzA": A.nnz,
         "products": res["P"], "nnzC": res["nnzC"], "steps": steps,
         "ms_per_step": round(res["ms_per_step"], 4),
-        "eager_ms_per_step": round(res["eager_ms_per_step"], 4) if res["eager_ms_per_step"] else None,
+        "eager_ms_per_step": round(eager_ms, 4) if eager_ms else None,
         "value": round(res["gflops"], 3), "unit": "GFLOP/s",
+        "value_eager": round(2.0 * res["P"] / (eager_ms * 1e-3) / 1e9, 3) if eager_ms else None,
         "phases_ms": {"symbolic": round(res["sym_ms"], 4), "numeric": round(res["num_ms"], 4)},
         "roofline": roof,
         "kernels_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items() if v > 0},
@@ -535,11 +565,14 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the nlpkkt160 strong-scaling leg")
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the other single-GPU configurations")
     ap.add_argument("--no-verify", action="store_true", help="do not check the output of the last timed step")
+    ap.add_argument("--no-f32", action="store_true", help="N=1: skip the fp32 legs (mac_econ, cant)")
     ap.add_argument("--configs-steps", type=int, default=20)
     ap.add_argument("--config5-scale", type=float, default=1.0)
     ap.add_argument("--config5-steps", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (tuning)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     env = Env(args)
     n_gpus, rank = env.world, env.rank
 
@@ -571,6 +604,10 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"],
             "eager_ms_per_step": head["eager_ms_per_step"],
+            "value_eager": head["value_eager"],
+            "value_eager_note": "the same steps with the replay off (option use_graph = 0): what a caller pays whose "
+                                "structure changes from call to call; `value` is the reference's benchmark loop "
+                                "(source/Executor.cpp:59-72: same buffers every iteration), served by the replayed sequence",
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -580,6 +617,10 @@ def main():
                 "workload": wl_name, "rows": A.rows, "nnzA": A.nnz, "products": res["P"],
                 "nnzC": res["nnzC"], "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",
                 "gather": bool(n_gpus > 1 and not args.no_gather),
+                "exchange_floor_ms": res["exchange_floor_ms"],
+                "exchange_floor_note": ("largest peer shard (4 B per row + 12 B per entry of C) over one 153 GB/s xGMI link: "
+                                        "`value` includes the gatherv and cannot beat it; the >= 6x row-sharded speed-up of "
+                                        "the north star is a statement about `multiply_only`") if n_gpus > 1 else None,
                 "exchange_note": env.exchange_note,
                 "exchange": (f"pipelined gatherv to rank 0 ({env.exchange}: " +
                              ("speck_gather_* of the C ABI, " + ("host-staged transport" if env.shared_gpu else "RCCL")
@@ -620,6 +661,19 @@ def main():
             verdicts.append(entries[-1]["verified"])
             del Aw, rw
         out["configs"] = entries
+        # the <float, ...> instantiation (source/GPU/Multiply.cu:1130) on the two mid-density inputs: 8-byte table
+        # entries / 8 bytes per product in the byte model; checked against the product in fp64 (4 eps32 * sum|a*b|)
+        if not args.no_f32:
+            f32 = []
+            for w in ("mac_econ", "cant"):
+                Aw, label_w, name_w = load_workload(w, 1.0, args.seed)
+                Aw = sa.HostCSR(Aw.rows, Aw.cols, Aw.row_offsets, Aw.col_ids, Aw.data.astype(np.float32))
+                rw = measure(env, Aw, args.configs_steps, 3, gather=False, profile=True, verify=verify_mode(w, Aw),
+                             eager=True)
+                f32.append(config_entry(env, w, name_w + " (fp32 values)", label_w, Aw, rw, args.configs_steps))
+                verdicts.append(f32[-1]["verified"])
+                del Aw, rw
+            out["configs_f32"] = f32
 
     # ---- BASELINE.json configs[4]: the nlpkkt160 stand-in, STRONG scaling, at this N
     if not args.no_config5 and not (args.workload == "nlpkkt" and args.scaling == "strong"):
@@ -634,6 +688,7 @@ def main():
                 "multiply_only": r5["multiply_only"] if r5["multiply_only"] is not None else
                 {"value": round(r5["gflops"], 3), "unit": "GFLOP/s", "ms_per_step": round(r5["ms_per_step"], 4),
                  "note": "N = 1: nothing to exchange"},
+                "exchange_floor_ms": r5["exchange_floor_ms"],
                 "verified": r5["verify"]["ok_all_ranks"] if r5["verify"] else None,
                 "verify": r5["verify"],
             }
@@ -653,6 +708,39 @@ def main():
         dist.destroy_process_group()
     if failed:
         sys.exit(3)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (what torch.distributed.run would do on one
+    node: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1), pass rank 0's output
+    through and return the worst exit code.  Refuses to run N ranks on fewer GPUs unless SPECK_BENCH_SHARED_GPU=1 (the
+    plumbing check of the tests): a line that says "n_gpus": N was measured on N GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("SPECK_BENCH_SHARED_GPU") != "1":
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); nothing measured "
+              f"(SPECK_BENCH_SHARED_GPU=1 runs the ranks on GPU 0 as a plumbing check)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    try:
+        for pr in procs:
+            rc = pr.wait()
+            worst = worst or rc
+    finally:
+        for pr in procs:          # a rank that died must not leave the others waiting in a collective forever
+            if pr.poll() is None:
+                pr.terminate()
+    return worst
 
 
 def cpu_baseline(A, P):

@@ -72,32 +72,41 @@ CSR<T> loadMTXasCSR(const char* file)
     return speck_detail::from_handle<T>(h);
 }
 
-// ---- convert() (reference source/dCSR.cpp:51-115)
+// ---- convert() (reference source/dCSR.cpp:51-115).  `padding`: buffers for rows + padding rows and nnz + 8 * padding
+// entries, rows / nnz / cols of the source (dCSR.cpp:53-54, 70-71, 83-84, 94-95).
 template <typename T>
-void convert(dCSR<T>& dst, const CSR<T>& src, unsigned int /*padding*/)
+void convert(dCSR<T>& dst, const CSR<T>& src, unsigned int padding)
 {
     speck_dcsr d = dst.raw();
-    speck_dcsr_upload(&d, src.rows, src.cols, src.nnz, src.row_offsets.get(), src.col_ids.get(), src.data.get(), sizeof(T));
+    speck_dcsr_upload_padded(&d, src.rows, src.cols, src.nnz, src.row_offsets.get(), src.col_ids.get(), src.data.get(),
+                             sizeof(T), padding);
     dst.adopt(d);
 }
 template <typename T>
-void convert(CSR<T>& dst, const dCSR<T>& src, unsigned int /*padding*/)
+void convert(CSR<T>& dst, const dCSR<T>& src, unsigned int padding)
 {
-    dst.alloc(src.rows, src.cols, src.nnz);
+    dst.alloc(src.rows + padding, src.cols, src.nnz + 8 * size_t(padding));
+    dst.rows = src.rows;
+    dst.nnz = src.nnz;
+    dst.cols = src.cols;
     speck_dcsr d = src.raw();
     speck_dcsr_download(&d, dst.row_offsets.get(), dst.col_ids.get(), dst.data.get(), sizeof(T));
 }
+// device to device: no host round trip (dCSR.cpp:81-89)
 template <typename T>
-void convert(dCSR<T>& dst, const dCSR<T>& src, unsigned int /*padding*/)
+void convert(dCSR<T>& dst, const dCSR<T>& src, unsigned int padding)
 {
-    CSR<T> tmp;
-    convert(tmp, src, 0u);
-    convert(dst, tmp, 0u);
+    speck_dcsr d = dst.raw(), s = src.raw();
+    speck_dcsr_copy(&d, &s, sizeof(T), padding);
+    dst.adopt(d);
 }
 template <typename T>
-void convert(CSR<T>& dst, const CSR<T>& src, unsigned int /*padding*/)
+void convert(CSR<T>& dst, const CSR<T>& src, unsigned int padding)
 {
-    dst.alloc(src.rows, src.cols, src.nnz);
+    dst.alloc(src.rows + padding, src.cols, src.nnz + 8 * size_t(padding));
+    dst.rows = src.rows;
+    dst.nnz = src.nnz;
+    dst.cols = src.cols;
     std::memcpy(dst.data.get(), src.data.get(), src.nnz * sizeof(T));
     std::memcpy(dst.col_ids.get(), src.col_ids.get(), src.nnz * sizeof(unsigned int));
     std::memcpy(dst.row_offsets.get(), src.row_offsets.get(), (src.rows + 1) * sizeof(unsigned int));

@@ -26,6 +26,17 @@ void MultiplyspECK(const dCSR<DataType>& A, const dCSR<DataType>& B, dCSR<DataTy
 template <typename DataType, int BLOCKS_PER_SM, int THREADS_PER_BLOCK, int MAX_DYNAMIC_SHARED, int MAX_STATIC_SHARED>
 void MultiplyspECKImplementation(const dCSR<DataType>& A, const dCSR<DataType>& B, dCSR<DataType>& matOut,
                                  spECKConfig& config, Timings& timings);
+// The reference declares the last argument as `Timings &timings = Timings()` (include/Multiply.h:19) -- a temporary
+// bound to a non-const reference, which only its own compiler accepts.  The call it permits, without the timings
+// argument, is this overload.
+template <typename DataType, int BLOCKS_PER_SM, int THREADS_PER_BLOCK, int MAX_DYNAMIC_SHARED, int MAX_STATIC_SHARED>
+inline void MultiplyspECKImplementation(const dCSR<DataType>& A, const dCSR<DataType>& B, dCSR<DataType>& matOut,
+                                        spECKConfig& config)
+{
+    Timings timings;
+    MultiplyspECKImplementation<DataType, BLOCKS_PER_SM, THREADS_PER_BLOCK, MAX_DYNAMIC_SHARED, MAX_STATIC_SHARED>(
+        A, B, matOut, config, timings);
+}
 
 #ifndef SPECK_DECLARATIONS_ONLY
 template <typename DataType, int BLOCKS_PER_SM, int THREADS_PER_BLOCK, int MAX_DYNAMIC_SHARED, int MAX_STATIC_SHARED>

@@ -115,7 +115,13 @@ int speck_last_stats(const speck_config *cfg, speck_stats *out);
  * Ownership as in the reference: A,B caller-owned, read-only; C is
  * allocated by the callee and freed by the caller (speck_dcsr_free); if
  * C->rows == A->rows and C->row_offsets != NULL that buffer is reused; data/col_ids are
- * re-allocated only when C->nnz != nnz(C).  On error C is left untouched. */
+ * re-allocated only when C->nnz != nnz(C).  On error the C STRUCT and its allocations are left untouched
+ * (no field rewritten, nothing freed or allocated).  The CONTENTS of the buffers are untouched too, with one
+ * exception: a repeated call on the same buffers that runs the replayed launch sequence places finished rows
+ * straight into C->col_ids / C->data (options nf_direct / esc_fused, both on by default) before the device-side
+ * checks of that sequence can reject it; if the eager re-run that follows then fails as well (inputs changed in
+ * place into something invalid, out of memory for a grown C), the call returns the error with the contents of
+ * col_ids / data unspecified.  row_offsets is rewritten only by a call that completes. */
 int speck_multiply_f64(speck_config *cfg, const speck_dcsr *A, const speck_dcsr *B, speck_dcsr *C,
                        speck_timings *timings);
 /* the <float,...> instantiation, source/GPU/Multiply.cu:1130 */
@@ -148,6 +154,14 @@ int speck_dcsr_upload(speck_dcsr *dst, uint64_t rows, uint64_t cols, uint64_t nn
                       size_t value_size);
 int speck_dcsr_download(const speck_dcsr *src, uint32_t *h_row_offsets, uint32_t *h_col_ids,
                         void *h_data, size_t value_size);
+/* convert(dCSR&, const CSR&, padding) -- source/dCSR.cpp:51-66: buffers for rows + padding rows and nnz + 8 * padding
+ * entries, rows / nnz of the source, the padding zero-filled.  speck_dcsr_upload = padding 0. */
+int speck_dcsr_upload_padded(speck_dcsr *dst, uint64_t rows, uint64_t cols, uint64_t nnz,
+                             const uint32_t *h_row_offsets, const uint32_t *h_col_ids, const void *h_data,
+                             size_t value_size, uint32_t padding);
+/* convert(dCSR&, const dCSR&, padding) -- source/dCSR.cpp:81-89: device-to-device, no host round trip.  `src` may be
+ * a row-range view with absolute offsets: the copy is rebased to start at 0.  dst must not alias src. */
+int speck_dcsr_copy(speck_dcsr *dst, const speck_dcsr *src, size_t value_size, uint32_t padding);
 /* overwrite the contents of an existing device matrix in place (same rows / nnz, same device
  * pointers); any of the host arrays may be NULL */
 int speck_dcsr_update(speck_dcsr *dst, const uint32_t *h_row_offsets, const uint32_t *h_col_ids,

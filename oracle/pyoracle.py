@@ -158,6 +158,17 @@ def spgemm(A, B, threads=0, with_abs=True, out=None):
     return HostCSR(A.rows, B.cols, cnt, ci, da), ab
 
 
+def spgemm_f64_of(A, B, threads=0):
+    """The product of fp32 inputs computed in fp64 (the inputs convert exactly): the reference value a float
+    implementation is judged against -- |c - c_ref| <= k * eps32 * sum|a*b| -- without the error of the checker's
+    own float accumulation.  fp64 inputs: spgemm itself."""
+    if A.data.dtype == np.float64 and B.data.dtype == np.float64:
+        return spgemm(A, B, threads=threads)
+    A64 = HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float64))
+    B64 = A64 if B is A else HostCSR(B.rows, B.cols, B.row_offsets, B.col_ids, B.data.astype(np.float64))
+    return spgemm(A64, B64, threads=threads)
+
+
 def transpose(A):
     tro = np.zeros(A.cols + 1, dtype=np.uint32)
     tci = np.zeros(A.nnz, dtype=np.uint32)

@@ -13,16 +13,22 @@ import numpy as np
 from . import pyoracle as po
 
 TOL64 = 1e-12
+# fp32: every product is rounded to float once (eps32 / 2 each), the sum is accumulated in fp64 cells and rounded to float
+# once -- |c - c_ref| <= eps32 * sum|a*b| against the product computed in fp64; 4 eps32 asserted (eps32 = 2^-23)
+TOL32 = 4.0 * 2.0 ** -23
 
 
 def _as_po(A):
     return A if isinstance(A, po.HostCSR) else po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data)
 
 
-def compare_with_oracle(A, B, got_ro, got_col, got_val, tol=TOL64, threads=0):
-    """Full comparison.  Returns (ok, detail dict)."""
-    R, ab = po.spgemm(_as_po(A), _as_po(B), threads=threads)
-    d = {"oracle_nnz": int(R.nnz), "got_nnz": int(len(got_col))}
+def compare_with_oracle(A, B, got_ro, got_col, got_val, tol=None, threads=0):
+    """Full comparison.  Returns (ok, detail dict).  fp32 inputs are compared with their product in fp64 (TOL32)."""
+    A, B = _as_po(A), _as_po(B)
+    if tol is None:
+        tol = TOL32 if A.data.dtype == np.float32 else TOL64
+    R, ab = po.spgemm_f64_of(A, B, threads=threads)
+    d = {"oracle_nnz": int(R.nnz), "got_nnz": int(len(got_col)), "tol": tol}
     if len(got_col) != R.nnz or len(got_ro) != len(R.row_offsets):
         return False, dict(d, why="nnz / rows differ")
     if not (np.asarray(got_ro) == R.row_offsets).all():

@@ -61,6 +61,9 @@ _SIGS = {
     "speck_dcsr_free": (C.c_int, [_P(DCsr)]),
     "speck_dcsr_upload": (C.c_int, [_P(DCsr), C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_size_t]),
+    "speck_dcsr_upload_padded": (C.c_int, [_P(DCsr), C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),
+    "speck_dcsr_copy": (C.c_int, [_P(DCsr), _P(DCsr), C.c_size_t, C.c_uint32]),
     "speck_dcsr_download": (C.c_int, [_P(DCsr), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "speck_dcsr_update": (C.c_int, [_P(DCsr), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "speck_compare_f64": (C.c_int, [C.c_void_p, _P(DCsr), _P(DCsr), C.c_int, C.c_double, _P(C.c_uint64)]),

@@ -208,6 +208,15 @@ class dCSR:
                    "convert(CSR<-dCSR)")
         return HostCSR(self.rows, self.cols, ro, ci, da)
 
+    # convert(dCSR <- dCSR, padding), source/dCSR.cpp:81-89: device to device
+    def copy(self, padding=0):
+        d = dCSR(self.dtype)
+        _check(_lib.load().speck_dcsr_copy(C.byref(d._c), C.byref(self._c), self.dtype.itemsize, int(padding)),
+               "convert(dCSR<-dCSR)")
+        if self._host_row_offsets is not None:
+            d._host_row_offsets = (self._host_row_offsets - self._host_row_offsets[0]).astype(np.uint32)
+        return d
+
     def row_view(self, r0, r1):
         """Non-owning view of rows [r0, r1): row_offsets stay absolute (shard of A)."""
         if self._host_row_offsets is None:

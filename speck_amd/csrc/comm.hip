@@ -104,7 +104,7 @@ constexpr int kMaxRanks = 64, kMaxSlots = 4;
 struct ShmControl {
     std::atomic<uint32_t> arrived;
     std::atomic<uint32_t> bar_count, bar_gen;
-    std::atomic<uint64_t> sizes[kMaxRanks][2];
+    std::atomic<uint64_t> sizes[kMaxRanks][3];         // rows, nnz, the plan id the rank is creating
     std::atomic<uint64_t> sizes_gen[kMaxRanks];
     std::atomic<uint64_t> ready[kMaxRanks][kMaxSlots];  // generation the rank's segment of a slot holds
     std::atomic<uint64_t> taken[kMaxRanks][kMaxSlots];  // generation the root has consumed
@@ -171,13 +171,16 @@ struct speck_comm {
     int nranks = 1, rank = 0, transport = SPECK_TRANSPORT_RCCL, device = 0;
     ncclComm_t nccl = nullptr;
     hipStream_t stream = nullptr;
-    uint64_t* d_sizes = nullptr;  // RCCL: 2 (mine) + 2 * nranks (everyone's)
+    uint64_t* d_sizes = nullptr;  // RCCL: 3 (mine: rows, nnz, plan id) + 3 * nranks (everyone's)
     uint64_t* h_sizes = nullptr;  // ... and their PINNED host mirror: asynchronous copies never touch pageable memory
                                   //   (the runtime locks such pages behind the caller's back; a later copy of other
                                   //   pageable memory then faulted on the GPU -- found with the replay stress)
     std::string shm_token;
     Segment ctl;
     uint64_t sizes_gen = 0;
+    uint64_t next_plan_id = 1;    // plans are created collectively: every rank counts them per COMMUNICATOR (a process-wide
+                                  //   counter disagrees as soon as one rank owns a second communicator or made a plan the
+                                  //   others did not); the sizes exchange carries the id and every rank checks it
     ShmControl* control() const { return static_cast<ShmControl*>(ctl.p); }
 };
 
@@ -194,6 +197,8 @@ struct speck_gather_plan {
     std::vector<Segment> mine;            // ... my segment of each slot
     std::vector<std::vector<Segment>> theirs;  // ... root: every rank's segment of each slot
     uint64_t* d_off = nullptr;            // root: r_off | n_off on the device (rebase kernel)
+    uint32_t* d_zero_ro = nullptr;        // rows(mine) zero offsets: what a shard WITHOUT products stands for -- the multiply
+                                          //   leaves such a C with nnz = 0 and no row_offsets at all (Multiply.cu:67-70, 256-261)
     uint64_t id = 0;
 };
 
@@ -234,7 +239,8 @@ int shm_barrier(speck_comm* c)
     return SPECK_OK;
 }
 
-int exchange_sizes(speck_comm* c, uint64_t rows, uint64_t nnz, std::vector<uint64_t>& all_rows, std::vector<uint64_t>& all_nnz)
+int exchange_sizes(speck_comm* c, uint64_t rows, uint64_t nnz, uint64_t plan_id, std::vector<uint64_t>& all_rows,
+                   std::vector<uint64_t>& all_nnz)
 {
     all_rows.assign(c->nranks, 0);
     all_nnz.assign(c->nranks, 0);
@@ -243,32 +249,38 @@ int exchange_sizes(speck_comm* c, uint64_t rows, uint64_t nnz, std::vector<uint6
         all_nnz[0] = nnz;
         return SPECK_OK;
     }
+    bool same_plan = true;  // every rank is creating the plan with THIS id (else: a rank skipped or repeated a create)
     if (c->transport == SPECK_TRANSPORT_RCCL) {
         c->h_sizes[0] = rows;
         c->h_sizes[1] = nnz;
-        COMM_HIP(hipMemcpyAsync(c->d_sizes, c->h_sizes, 16, hipMemcpyHostToDevice, c->stream));
-        COMM_NCCL(rccl()->AllGather(c->d_sizes, c->d_sizes + 2, 2, ncclUint64, c->nccl, c->stream));
-        uint64_t* all = c->h_sizes + 2;
-        COMM_HIP(hipMemcpyAsync(all, c->d_sizes + 2, size_t(2 * c->nranks) * 8, hipMemcpyDeviceToHost, c->stream));
+        c->h_sizes[2] = plan_id;
+        COMM_HIP(hipMemcpyAsync(c->d_sizes, c->h_sizes, 24, hipMemcpyHostToDevice, c->stream));
+        COMM_NCCL(rccl()->AllGather(c->d_sizes, c->d_sizes + 3, 3, ncclUint64, c->nccl, c->stream));
+        uint64_t* all = c->h_sizes + 3;
+        COMM_HIP(hipMemcpyAsync(all, c->d_sizes + 3, size_t(3 * c->nranks) * 8, hipMemcpyDeviceToHost, c->stream));
         COMM_HIP(hipStreamSynchronize(c->stream));
         for (int p = 0; p < c->nranks; ++p) {
-            all_rows[p] = all[2 * p];
-            all_nnz[p] = all[2 * p + 1];
+            all_rows[p] = all[3 * p];
+            all_nnz[p] = all[3 * p + 1];
+            same_plan = same_plan && all[3 * p + 2] == plan_id;
         }
-        return SPECK_OK;
+        return same_plan ? SPECK_OK : SPECK_ERR_COMM;
     }
     ShmControl* k = c->control();
     const uint64_t g = ++c->sizes_gen;
     k->sizes[c->rank][0].store(rows);
     k->sizes[c->rank][1].store(nnz);
+    k->sizes[c->rank][2].store(plan_id);
     k->sizes_gen[c->rank].store(g, std::memory_order_release);
     for (int p = 0; p < c->nranks; ++p) {
         if (!spin_until([&] { return k->sizes_gen[p].load(std::memory_order_acquire) >= g; })) return SPECK_ERR_COMM;
         all_rows[p] = k->sizes[p][0].load();
         all_nnz[p] = k->sizes[p][1].load();
+        same_plan = same_plan && k->sizes[p][2].load() == plan_id;
     }
     // nobody starts the next exchange of sizes before everyone has read this one
-    return shm_barrier(c);
+    const int rc = shm_barrier(c);
+    return rc != SPECK_OK ? rc : (same_plan ? SPECK_OK : SPECK_ERR_COMM);
 }
 
 }  // namespace
@@ -318,8 +330,8 @@ int speck_comm_init(int device, int nranks, int rank, int transport, const void*
             c->nccl = nullptr;
             return fail(SPECK_ERR_COMM);
         }
-        if (hipMalloc(reinterpret_cast<void**>(&c->d_sizes), (2 + 2 * size_t(nranks)) * 8) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void**>(&c->h_sizes), (2 + 2 * size_t(nranks)) * 8, hipHostMallocDefault) !=
+        if (hipMalloc(reinterpret_cast<void**>(&c->d_sizes), (3 + 3 * size_t(nranks)) * 8) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&c->h_sizes), (3 + 3 * size_t(nranks)) * 8, hipHostMallocDefault) !=
                 hipSuccess)
             return fail(SPECK_ERR_OOM);
     } else {
@@ -384,17 +396,16 @@ static int fill_plan(speck_gather_plan* p, speck_comm* c, int root, uint64_t row
                      uint64_t nnz_local, size_t value_size, int slots)
 {
     COMM_HIP(hipSetDevice(c->device));
-    static std::atomic<uint64_t> next_id{1};
     p->comm = c;
     p->root = root;
     p->slots = slots;
     p->vsize = value_size;
     p->cols = cols;
-    p->id = next_id++;
+    p->id = c->next_plan_id++;  // (counted at ENTRY: a create that fails later on one rank still advances every rank)
     std::vector<uint64_t> all_rows, all_nnz;
     p->pending.assign(slots, 0);
     p->gen.assign(slots, 0);
-    int rc = exchange_sizes(c, rows_local, nnz_local, all_rows, all_nnz);
+    int rc = exchange_sizes(c, rows_local, nnz_local, p->id, all_rows, all_nnz);
     if (rc != SPECK_OK) return rc;
     // the concatenation must fit the u32 row offsets of the dCSR layout
     if (!speck::gather_layout(all_rows.data(), all_nnz.data(), c->nranks, &p->lay)) return SPECK_ERR_NNZ_OVERFLOW;
@@ -417,7 +428,8 @@ static int fill_plan(speck_gather_plan* p, speck_comm* c, int root, uint64_t row
                            hipMemcpyHostToDevice));
     }
     if (c->transport == SPECK_TRANSPORT_HOSTMEM && c->nranks > 1) {
-        // every plan of a communicator is created collectively and in the same order: p->id agrees across ranks
+        // every plan of a communicator is created collectively and in the same order: p->id is the communicator's own
+        // count and the sizes exchange above has checked that every rank holds the same one
         auto seg_name = [&](int rank, int slot) {
             return c->shm_token + "_p" + std::to_string(p->id) + "_r" + std::to_string(rank) + "_s" + std::to_string(slot);
         };
@@ -446,16 +458,27 @@ int speck_gather_start(speck_gather_plan* p, int slot, const speck_dcsr* shard)
     if (!p || !shard || slot < 0 || slot >= p->slots) return SPECK_ERR_INVALID;
     speck_comm* c = p->comm;
     if (p->pending[slot]) return SPECK_ERR_INVALID;  // wait for the slot first
-    if (shard->rows != p->lay.rows[c->rank] || shard->nnz != p->lay.nnz[c->rank]) return SPECK_ERR_INVALID;
+    // A shard whose rows of A hold no products: the multiply returned nnz = 0 and either no row_offsets (and, on the
+    // nnz(A) == 0 early-out, not even the row count).  It stands for rows(plan) rows of zero entries.
+    const bool no_products = shard->nnz == 0 && p->lay.nnz[c->rank] == 0 && (shard->row_offsets == nullptr || shard->rows == 0);
+    if (!no_products && (shard->rows != p->lay.rows[c->rank] || shard->nnz != p->lay.nnz[c->rank])) return SPECK_ERR_INVALID;
     COMM_HIP(hipSetDevice(c->device));
     const bool is_root = c->rank == p->root;
-    const uint64_t rows = shard->rows, nnz = shard->nnz;
+    const uint64_t rows = p->lay.rows[c->rank], nnz = p->lay.nnz[c->rank];
     hipStream_t s = c->stream;
+    const uint32_t* my_ro = shard->row_offsets;
+    if (no_products && rows) {
+        if (!p->d_zero_ro) {
+            COMM_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_zero_ro), rows * 4));
+            COMM_HIP(hipMemset(p->d_zero_ro, 0, rows * 4));
+        }
+        my_ro = p->d_zero_ro;
+    }
     if (is_root) {
         // my own shard: device-to-device, at my displacement
         speck_dcsr& o = p->out[slot];
         const uint64_t r0 = p->lay.r_off[c->rank], n0 = p->lay.n_off[c->rank];
-        if (rows) COMM_HIP(hipMemcpyAsync(o.row_offsets + r0, shard->row_offsets, rows * 4, hipMemcpyDeviceToDevice, s));
+        if (rows) COMM_HIP(hipMemcpyAsync(o.row_offsets + r0, my_ro, rows * 4, hipMemcpyDeviceToDevice, s));
         if (nnz) {
             COMM_HIP(hipMemcpyAsync(o.col_ids + n0, shard->col_ids, nnz * 4, hipMemcpyDeviceToDevice, s));
             COMM_HIP(hipMemcpyAsync(static_cast<char*>(o.data) + n0 * p->vsize, shard->data, nnz * p->vsize,
@@ -465,26 +488,33 @@ int speck_gather_start(speck_gather_plan* p, int slot, const speck_dcsr* shard)
     if (c->nranks > 1 && c->transport == SPECK_TRANSPORT_RCCL) {
         Rccl* n = rccl();
         COMM_NCCL(n->GroupStart());
+        // (no early return inside the group: a thread that leaves it open queues every later collective -- the sizes
+        //  all-gather of the next plan included -- and never issues it.  The first error is kept, the group is closed.)
+        ncclResult_t first = ncclSuccess;
+        auto post = [&](ncclResult_t r) {
+            if (r != ncclSuccess && first == ncclSuccess) first = r;
+        };
         if (!is_root) {
-            if (rows) COMM_NCCL(n->Send(shard->row_offsets, rows, ncclUint32, p->root, c->nccl, s));
+            if (rows) post(n->Send(my_ro, rows, ncclUint32, p->root, c->nccl, s));
             if (nnz) {
-                COMM_NCCL(n->Send(shard->col_ids, nnz, ncclUint32, p->root, c->nccl, s));
-                COMM_NCCL(n->Send(shard->data, nnz * p->vsize, ncclUint8, p->root, c->nccl, s));
+                post(n->Send(shard->col_ids, nnz, ncclUint32, p->root, c->nccl, s));
+                post(n->Send(shard->data, nnz * p->vsize, ncclUint8, p->root, c->nccl, s));
             }
         } else {
             speck_dcsr& o = p->out[slot];
             for (int r = 0; r < c->nranks; ++r) {
                 if (r == p->root) continue;
                 const uint64_t r0 = p->lay.r_off[r], n0 = p->lay.n_off[r];
-                if (p->lay.rows[r]) COMM_NCCL(n->Recv(o.row_offsets + r0, p->lay.rows[r], ncclUint32, r, c->nccl, s));
+                if (p->lay.rows[r]) post(n->Recv(o.row_offsets + r0, p->lay.rows[r], ncclUint32, r, c->nccl, s));
                 if (p->lay.nnz[r]) {
-                    COMM_NCCL(n->Recv(o.col_ids + n0, p->lay.nnz[r], ncclUint32, r, c->nccl, s));
-                    COMM_NCCL(n->Recv(static_cast<char*>(o.data) + n0 * p->vsize, p->lay.nnz[r] * p->vsize, ncclUint8, r,
-                                      c->nccl, s));
+                    post(n->Recv(o.col_ids + n0, p->lay.nnz[r], ncclUint32, r, c->nccl, s));
+                    post(n->Recv(static_cast<char*>(o.data) + n0 * p->vsize, p->lay.nnz[r] * p->vsize, ncclUint8, r,
+                                 c->nccl, s));
                 }
             }
         }
-        COMM_NCCL(n->GroupEnd());
+        post(n->GroupEnd());
+        COMM_NCCL(first);
     } else if (c->nranks > 1 && !is_root) {
         // host-staged: my shard into my segment of the slot (once the root has taken the previous content)
         ShmControl* k = c->control();
@@ -493,7 +523,8 @@ int speck_gather_start(speck_gather_plan* p, int slot, const speck_dcsr* shard)
         if (g && !spin_until([&] { return k->taken[c->rank][slot].load(std::memory_order_acquire) == tag; }))
             return SPECK_ERR_COMM;
         char* base = static_cast<char*>(p->mine[slot].p);
-        if (rows) COMM_HIP(hipMemcpy(base, shard->row_offsets, rows * 4, hipMemcpyDeviceToHost));
+        if (rows && no_products) std::memset(base, 0, rows * 4);
+        else if (rows) COMM_HIP(hipMemcpy(base, my_ro, rows * 4, hipMemcpyDeviceToHost));
         if (nnz) {
             COMM_HIP(hipMemcpy(base + rows * 4, shard->col_ids, nnz * 4, hipMemcpyDeviceToHost));
             COMM_HIP(hipMemcpy(base + rows * 4 + nnz * 4, shard->data, nnz * p->vsize, hipMemcpyDeviceToHost));
@@ -582,6 +613,7 @@ int speck_gather_plan_destroy(speck_gather_plan* p)
     for (auto& v : p->theirs)
         for (auto& m : v) unmap_segment(m);
     if (p->d_off) (void)hipFree(p->d_off);
+    if (p->d_zero_ro) (void)hipFree(p->d_zero_ro);
     delete p;
     return SPECK_OK;
 }

@@ -109,12 +109,16 @@ __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductS
         // ---- sort by (column, product number)
         esc_sort<L>(key, gl);
         // ---- compress: sums of the runs of equal columns, in sorted order
+        // (validity by POSITION, not by the sentinel: the `total` valid keys sort to the front, and the packed key of
+        //  the last product of a full row that ends in column 2^27 - 1 (2^26 - 1 for 16 lanes) IS 0xFFFFFFFF --
+        //  check_inputs admits cols(B) == 2^27, Multiply.cu:57-66)
         u32 col[PER];
         Acc<T> sum[PER];
 #pragma unroll
         for (u32 r = 0; r < PER; ++r) {
-            col[r] = key[r] == kEscInvalid ? kEscInvalid : key[r] >> TAG;
-            sum[r] = key[r] == kEscInvalid ? Acc<T>(0) : s_vals[key[r] & (NP - 1u)];
+            const bool valid = gl * PER + r < total;
+            col[r] = valid ? key[r] >> TAG : kEscInvalid;
+            sum[r] = valid ? s_vals[key[r] & (NP - 1u)] : Acc<T>(0);
         }
         bool lead[PER];  // element r continues the run of element 0 of this lane
         lead[0] = true;

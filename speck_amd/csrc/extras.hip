@@ -288,13 +288,20 @@ int transpose_impl(const speck_dcsr* A, speck_dcsr* At)
     }
     u32 base = 0;
     HIP_TRY(hipMemcpy(&base, A->row_offsets, 4, hipMemcpyDeviceToHost));
-    u32 *row_of = nullptr, *perm_a = nullptr, *perm_b = nullptr, *keys_a = nullptr, *keys_b = nullptr, *hist = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&row_of), size_t(nnz) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&perm_a), size_t(nnz) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&perm_b), size_t(nnz) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&keys_a), size_t(nnz) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&keys_b), size_t(nnz) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hist), size_t(256) * kRadixBlocks * 4));
+    // the six temporaries are ONE allocation, released on every way out (a failing HIP call used to leak them)
+    struct Temp {
+        void* p = nullptr;
+        ~Temp() { if (p) (void)hipFree(p); }
+    } temp;
+    const size_t n4 = (size_t(nnz) * 4 + 255) & ~size_t(255);
+    HIP_TRY(hipMalloc(&temp.p, 5 * n4 + size_t(256) * kRadixBlocks * 4));
+    unsigned char* tb = static_cast<unsigned char*>(temp.p);
+    u32* row_of = reinterpret_cast<u32*>(tb);
+    u32* perm_a = reinterpret_cast<u32*>(tb + n4);
+    u32* perm_b = reinterpret_cast<u32*>(tb + 2 * n4);
+    u32* keys_a = reinterpret_cast<u32*>(tb + 3 * n4);
+    u32* keys_b = reinterpret_cast<u32*>(tb + 4 * n4);
+    u32* hist = reinterpret_cast<u32*>(tb + 5 * n4);
     u32 blocks = (rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, 0, A->row_offsets,
@@ -311,12 +318,6 @@ int transpose_impl(const speck_dcsr* A, speck_dcsr* At)
     hipLaunchKernelGGL(offsets_from_sorted_kernel, dim3(2048), dim3(256), 0, 0, keys_out, nnz, cols,
                        At->row_offsets);
     HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(row_of);
-    (void)hipFree(perm_a);
-    (void)hipFree(perm_b);
-    (void)hipFree(keys_a);
-    (void)hipFree(keys_b);
-    (void)hipFree(hist);
     return SPECK_OK;
 }
 

@@ -100,6 +100,28 @@ def test_bench_two_ranks_share_the_gpu():
     assert c5["verified"] is True
 
 
+def test_bench_launches_its_own_ranks_when_called_without_a_launcher():
+    """`python bench.py --gpus N` as the driver calls it -- no torch.distributed.run in front: bench.py starts the N
+    ranks itself and rank 0 prints the line with n_gpus = N.  On a box with fewer GPUs it refuses (exit code 2, no
+    line) instead of printing a one-GPU number, unless the ranks may share GPU 0 (plumbing check)."""
+    import json
+    import sys
+    import torch
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--scale", "0.1",
+           "--no-config5", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(base, SPECK_BENCH_SHARED_GPU="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "rows2" and d["verified"] is True
+    assert d["config"]["exchange_floor_ms"] > 0 and d["multiply_only"]["value"] > 0
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run(cmd, cwd=ROOT, env=base, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 2 and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
 def test_bench_falls_back_to_the_torch_exchange_when_the_native_one_fails_its_self_test():
     """bench.py brings the library's exchange up with a tiny self-checked gatherv; if that fails (here: forced on every
     rank) all ranks switch to the torch.distributed exchange together, and the line says so."""
@@ -241,3 +263,33 @@ def test_declarations_only_caller_runs(tmp_path):
     _build_decl_only_caller(exe)
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert p.returncode == 0 and "decl-only caller ok" in p.stdout.decode(), p.stdout.decode()
+
+
+def test_device_to_device_convert_makes_no_host_round_trip(tmp_path):
+    """convert(dCSR&, const dCSR&, padding) (reference source/dCSR.cpp:81-89) through speck_dcsr_copy: own buffers,
+    identical contents, a row-range view rebased to 0, the padding honoured -- and no device-to-host copy: under
+    rocprofv3 --memory-copy-trace the K = 1 and the K = 9 run of tests/cpp/convert_d2d.cpp show the SAME number of
+    device-to-host copies (those of the final download that checks the contents)."""
+    import csv
+    import glob
+    exe = str(tmp_path / "convert_d2d")
+    subprocess.check_call(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                           "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "convert_d2d.cpp"),
+                           "-L", os.path.join(ROOT, "speck_amd"), "-lspeck_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "speck_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 0 and "convert d2d ok" in p.stdout.decode(), p.stdout.decode()
+    counts = {}
+    for k in (1, 9):
+        out = tmp_path / f"trace{k}"
+        env = dict(os.environ, TMPDIR=str(tmp_path))
+        q = subprocess.run(["rocprofv3", "--memory-copy-trace", "--output-format", "csv", "-d", str(out), "-o", "r", "--",
+                            exe, str(k)], cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=300)
+        assert q.returncode == 0 and "convert d2d ok" in q.stdout.decode(), q.stdout.decode()[-1500:]
+        files = glob.glob(str(out / "**" / "*memory_copy_trace.csv"), recursive=True)
+        assert files, q.stdout.decode()[-1500:]
+        rows = list(csv.DictReader(open(files[0])))
+        counts[k] = sum(1 for r in rows if "DEVICE_TO_HOST" in (r.get("Direction") or "").upper().replace(" ", "_"))
+        assert len(rows) > 0
+    assert counts[1] == counts[9] and counts[1] > 0, counts

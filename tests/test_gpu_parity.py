@@ -20,7 +20,7 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 TOL64 = 1e-12
-TOL32 = 2e-5
+TOL32 = 4.0 * 2.0 ** -23   # fp32 against the product computed in fp64: <= 4 eps32 * sum|a*b| (oracle/verify.py)
 
 
 @pytest.fixture(scope="module")
@@ -57,7 +57,7 @@ def check(cfg, A, B, expect_classes=None, tol=TOL64, C_reuse=None, threads=0):
     dC = C_reuse if C_reuse is not None else sa.dCSR(A.data.dtype)
     sa.MultiplyspECK(dA, dB, dC, cfg)
     st = cfg.last_stats()
-    R, ab = po.spgemm(A, B, threads=threads)
+    R, ab = po.spgemm_f64_of(A, B, threads=threads)   # (fp32 inputs: their product in fp64)
     got = dC.to_host()
     assert got.rows == R.rows and got.cols == R.cols and got.nnz == R.nnz
     assert (got.row_offsets == R.row_offsets).all(), "row_offsets differ"
@@ -872,6 +872,49 @@ def test_dimensions_exactly_at_the_2_27_limit(cfg):
         cfg.set_option("gh_per_window", 8192)
 
 
+@pytest.mark.parametrize("log_cols,per_row", [(27, 8), (26, 16), (26, 8)])
+def test_register_class_row_whose_last_product_packs_to_all_ones(cfg, log_cols, per_row):
+    """cols(B) = 2^27 (8 lanes) / 2^26 (16 lanes) and FULL register-class rows -- 4 products per lane -- whose last
+    product lies in column cols - 1: its packed sort key (column << 5 | 31, column << 6 | 63) is 0xFFFFFFFF, the
+    value the sort pads with.  Validity is by position, so the product is kept (eager, and finished in the symbolic
+    phase of a replay); check_inputs admits these widths (Multiply.cu:57-66)."""
+    n = 1 << log_cols
+    rng = np.random.default_rng(100 + log_cols + per_row)
+    kb = 64
+    bc = np.sort(rng.integers(0, n - 1, size=(kb, 4), dtype=np.int64), axis=1)
+    bc[:, 1:] += (bc[:, 1:] <= bc[:, :-1]) * 1                       # (distinct with overwhelming odds; fixed below)
+    bc = np.sort(bc, axis=1)
+    for r in range(kb):
+        while len(set(bc[r])) < 4:
+            bc[r] = np.sort(rng.integers(0, n - 1, size=4))
+    bc[kb // 2:, 3] = n - 1                                          # the rows of the second half END in the last column
+    bc[kb // 2:kb // 2 + 8, 2] = n - 2                               # ... some with the column before it as well
+    B = po.HostCSR(kb, n, np.arange(kb + 1, dtype=np.uint32) * 4, bc.reshape(-1).astype(np.uint32),
+                   0.5 + rng.random(kb * 4))
+    rows = 300
+    acol = np.empty((rows, per_row), dtype=np.int64)
+    for r in range(rows):
+        head = np.sort(rng.choice(kb // 2, size=per_row - 2, replace=False))
+        tail = np.sort(rng.choice(np.arange(kb // 2, kb), size=2, replace=False))
+        acol[r] = np.concatenate([head, tail])                      # ascending; the LAST entry's B row ends in n - 1
+    A = po.HostCSR(rows, kb, np.arange(rows + 1, dtype=np.uint32) * per_row, acol.reshape(-1).astype(np.uint32),
+                   (0.5 + rng.random(rows * per_row)) * rng.choice([-1.0, 1.0], size=rows * per_row))
+    cls = "g8" if per_row == 8 else "g16"
+    dC, st, R = check(cfg, A, B, [("sym", cls), ("num", cls)], threads=2)
+    assert st["max_row_ops"] == 4 * per_row
+    got = dC.to_host()
+    assert (got.col_ids[got.row_offsets[1:] - 1] == n - 1).all()     # every row ends in the last column
+    dA, dB = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B))
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    st = cfg.last_stats()
+    assert st["replayed"] and st["esc_fused"]
+    got = dC.to_host()
+    assert (got.row_offsets == R.row_offsets).all() and (got.col_ids == R.col_ids).all()
+    _, ab = po.spgemm(A, B, threads=2)
+    assert (np.abs(got.data - R.data) <= TOL64 * ab + 1e-300).all()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # round 3: input checks, scratch-pool fallbacks, replayed sequences at full size
 def test_column_of_a_beyond_the_rows_of_b_is_rejected(cfg):
@@ -1086,7 +1129,7 @@ def test_register_class_rows_are_finished_in_the_symbolic_phase_of_a_replay(cfg)
     for _ in range(4):
         sa.MultiplyspECK(dAf, dAf, dCf, cfg)
     assert cfg.last_stats()["esc_fused"]
-    Rf, abf = po.spgemm(Af, Af)
+    Rf, abf = po.spgemm_f64_of(Af, Af)
     got = dCf.to_host()
     assert got.nnz == Rf.nnz and (got.row_offsets == Rf.row_offsets).all() and (got.col_ids == Rf.col_ids).all()
     assert (np.abs(got.data.astype(np.float64) - Rf.data.astype(np.float64)) <= TOL32 * abf + 1e-30).all()
