@@ -293,10 +293,11 @@ def profile_prepass(job, split, merged, prof_steps=5):
     cfg.profile_kernels(1)
     # the 256-thread numeric classes run as ONE launch ("light": num_light_kernel), or with option split_light=1
     # as two ("light": the big-LDS classes, "tiny": num_tiny_kernel); the other classes launch separately
-    LIGHT, TINY = ("dense4k", "block2k", "wave512", "wave256"), ("wave128", "g16", "g8", "direct")
+    LIGHT, TINY = ("dense4k", "block2k", "wave512", "wave256"), ("r64", "r32", "wave128", "g16", "g8", "direct")
     if not split:
         LIGHT, TINY = LIGHT + TINY, ()
-    SYM_LIGHT = ("bitmap256k", "block4k", "wave1k", "wave256", "wave128", "g16", "g8")
+    SYM_LIGHT = ("bitmap256k", "block4k", "wave1k", "wave256", "r64", "r32", "wave128", "g16", "g8")
+    ESC = ("g8", "g16", "r32", "r64")   # the register classes: finished in the symbolic phase of a fused replay
     kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny", "numeric_first", "fused_light"]}
     sym_ms = num_ms = 0.0
     fused = False
@@ -330,9 +331,10 @@ def profile_prepass(job, split, merged, prof_steps=5):
     # copy of the finished rows into C is extra traffic outside the model (listed by time only)
     kernel_bytes["numeric_first"] = kernel_bytes.pop("nfcopy")
     if fused:
-        kernel_bytes["fused_light"] = (kernel_bytes.pop("g8") + kernel_bytes.pop("g16") +
-                                       sum(st["sym_bin_bytes"][k] for k in SYM_LIGHT if k not in ("g8", "g16")))
-        kernel_bytes["g8"] = kernel_bytes["g16"] = 0
+        kernel_bytes["fused_light"] = (sum(kernel_bytes.pop(k) for k in ESC) +
+                                       sum(st["sym_bin_bytes"][k] for k in SYM_LIGHT if k not in ESC))
+        for k in ESC:
+            kernel_bytes[k] = 0
     if merged:
         kernel_bytes["light"] = sum(kernel_bytes.pop(k) for k in LIGHT)
         kernel_bytes["tiny"] = sum(kernel_bytes.pop(k) for k in TINY)

@@ -53,8 +53,8 @@ typedef struct speck_timings {
 } speck_timings;
 
 /* ---- what the last multiply did (drives bench.py's roofline object) ---- */
-#define SPECK_NUM_SYM_BINS 12
-#define SPECK_NUM_NUM_BINS 12
+#define SPECK_NUM_SYM_BINS 16
+#define SPECK_NUM_NUM_BINS 16
 typedef struct speck_stats {
     uint64_t sum_products;                       /* P, u64 (reference: u32, Multiply.cu:237) */
     uint64_t nnz_c;

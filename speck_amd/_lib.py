@@ -5,8 +5,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspeck_amd.so")
 
-NUM_SYM_BINS = 12
-NUM_NUM_BINS = 12
+NUM_SYM_BINS = 16
+NUM_NUM_BINS = 16
 
 
 class DCsr(C.Structure):

@@ -11,7 +11,7 @@ using u64 = uint64_t;
 using u8 = uint8_t;
 
 constexpr u32 kEmptyKey = 0xFFFFFFFFu;
-constexpr int kMaxClasses = 12;  // array extent of every per-class table
+constexpr int kMaxClasses = 16;  // array extent of every per-class table
 
 // Trivially-copyable CSR view handed to kernels (reference: dCSRNoDealloc<T>,
 // include/dCSR.h:24-35).  row_offsets may be absolute offsets of a row-range view.
@@ -47,7 +47,10 @@ enum SymClass : u8 {
                     //   fixed ~8 us, a global compare-and-swap a fraction of a nanosecond at 4096 in flight
     SYM_G8 = 10,    // 8 lanes per row (8 rows per wave), 32-key LDS set (ops <= 25)
     SYM_W128 = 11,  // 16 lanes per row (four rows per wave), 128-key LDS set (ops <= 102)
-    SYM_CLASSES = 12,
+    SYM_R32 = 12,   // 32 lanes per row (two rows per wave): <= 128 products from <= 32 entries of A, columns sorted in
+                    //   registers (esc_wide.hpp) -- no key set
+    SYM_R64 = 13,   // a wave per row: <= 256 products from <= 64 entries of A, sorted in registers
+    SYM_CLASSES = 14,
     SYM_NONE = 0xFF  // resolved by the analysis kernel itself (empty / single-entry A rows)
 };
 // Numeric classes: chosen from the EXACT nnz of the C row (symbolic result).
@@ -66,7 +69,10 @@ enum NumClass : u8 {
     NUM_NFCOPY = 10, // row already computed by the symbolic phase (SYM_NF): copy scratch slot -> C
     NUM_G8 = 11,     // 8 lanes per row (8 rows per wave), 32-entry table, rank sort   (nnz <= 21): the small-row
                      //   kernel is latency x occupancy bound -- twice the rows in flight per wave
-    NUM_CLASSES = 12,
+    NUM_R32 = 12,    // 32 lanes per row: <= 128 products from <= 32 entries of A, column range < 2^25 -- expand / sort /
+                     //   compress in registers (esc_wide.hpp), whatever the nnz
+    NUM_R64 = 13,    // a wave per row: <= 256 products from <= 64 entries, column range < 2^24
+    NUM_CLASSES = 14,
     NUM_NONE = 0xFF
 };
 
@@ -116,6 +122,10 @@ __host__ __device__ inline u32 table_bits(u32 nnz, u32 pct)
 constexpr u32 kNumG8Cap = 32, kNumG8MaxNnz = max_nnz_of(32, SPECK_LOAD_TINY_PCT);
 constexpr u32 kNumEscMaxOps = 32, kNumEscMaxLen = 8;  // NUM_G8 / SYM_G8 = the register-resident classes (esc.hpp)
 constexpr u32 kNumEsc16MaxOps = 64, kNumEsc16MaxLen = 16;  // NUM_G16 / SYM_G16: 16 lanes; columns < 2^26 (ClassifyParams::esc16)
+// the WIDE register classes (esc_wide.hpp): the sort key packs (column - first reachable column of the row) with the
+// product number into 32 bits -- a condition on the row's column RANGE (analysis), not on cols(B)
+constexpr u32 kNumEsc32MaxOps = 128, kNumEsc32MaxLen = 32, kNumEsc32RangeBits = 25;
+constexpr u32 kNumEsc64MaxOps = 256, kNumEsc64MaxLen = 64, kNumEsc64RangeBits = 24;
 constexpr u32 kNumG16Cap = 64, kNumG16MaxNnz = max_nnz_of(64, SPECK_LOAD_TINY_PCT);
 constexpr u32 kNumW128Cap = 128, kNumW128MaxNnz = max_nnz_of(128, SPECK_LOAD_TINY_PCT);
 constexpr u32 kNumW512Cap = 512, kNumW512MaxNnz = max_nnz_of(512, SPECK_LOAD_TINY_PCT);
@@ -135,6 +145,7 @@ struct ClassifyParams {
     u32 num_global_passes;  // use the global-hash spill when dense windows would exceed this
     u32 num_w256;           // rows of 86..170 nnz: 32 lanes per row (else they join NUM_W512)
     u32 esc16;              // cols(B) <= 2^26: the 16-lane register class may pack (column, product number) into 32 bits
+    u32 esc32, esc64;       // the wide register classes (32 / 64 lanes per row, 128 / 256 products)
     u32 esc_fused;          // replayed sequence with direct placement: the rows of the register classes are finished
                             //   in the symbolic phase (esc_rows.hpp) -- the numeric phase only accounts for them
     u32 num_g8;             // rows of <= kNumG8MaxNnz entries: 8 lanes per row (else they join NUM_G16)
@@ -173,6 +184,16 @@ __host__ __device__ inline u32 gh_table_slots(u32 ops)
     return slots;
 }
 
+// Rows of the wide register classes: the same predicate in both phases (a fused row must be one in BOTH).
+__host__ __device__ inline bool is_esc32(u32 len_a, u32 ops, u32 cmin, u32 cmax, const ClassifyParams& p)
+{
+    return p.esc32 && ops <= kNumEsc32MaxOps && len_a <= kNumEsc32MaxLen && ((cmax - cmin) >> kNumEsc32RangeBits) == 0;
+}
+__host__ __device__ inline bool is_esc64(u32 len_a, u32 ops, u32 cmin, u32 cmax, const ClassifyParams& p)
+{
+    return p.esc64 && ops <= kNumEsc64MaxOps && len_a <= kNumEsc64MaxLen && ((cmax - cmin) >> kNumEsc64RangeBits) == 0;
+}
+
 __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u32 cmax,
                                                 const ClassifyParams& p)
 {
@@ -181,6 +202,8 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
     // at most 32 products from at most 8 entries of A: sorted in registers (esc.hpp)
     if (p.sym_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return SYM_G8;
     if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return SYM_G16;  // 16 lanes, 64 products
+    if (is_esc32(len_a, ops, cmin, cmax, p)) return SYM_R32;                             // 32 lanes, 128 products
+    if (is_esc64(len_a, ops, cmin, cmax, p)) return SYM_R64;                             // a wave, 256 products
     if (p.sym_w128 && ops <= kSymW128MaxOps) return SYM_W128;
     if (ops <= kSymW256MaxOps) return SYM_W256;
     const u64 range = u64(cmax) - u64(cmin) + 1;
@@ -211,6 +234,8 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     // (num_g8 and sym_g8 are switched together: a fused row must be a register-class row in BOTH phases)
     if (p.num_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G8;
     if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G16;
+    if (is_esc32(len_a, ops, cmin, cmax, p)) return p.esc_fused ? NUM_NFCOPY : NUM_R32;
+    if (is_esc64(len_a, ops, cmin, cmax, p)) return p.esc_fused ? NUM_NFCOPY : NUM_R64;
     if (nnz <= kNumW128MaxNnz) return NUM_W128;
     const u64 range = u64(cmax) - u64(cmin) + 1;
     if (range <= kNumD1Cols && range <= u64(p.num_dense_ratio) * nnz) return NUM_D1;

@@ -29,6 +29,7 @@
 #include "launch.hpp"
 #include "row_groups.hpp"
 #include "esc_rows.hpp"
+#include "esc_wide.hpp"
 
 namespace speck {
 
@@ -749,6 +750,15 @@ __global__ __launch_bounds__(256) void num_esc_kernel(ProductSrc<T> src, const u
     num_esc_body<T, L, 256>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
 }
 
+template <typename T, u32 L>
+__global__ __launch_bounds__(256) void num_escw_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                       u32* __restrict__ c_col, T* __restrict__ c_val, int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    src.rebase(a_ro);
+    num_escw_body<T, L, 256>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
+}
+
 constexpr u32 kW256W1 = 256;   // 256 Ki columns per sort window
 constexpr u32 kW512W1 = 768;   // 768 Ki columns per sort window (its level-1 pairs fill the 6 KiB table exactly)
 constexpr u32 kB2KW1 = 1024;   // 1 Mi columns per sort window
@@ -762,7 +772,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    // launch order (ClassGrid slots): D1, B2K, W512, W256, W128, G16, G8, DIRECT
+    // launch order (ClassGrid slots): D1, B2K, W512, W256, R64, R32, W128, G16, G8, DIRECT
     // (every body starts with open_list: its first record is requested from the hinted list position while the
     //  device-side table and the capacity_miss flag are still on their way)
     if (b < cg.first[1])
@@ -777,14 +787,18 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
         num_hash_body<SubWave<32>, T, kNumW256Cap, kW256W1, kNumW256MaxNnz, SORT_BITMAP, 256>(
             smem, src, w, c_col, c_val, NUM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.hint[3]);
     else if (b < cg.first[5])
-        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
+        num_escw_body<T, 64, 256>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
     else if (b < cg.first[6])
-        num_esc_body<T, 16, 256>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+        num_escw_body<T, 32, 256>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else if (b < cg.first[7])
-        num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+    else if (b < cg.first[8])
+        num_esc_body<T, 16, 256>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
+    else if (b < cg.first[9])
+        num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
     else
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
 }
 
 // The three smallest classes alone: the merged kernel above takes the register count of its
@@ -799,14 +813,18 @@ __global__ __launch_bounds__(TT) void num_tiny_kernel(ProductSrc<T> src, const u
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
     if (b < cg.first[5])
-        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, TT>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
+        num_escw_body<T, 64, TT>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
     else if (b < cg.first[6])
-        num_esc_body<T, 16, TT>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+        num_escw_body<T, 32, TT>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
     else if (b < cg.first[7])
-        num_esc_body<T, 8, TT>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, TT>(
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+    else if (b < cg.first[8])
+        num_esc_body<T, 16, TT>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
+    else if (b < cg.first[9])
+        num_esc_body<T, 8, TT>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
     else
-        num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
+        num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
 }
 
 // ------------------------------------------------------------------ NUM_G
@@ -1244,6 +1262,8 @@ u32 numeric_lds_bytes_t(int cls)
         case NUM_DIRECT: return num_direct_lds<T, 256>();
         case NUM_G8: return 32 * num_esc_group_lds<T, 8>();
         case NUM_G16: return 16 * num_esc_group_lds<T, 16>();
+        case NUM_R32: return 8 * num_escw_group_lds<T, 32>();
+        case NUM_R64: return 4 * num_escw_group_lds<T, 64>();
         case NUM_W128: return 8 * num_group_lds<SubWave<32>, T, kNumW128Cap, 256>();
         case NUM_W512: return 4 * num_group_lds<SubWave<64>, T, kNumW512Cap, 256>();
         case NUM_W256: return 8 * num_group_lds<SubWave<32>, T, kNumW256Cap, 256>();
@@ -1289,8 +1309,9 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
                           const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count, bool exact,
                           hipEvent_t e0, hipEvent_t e1)
 {
-    static const int slots[8] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W256, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
-    static const u32 rows_per_block[8] = {1, 1, 4, 8, 8, 16, 32, 256};
+    constexpr int NS = 10;
+    static const int slots[NS] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W256, NUM_R64, NUM_R32, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
+    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 8, 16, 32, 256};
     bool tiny_only = true;
     for (int k = 0; k < 4; ++k)
         if ((mask >> slots[k] & 1u) && counts_hint[slots[k]]) tiny_only = false;
@@ -1304,19 +1325,19 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
         return threads == 64 ? num_direct_lds<T, 64>() : threads == 128 ? num_direct_lds<T, 128>() : num_direct_lds<T, 256>();
     };
     u32 lds = 0;
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < NS; ++k)
         if (mask >> slots[k] & 1u) lds = lds > class_lds(slots[k]) ? lds : class_lds(slots[k]);
     ClassGrid cg{};
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NS; ++k) {
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
         const u32 rpb = rows_per_block[k] >= div ? rows_per_block[k] / div : 1u;
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, threads, cu_count, rpb) : 0u);
     }
-    if (cg.first[8] == 0) {
+    if (cg.first[NS] == 0) {
         if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);  // (nothing to time: an empty interval)
         return;
     }
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NS; ++k) {
         cg.hint[k] = kNoHint;
         if (!exact) continue;
         u32 off = 0;  // class lists follow each other in class order (publish_bins)
@@ -1325,16 +1346,16 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
     }
     const ProductSrc<T> src{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
     if (!tiny_only)
-        SPECK_LAUNCH_TIMED((num_light_kernel<T>), dim3(cg.first[8]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_light_kernel<T>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else if (threads == 64)
-        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 64>), dim3(cg.first[8]), dim3(64), lds, s, e0, e1, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 64>), dim3(cg.first[NS]), dim3(64), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else if (threads == 128)
-        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 128>), dim3(cg.first[8]), dim3(128), lds, s, e0, e1, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 128>), dim3(cg.first[NS]), dim3(128), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else
-        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 256>), dim3(cg.first[8]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 256>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
 }
 
@@ -1377,6 +1398,14 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             break;
         case NUM_G16:
             hipLaunchKernelGGL((num_esc_kernel<T, 16>), dim3(grid_for(count, lds, 256, cu_count, 16)), dim3(256), lds, s, A, B,
+                               w, c_col, c_val, cls);
+            break;
+        case NUM_R32:
+            hipLaunchKernelGGL((num_escw_kernel<T, 32>), dim3(grid_for(count, lds, 256, cu_count, 8)), dim3(256), lds, s, A, B,
+                               w, c_col, c_val, cls);
+            break;
+        case NUM_R64:
+            hipLaunchKernelGGL((num_escw_kernel<T, 64>), dim3(grid_for(count, lds, 256, cu_count, 4)), dim3(256), lds, s, A, B,
                                w, c_col, c_val, cls);
             break;
         case NUM_W128:

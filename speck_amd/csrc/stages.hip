@@ -764,15 +764,15 @@ static inline int scan_items(u32 m) { return m <= (1u << 19) ? 2 : (m <= (1u << 
 // One 16-bit counter per numeric class, four per u64: a count never exceeds the rows of a block
 // (256 threads x 32 items = 8192), and sums of whole structs are plain u64 additions.
 struct PackedCounts {
-    u64 a = 0, b = 0, c = 0;
+    u64 a = 0, b = 0, c = 0, d = 0;
     __device__ __forceinline__ void add(u32 cls)
     {
         const u64 one = 1ull << (16 * (cls & 3u));
-        if (cls < 4) a += one; else if (cls < 8) b += one; else c += one;
+        if (cls < 4) a += one; else if (cls < 8) b += one; else if (cls < 12) c += one; else d += one;
     }
     __device__ __forceinline__ u32 get(u32 cls) const
     {
-        const u64 w = cls < 4 ? a : (cls < 8 ? b : c);
+        const u64 w = cls < 4 ? a : (cls < 8 ? b : (cls < 12 ? c : d));
         return (u32)(w >> (16 * (cls & 3u))) & 0xFFFFu;
     }
     __device__ __forceinline__ PackedCounts& operator+=(const PackedCounts& o)
@@ -780,10 +780,11 @@ struct PackedCounts {
         a += o.a;
         b += o.b;
         c += o.c;
+        d += o.d;
         return *this;
     }
 };
-static_assert(kMaxClasses <= 12, "PackedCounts holds 12 classes");
+static_assert(kMaxClasses <= 16, "PackedCounts holds 16 classes");
 
 template <int ITEMS>
 __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
@@ -828,6 +829,7 @@ __global__ __launch_bounds__(kScanThreads) void num_count_kernel(
     packed.a = wave_reduce_add(packed.a);
     packed.b = wave_reduce_add(packed.b);
     packed.c = wave_reduce_add(packed.c);
+    packed.d = wave_reduce_add(packed.d);
     my_max = wave_reduce_max(my_max);
     g_ops = wave_reduce_add(g_ops);
     const u32 wid = threadIdx.x >> 6;
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     __shared__ Fold s_fold;
     __shared__ u64 s_bytes[kMaxClasses];
     __shared__ u32 s_scan[NW + 1];
-    __shared__ u64 s_wave[NW][3];
+    __shared__ u64 s_wave[NW][4];
     const u32 lane = lane_id(), wid = threadIdx.x >> 6;
     // my rows' counts and classes are requested BEFORE the fold (dependent loads + barriers)
     const u64 base = u64(blockIdx.x) * (kScanThreads * ITEMS) + u64(threadIdx.x) * ITEMS;
@@ -922,8 +924,8 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
         const PartialArrays pa(parts, nb);
         auto shaped = [&](auto&& get, u32 k) -> u32 {
             if (!pred_fold_esc) return get(k);
-            if (k == NUM_G8 || k == NUM_G16) return 0u;
-            return k == NUM_NFCOPY ? get(NUM_NFCOPY) + get(NUM_G8) + get(NUM_G16) : get(k);
+            if (k == NUM_G8 || k == NUM_G16 || k == NUM_R32 || k == NUM_R64) return 0u;
+            return k == NUM_NFCOPY ? get(NUM_NFCOPY) + get(NUM_G8) + get(NUM_G16) + get(NUM_R32) + get(NUM_R64) : get(k);
         };
         const u32 k = threadIdx.x;
         u32 pos = shaped([&](u32 q) { return s_fold.prefix[q]; }, k);
@@ -969,27 +971,32 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     PackedCounts incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const u64 ta = __shfl_up(incl.a, o, 64), tb = __shfl_up(incl.b, o, 64), tc = __shfl_up(incl.c, o, 64);
+        const u64 ta = __shfl_up(incl.a, o, 64), tb = __shfl_up(incl.b, o, 64), tc = __shfl_up(incl.c, o, 64),
+                  td = __shfl_up(incl.d, o, 64);
         if (lane >= (u32)o) {
             incl.a += ta;
             incl.b += tb;
             incl.c += tc;
+            incl.d += td;
         }
     }
     if (lane == 63) {
         s_wave[wid][0] = incl.a;
         s_wave[wid][1] = incl.b;
         s_wave[wid][2] = incl.c;
+        s_wave[wid][3] = incl.d;
     }
     __syncthreads();
     PackedCounts before;  // rows of each class in the threads before mine (exclusive)
     before.a = incl.a - mine.a;
     before.b = incl.b - mine.b;
     before.c = incl.c - mine.c;
+    before.d = incl.d - mine.d;
     for (u32 w = 0; w < wid; ++w) {
         before.a += s_wave[w][0];
         before.b += s_wave[w][1];
         before.c += s_wave[w][2];
+        before.d += s_wave[w][3];
     }
     PackedCounts used;
 #pragma unroll
@@ -1025,7 +1032,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
 {
     constexpr int NW = kScanThreads / 64;
     __shared__ u32 s_scan[NW + 1];
-    __shared__ u64 s_wave[NW][3];
+    __shared__ u64 s_wave[NW][4];
     __shared__ u64 s_g[NW];
     __shared__ u32 s_pos[kMaxClasses];
     __shared__ u32 s_bad;
@@ -1118,11 +1125,13 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
     PackedCounts incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const u64 ta = __shfl_up(incl.a, o, 64), tb = __shfl_up(incl.b, o, 64), tc = __shfl_up(incl.c, o, 64);
+        const u64 ta = __shfl_up(incl.a, o, 64), tb = __shfl_up(incl.b, o, 64), tc = __shfl_up(incl.c, o, 64),
+                  td = __shfl_up(incl.d, o, 64);
         if (lane >= (u32)o) {
             incl.a += ta;
             incl.b += tb;
             incl.c += tc;
+            incl.d += td;
         }
     }
     g_ops = wave_reduce_add(g_ops);
@@ -1130,6 +1139,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
         s_wave[wid][0] = incl.a;
         s_wave[wid][1] = incl.b;
         s_wave[wid][2] = incl.c;
+        s_wave[wid][3] = incl.d;
     }
     if (lane == 0) s_g[wid] = g_ops;
     if (__ballot(bad) != 0 && lane == 0) s_bad = 1;
@@ -1140,6 +1150,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
             all.a += s_wave[w][0];
             all.b += s_wave[w][1];
             all.c += s_wave[w][2];
+            all.d += s_wave[w][3];
         }
         if (all.get(threadIdx.x) != tab[kMaxClasses + threadIdx.x]) s_bad = 1;
         if (threadIdx.x == 0) {
@@ -1161,10 +1172,12 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
     before.a = incl.a - mine.a;
     before.b = incl.b - mine.b;
     before.c = incl.c - mine.c;
+    before.d = incl.d - mine.d;
     for (u32 w = 0; w < wid; ++w) {
         before.a += s_wave[w][0];
         before.b += s_wave[w][1];
         before.c += s_wave[w][2];
+        before.d += s_wave[w][3];
     }
     PackedCounts used;
 #pragma unroll

@@ -18,6 +18,7 @@
 #include "row_groups.hpp"
 #include "esc.hpp"
 #include "esc_rows.hpp"
+#include "esc_wide.hpp"
 
 namespace speck {
 
@@ -311,6 +312,15 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> s
 }
 
 template <u32 L>
+__global__ __launch_bounds__(256) void sym_escw_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
+                                                       u32* __restrict__ counts, int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    src.rebase(a_ro);
+    sym_escw_body<L, 256>(smem, src, w, counts, cls, blockIdx.x, gridDim.x);
+}
+
+template <u32 L>
 __global__ __launch_bounds__(256) void sym_esc_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
                                                       u32* __restrict__ counts, int cls)
 {
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    // launch order (ClassGrid slots): BM1, B4K, W1K, W256, W128, G16, G8
+    // launch order (ClassGrid slots): BM1, B4K, W1K, W256, R64, R32, W128, G16, G8
     if (b < cg.first[1])
         sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], cg.hint[0]);
     else if (b < cg.first[2])
@@ -335,11 +345,15 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     else if (b < cg.first[4])
         sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.hint[3]);
     else if (b < cg.first[5])
-        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
+        sym_escw_body<64, 256>(smem, src, w, counts, SYM_R64, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
     else if (b < cg.first[6])
-        sym_esc_body<16, 256>(smem, src, w, counts, SYM_G16, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+        sym_escw_body<32, 256>(smem, src, w, counts, SYM_R32, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+    else if (b < cg.first[7])
+        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+    else if (b < cg.first[8])
+        sym_esc_body<16, 256>(smem, src, w, counts, SYM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
     else
-        sym_esc_body<8, 256>(smem, src, w, counts, SYM_G8, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        sym_esc_body<8, 256>(smem, src, w, counts, SYM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
 }
 
 // The light launch of a REPLAYED sequence: the rows of the two register classes are finished here -- products
@@ -362,13 +376,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     else if (b < cg.first[4])
         sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.hint[3]);
     else if (b < cg.first[5])
-        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
+        num_escw_body<T, 64, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_R64,
+                                        b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4], counts);
     else if (b < cg.first[6])
+        num_escw_body<T, 32, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_R32,
+                                        b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5], counts);
+    else if (b < cg.first[7])
+        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+    else if (b < cg.first[8])
         num_esc_body<T, 16, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G16,
-                                       b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5], counts);
+                                       b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7], counts);
     else
         num_esc_body<T, 8, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G8,
-                                      b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6], counts);
+                                      b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8], counts);
 }
 
 u32 symbolic_lds_bytes(int cls)
@@ -376,6 +396,8 @@ u32 symbolic_lds_bytes(int cls)
     switch (cls) {
         case SYM_G8: return 32 * sym_esc_group_lds<8>();
         case SYM_G16: return 16 * sym_esc_group_lds<16>();
+        case SYM_R32: return 8 * sym_escw_group_lds<32>();
+        case SYM_R64: return 4 * sym_escw_group_lds<64>();
         case SYM_W128: return 16 * sym_group_lds<SubWave<16>, kSymW128Cap, 256>();
         case SYM_W256: return 8 * sym_group_lds<SubWave<32>, kSymW256Cap, 256>();
         case SYM_W1K: return 4 * sym_group_lds<SubWave<64>, kSymW1KCap, 256>();
@@ -442,27 +464,30 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
                            u32* counts, int cu_count, bool exact, u32 fused_vsize, const void* a_val,
                            const void* b_val, hipEvent_t e0, hipEvent_t e1)
 {
-    static const int slots[7] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_W128, SYM_G16, SYM_G8};
-    static const u32 rows_per_block[7] = {1, 1, 4, 8, 16, 16, 32};
-    const bool fused = fused_vsize != 0 && (mask & ((1u << SYM_G8) | (1u << SYM_G16))) != 0;
+    constexpr int NS = 9;
+    static const int slots[NS] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_R64, SYM_R32, SYM_W128, SYM_G16, SYM_G8};
+    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 16, 16, 32};
+    const bool fused = fused_vsize != 0 && (mask & kSymEscMask) != 0;
     auto class_lds = [&](int cls) -> u32 {
         if (fused && cls == SYM_G8) return 32 * (fused_vsize == 8 ? num_esc_group_lds<double, 8>() : num_esc_group_lds<float, 8>());
         if (fused && cls == SYM_G16) return 16 * (fused_vsize == 8 ? num_esc_group_lds<double, 16>() : num_esc_group_lds<float, 16>());
+        if (fused && cls == SYM_R32) return 8 * (fused_vsize == 8 ? num_escw_group_lds<double, 32>() : num_escw_group_lds<float, 32>());
+        if (fused && cls == SYM_R64) return 4 * (fused_vsize == 8 ? num_escw_group_lds<double, 64>() : num_escw_group_lds<float, 64>());
         return symbolic_lds_bytes(cls);
     };
     u32 lds = 0;
-    for (int k = 0; k < 7; ++k)
+    for (int k = 0; k < NS; ++k)
         if (mask >> slots[k] & 1u) lds = lds > class_lds(slots[k]) ? lds : class_lds(slots[k]);
     ClassGrid cg{};
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < NS; ++k) {
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
     }
-    if (cg.first[7] == 0) {
+    if (cg.first[NS] == 0) {
         if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);  // (nothing to time: an empty interval)
         return;
     }
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < NS; ++k) {
         cg.hint[k] = kNoHint;
         if (!exact) continue;
         u32 off = 0;  // class lists follow each other in class order (publish_bins)
@@ -471,16 +496,16 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
     }
     if (fused && fused_vsize == 8) {
         const ProductSrc<double> nsrc{b_sl, static_cast<const double*>(a_val), b_col, static_cast<const double*>(b_val), w.w_sl};
-        SPECK_LAUNCH_TIMED((sym_light_fused_kernel<double>), dim3(cg.first[7]), dim3(256), lds, s, e0, e1, nsrc, a_ro, w, counts, cg);
+        SPECK_LAUNCH_TIMED((sym_light_fused_kernel<double>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, nsrc, a_ro, w, counts, cg);
         return;
     }
     if (fused) {
         const ProductSrc<float> nsrc{b_sl, static_cast<const float*>(a_val), b_col, static_cast<const float*>(b_val), w.w_sl};
-        SPECK_LAUNCH_TIMED((sym_light_fused_kernel<float>), dim3(cg.first[7]), dim3(256), lds, s, e0, e1, nsrc, a_ro, w, counts, cg);
+        SPECK_LAUNCH_TIMED((sym_light_fused_kernel<float>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, nsrc, a_ro, w, counts, cg);
         return;
     }
     const ProductSrc<float> src{b_sl, nullptr, b_col, nullptr, w.w_sl};
-    SPECK_LAUNCH_TIMED(sym_light_kernel, dim3(cg.first[7]), dim3(256), lds, s, e0, e1, src, a_ro, w, counts, cg);
+    SPECK_LAUNCH_TIMED(sym_light_kernel, dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, src, a_ro, w, counts, cg);
 }
 
 void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const uint2* b_sl,
@@ -498,6 +523,14 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
             break;
         case SYM_G16:
             hipLaunchKernelGGL(sym_esc_kernel<16>, dim3(grid_for(count, lds, 256, cu_count, 16)), dim3(256), lds, s, A, B, w,
+                               counts, cls);
+            break;
+        case SYM_R32:
+            hipLaunchKernelGGL(sym_escw_kernel<32>, dim3(grid_for(count, lds, 256, cu_count, 8)), dim3(256), lds, s, A, B, w,
+                               counts, cls);
+            break;
+        case SYM_R64:
+            hipLaunchKernelGGL(sym_escw_kernel<64>, dim3(grid_for(count, lds, 256, cu_count, 4)), dim3(256), lds, s, A, B, w,
                                counts, cls);
             break;
         case SYM_W128: launch_sym_hash<SubWave<16>, kSymW128Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;

@@ -52,6 +52,22 @@ def fast_random_csr(rows, cols, k, seed, signed=True, jitter=True):
     return po.HostCSR(rows, cols, ro, ci, v)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def options(cfg, **kv):
+    """Library options for the duration of a block (restored to the given defaults afterwards)."""
+    defaults = {"esc32": 1, "esc64": 1}
+    for k, v in kv.items():
+        cfg.set_option(k, v)
+    try:
+        yield
+    finally:
+        for k in kv:
+            cfg.set_option(k, defaults[k])
+
+
 def check(cfg, A, B, expect_classes=None, tol=TOL64, C_reuse=None, threads=0):
     dA, dB = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B))
     dC = C_reuse if C_reuse is not None else sa.dCSR(A.data.dtype)
@@ -180,7 +196,75 @@ def test_eight_lane_rows(cfg):
 def test_wave_classes(cfg):
     A = fast_random_csr(900, 3000, 10, 61)
     B = fast_random_csr(3000, 20000, 12, 62)
-    check(cfg, A, B, [("sym", "wave256"), ("num", "wave128"), ("num", "g16")])
+    # ~70 .. 120 products per row: the 32-lane register class (round 4); the hash classes with it switched off
+    check(cfg, A, B, [("sym", "r32"), ("num", "r32"), ("num", "g16")])
+    with options(cfg, esc32=0, esc64=0):
+        check(cfg, A, B, [("sym", "wave256"), ("num", "wave128"), ("num", "g16")])
+
+
+def test_wide_register_classes(cfg):
+    """SYM_R32 / NUM_R32 (32 lanes per row, <= 128 products from <= 32 entries of A) and SYM_R64 / NUM_R64 (a wave per
+    row, <= 256 products from <= 64 entries): the sorting network across the 16-lane DPP rows (v_permlane16_swap,
+    v_permlane32_swap), the ends mask in LDS, segmented sums across the rows.  Full rows (exactly 128 / 256 products),
+    rows of 32 / 64 entries of A, empty B rows, heavy duplication (300 columns), a wide column range (2^24 - 1 keeps
+    the class, 2^24 leaves R64 for the hash classes), fp32, eager and replayed."""
+    rng = np.random.default_rng(404)
+    # (a) random lengths: both classes, many duplicates
+    A = fast_random_csr(4000, 900, 24, 11)
+    B = fast_random_csr(900, 300, 9, 12)
+    _, st, _ = check(cfg, A, B, [("sym", "r32"), ("num", "r32"), ("sym", "r64"), ("num", "r64")])
+    A32 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float32))
+    B32 = po.HostCSR(B.rows, B.cols, B.row_offsets, B.col_ids, B.data.astype(np.float32))
+    check(cfg, A32, B32, [("num", "r32"), ("num", "r64")], tol=TOL32)
+    # (b) FULL rows: 32 entries x 4 = 128 products and 64 x 4 = 256, every B row four entries, 40 % of them empty
+    kb = 3000
+    B4 = fast_random_csr(kb, 200000, 4, 13, jitter=False)
+    ln = np.diff(B4.row_offsets.astype(np.int64))
+    for per in (32, 64):
+        full = np.flatnonzero(ln == 4)
+        rows = 700
+        acol = np.stack([np.sort(rng.choice(full, size=per, replace=False)) for _ in range(rows)])
+        Af = po.HostCSR(rows, kb, np.arange(rows + 1, dtype=np.uint32) * per, acol.reshape(-1).astype(np.uint32),
+                        (0.5 + rng.random(rows * per)) * rng.choice([-1.0, 1.0], size=rows * per))
+        cls = "r32" if per == 32 else "r64"
+        _, stf, _ = check(cfg, Af, B4, [("sym", cls), ("num", cls)])
+        assert stf["num_bin_rows"][cls] == rows and stf["max_row_ops"] == 4 * per
+    # (c) empty B rows in between, A rows up to 64 entries
+    ro = B4.row_offsets.astype(np.int64)
+    ln2 = ln.copy()
+    ln2[rng.random(kb) < 0.4] = 0
+    keep = np.concatenate([np.arange(ro[i], ro[i] + ln2[i]) for i in range(kb)]).astype(np.int64)
+    nro = np.zeros(kb + 1, dtype=np.uint32)
+    nro[1:] = np.cumsum(ln2)
+    Be = po.HostCSR(kb, 200000, nro, B4.col_ids[keep], B4.data[keep])
+    Ae = fast_random_csr(1500, kb, 64, 14)
+    check(cfg, Ae, Be, [("num", "r32"), ("num", "r64")])
+    # (d) the column range of a row against the key packing: a range of 2^24 - 1 stays in R64, one column more leaves it
+    n = 1 << 26
+    Aw = fast_random_csr(600, kb, 40, 16)                       # 20 .. 40 entries x 6: 120 .. 240 products
+    for lim, expect in (((1 << 24) + 4, "r64"), ((1 << 24) + 5, "r32 only"), ((1 << 25) + 5, "hash")):
+        mid = np.sort(rng.integers(6, lim, size=(kb, 4), dtype=np.int64), axis=1)
+        for i in range(kb):
+            while len(set(mid[i])) < 4:
+                mid[i] = np.sort(rng.integers(6, lim, size=4))
+        bc = np.concatenate([np.full((kb, 1), 5), mid, np.full((kb, 1), lim)], axis=1)   # every B row spans [5, lim]
+        Bl = po.HostCSR(kb, n, np.arange(kb + 1, dtype=np.uint32) * 6, bc.reshape(-1).astype(np.uint32),
+                        0.5 + rng.random(kb * 6))
+        _, stw, _ = check(cfg, Aw, Bl, threads=4)
+        assert (stw["num_bin_rows"]["r64"] > 0) == (expect == "r64"), stw["num_bin_rows"]
+        assert (stw["num_bin_rows"]["r32"] > 0) == (expect != "hash"), stw["num_bin_rows"]     # (its limit: 2^25)
+    # (e) replayed: the rows are finished in the symbolic phase, at the offsets of the previous identical call
+    dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR()
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    st2 = cfg.last_stats()
+    assert st2["replayed"] and st2["esc_fused"] and st2["num_bin_rows"]["r32"] == 0 == st2["num_bin_rows"]["r64"]
+    assert st2["num_bin_rows"]["nfcopy"] >= st["num_bin_rows"]["r32"] + st["num_bin_rows"]["r64"]
+    _assert_matches_oracle(dC, A, B)
+    # (f) and with the classes switched off the same rows take the hash classes
+    with options(cfg, esc32=0, esc64=0):
+        _, st0, _ = check(cfg, A, B)
+        assert st0["num_bin_rows"]["r32"] == 0 == st0["num_bin_rows"]["r64"] == st0["sym_bin_rows"]["r32"]
 
 
 def test_hash_classes_wave256_wave512_block2k(cfg):
@@ -192,21 +276,24 @@ def test_hash_classes_wave256_wave512_block2k(cfg):
     check(cfg, A2, B2, [("sym", "block4k"), ("num", "block2k")])
     # NUM_W256: rows of 86..170 entries at 32 lanes per row (two rows per wave), bitmap sort in a 256-entry table;
     # narrow and very wide column ranges (one and several sort windows), fp32, and the class switched off
+    # (rows of <= 256 products are register-class rows since round 4: the hash classes with those switched off)
     A3 = fast_random_csr(800, 4000, 12, 5)
     B3 = fast_random_csr(4000, 3000000, 14, 6)
-    _, st, _ = check(cfg, A3, B3, [("num", "wave256"), ("num", "wave128")])
-    B4 = fast_random_csr(4000, 9000, 14, 7)                           # range < 16 x nnz is NUM_D1's: stay above
-    check(cfg, A3, B4, [("num", "wave256")])
-    A32 = po.HostCSR(A3.rows, A3.cols, A3.row_offsets, A3.col_ids, A3.data.astype(np.float32))
-    B32 = po.HostCSR(B3.rows, B3.cols, B3.row_offsets, B3.col_ids, B3.data.astype(np.float32))
-    check(cfg, A32, B32, [("num", "wave256")], tol=TOL32)
-    cfg.set_option("num_w256", 0)
-    try:
-        _, st0, _ = check(cfg, A3, B3, [("num", "wave512")])
-        assert st0["num_bin_rows"]["wave256"] == 0
-        assert st0["num_bin_rows"]["wave512"] == st["num_bin_rows"]["wave512"] + st["num_bin_rows"]["wave256"]
-    finally:
-        cfg.set_option("num_w256", 1)
+    check(cfg, A3, B3, [("num", "r32"), ("num", "r64")])
+    with options(cfg, esc32=0, esc64=0):
+        _, st, _ = check(cfg, A3, B3, [("num", "wave256"), ("num", "wave128")])
+        B4 = fast_random_csr(4000, 9000, 14, 7)                           # range < 16 x nnz is NUM_D1's: stay above
+        check(cfg, A3, B4, [("num", "wave256")])
+        A32 = po.HostCSR(A3.rows, A3.cols, A3.row_offsets, A3.col_ids, A3.data.astype(np.float32))
+        B32 = po.HostCSR(B3.rows, B3.cols, B3.row_offsets, B3.col_ids, B3.data.astype(np.float32))
+        check(cfg, A32, B32, [("num", "wave256")], tol=TOL32)
+        cfg.set_option("num_w256", 0)
+        try:
+            _, st0, _ = check(cfg, A3, B3, [("num", "wave512")])
+            assert st0["num_bin_rows"]["wave256"] == 0
+            assert st0["num_bin_rows"]["wave512"] == st["num_bin_rows"]["wave512"] + st["num_bin_rows"]["wave256"]
+        finally:
+            cfg.set_option("num_w256", 1)
 
 
 def test_empty_b_rows_and_long_a_rows(cfg):
@@ -518,7 +605,7 @@ def test_transpose_is_a_stable_sort_by_column_at_size(cfg):
 # both must have put the same rows into the same classes.
 @pytest.mark.parametrize("kind,scale,expect", [
     ("scircuit", 1.0, [("num", "g16"), ("num", "wave512"), ("num", "block2k")]),
-    ("mac_econ", 1.0, [("num", "g16"), ("num", "wave128")]),
+    ("mac_econ", 1.0, [("num", "g16"), ("num", "r32"), ("num", "r64")]),
     ("cant", 1.0, [("sym", "numeric_first"), ("num", "nfcopy")]),
     ("webbase", 1.0, [("num", "global"), ("num", "block8k"), ("num", "direct"), ("sym", "block16k")]),
     ("nlpkkt", 0.002, None)])
@@ -564,8 +651,8 @@ def test_suitesparse_standins_full_parity(cfg, kind, scale, expect):
     same_as_oracle("replayed")
     want = dict(st["num_bin_rows"])
     if st2["esc_fused"]:  # the rows of the register classes were finished in the symbolic phase: "already in place"
-        want["nfcopy"] += want["g8"] + want["g16"]
-        want["g8"] = want["g16"] = 0
+        want["nfcopy"] += want["g8"] + want["g16"] + want["r32"] + want["r64"]
+        want["g8"] = want["g16"] = want["r32"] = want["r64"] = 0
     assert st2["num_bin_rows"] == want and st2["sym_bin_rows"] == st["sym_bin_rows"]
     # the statistics of a sequence whose integer stages verify the previous call instead of folding again
     for k in ("sum_products", "max_row_ops", "nnz_c", "max_row_nnz_c"):
