@@ -52,13 +52,24 @@ __device__ __forceinline__ u32 esc_xor4(u32 v)
     return t;
 }
 
-// compare-exchange with the same register of a partner lane: the lower lane of the pair keeps the minimum
-template <int CTRL>
-__device__ __forceinline__ void esc_cx_lane(u32& x, u32 src, bool lower)
+// median of three unsigned values in ONE instruction.  With k = 0 it is min(x, p), with k = 0xFFFFFFFF max(x, p): a
+// compare-exchange whose direction differs from lane to lane is mov_dpp + v_med3_u32 instead of min + max + select
+// (the launches of the register classes are bound by VALU issue since they took the rows of the hash classes, round 4).
+__device__ __forceinline__ u32 esc_med3(u32 x, u32 p, u32 k)
 {
-    const u32 p = dpp_move<CTRL>(0u, src);
-    const u32 mn = min(x, p), mx = max(x, p);
-    x = lower ? mn : mx;
+    u32 r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(p), "v"(k));
+    return r;
+}
+// k of a lane for the compare-exchanges that pair lanes across bit `b` of the lane number: the lower lane of a pair
+// (bit clear) keeps the minimum
+__device__ __forceinline__ u32 esc_dir(u32 gl, u32 b) { return 0u - ((gl >> b) & 1u); }
+
+// compare-exchange with the same register of a partner lane: k = 0 keeps the minimum, k = ~0 the maximum
+template <int CTRL>
+__device__ __forceinline__ void esc_cx_lane(u32& x, u32 src, u32 k)
+{
+    x = esc_med3(x, dpp_move<CTRL>(0u, src), k);
 }
 __device__ __forceinline__ void esc_cx(u32& lo, u32& hi)
 {
@@ -71,7 +82,7 @@ __device__ __forceinline__ void esc_cx(u32& lo, u32& hi)
 // every compare-exchange gives the lower index the minimum).  `gl` = lane inside the group.
 __device__ __forceinline__ void esc_sort32(u32 (&x)[4], u32 gl)
 {
-    const bool l0 = (gl & 1u) == 0, l1 = (gl & 2u) == 0, l2 = (gl & 4u) == 0;
+    const u32 l0 = esc_dir(gl, 0), l1 = esc_dir(gl, 1), l2 = esc_dir(gl, 2);
     // k = 1, 2: inside the lane
     esc_cx(x[0], x[1]);
     esc_cx(x[2], x[3]);
@@ -126,7 +137,7 @@ __device__ __forceinline__ void esc_sort32(u32 (&x)[4], u32 gl)
 // ... and of the 64 elements of a 16-lane group (one DPP row)
 __device__ __forceinline__ void esc_sort64(u32 (&x)[4], u32 gl)
 {
-    const bool l0 = (gl & 1u) == 0, l1 = (gl & 2u) == 0, l2 = (gl & 4u) == 0, l3 = (gl & 8u) == 0;
+    const u32 l0 = esc_dir(gl, 0), l1 = esc_dir(gl, 1), l2 = esc_dir(gl, 2), l3 = esc_dir(gl, 3);
     esc_sort32(x, gl);  // every half of 8 lanes ascending (the k = 1 .. 5 stages never leave the half)
     // k = 6: flip over 64 = lane ^ 15, register 3 - r; distances 32 .. 4 = lane ^ 4, ^ 2, ^ 1; then 2, 1 inside the lane
     {
@@ -137,11 +148,7 @@ __device__ __forceinline__ void esc_sort64(u32 (&x)[4], u32 gl)
         esc_cx_lane<kDppRowMirror>(x[3], y0, l3);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const u32 p = esc_xor4(x[r]);
-        const u32 mn = min(x[r], p), mx = max(x[r], p);
-        x[r] = l2 ? mn : mx;
-    }
+    for (int r = 0; r < 4; ++r) x[r] = esc_med3(x[r], esc_xor4(x[r]), l2);
 #pragma unroll
     for (int r = 0; r < 4; ++r) esc_cx_lane<kDppQuadXor2>(x[r], x[r], l1);
 #pragma unroll

@@ -34,7 +34,7 @@ namespace speck {
 
 constexpr int kDppRowRor8 = 0x128, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
 
-// the value the lane (lane ^ M) holds; M = 16 / 32 (and the masks that contain them) cross the 16-lane DPP rows
+// the value the lane (lane ^ M) holds (M inside a 16-lane DPP row)
 template <u32 M>
 __device__ __forceinline__ u32 fetch_xor(u32 v)
 {
@@ -44,21 +44,40 @@ __device__ __forceinline__ u32 fetch_xor(u32 v)
     else if constexpr (M == 4) return esc_xor4(v);
     else if constexpr (M == 7) return dpp_move<kDppRowHalfMirror>(0u, v);
     else if constexpr (M == 8) return dpp_move<kDppRowRor8>(0u, v);
-    else if constexpr (M == 15) return dpp_move<kDppRowMirror>(0u, v);
-    else if constexpr (M == 16) {
-        // v_permlane16_swap: the odd rows of the first operand <-> the even rows of the second.  With both = v:
-        // first = {row0, row0, row2, row2}, second = {row1, row1, row3, row3}
-        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-        return (lane_id() & 16u) ? r[0] : r[1];
-    } else if constexpr (M == 31) return fetch_xor<16>(fetch_xor<15>(v));
-    else if constexpr (M == 32) {
-        // v_permlane32_swap: the upper half of the first operand <-> the lower half of the second
-        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-        return (lane_id() & 32u) ? r[0] : r[1];
-    } else {
-        static_assert(M == 63, "lane masks of the 32- .. 256-element networks");
-        return fetch_xor<32>(fetch_xor<16>(fetch_xor<15>(v)));
+    else {
+        static_assert(M == 15, "lane masks inside a DPP row");
+        return dpp_move<kDppRowMirror>(0u, v);
     }
+}
+
+// compare-exchange of x with the value `v` holds in lane ^ M: k = 0 keeps the minimum, k = ~0 the maximum.
+// Across the DPP rows: v_permlane16_swap_b32 swaps the odd rows of its first operand with the even rows of its second
+// (v_permlane32_swap_b32: the upper half with the lower half).  With both operands = v the two results hold, in EVERY
+// lane, the value of the even-row lane and of the odd-row lane of the pair -- min / max do not care which is which, so the
+// exchange is one swap + one median, no select.
+template <u32 M>
+__device__ __forceinline__ u32 esc_cx_xor(u32 x, u32 v, u32 k)
+{
+    if constexpr (M <= 15) return esc_med3(x, fetch_xor<M>(v), k);
+    else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return esc_med3(r[0], r[1], k);  // (only when v IS x: the half-cleaners)
+    } else {
+        static_assert(M == 32, "half-cleaner masks");
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return esc_med3(r[0], r[1], k);
+    }
+}
+// the value of lane ^ 16 / lane ^ 32 (the flips need the partner itself: it is another register's value)
+__device__ __forceinline__ u32 fetch_xor16(u32 v)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (lane_id() & 16u) ? r[0] : r[1];
+}
+__device__ __forceinline__ u32 fetch_xor32(u32 v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane_id() & 32u) ? r[0] : r[1];
 }
 
 // One stage of the bitonic network ("flip" form, element i = lane * 4 + register, every compare-exchange gives the
@@ -66,27 +85,25 @@ __device__ __forceinline__ u32 fetch_xor(u32 v)
 template <u32 K>
 __device__ __forceinline__ void esc_merge_stage(u32 (&x)[4], u32 gl)
 {
-    static_assert(K >= 3 && K <= 8, "stages that leave the lane");
+    static_assert(K == 7 || K == 8, "the stages that leave the 16-lane row");
     // flip: partner index = i ^ (2^K - 1) -> lane ^ (2^(K-2) - 1), register 3 - r; lower <=> lane bit K-3 clear
     {
-        constexpr u32 M = (1u << (K - 2)) - 1u;
-        const bool lower = (gl & (1u << (K - 3))) == 0;
-        const u32 p0 = fetch_xor<M>(x[3]), p1 = fetch_xor<M>(x[2]), p2 = fetch_xor<M>(x[1]), p3 = fetch_xor<M>(x[0]);
-        x[0] = lower ? min(x[0], p0) : max(x[0], p0);
-        x[1] = lower ? min(x[1], p1) : max(x[1], p1);
-        x[2] = lower ? min(x[2], p2) : max(x[2], p2);
-        x[3] = lower ? min(x[3], p3) : max(x[3], p3);
+        const u32 k = esc_dir(gl, K - 3);
+        u32 p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = fetch_xor16(fetch_xor<15>(x[3 - r]));    // lane ^ 31
+            if constexpr (K == 8) p[r] = fetch_xor32(p[r]);  // lane ^ 63
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = esc_med3(x[r], p[r], k);
     }
     // half-cleaners of distance 2^j, j = K-2 .. 2: partner lane ^ 2^(j-2), same register; lower <=> lane bit j-2 clear
-#define SPECK_HALF(J_)                                                    \
-    if constexpr (K - 2 >= (J_)) {                                        \
-        constexpr u32 M = 1u << ((J_) - 2);                               \
-        const bool lower = (gl & M) == 0;                                 \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r)                     \
-        {                                                                 \
-            const u32 p = fetch_xor<M>(x[r]);                             \
-            x[r] = lower ? min(x[r], p) : max(x[r], p);                   \
-        }                                                                 \
+#define SPECK_HALF(J_)                                                               \
+    if constexpr (K - 2 >= (J_)) {                                                   \
+        constexpr u32 M = 1u << ((J_) - 2);                                          \
+        const u32 k = esc_dir(gl, (J_) - 2);                                         \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) x[r] = esc_cx_xor<M>(x[r], x[r], k); \
     }
     SPECK_HALF(6)
     SPECK_HALF(5)

@@ -18,7 +18,9 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      uint2* b_sl, hipEvent_t between = nullptr, u64* nf_off = nullptr,
                      u64 expect_nf = ~0ull, u32 b_rows = ~0u, u32* pred_block_out = nullptr,
                      const u32* pred_block = nullptr, const DeviceStats* pred_stats = nullptr, u32 b_cols = 0,
-                     u64 b_nnz = 0, u32 validate_epoch = 0 /* != 0: also check B's rows (DeviceStats::b_bad_epoch) */);
+                     u64 b_nnz = 0, u32 validate_epoch = 0 /* != 0: also check B's rows (DeviceStats::b_bad_epoch) */,
+                     u32* a_ro_copy = nullptr /* A's row offsets as this call saw them (a later VERIFY compares) */,
+                     bool verify = false /* compare everything with what is stored, write nothing (analysis_kernel) */);
 
 // completion ticket of a replayed launch sequence (pinned host word the host spins on)
 // (the kernel also copies the statistics block into its pinned mirror, before the ticket)
@@ -49,7 +51,8 @@ constexpr u32 kPredBlockWords = 2 * kMaxClasses + 2;
 void launch_scan_predicted(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro,
                            const u32* row_ops, const u32* row_col_min, const u32* row_col_max, RowRec* recs,
                            DeviceStats* st, const ClassifyParams& cp, const u32* pred_off, const u32* pred_tile,
-                           const DeviceStats* pred_stats, BlockPartial* analysis_partials = nullptr);
+                           const DeviceStats* pred_stats, BlockPartial* analysis_partials = nullptr,
+                           bool totals_from_pred = false);
 
 // Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
 // and two product pools (expanded by column bucket; reduced and sorted).

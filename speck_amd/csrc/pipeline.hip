@@ -67,6 +67,8 @@ struct ReplayPlan {
     u32 num_mask, launch_mask;
     u32 num_counts[kMaxClasses];
     bool direct, fused, pred_scan, pred_sym;
+    bool overlap;  // the analysis only VERIFIES what the previous identical call left in the arena, on a stream of its
+                   //   own beside the symbolic / scan / numeric launches (which read that: DESIGN.md 4.3)
     // ... and everything else of "the last eager call" the launches are sized from: a sequence that is enqueued anew at
     // every call (caller's stream, replay_uncaptured, profile_replay) must not pick up what a multiply of ANOTHER
     // problem left in the config since (a captured graph has it baked in)
@@ -169,6 +171,13 @@ struct speck_config {
     bool graph_pred_sym = false;     // ... and has no scatter kernel
     ReplayPlan graph_plan{};
     bool exec_dirty = false;         // other launches went onto the pipeline stream since graph_exec was last launched
+    bool overlap_analysis = true;    // option overlap_analysis: a replayed sequence runs its analysis as a verifier beside it
+    bool capture_overlap = false;    // set while such a sequence is being enqueued
+    bool graph_overlap = false;      // the captured sequence does so
+    hipStream_t vstream = nullptr;   // the verifier's stream, forked from / joined into the pipeline stream
+    hipEvent_t vfork = nullptr, vdone = nullptr;
+    GraphKey arena_key;              // what the per-row / per-entry metadata in the arena (b_sl, row arrays, symbolic records,
+    bool arena_key_valid = false;    //   class table) was last written for -- by a multiply that COMPLETED
     bool replay_uncaptured = false;  // option replay_uncaptured (debugging): enqueue the sequence instead of launching its graph
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
@@ -207,6 +216,7 @@ int ensure_arena(speck_config* c, size_t bytes)
     if (bytes <= c->arena_bytes) return SPECK_OK;
     drop_graph(c);
     c->last_key_valid = false;
+    c->arena_key_valid = false;
     if (c->arena) HIP_TRY(hipFree(c->arena));
     c->arena = nullptr;
     c->arena_bytes = 0;
@@ -233,8 +243,12 @@ struct Carver {
 
 struct Scratch {
     u32 *row_ops, *row_max_ops, *row_col_min, *row_col_max;
-    RowRec* recs;  // one 32-byte record per row, grouped by kernel class
-    u8* cls;
+    RowRec* recs;  // one 32-byte record per row, grouped by (numeric) kernel class
+    RowRec* recs_sym;  // ... and by symbolic class: kept apart, so that the symbolic records of a call survive its scan
+                       //   (a replayed sequence whose analysis only verifies reads those of the previous identical call)
+    u8* cls;       // numeric class of every row
+    u8* cls_sym;   // symbolic class of every row
+    u32* a_ro_copy;  // A's row offsets as the analysis saw them
     BlockPartial* partials;
     uint2* b_sl;  // per A entry: (start, length) of the referenced B row (written by the analysis)
     uint2* w_sl;  // per A entry: its B entries inside the current column window (multi-window rows)
@@ -251,8 +265,9 @@ size_t scratch_bytes(u32 m, u64 nnz_a)
     b += 4 * Carver::need(m, 4);
     b += 2 * Carver::need(size_t(m) + 1, 4);
     b += Carver::need(m, 8);
-    b += Carver::need(m, sizeof(RowRec));
-    b += Carver::need(m, 1);
+    b += 2 * Carver::need(m, sizeof(RowRec));
+    b += 2 * Carver::need(m, 1);
+    b += Carver::need(size_t(m) + 1, 4);
     b += Carver::need(partial_blocks(m), sizeof(BlockPartial));
     return b + 4096;
 }
@@ -265,6 +280,9 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
     s.w_sl = cv.take<uint2>(nnz_a);
     s.nf_off = cv.take<u64>(m);
     s.recs = cv.take<RowRec>(m);
+    s.recs_sym = cv.take<RowRec>(m);
+    s.cls_sym = cv.take<u8>(m);
+    s.a_ro_copy = cv.take<u32>(size_t(m) + 1);
     s.row_ops = cv.take<u32>(m);
     s.row_max_ops = cv.take<u32>(m);
     s.row_col_min = cv.take<u32>(m);
@@ -329,10 +347,10 @@ int ensure_nfpool(speck_config* c, u64 entries, size_t vsize)
     return SPECK_OK;
 }
 
-RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill)
+RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill, bool symbolic_phase = false)
 {
     RowWork w{};
-    w.recs = sc.recs;
+    w.recs = symbolic_phase ? sc.recs_sym : sc.recs;
     w.st = c->d_stats;
     w.b_sl = sc.b_sl;
     w.spill = spill;
@@ -510,7 +528,7 @@ struct Timing {
 
 // analysis -> symbolic classes -> scan + numeric classification.  Nothing here needs a host
 // decision: `sym_mask` only prunes kernels of classes known to be empty (eager path: all).
-int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
+int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const speck_dcsr* B,
                   const Scratch& sc, u32* offsets_out, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
                   bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr,
                   DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
@@ -518,7 +536,13 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
                   const Prediction* pred_out = nullptr /* eager: what this call leaves for a replay */,
                   bool pred_fold_esc = false)
 {
-    const u32 m = (u32)A->rows;
+    const u32 m = (u32)A_in->rows;
+    // A sequence whose analysis only verifies (capture_overlap) reads A's row offsets where the previous identical call
+    // left them, like the rest of the structure-derived metadata: whatever the caller does to A.row_offsets while the
+    // sequence runs, its kernels see ONE consistent structure, and the verifier says whether it is still A's.
+    speck_dcsr a_stored = *A_in;
+    if (c->capture_overlap) a_stored.row_offsets = sc.a_ro_copy;
+    const speck_dcsr* const A = &a_stored;
     u32* const c_ro = sc.counts;  // the symbolic kernels count into scratch; the scan writes offsets_out
     ClassifyParams cp = c->cp;
     cp.sym_allowed = sym_mask;
@@ -536,11 +560,21 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
             tm->ev_between = tm->ev;
             between = kernel_event(c, tm->ev++);
         }
+        if (c->capture_overlap) {
+            // the verifier: forked here, joined in front of the sequence's ticket (enqueue_replay)
+            HIP_TRY(hipEventRecord(c->vfork, s));
+            HIP_TRY(hipStreamWaitEvent(c->vstream, c->vfork, 0));
+            launch_analysis(c->vstream, A_in->row_offsets, A_in->col_ids, B->row_offsets, B->col_ids, m, A_in->nnz, sc.row_ops,
+                            sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, c_ro, sc.partials, sc.recs_sym,
+                            c->d_stats, cp, sc.b_sl, nullptr, sc.nf_off, expect_nf, (u32)B->rows, nullptr, nullptr,
+                            nullptr, (u32)B->cols, B->nnz, 0u, sc.a_ro_copy, true);
+            HIP_TRY(hipEventRecord(c->vdone, c->vstream));
+        } else
         launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
-                        sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls, c_ro, sc.partials, sc.recs,
+                        sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, c_ro, sc.partials, sc.recs_sym,
                         c->d_stats, cp, sc.b_sl, between, sc.nf_off, expect_nf, (u32)B->rows,
                         pred_out ? pred_out->sym_block : nullptr, c->capture_pred_sym ? c->gpred.sym_block : nullptr,
-                        c->gpred.stats, (u32)B->cols, B->nnz, c->check_epoch);
+                        c->gpred.stats, (u32)B->cols, B->nnz, c->check_epoch, sc.a_ro_copy);
         if (timed) {
             tm->ev_analysis_end = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -548,7 +582,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
         HIP_TRY(hipGetLastError());
     }
     if (!(parts & 2u)) return SPECK_OK;
-    const RowWork w = make_work(c, sc, SpillBuffers{});
+    const RowWork w = make_work(c, sc, SpillBuffers{}, true);
     // heaviest classes first: they have the longest tails
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
@@ -604,7 +638,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     if (c->capture_pred_scan)
         launch_scan_predicted(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                               sc.recs, c->d_stats, cp, c->gpred.off, c->gpred.num_tile, c->gpred.stats,
-                              c->capture_pred_sym ? sc.partials : nullptr);
+                              (c->capture_pred_sym && !c->capture_overlap) ? sc.partials : nullptr, c->capture_overlap);
     else
         launch_scan(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                     classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
@@ -621,7 +655,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
                  const u32* counts /*host-known, or nullptr*/, Timing* tm)
 {
     const u32 m = (u32)A->rows;
-    CsrView<T> Av{A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
+    CsrView<T> Av{c->capture_overlap ? sc.a_ro_copy : A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
     const RowWork w = make_work(c, sc, c->spill);
@@ -811,6 +845,9 @@ ReplayPlan plan_replay(const speck_config* c)
     // that are not placed directly) keep the scatter kernel.
     p.pred_sym = c->pred_sym && p.pred_scan && !(c->last_sym_mask >> SYM_GH & 1u) &&
                  (!(c->last_sym_mask >> SYM_NF & 1u) || p.direct);
+    // ... and then nothing downstream needs what the analysis WRITES any more: the previous identical call left all of it
+    // in the arena.  The analysis becomes a verifier beside the sequence (its own stream, joined in front of the ticket).
+    p.overlap = c->overlap_analysis && p.pred_sym && c->vstream != nullptr;
     return p;
 }
 
@@ -825,6 +862,7 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
     c->capture_direct = p.direct;
     c->capture_pred_scan = p.pred_scan;
     c->capture_pred_sym = p.pred_sym;
+    c->capture_overlap = p.overlap;
     c->capture_c_col = C->col_ids;
     c->capture_c_val = C->data;
     struct Reset {
@@ -832,7 +870,7 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
         u32 wcols;
         ~Reset()
         {
-            c->capture_direct = c->capture_fused = c->capture_pred_scan = c->capture_pred_sym = false;
+            c->capture_direct = c->capture_fused = c->capture_pred_scan = c->capture_pred_sym = c->capture_overlap = false;
             c->nf_wcols = wcols;
         }
     } reset{c, c->nf_wcols};
@@ -852,6 +890,7 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
         *ev_num_end = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
+    if (p.overlap) HIP_TRY(hipStreamWaitEvent(s, c->vdone, 0));  // the verifier's verdict is in before the ticket
     // no copy node: the last kernel mirrors the (final) statistics block into pinned host memory, then stores
     // the completion ticket
     launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
@@ -874,6 +913,7 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     c->graph_fused = plan.fused;
     c->graph_pred_scan = plan.pred_scan;
     c->graph_pred_sym = plan.pred_sym;
+    c->graph_overlap = plan.overlap;
     if (c->use_user_stream || c->replay_uncaptured) {
         // the launches of this sequence are enqueued one by one at every call (multiply_impl): only the plan and the
         // sequence's copy of the prediction are kept -- a caller's stream is never put into capture mode
@@ -991,6 +1031,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->pred_valid = c->pred_tiles_valid = false;
                 plan = plan_replay(c);
             }
+            // (a verifying analysis needs the metadata of THIS problem in the arena)
+            if (!(c->arena_key_valid && c->arena_key == key)) plan.overlap = false;
+            c->arena_key_valid = false;
             Timing tm;
             size_t ev_num_end = 0;
             rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, &tm, &ev_num_end);
@@ -998,12 +1041,14 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             HIP_TRY(hipStreamSynchronize(s));
             c->ticket_expected = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE);
             if (!c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
+                c->arena_key = key;
+                c->arena_key_valid = true;
                 publish_counts(c);
                 publish_kernel_times(c, tm, ev_num_end);
                 c->last.replayed = 0;  // (not served by the graph: graph_replays does not count it)
                 c->last.nf_direct = plan.direct ? 1 : 0;
                 c->last.esc_fused = plan.fused ? 1 : 0;
-                c->last.pred_stages = (plan.pred_scan ? 1 : 0) | (plan.pred_sym ? 2 : 0);
+                c->last.pred_stages = (plan.pred_scan ? 1 : 0) | (plan.pred_sym ? 2 : 0) | (plan.overlap ? 4 : 0);
                 return finish_complete();
             }
         }
@@ -1033,7 +1078,21 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             // hundred us, once per switch between problems); on a CALLER's stream, whose traffic the library cannot
             // see, the launches of the sequence are enqueued one by one instead (option replay_uncaptured does the same
             // everywhere: +1..6 % per multiply).
-            if (c->replay_uncaptured || c->use_user_stream) {
+            // A sequence whose analysis only VERIFIES reads the metadata the previous multiply of THIS problem left in the
+            // arena.  If something else has used the arena since (another problem on this config, a stage entry point) the
+            // same sequence runs with a writing analysis in front instead -- enqueued, not from the graph -- and leaves
+            // the arena as the next replay needs it.
+            const bool arena_ok = c->arena_key_valid && c->arena_key == key;
+            bool overlapped = c->graph_overlap;
+            c->arena_key_valid = false;  // (until this call has completed)
+            if (c->graph_overlap && !arena_ok) {
+                ReplayPlan p2 = c->graph_plan;
+                p2.overlap = false;
+                overlapped = false;
+                c->exec_dirty = true;
+                rc = enqueue_replay<T>(c, s, A, B, C, sc, p2, nullptr, nullptr);
+                if (rc != SPECK_OK) return rc;
+            } else if (c->replay_uncaptured || c->use_user_stream) {
                 rc = enqueue_replay<T>(c, s, A, B, C, sc, c->graph_plan, nullptr, nullptr);
                 if (rc != SPECK_OK) return rc;
             } else {
@@ -1043,12 +1102,14 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             rc = wait_ticket(c, s);
             if (rc != SPECK_OK) return rc;
             if (!c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
+                c->arena_key = key;
+                c->arena_key_valid = true;
                 ++c->graph_replays;
                 publish_counts(c);
                 c->last.replayed = 1;
                 c->last.nf_direct = c->graph_direct ? 1 : 0;
                 c->last.esc_fused = c->graph_fused ? 1 : 0;
-                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0) | (c->graph_pred_sym ? 2 : 0);
+                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0) | (c->graph_pred_sym ? 2 : 0) | (overlapped ? 4 : 0);
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -1058,6 +1119,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     // ------------------------------------------------------------------ eager path
     c->exec_dirty = true;  // (a captured sequence of another problem must not be launched again as it is)
+    c->arena_key_valid = false;  // (the arena is rewritten: it is this problem's once the call has completed)
     // INIT: C.row_offsets reuse rule (Multiply.cu:156-165)
     u32* c_ro = nullptr;
     bool own_ro = false;
@@ -1278,6 +1340,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     std::memcpy(c->last_num_counts, c->h_stats->num.count, sizeof(c->last_num_counts));
     c->last_key = make_key<T>(c, A, B, C, s);
     c->last_key_valid = true;
+    c->arena_key = c->last_key;
+    c->arena_key_valid = true;
     // ... and where every row went: the scan kernel wrote the prediction (offsets, tile tables) as it went
     c->pred_valid = c->pred_tiles_valid = keep_pred;
     c->pred_fold_esc = fold_esc;
@@ -1378,6 +1442,9 @@ int speck_config_create(int device, speck_config** out)
         c->aux_done.push_back(e);
     }
     HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&c->vstream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->vfork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->vdone, hipEventDisableTiming));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(DeviceStats)));
     // (b_bad_epoch is the one word no kernel zeroes: recycled memory of a destroyed config must not hold an epoch
     //  this config is going to use)
@@ -1422,6 +1489,9 @@ int speck_config_destroy(speck_config* c)
     for (auto s : c->aux) (void)hipStreamDestroy(s);
     for (auto e : c->aux_done) (void)hipEventDestroy(e);
     if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->vstream) (void)hipStreamDestroy(c->vstream);
+    if (c->vfork) (void)hipEventDestroy(c->vfork);
+    if (c->vdone) (void)hipEventDestroy(c->vdone);
     if (c->arena) (void)hipFree(c->arena);
     if (c->gpool) (void)hipFree(c->gpool);
     if (c->nfpool) (void)hipFree(c->nfpool);
@@ -1493,6 +1563,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         set_analysis_wide_rows((u32)value);
         drop_graph(c);
         c->last_key_valid = false;
+    }
+    else if (n == "overlap_analysis") {
+        c->overlap_analysis = value != 0;
+        drop_graph(c);
     }
     else if (n == "pred_sym") {
         c->pred_sym = value != 0;
@@ -1632,6 +1706,7 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = main_stream(c);
     c->exec_dirty = true;  // (stage entry point: launches on the pipeline stream)
+    c->arena_key_valid = false;  // (... and writes the arena)
     const u32 m = (u32)A->rows;
     if (m == 0 || A->nnz == 0 || B->nnz == 0) {
         if (h_sum_products) *h_sum_products = 0;
@@ -1674,6 +1749,7 @@ int speck_symbolic(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = main_stream(c);
     c->exec_dirty = true;  // (stage entry point: launches on the pipeline stream)
+    c->arena_key_valid = false;  // (... and writes the arena)
     const u32 m = (u32)A->rows;
     if (A->nnz == 0 || B->nnz == 0) {
         HIP_TRY(hipMemsetAsync(d_row_offsets, 0, (size_t(m) + 1) * 4, s));

@@ -90,15 +90,20 @@ __device__ __forceinline__ void validate_b_slice(const u32* __restrict__ b_ro, c
     if (__ballot(bad) != 0 && lane_id() == 0) st->b_bad_epoch = epoch;  // plain store: every writer stores the same value
 }
 
-template <int NW, u32 R>
+// VERIFY (replayed sequence with the analysis OFF the critical path): nothing is written.  Every
+// quantity this kernel would produce -- the (start, length) pair of every entry, ops / longest B row / column range / class
+// of every row, A's row offsets -- is recomputed from the inputs as they are NOW and compared with what the previous
+// identical call left in the arena (which the symbolic, scan and numeric kernels of this sequence are reading while this
+// kernel runs beside them on its own stream); any difference raises capacity_miss and the eager path re-runs the call.
+template <int NW, u32 R, bool VERIFY = false>
 __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     const u32* __restrict__ a_ro, const u32* __restrict__ a_col, const u32* __restrict__ b_ro,
-    const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* __restrict__ row_ops,
-    u32* __restrict__ row_max_ops, u32* __restrict__ row_col_min, u32* __restrict__ row_col_max,
-    u8* __restrict__ sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
-    ClassifyParams cp, uint2* __restrict__ b_sl, DeviceStats* __restrict__ st, u32 b_rows,
+    const u32* __restrict__ b_col, u32 m, u32 rows_per_block, u32* row_ops,
+    u32* row_max_ops, u32* row_col_min, u32* row_col_max,
+    u8* sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
+    ClassifyParams cp, uint2* b_sl, DeviceStats* __restrict__ st, u32 b_rows,
     const u32* __restrict__ pred_block, const DeviceStats* __restrict__ pred_stats, RowRec* __restrict__ recs,
-    u32 an_blocks, u32 b_cols, u32 validate_epoch)
+    u32 an_blocks, u32 b_cols, u32 validate_epoch, u32* a_ro_copy)
 {
     // workgroups behind the analysis grid (eager path): the input check of B, next to the analysis instead of in a
     // launch of its own behind it
@@ -120,9 +125,9 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     //  when such a sequence starts: it only ever follows a call that completed -- or it finds a flag of a failed one,
     //  stops, and the eager path, which starts from zero, re-runs.  Block 0 then writes what the symbolic kernels
     //  read: the class table of the predicted call, which every block checks its own share of.)
-    if (blockIdx.x == 0 && !pred_block)
+    if (!VERIFY && blockIdx.x == 0 && !pred_block)
         for (u32 i = threadIdx.x; i < sizeof(DeviceStats) / 4 - 1; i += kAnThreads) reinterpret_cast<u32*>(st)[i] = 0;  // (all but b_bad_epoch)
-    if (blockIdx.x == 0 && pred_block) {
+    if (!VERIFY && blockIdx.x == 0 && pred_block) {
         constexpr u32 kWords = sizeof(BinTable) / 4;
         const u32* src = reinterpret_cast<const u32*>(&pred_stats->sym);
         u32* dst = reinterpret_cast<u32*>(&st->sym);
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     u64 my_products = 0, my_nf = 0;
     u32 my_max = 0, my_nfr = 0;
     bool bad_col = false;  // a column id of A beyond the rows of B: clamped here, reported through the partials
+    bool bad_meta = false; // VERIFY: something differs from what the previous identical call left behind
     u32 hist[SYM_CLASSES];
 #pragma unroll
     for (int c = 0; c < SYM_CLASSES; ++c) hist[c] = 0;
@@ -178,7 +184,12 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
                 bs[u] = ok[u] ? pr.x : 0u;
                 be[u] = ok[u] ? pr.y : 0u;
                 // hand the B-row bounds to the symbolic / numeric kernels
-                if (ok[u] && b_sl) b_sl[e - e_base] = make_uint2(bs[u], be[u] - bs[u]);
+                if constexpr (VERIFY) {
+                    if (ok[u]) {
+                        const uint2 was = b_sl[e - e_base];
+                        bad_meta |= was.x != bs[u] || was.y != be[u] - bs[u];
+                    }
+                } else if (ok[u] && b_sl) b_sl[e - e_base] = make_uint2(bs[u], be[u] - bs[u]);
             }
             AN_MARK(1);
 #pragma unroll
@@ -256,13 +267,18 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
             const u32 ops32 = ops > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)ops;
             const u32 len_a = ro_[lane + 1] - ro_[lane];
             const u32 cmin = cmin_[lane], cmax = cmax_[lane];
+            if constexpr (VERIFY) {
+                bad_meta |= row_ops[row] != ops32 || row_max_ops[row] != mx_[lane] || row_col_min[row] != cmin ||
+                            row_col_max[row] != cmax || sym_cls[row] != classify_symbolic(len_a, ops32, cmin, cmax, cp);
+            } else {
             if (row_ops) row_ops[row] = ops32;
             if (row_max_ops) row_max_ops[row] = mx_[lane];
             if (row_col_min) row_col_min[row] = cmin;
             if (row_col_max) row_col_max[row] = cmax;
             my_products += ops;
             my_max = max(my_max, ops32);
-            if (sym_cls) {
+            }
+            if (!VERIFY && sym_cls) {
                 cls = classify_symbolic(len_a, ops32, cmin, cmax, cp);
                 sym_cls[row] = cls;
                 if (cls == SYM_NF) {
@@ -278,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
                 }
             }
         }
-        if (sym_cls) {
+        if (!VERIFY && sym_cls) {
 #pragma unroll
             for (int c = 0; c < SYM_CLASSES; ++c) hist[c] += __popcll(__ballot(cls == c));
         }
@@ -294,8 +310,18 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     for (u32 row0 = row_begin + wid * R; row0 < row_end; row0 += NW * R) {
         const u32 nrows = min(R, row_end - row0);
         wave_lds_fence();
-        if (lane <= nrows) s_ro[lane] = a_ro[row0 + lane];
-        if (lane == 0 && nrows == R) s_ro[R] = a_ro[row0 + R];
+        if (lane <= nrows) {
+            const u32 v = a_ro[row0 + lane];
+            s_ro[lane] = v;
+            if constexpr (VERIFY) bad_meta |= a_ro_copy[row0 + lane] != v;
+            else if (a_ro_copy) a_ro_copy[row0 + lane] = v;
+        }
+        if (lane == 0 && nrows == R) {
+            const u32 v = a_ro[row0 + R];
+            s_ro[R] = v;
+            if constexpr (VERIFY) bad_meta |= a_ro_copy[row0 + R] != v;
+            else if (a_ro_copy) a_ro_copy[row0 + R] = v;
+        }
         if (lane < R) {
             s_ops[lane] = 0;
             s_mx[lane] = 0;
@@ -338,7 +364,12 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
                     const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
                     bs[u] = ok[u] ? pr.x : 0u;
                     be[u] = ok[u] ? pr.y : 0u;
-                    if (ok[u] && b_sl) b_sl[e - e_base] = make_uint2(bs[u], be[u] - bs[u]);
+                    if constexpr (VERIFY) {
+                        if (ok[u]) {
+                            const uint2 was = b_sl[e - e_base];
+                            bad_meta |= was.x != bs[u] || was.y != be[u] - bs[u];
+                        }
+                    } else if (ok[u] && b_sl) b_sl[e - e_base] = make_uint2(bs[u], be[u] - bs[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -388,6 +419,15 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
         __syncthreads();
     }
     AN_MARK(5);
+    if constexpr (VERIFY) {
+        // (plain stores of the same value by whoever objects; the join before the sequence's ticket orders them)
+        const bool any_bad = __ballot(bad_meta || bad_col) != 0, any_col = __ballot(bad_col) != 0;
+        if (any_bad && lane == 0) {
+            st->capacity_miss = 1;
+            if (any_col) st->a_invalid = 1;
+        }
+        return;
+    }
     my_products = wave_reduce_add(my_products);
     my_nf = wave_reduce_add(my_nf);
     my_max = wave_reduce_max(my_max);
@@ -1028,7 +1068,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
     const u32* __restrict__ a_ro, const u32* __restrict__ row_ops, const u32* __restrict__ row_col_min,
     const u32* __restrict__ row_col_max, RowRec* __restrict__ recs, ClassifyParams cp,
     const u32* __restrict__ pred_off, const u32* __restrict__ pred_tile, const DeviceStats* __restrict__ pred_stats,
-    BlockPartial* __restrict__ an_parts, u32 an_blocks)
+    BlockPartial* __restrict__ an_parts, u32 an_blocks, bool totals_from_pred)
 {
     constexpr int NW = kScanThreads / 64;
     __shared__ u32 s_scan[NW + 1];
@@ -1073,6 +1113,13 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_pred_kernel(
             st->nnz_c = pred_stats->nnz_c;
             st->max_row_nnz_c = pred_stats->max_row_nnz_c;
             st->g_products = pred_stats->g_products;
+        }
+        // the analysis of this sequence only VERIFIES, beside it (every row's products compared with the previous
+        // identical call's): the totals are that call's
+        if (totals_from_pred && threadIdx.x == 0) {
+            st->sum_products = pred_stats->sum_products;
+            st->max_row_ops = pred_stats->max_row_ops;
+            st->nf_max_range = pred_stats->nf_max_range;
         }
         // the sequence had no scatter kernel (predicted symbolic binning): the totals of the analysis are folded here
         if (an_parts) {
@@ -1252,7 +1299,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
                      uint2* b_sl, hipEvent_t between, u64* nf_off, u64 expect_nf, u32 b_rows, u32* pred_block_out,
-                     const u32* pred_block, const DeviceStats* pred_stats, u32 b_cols, u64 b_nnz, u32 validate_epoch)
+                     const u32* pred_block, const DeviceStats* pred_stats, u32 b_cols, u64 b_nnz, u32 validate_epoch,
+                     u32* a_ro_copy, bool verify)
 {
     // eager path with the input check on: workgroups behind the analysis grid walk B's entries (validate_b_slice)
     auto vblocks = [&](u32 threads) -> u32 {
@@ -1264,15 +1312,28 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
     row_chunking(m, &rows_per_block, &blocks);
     // 64 rows per wave for short rows (g_an_wide_rows: average entries per row up to which; 0 = never)
     const bool wide = g_an_wide_rows && m && nnz_a / m <= g_an_wide_rows;
+    if (verify) {  // replayed sequence with the analysis beside it: compare, write nothing (analysis_kernel, VERIFY)
+        if (wide)
+            hipLaunchKernelGGL((analysis_kernel<4, 64, true>), dim3(blocks), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
+                               rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
+                               partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
+                               (RowRec*)nullptr, blocks, 0u, 0u, a_ro_copy);
+        else
+            hipLaunchKernelGGL((analysis_kernel<8, 32, true>), dim3(blocks), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
+                               rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
+                               partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
+                               (RowRec*)nullptr, blocks, 0u, 0u, a_ro_copy);
+        return;
+    }
     if (pred_block && sym_cls) {  // replayed sequence, symbolic binning predicted: no scatter kernel
         if (wide)
             hipLaunchKernelGGL((analysis_kernel<4, 64>), dim3(blocks), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
                                rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u);
+                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u, a_ro_copy);
         else
             hipLaunchKernelGGL((analysis_kernel<8, 32>), dim3(blocks), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
                                rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u);
+                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u, a_ro_copy);
         if (between) (void)hipEventRecord(between, s);
         return;
     }
@@ -1280,12 +1341,12 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
         hipLaunchKernelGGL((analysis_kernel<4, 64>), dim3(blocks + vblocks(256)), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
                            rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                            partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
-                           (RowRec*)nullptr, blocks, b_cols, validate_epoch);
+                           (RowRec*)nullptr, blocks, b_cols, validate_epoch, a_ro_copy);
     else
         hipLaunchKernelGGL((analysis_kernel<8, 32>), dim3(blocks + vblocks(512)), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
                            rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                            partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
-                           (RowRec*)nullptr, blocks, b_cols, validate_epoch);
+                           (RowRec*)nullptr, blocks, b_cols, validate_epoch, a_ro_copy);
     if (between) (void)hipEventRecord(between, s);  // analysis | binning (Timings::countProducts / loadBalanceCounting)
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,
@@ -1321,14 +1382,14 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
 void launch_scan_predicted(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro,
                            const u32* row_ops, const u32* row_col_min, const u32* row_col_max, RowRec* recs,
                            DeviceStats* st, const ClassifyParams& cp, const u32* pred_off, const u32* pred_tile,
-                           const DeviceStats* pred_stats, BlockPartial* analysis_partials)
+                           const DeviceStats* pred_stats, BlockPartial* analysis_partials, bool totals_from_pred)
 {
     const u32 tiles = scan_tiles(m);
     auto go = [&](auto items) {
         constexpr int I = decltype(items)::value;
         hipLaunchKernelGGL(num_apply_pred_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, st,
                            a_ro, row_ops, row_col_min, row_col_max, recs, cp, pred_off, pred_tile, pred_stats,
-                           analysis_partials, analysis_partials ? analysis_blocks(m) : 0u);
+                           analysis_partials, analysis_partials ? analysis_blocks(m) : 0u, totals_from_pred);
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;
