@@ -28,12 +28,20 @@ constexpr int kDppQuadXor2 = 0x4E;   // quad_perm [2,3,0,1]
 constexpr int kDppQuadMirror = 0x1B; // quad_perm [3,2,1,0]
 constexpr int kDppRowHalfMirror = 0x141;
 
+// a DPP move whose every lane has a source (quad permutations, mirrors, rotations): no `old` operand -- update_dpp with
+// one costs a v_mov per move to set it up (a third of the VALU instructions of the sorting networks)
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_fetch(u32 v)
+{
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+
 // OR over the 8 lanes of a group, result in every lane
 __device__ __forceinline__ u32 esc_group_or(u32 v)
 {
-    v |= dpp_move<kDppQuadXor1>(0u, v);
-    v |= dpp_move<kDppQuadXor2>(0u, v);
-    v |= dpp_move<kDppRowHalfMirror>(0u, v);
+    v |= dpp_fetch<kDppQuadXor1>(v);
+    v |= dpp_fetch<kDppQuadXor2>(v);
+    v |= dpp_fetch<kDppRowHalfMirror>(v);
     return v;
 }
 
@@ -41,7 +49,7 @@ __device__ __forceinline__ u32 esc_group_or(u32 v)
 __device__ __forceinline__ u32 esc_row_or(u32 v)
 {
     v = esc_group_or(v);
-    v |= dpp_move<kDppRowMirror>(0u, v);
+    v |= dpp_fetch<kDppRowMirror>(v);
     return v;
 }
 // the value of lane ^ 4 (two bank-masked row shifts: quads 0 / 2 read the quad above, quads 1 / 3 the quad below)
@@ -69,7 +77,7 @@ __device__ __forceinline__ u32 esc_dir(u32 gl, u32 b) { return 0u - ((gl >> b) &
 template <int CTRL>
 __device__ __forceinline__ void esc_cx_lane(u32& x, u32 src, u32 k)
 {
-    x = esc_med3(x, dpp_move<CTRL>(0u, src), k);
+    x = esc_med3(x, dpp_fetch<CTRL>(src), k);
 }
 __device__ __forceinline__ void esc_cx(u32& lo, u32& hi)
 {

@@ -38,15 +38,15 @@ constexpr int kDppRowRor8 = 0x128, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
 template <u32 M>
 __device__ __forceinline__ u32 fetch_xor(u32 v)
 {
-    if constexpr (M == 1) return dpp_move<kDppQuadXor1>(0u, v);
-    else if constexpr (M == 2) return dpp_move<kDppQuadXor2>(0u, v);
-    else if constexpr (M == 3) return dpp_move<kDppQuadMirror>(0u, v);
+    if constexpr (M == 1) return dpp_fetch<kDppQuadXor1>(v);
+    else if constexpr (M == 2) return dpp_fetch<kDppQuadXor2>(v);
+    else if constexpr (M == 3) return dpp_fetch<kDppQuadMirror>(v);
     else if constexpr (M == 4) return esc_xor4(v);
-    else if constexpr (M == 7) return dpp_move<kDppRowHalfMirror>(0u, v);
-    else if constexpr (M == 8) return dpp_move<kDppRowRor8>(0u, v);
+    else if constexpr (M == 7) return dpp_fetch<kDppRowHalfMirror>(v);
+    else if constexpr (M == 8) return dpp_fetch<kDppRowRor8>(v);
     else {
         static_assert(M == 15, "lane masks inside a DPP row");
-        return dpp_move<kDppRowMirror>(0u, v);
+        return dpp_fetch<kDppRowMirror>(v);
     }
 }
 

@@ -20,7 +20,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      const u32* pred_block = nullptr, const DeviceStats* pred_stats = nullptr, u32 b_cols = 0,
                      u64 b_nnz = 0, u32 validate_epoch = 0 /* != 0: also check B's rows (DeviceStats::b_bad_epoch) */,
                      u32* a_ro_copy = nullptr /* A's row offsets as this call saw them (a later VERIFY compares) */,
-                     bool verify = false /* compare everything with what is stored, write nothing (analysis_kernel) */);
+                     u32* verdict = nullptr /* != nullptr: VERIFY -- compare everything with what is stored, write nothing but
+                                               this word (pinned host memory) on a difference: 1, | 2 for a bad column of A */);
 
 // completion ticket of a replayed launch sequence (pinned host word the host spins on)
 // (the kernel also copies the statistics block into its pinned mirror, before the ticket)

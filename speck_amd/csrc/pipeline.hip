@@ -174,8 +174,9 @@ struct speck_config {
     bool overlap_analysis = true;    // option overlap_analysis: a replayed sequence runs its analysis as a verifier beside it
     bool capture_overlap = false;    // set while such a sequence is being enqueued
     bool graph_overlap = false;      // the captured sequence does so
-    hipStream_t vstream = nullptr;   // the verifier's stream, forked from / joined into the pipeline stream
-    hipEvent_t vfork = nullptr, vdone = nullptr;
+    hipStream_t vstream = nullptr;   // the verifier's stream
+    u32* h_verify = nullptr;         // its verdict: pinned, mapped
+    u32* h_verify_dev = nullptr;
     GraphKey arena_key;              // what the per-row / per-entry metadata in the arena (b_sl, row arrays, symbolic records,
     bool arena_key_valid = false;    //   class table) was last written for -- by a multiply that COMPLETED
     bool replay_uncaptured = false;  // option replay_uncaptured (debugging): enqueue the sequence instead of launching its graph
@@ -560,16 +561,9 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
             tm->ev_between = tm->ev;
             between = kernel_event(c, tm->ev++);
         }
-        if (c->capture_overlap) {
-            // the verifier: forked here, joined in front of the sequence's ticket (enqueue_replay)
-            HIP_TRY(hipEventRecord(c->vfork, s));
-            HIP_TRY(hipStreamWaitEvent(c->vstream, c->vfork, 0));
-            launch_analysis(c->vstream, A_in->row_offsets, A_in->col_ids, B->row_offsets, B->col_ids, m, A_in->nnz, sc.row_ops,
-                            sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, c_ro, sc.partials, sc.recs_sym,
-                            c->d_stats, cp, sc.b_sl, nullptr, sc.nf_off, expect_nf, (u32)B->rows, nullptr, nullptr,
-                            nullptr, (u32)B->cols, B->nnz, 0u, sc.a_ro_copy, true);
-            HIP_TRY(hipEventRecord(c->vdone, c->vstream));
-        } else
+        // (capture_overlap: no analysis IN the sequence -- launch_verifier puts it on a stream of its own, outside any
+        //  graph: a fork / join inside the captured graph cost ~25 us of cross-queue hand-offs, more than it hid)
+        if (!c->capture_overlap)
         launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
                         sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, c_ro, sc.partials, sc.recs_sym,
                         c->d_stats, cp, sc.b_sl, between, sc.nf_off, expect_nf, (u32)B->rows,
@@ -890,7 +884,6 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
         *ev_num_end = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
-    if (p.overlap) HIP_TRY(hipStreamWaitEvent(s, c->vdone, 0));  // the verifier's verdict is in before the ticket
     // no copy node: the last kernel mirrors the (final) statistics block into pinned host memory, then stores
     // the completion ticket
     launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
@@ -973,6 +966,43 @@ void publish_kernel_times(speck_config* c, const Timing& tm, size_t ev_num_end)
     c->last.kernel_events_valid = 1;
 }
 
+// The analysis of a replayed sequence as a VERIFIER (ReplayPlan::overlap): on its own stream, enqueued by the host
+// right behind the sequence, so that it runs beside it.  It compares what it computes from A and B as they are now with
+// what the previous identical call left in the arena -- which is what the sequence's kernels read -- and reports to
+// pinned host memory.  wait_verifier: the verdict, once that stream is idle (it is, long before the sequence's ticket).
+int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, const Scratch& sc)
+{
+    __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
+    ClassifyParams cp = c->cp;
+    cp.sym_allowed = cp.num_allowed = 0xFFFFFFFFu;
+    cp.esc16 = (c->cp.esc16 && B->cols <= (1ull << 26)) ? 1u : 0u;  // (as enqueue_front classifies)
+    cp.esc_fused = 0;
+    launch_analysis(c->vstream, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, (u32)A->rows, A->nnz, sc.row_ops,
+                    sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, sc.counts, sc.partials, sc.recs_sym,
+                    c->d_stats, cp, sc.b_sl, nullptr, sc.nf_off, ~0ull, (u32)B->rows, nullptr, nullptr, nullptr,
+                    (u32)B->cols, B->nnz, 0u, sc.a_ro_copy, c->h_verify_dev);
+    HIP_TRY(hipGetLastError());
+    return SPECK_OK;
+}
+int wait_verifier(speck_config* c, bool* changed)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    while ((q = hipStreamQuery(c->vstream)) == hipErrorNotReady) {
+        cpu_relax();
+        if (std::chrono::steady_clock::now() - t0 > kSpinBudget) {
+            q = hipStreamSynchronize(c->vstream);
+            break;
+        }
+    }
+    if (q != hipSuccess) {
+        (void)hipGetLastError();
+        return SPECK_ERR_HIP;
+    }
+    *changed = __atomic_load_n(c->h_verify, __ATOMIC_ACQUIRE) != 0u;
+    return SPECK_OK;
+}
+
 template <typename T>
 int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, speck_dcsr* C,
                   speck_timings* t)
@@ -1038,9 +1068,18 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             size_t ev_num_end = 0;
             rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, &tm, &ev_num_end);
             if (rc != SPECK_OK) return rc;
+            if (plan.overlap) {
+                rc = launch_verifier(c, A, B, sc);
+                if (rc != SPECK_OK) return rc;
+            }
             HIP_TRY(hipStreamSynchronize(s));
             c->ticket_expected = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE);
-            if (!c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
+            bool changed = false;
+            if (plan.overlap) {
+                rc = wait_verifier(c, &changed);
+                if (rc != SPECK_OK) return rc;
+            }
+            if (!changed && !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 c->arena_key = key;
                 c->arena_key_valid = true;
                 publish_counts(c);
@@ -1098,10 +1137,20 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             } else {
                 HIP_TRY(hipGraphLaunch(c->graph_exec, s));
             }
+            // (behind the sequence, while it runs: the host would only spin otherwise)
+            if (overlapped) {
+                rc = launch_verifier(c, A, B, sc);
+                if (rc != SPECK_OK) return rc;
+            }
             // the last node of the sequence stores a ticket into pinned memory
             rc = wait_ticket(c, s);
             if (rc != SPECK_OK) return rc;
-            if (!c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
+            bool changed = false;
+            if (overlapped) {
+                rc = wait_verifier(c, &changed);
+                if (rc != SPECK_OK) return rc;
+            }
+            if (!changed && !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 c->arena_key = key;
                 c->arena_key_valid = true;
                 ++c->graph_replays;
@@ -1443,8 +1492,9 @@ int speck_config_create(int device, speck_config** out)
     }
     HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&c->vstream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->vfork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->vdone, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_verify), 64, hipHostMallocMapped));
+    *c->h_verify = 0;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_verify_dev), c->h_verify, 0));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(DeviceStats)));
     // (b_bad_epoch is the one word no kernel zeroes: recycled memory of a destroyed config must not hold an epoch
     //  this config is going to use)
@@ -1490,8 +1540,7 @@ int speck_config_destroy(speck_config* c)
     for (auto e : c->aux_done) (void)hipEventDestroy(e);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->vstream) (void)hipStreamDestroy(c->vstream);
-    if (c->vfork) (void)hipEventDestroy(c->vfork);
-    if (c->vdone) (void)hipEventDestroy(c->vdone);
+    if (c->h_verify) (void)hipHostFree(c->h_verify);
     if (c->arena) (void)hipFree(c->arena);
     if (c->gpool) (void)hipFree(c->gpool);
     if (c->nfpool) (void)hipFree(c->nfpool);

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     u8* sym_cls, u32* __restrict__ counts, BlockPartial* __restrict__ partials,
     ClassifyParams cp, uint2* b_sl, DeviceStats* __restrict__ st, u32 b_rows,
     const u32* __restrict__ pred_block, const DeviceStats* __restrict__ pred_stats, RowRec* __restrict__ recs,
-    u32 an_blocks, u32 b_cols, u32 validate_epoch, u32* a_ro_copy)
+    u32 an_blocks, u32 b_cols, u32 validate_epoch, u32* a_ro_copy, u32* __restrict__ verdict)
 {
     // workgroups behind the analysis grid (eager path): the input check of B, next to the analysis instead of in a
     // launch of its own behind it
@@ -421,11 +421,10 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     AN_MARK(5);
     if constexpr (VERIFY) {
         // (plain stores of the same value by whoever objects; the join before the sequence's ticket orders them)
+        // (the verdict goes to pinned host memory: this kernel runs on a stream of its own beside the sequence, whose
+        //  last kernel mirrors the statistics block -- the host reads both once both streams are idle)
         const bool any_bad = __ballot(bad_meta || bad_col) != 0, any_col = __ballot(bad_col) != 0;
-        if (any_bad && lane == 0) {
-            st->capacity_miss = 1;
-            if (any_col) st->a_invalid = 1;
-        }
+        if (any_bad && lane == 0) __hip_atomic_fetch_or(verdict, any_col ? 3u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     my_products = wave_reduce_add(my_products);
@@ -1300,8 +1299,9 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
                      uint2* b_sl, hipEvent_t between, u64* nf_off, u64 expect_nf, u32 b_rows, u32* pred_block_out,
                      const u32* pred_block, const DeviceStats* pred_stats, u32 b_cols, u64 b_nnz, u32 validate_epoch,
-                     u32* a_ro_copy, bool verify)
+                     u32* a_ro_copy, u32* verdict)
 {
+    const bool verify = verdict != nullptr;
     // eager path with the input check on: workgroups behind the analysis grid walk B's entries (validate_b_slice)
     auto vblocks = [&](u32 threads) -> u32 {
         if (!validate_epoch || b_rows == 0 || b_rows == ~0u) return 0u;
@@ -1317,23 +1317,23 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
             hipLaunchKernelGGL((analysis_kernel<4, 64, true>), dim3(blocks), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
                                rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                                partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
-                               (RowRec*)nullptr, blocks, 0u, 0u, a_ro_copy);
+                               (RowRec*)nullptr, blocks, 0u, 0u, a_ro_copy, verdict);
         else
             hipLaunchKernelGGL((analysis_kernel<8, 32, true>), dim3(blocks), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
                                rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                                partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
-                               (RowRec*)nullptr, blocks, 0u, 0u, a_ro_copy);
+                               (RowRec*)nullptr, blocks, 0u, 0u, a_ro_copy, verdict);
         return;
     }
     if (pred_block && sym_cls) {  // replayed sequence, symbolic binning predicted: no scatter kernel
         if (wide)
             hipLaunchKernelGGL((analysis_kernel<4, 64>), dim3(blocks), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
                                rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u, a_ro_copy);
+                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u, a_ro_copy, (u32*)nullptr);
         else
             hipLaunchKernelGGL((analysis_kernel<8, 32>), dim3(blocks), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
                                rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
-                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u, a_ro_copy);
+                               partials, cp, b_sl, st, b_rows, pred_block, pred_stats, recs, blocks, 0u, 0u, a_ro_copy, (u32*)nullptr);
         if (between) (void)hipEventRecord(between, s);
         return;
     }
@@ -1341,12 +1341,12 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
         hipLaunchKernelGGL((analysis_kernel<4, 64>), dim3(blocks + vblocks(256)), dim3(256), 0, s, a_ro, a_col, b_ro, b_col, m,
                            rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                            partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
-                           (RowRec*)nullptr, blocks, b_cols, validate_epoch, a_ro_copy);
+                           (RowRec*)nullptr, blocks, b_cols, validate_epoch, a_ro_copy, (u32*)nullptr);
     else
         hipLaunchKernelGGL((analysis_kernel<8, 32>), dim3(blocks + vblocks(512)), dim3(512), 0, s, a_ro, a_col, b_ro, b_col, m,
                            rows_per_block, row_ops, row_max_ops, row_col_min, row_col_max, sym_cls, counts,
                            partials, cp, b_sl, st, b_rows, (const u32*)nullptr, (const DeviceStats*)nullptr,
-                           (RowRec*)nullptr, blocks, b_cols, validate_epoch, a_ro_copy);
+                           (RowRec*)nullptr, blocks, b_cols, validate_epoch, a_ro_copy, (u32*)nullptr);
     if (between) (void)hipEventRecord(between, s);  // analysis | binning (Timings::countProducts / loadBalanceCounting)
     // with sym_cls == nullptr only block 0 does anything: it folds the totals (P, max row ops)
     hipLaunchKernelGGL(sym_scatter_kernel, dim3(sym_cls ? blocks : 1), dim3(kChunk), 0, s,

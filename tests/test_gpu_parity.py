@@ -1273,7 +1273,7 @@ def test_a_captured_sequence_owns_its_prediction(cfg):
     for _ in range(4):
         sa.MultiplyspECK(dA, dA, dC, cfg)
     st = cfg.last_stats()
-    assert st["replayed"] and st["pred_stages"] == 3
+    assert st["replayed"] and (st["pred_stages"] & 3) == 3
     replays = st["graph_replays"]
     sa.MultiplyspECK(dB, dB, dD, cfg)                          # eager, other buffers: rewrites the config's prediction
     _assert_matches_oracle(dD, Bg, Bg)
