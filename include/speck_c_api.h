@@ -84,8 +84,12 @@ typedef struct speck_stats {
     int32_t pred_stages;                         /* that sequence's integer stages verified the previous identical call's
                                                   *    decisions instead of folding them again: bit 0 the row-offset scan +
                                                   *    numeric binning (one kernel), bit 1 the symbolic binning (inside the
-                                                  *    analysis kernel) -- DESIGN.md 4.3 */
-    int32_t reserved_;
+                                                  *    analysis kernel), bit 2 the analysis itself (a verifier on its own
+                                                  *    stream beside the sequence) -- DESIGN.md 4.3 */
+    int32_t eager_speculated;                    /* an EAGER call that ran analysis .. scan as one batch sized from the previous
+                                                  * eager call on the config (one read-back instead of two; option
+                                                  * eager_speculate): 1 = its device-side checks held, -1 = they did not and
+                                                  * the two-read-back sequence re-ran, 0 = not attempted */
 } speck_stats;
 
 typedef struct speck_config speck_config; /* opaque; reference: spECKConfig, include/spECKConfig.h:8-53 */

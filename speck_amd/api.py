@@ -298,7 +298,8 @@ class spECKConfig:
             graph_replays=int(s.graph_replays), graph_captures=int(s.graph_captures),
             sym_phase_ms=float(s.sym_phase_ms), num_phase_ms=float(s.num_phase_ms),
             replayed=bool(s.replayed), nf_direct=bool(s.nf_direct), esc_fused=bool(s.esc_fused), pool_fallbacks=int(s.pool_fallbacks),
-            scratch_pool_bytes=int(s.scratch_pool_bytes), pred_stages=int(s.pred_stages))
+            scratch_pool_bytes=int(s.scratch_pool_bytes), pred_stages=int(s.pred_stages),
+            eager_speculated=int(s.eager_speculated))
 
 
 _NO_TIMINGS = CTimings()  # scratch for calls that do not ask for stage times

@@ -109,6 +109,13 @@ struct speck_config {
     std::vector<hipStream_t> aux;  // one stream per kernel class: classes run concurrently
     std::vector<hipEvent_t> aux_done;
     hipEvent_t fork = nullptr;
+    bool eager_speculate = true;  // option eager_speculate: an eager call that follows another one on this config sizes
+                                  //   its symbolic phase (grids, launched classes, scratch pool, numeric-first window) from
+                                  //   THAT call and runs analysis .. scan as one batch -- one read-back instead of two; the
+                                  //   device checks every assumption (capacity_miss: the two-read-back sequence re-runs)
+    bool spec_valid = false;      // such a call has completed (last_sym_* describe it)
+    u64 spec_rows_a = 0, spec_rows_b = 0;
+    int eager_spec_hits = 0, eager_spec_misses = 0;
     bool validate_inputs = true;  // eager path: B's rows strictly ascending and in range
     u32 epoch_counter = 0, check_epoch = 0;  // ... reported as the call's epoch (DeviceStats::b_bad_epoch); set while
                                              //   an eager call that checks is in flight
@@ -175,8 +182,10 @@ struct speck_config {
     bool capture_overlap = false;    // set while such a sequence is being enqueued
     bool graph_overlap = false;      // the captured sequence does so
     hipStream_t vstream = nullptr;   // the verifier's stream
-    u32* h_verify = nullptr;         // its verdict: pinned, mapped
+    u32* h_verify = nullptr;         // its verdict (word 0) and its completion ticket (word 16): pinned, mapped
     u32* h_verify_dev = nullptr;
+    u32* d_vticket = nullptr;
+    u32 vticket_expected = 0;
     GraphKey arena_key;              // what the per-row / per-entry metadata in the arena (b_sl, row arrays, symbolic records,
     bool arena_key_valid = false;    //   class table) was last written for -- by a multiply that COMPLETED
     bool replay_uncaptured = false;  // option replay_uncaptured (debugging): enqueue the sequence instead of launching its graph
@@ -535,7 +544,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
                   DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
                   u32 parts = 3 /* 1: analysis + binning, 2: symbolic launches + scan */, u64 expect_nf = ~0ull,
                   const Prediction* pred_out = nullptr /* eager: what this call leaves for a replay */,
-                  bool pred_fold_esc = false)
+                  bool pred_fold_esc = false, bool hint_exact = true /* sym_hint holds THIS call's counts (list positions) */)
 {
     const u32 m = (u32)A_in->rows;
     // A sequence whose analysis only verifies (capture_overlap) reads A's row offsets where the previous identical call
@@ -607,7 +616,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
                                  const u32 part = cls == kLightBig ? sym_big : ~sym_big;
                                  launch_symbolic_light(ks, hint, sym_mask & kSymLightMask & part, A->row_offsets,
                                                        sc.b_sl, B->col_ids, w, c_ro, c->sm,
-                                                       sym_hint != nullptr, c->capture_fused ? vsize : 0u, A->data,
+                                                       sym_hint != nullptr && hint_exact, c->capture_fused ? vsize : 0u, A->data,
                                                        B->data, e0, e1);
                              } else if (cls == SYM_NF) {
                                  // the numeric dense-window kernel, in the symbolic phase (numeric.hip)
@@ -981,24 +990,22 @@ int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, c
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, sc.counts, sc.partials, sc.recs_sym,
                     c->d_stats, cp, sc.b_sl, nullptr, sc.nf_off, ~0ull, (u32)B->rows, nullptr, nullptr, nullptr,
                     (u32)B->cols, B->nnz, 0u, sc.a_ro_copy, c->h_verify_dev);
+    launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
 }
 int wait_verifier(speck_config* c, bool* changed)
 {
+    // (the verifier finishes long before the sequence: by the time the host looks its ticket is there -- no API call)
+    const u32 want = ++c->vticket_expected;
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t q;
-    while ((q = hipStreamQuery(c->vstream)) == hipErrorNotReady) {
-        cpu_relax();
-        if (std::chrono::steady_clock::now() - t0 > kSpinBudget) {
-            q = hipStreamSynchronize(c->vstream);
-            break;
-        }
+    bool seen = false;
+    while (!(seen = __atomic_load_n(c->h_verify + 16, __ATOMIC_ACQUIRE) == want)) {
+        for (int i = 0; i < 64; ++i) cpu_relax();
+        if (std::chrono::steady_clock::now() - t0 > kSpinBudget) break;
     }
-    if (q != hipSuccess) {
-        (void)hipGetLastError();
-        return SPECK_ERR_HIP;
-    }
+    if (!seen) HIP_TRY(hipStreamSynchronize(c->vstream));
+    c->vticket_expected = __atomic_load_n(c->h_verify + 16, __ATOMIC_ACQUIRE);
     *changed = __atomic_load_n(c->h_verify, __ATOMIC_ACQUIRE) != 0u;
     return SPECK_OK;
 }
@@ -1201,6 +1208,36 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                              parts == 2u ? sym_known : nullptr, nullptr, ~0ull, ~0u, parts, ~0ull,
                              keep_pred ? &c->pred : nullptr, fold_esc);
     };
+    // ONE batch, sized from the previous eager call on this config (same shapes): the classes that call had rows in
+    // (a row in any other class raises capacity_miss: publish_bins), grids from its counts, its scratch pool and
+    // numeric-first window (checked by the scatter / numeric-first kernels).  Saves the first of the two read-backs --
+    // a ticket, a spin and the launch latency behind it, ~15 us of a 170 us multiply.
+    bool speculated = false;
+    u32 spec_counts[kMaxClasses];
+    if (c->eager_speculate && c->spec_valid && c->spec_rows_a == A->rows && c->spec_rows_b == B->rows &&
+        (c->cp.nf_min_ops || c->cp.gh_per_window) && !c->profile_kernels) {
+        u32 mask = 0;
+        for (int k = 0; k < kMaxClasses; ++k) {
+            spec_counts[k] = c->last_sym_counts[k] ? c->last_sym_counts[k] + c->last_sym_counts[k] / 4 + 64 : 0;
+            if (spec_counts[k]) mask |= 1u << k;
+        }
+        // (the light launch is one kernel whatever it holds: every class of it may have rows)
+        for (int k = 0; k < kMaxClasses; ++k)
+            if ((kSymLightMask >> k & 1u) && !spec_counts[k]) spec_counts[k] = 256;
+        mask |= kSymLightMask;
+        c->check_epoch = c->validate_inputs ? (++c->epoch_counter ? c->epoch_counter : ++c->epoch_counter) : 0u;
+        rc = enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, mask, kAllNum, true, &tm, spec_counts,
+                           nullptr, ~0ull, ~0u, 3u, c->nf_cap_entries, keep_pred ? &c->pred : nullptr, fold_esc, false);
+        if (rc == SPECK_OK) rc = read_stats(c, s);
+        c->check_epoch = 0;
+        if (rc != SPECK_OK) return fail(rc);
+        if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
+        if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
+        speculated = !c->h_stats->capacity_miss;
+        ++(speculated ? c->eager_spec_hits : c->eager_spec_misses);
+        c->last.eager_speculated = speculated ? 1 : -1;
+    }
+    if (!speculated) {
     // analysis + binning, and in the same launch the input check: B's rows strictly ascending and in range (one
     // coalesced pass by extra workgroups of the analysis kernel; A's column ids are checked -- and clamped -- by the
     // analysis itself).  The verdict is the call's epoch in a word block 0 of that kernel does not zero.
@@ -1248,6 +1285,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     if (rc != SPECK_OK) return fail(rc);
     if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
     if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
+    }  // !speculated
     t->countProducts = 0.f;
     t->loadBalanceCounting = 0.f;
     t->globalMapsCounting = 0.f;
@@ -1391,6 +1429,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     c->last_key_valid = true;
     c->arena_key = c->last_key;
     c->arena_key_valid = true;
+    c->spec_valid = true;
+    c->spec_rows_a = A->rows;
+    c->spec_rows_b = B->rows;
     // ... and where every row went: the scan kernel wrote the prediction (offsets, tile tables) as it went
     c->pred_valid = c->pred_tiles_valid = keep_pred;
     c->pred_fold_esc = fold_esc;
@@ -1492,8 +1533,10 @@ int speck_config_create(int device, speck_config** out)
     }
     HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&c->vstream, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_verify), 64, hipHostMallocMapped));
-    *c->h_verify = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_verify), 128, hipHostMallocMapped));
+    std::memset(c->h_verify, 0, 128);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_vticket), sizeof(u32)));
+    HIP_TRY(hipMemset(c->d_vticket, 0, sizeof(u32)));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_verify_dev), c->h_verify, 0));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(DeviceStats)));
     // (b_bad_epoch is the one word no kernel zeroes: recycled memory of a destroyed config must not hold an epoch
@@ -1541,6 +1584,7 @@ int speck_config_destroy(speck_config* c)
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->vstream) (void)hipStreamDestroy(c->vstream);
     if (c->h_verify) (void)hipHostFree(c->h_verify);
+    if (c->d_vticket) (void)hipFree(c->d_vticket);
     if (c->arena) (void)hipFree(c->arena);
     if (c->gpool) (void)hipFree(c->gpool);
     if (c->nfpool) (void)hipFree(c->nfpool);
@@ -1613,6 +1657,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         drop_graph(c);
         c->last_key_valid = false;
     }
+    else if (n == "eager_speculate") c->eager_speculate = value != 0;
     else if (n == "overlap_analysis") {
         c->overlap_analysis = value != 0;
         drop_graph(c);

@@ -1274,6 +1274,20 @@ __global__ __launch_bounds__(64) void done_kernel(u32* __restrict__ dev_ticket, 
         __hip_atomic_store(host_ticket, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// ... and the ticket of the verifier's stream (launch_verifier): the kernel boundary in front of it orders the verifier's
+// verdict (system-scope atomics on pinned memory) before the ticket
+__global__ __launch_bounds__(64) void ticket_kernel(u32* __restrict__ dev_ticket, u32* __restrict__ host_ticket)
+{
+    if (threadIdx.x == 0) {
+        const u32 t = *dev_ticket + 1u;
+        *dev_ticket = t;
+        __hip_atomic_store(host_ticket, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+void launch_ticket(hipStream_t s, u32* dev_ticket, u32* host_ticket)
+{
+    hipLaunchKernelGGL(ticket_kernel, dim3(1), dim3(64), 0, s, dev_ticket, host_ticket);
+}
 void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceStats* st, DeviceStats* host_mirror)
 {
     hipLaunchKernelGGL(done_kernel, dim3(1), dim3(64), 0, s, dev_ticket, host_ticket, st, host_mirror);

@@ -1002,6 +1002,67 @@ def test_register_class_row_whose_last_product_packs_to_all_ones(cfg, log_cols, 
     assert (np.abs(got.data - R.data) <= TOL64 * ab + 1e-300).all()
 
 
+def test_eager_call_sized_from_the_previous_one_needs_one_read_back():
+    """An EAGER call (no replay: the structure changes from call to call) that follows another eager call of the same
+    shape runs analysis .. scan as ONE batch sized from that call -- launched classes, grids, scratch pool, numeric-first
+    window -- and every assumption is checked on the device (speck_stats::eager_speculated = 1); when one fails (here: rows
+    of a class the previous call did not have; a numeric-first pool that is too small) the two-read-back sequence re-runs
+    (-1).  Same results either way; an invalid B is still rejected with C untouched."""
+    cfg = sa.spECKConfig.initialize(0)
+    try:
+        cfg.set_option("use_graph", 0)
+        rows, inner, cols = 3000, 2500, 400000      # (wide: a 600-entry row is a SYM_B16K row, not a bitmap one)
+        dC = sa.dCSR()
+
+        def run(A, B, want):
+            dA, dB = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B))
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+            st = cfg.last_stats()
+            assert st["eager_speculated"] == want, (st["eager_speculated"], want)
+            assert not st["replayed"]
+            _assert_matches_oracle(dC, A, B)
+            return st
+
+        B = fast_random_csr(inner, cols, 8, 2)
+        run(fast_random_csr(rows, inner, 9, 1), B, 0)                 # the first call on the config: two read-backs
+        for seed in (3, 4, 5):                                        # other structures of the same kind: one
+            run(fast_random_csr(rows, inner, 9, seed), B, 1)
+        Ah = fast_random_csr(rows, inner, 9, 6)                       # ... then a row of 600 entries: a class that call had
+        ro = Ah.row_offsets.astype(np.int64).copy()                   #     no rows in -> the device objects, classic re-run
+        big = np.sort(np.random.default_rng(7).choice(inner, size=600, replace=False)).astype(np.uint32)
+        col = np.concatenate([Ah.col_ids[:ro[1]], big, Ah.col_ids[ro[2]:]])
+        val = np.concatenate([Ah.data[:ro[1]], np.ones(600), Ah.data[ro[2]:]])
+        ro[2:] += 600 - (ro[2] - ro[1])
+        Ah = po.HostCSR(rows, inner, ro.astype(np.uint32), col.astype(np.uint32), val)
+        run(Ah, B, -1)
+        run(Ah, B, 1)                                                 # (and now that class is expected)
+        # numeric-first rows appear (banded input of the same shape): the pool of the previous calls is too small
+        Ab = to_po(sa.gen_matrix("cant", 0.05, 3, signed=True))
+        dAb = sa.dCSR.from_host(to_sa(Ab))
+        for want in (0, 1):                                           # (other shape: not attempted; then attempted and held)
+            sa.MultiplyspECK(dAb, dAb, dC, cfg)
+            st = cfg.last_stats()
+            assert st["eager_speculated"] == want and st["sym_bin_rows"]["numeric_first"] > 0
+            _assert_matches_oracle(dC, Ab, Ab)
+        # an unsorted B in a speculated call
+        Bbad = po.HostCSR(B.rows, B.cols, B.row_offsets, B.col_ids.copy(), B.data)
+        r0 = int(np.flatnonzero(np.diff(B.row_offsets.astype(np.int64)) >= 2)[0])
+        e = int(B.row_offsets[r0])
+        Bbad.col_ids[e], Bbad.col_ids[e + 1] = Bbad.col_ids[e + 1], Bbad.col_ids[e]
+        A1 = fast_random_csr(rows, inner, 9, 8)
+        run(A1, B, 0)                                                 # (shape of the first family again: not attempted)
+        before = dC.to_host()
+        with pytest.raises(sa.SpeckError) as err:
+            sa.MultiplyspECK(sa.dCSR.from_host(to_sa(A1)), sa.dCSR.from_host(to_sa(Bbad)), dC, cfg)
+        assert err.value.status == 8
+        after = dC.to_host()
+        assert after.nnz == before.nnz and (after.col_ids == before.col_ids).all() and (after.data == before.data).all()
+        cfg.set_option("eager_speculate", 0)
+        run(fast_random_csr(rows, inner, 9, 9), B, 0)
+    finally:
+        cfg.cleanup()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # round 3: input checks, scratch-pool fallbacks, replayed sequences at full size
 def test_column_of_a_beyond_the_rows_of_b_is_rejected(cfg):
