@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""The bench line's launch durations against the rocprofv3 kernel trace of the SAME command.
+
+    python scripts/check_launch_ms.py profiles/r04_bench_scircuit.json profiles/r04_bench_scircuit_kernel_stats.csv [tol=0.05]
+
+bench.py times the launches of the replayed sequence in an untimed pre-pass (HIP events on the launch's own stream);
+`rocprofv3 --kernel-trace --stats` of the same command averages every dispatch of a kernel.  The kernels of the replayed
+sequence carry names of their own (sym_light_fused_kernel; num_light_kernel<T, false>: no register-class bodies;
+analysis_kernel<.., true>: the verifier; num_apply_pred_kernel), so the trace's average IS the replay launch's.  Exits 1
+if a launch of `roofline.launches` differs from the trace by more than tol."""
+import csv
+import json
+import sys
+
+KERNEL_OF = {  # bench launch name -> kernel name in the trace (fp64 legs)
+    "fused_light": "sym_light_fused_kernel<double>",
+    "light": "num_light_kernel<double, false>",
+    "numeric_first": "nf_dense_kernel<double, 256>",
+}
+
+
+def main():
+    line = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    stats = {r["kernel"]: r for r in csv.DictReader(open(sys.argv[2]))}
+    tol = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+    bad = 0
+    for launch in line["roofline"]["launches"]:
+        k = KERNEL_OF.get(launch["name"])
+        if not k:
+            continue
+        if k not in stats and launch["name"] == "light":      # a sequence that is not fused: the eager kernel's name
+            k = "num_light_kernel<double, true>"
+        if k not in stats:
+            print(f"{launch['name']:14s} {k}: not in the trace")
+            bad += 1
+            continue
+        avg_ms = float(stats[k]["avg_us"]) * 1e-3
+        rel = abs(launch["ms"] - avg_ms) / avg_ms
+        ok = rel <= tol
+        print(f"{launch['name']:14s} bench {launch['ms']*1e3:8.2f} us   trace avg {avg_ms*1e3:8.2f} us ({stats[k]['calls']} calls)   "
+              f"{rel*100:5.1f} %  {'ok' if ok else 'DIFFERS'}")
+        bad += 0 if ok else 1
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

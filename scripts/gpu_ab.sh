@@ -11,7 +11,7 @@ for w in $WL; do
     timeout 600 python bench.py --workload $w --no-cpu-baseline --no-config5 --no-configs --no-verify $BENCH_ARGS $opts 2>&1 | tail -n 1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('%-9s %-34s %.4f ms  %7.1f GF  sym %.3f num %.3f  %s' % ('$w', '$variant', d['ms_per_step'], d['value'], d['phases_ms']['symbolic'], d['phases_ms']['numeric'], d['kernels_ms']))
+print('%-9s %-34s %.4f ms  eager %.4f  %7.1f GF  sym %.3f num %.3f  phase %.3f  %s' % ('$w', '$variant', d['ms_per_step'], d['eager_ms_per_step'] or 0, d['value'], d['phases_ms']['symbolic'], d['phases_ms']['numeric'], d['roofline']['numeric_phase_frac'], d['kernels_ms']))
 "
   done
 done
