@@ -36,7 +36,8 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
                  DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
                  const u32* pred_off = nullptr, u32* pred_off_out = nullptr, u32* pred_tile_out = nullptr,
-                 bool pred_fold_esc = false);
+                 bool pred_fold_esc = false, u32* dev_ticket = nullptr, u32* host_ticket = nullptr
+                 /* with host_mirror: block 0 mirrors the statistics and stores the ticket as soon as it has folded */);
 
 // What a call leaves behind for a replay of the SAME call to verify instead of recompute (pipeline.hip: Prediction):
 // per scan tile the position of its rows in every numeric class list, how many there are, and the products of its
@@ -102,6 +103,12 @@ struct RowWork {
     uint2* w_sl;            // per A entry: (start, length) of its B row INSIDE the current column window
                             //   (multi-window rows, row_groups.hpp WindowCursors); a row's entries belong to its workgroup
     u32 xcd_aware;          // class lists are walked in per-XCD contiguous slices (row_groups.hpp)
+    // Eager call: the scan staged the row offsets of C in scratch (C.row_offsets -- possibly the caller's reused buffer --
+    // is written only once nothing can fail any more); extra workgroups of the numeric light launch move them to C
+    // instead of a copy of its own in front of the launch (-8 us).  off_n = 0: nothing to move.
+    const u32* off_src;
+    u32* off_dst;
+    u32 off_n;
 };
 
 // Block ranges of the classes inside a merged ("light") launch: class slot k owns the blocks

@@ -23,6 +23,7 @@
 // The product a*b is rounded first and then added with an LDS atomic (ds_add_f64), as the
 // reference does (spECK_HashSpGEMM.cuh:157-165) -- no FMA across the add.
 // Algorithmic bytes per row: 8 + 20*lenA + 12*ops + 4 + 12*nnz for fp64 (device_common.hpp).
+#include <algorithm>
 #include <type_traits>
 
 #include "device_common.hpp"
@@ -804,8 +805,11 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     } else if (b < cg.first[9]) {
         if constexpr (WITH_ESC)
             num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
-    } else
+    } else if (b < cg.first[10])
         num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
+    else  // the staged row offsets of an eager call -> C.row_offsets (RowWork::off_src)
+        for (u32 i = (b - cg.first[10]) * 256u + threadIdx.x; i < w.off_n; i += (cg.first[11] - cg.first[10]) * 256u)
+            w.off_dst[i] = w.off_src[i];
 }
 
 // The three smallest classes alone: the merged kernel above takes the register count of its
@@ -1352,14 +1356,17 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
         cg.hint[k] = ClassHint{off, counts_hint[slots[k]]};
     }
     const ProductSrc<T> src{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
+    // ... + the workgroups that move the staged row offsets (only the big kernel carries them)
+    cg.first[NS + 1] = cg.first[NS];
+    if (!tiny_only && w.off_n) cg.first[NS + 1] += std::min<u32>((w.off_n + 2047u) / 2048u, 512u);
     bool with_esc = false;  // (a class of the mask without rows has no blocks: its body is never entered)
     for (int k = 0; k < NS; ++k)
         if ((kNumEscMask >> slots[k] & 1u) && cg.first[k + 1] != cg.first[k]) with_esc = true;
     if (!tiny_only && with_esc)
-        SPECK_LAUNCH_TIMED((num_light_kernel<T, true>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_light_kernel<T, true>), dim3(cg.first[NS + 1]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else if (!tiny_only)
-        SPECK_LAUNCH_TIMED((num_light_kernel<T, false>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_light_kernel<T, false>), dim3(cg.first[NS + 1]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else if (threads == 64)
         SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 64>), dim3(cg.first[NS]), dim3(64), lds, s, e0, e1, src, Av.row_offsets, w,

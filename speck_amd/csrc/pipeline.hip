@@ -116,6 +116,9 @@ struct speck_config {
     bool spec_valid = false;      // such a call has completed (last_sym_* describe it)
     u64 spec_rows_a = 0, spec_rows_b = 0;
     int eager_spec_hits = 0, eager_spec_misses = 0;
+    const u32* stage_off_src = nullptr;  // eager call in flight: the staged row offsets ride to C in the numeric light
+    u32* stage_off_dst = nullptr;        //   launch (RowWork::off_src)
+    u32 stage_off_n = 0;
     bool validate_inputs = true;  // eager path: B's rows strictly ascending and in range
     u32 epoch_counter = 0, check_epoch = 0;  // ... reported as the call's epoch (DeviceStats::b_bad_epoch); set while
                                              //   an eager call that checks is in flight
@@ -373,6 +376,9 @@ RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill,
     w.nf_direct_val = c->capture_direct ? c->capture_c_val : nullptr;
     w.w_sl = sc.w_sl;
     w.xcd_aware = c->xcd_aware;
+    w.off_src = symbolic_phase ? nullptr : c->stage_off_src;
+    w.off_dst = symbolic_phase ? nullptr : c->stage_off_dst;
+    w.off_n = symbolic_phase ? 0u : c->stage_off_n;
     return w;
 }
 
@@ -646,7 +652,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
         launch_scan(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                     classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
                     host_mirror, expect_g, expect_g_rows, c->capture_direct ? c->gpred.off : nullptr,
-                    pred_out ? pred_out->off : nullptr, pred_out ? pred_out->num_tile : nullptr, pred_fold_esc);
+                    pred_out ? pred_out->off : nullptr, pred_out ? pred_out->num_tile : nullptr, pred_fold_esc,
+                    host_mirror ? c->d_ticket : nullptr, host_mirror ? c->h_ticket_dev : nullptr);
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -729,6 +736,17 @@ int read_stats(speck_config* c, hipStream_t s)
         HIP_TRY(hipStreamSynchronize(s));
     }
     // the input check of this (eager) call reports with the call's epoch
+    if (c->check_epoch && c->h_stats->b_bad_epoch == c->check_epoch) c->h_stats->b_invalid = 1;
+    return SPECK_OK;
+}
+
+// ... when the scan of the batch mirrors the block and stores the ticket itself (enqueue_front with a host mirror):
+// no done_kernel, the host has the statistics while the scan's last blocks are still running
+int await_scan_stats(speck_config* c, hipStream_t s)
+{
+    if (!c->spin_wait) return read_stats(c, s);
+    const int rc = wait_ticket(c, s);
+    if (rc != SPECK_OK) return rc;
     if (c->check_epoch && c->h_stats->b_bad_epoch == c->check_epoch) c->h_stats->b_invalid = 1;
     return SPECK_OK;
 }
@@ -1201,11 +1219,13 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     const bool keep_pred = (c->nf_direct || c->pred_scan) && c->use_graph && ensure_pred(c->pred, m);
     // (the shape of the tile tables: will that replay finish the register-class rows in its symbolic phase?)
     const bool fold_esc = keep_pred && c->esc_fused && c->nf_direct && c->cp.sym_g8 == c->cp.num_g8 && c->merge_light;
+    // (the scan mirrors the statistics and stores the ticket itself: await_scan_stats)
+    const bool early_stats = c->spin_wait && !c->profile_kernels;
     auto front = [&](u32 parts) {
         // (the offsets go to scratch: C.row_offsets -- possibly the caller's reused buffer -- is written only once
         //  nothing can fail any more)
         return enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm,
-                             parts == 2u ? sym_known : nullptr, nullptr, ~0ull, ~0u, parts, ~0ull,
+                             parts == 2u ? sym_known : nullptr, early_stats ? c->h_stats_dev : nullptr, ~0ull, ~0u, parts, ~0ull,
                              keep_pred ? &c->pred : nullptr, fold_esc);
     };
     // ONE batch, sized from the previous eager call on this config (same shapes): the classes that call had rows in
@@ -1227,8 +1247,9 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         mask |= kSymLightMask;
         c->check_epoch = c->validate_inputs ? (++c->epoch_counter ? c->epoch_counter : ++c->epoch_counter) : 0u;
         rc = enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, mask, kAllNum, true, &tm, spec_counts,
-                           nullptr, ~0ull, ~0u, 3u, c->nf_cap_entries, keep_pred ? &c->pred : nullptr, fold_esc, false);
-        if (rc == SPECK_OK) rc = read_stats(c, s);
+                           early_stats ? c->h_stats_dev : nullptr, ~0ull, ~0u, 3u, c->nf_cap_entries,
+                           keep_pred ? &c->pred : nullptr, fold_esc, false);
+        if (rc == SPECK_OK) rc = early_stats ? await_scan_stats(c, s) : read_stats(c, s);
         c->check_epoch = 0;
         if (rc != SPECK_OK) return fail(rc);
         if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
@@ -1281,7 +1302,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     //  read-back below)
     rc = front(2u);
     if (rc != SPECK_OK) return fail(rc);
-    rc = read_stats(c, s);
+    rc = early_stats ? await_scan_stats(c, s) : read_stats(c, s);
     if (rc != SPECK_OK) return fail(rc);
     if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
     if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
@@ -1389,7 +1410,20 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     C->col_ids = c_col;
     C->row_offsets = c_ro;
     own_ro = false;
-    HIP_TRY(hipMemcpyAsync(c_ro, sc.offsets, (size_t(m) + 1) * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    // the staged offsets -> C.row_offsets: by extra workgroups of the numeric light launch when there is one with the
+    // big kernel (launch_numeric_light), else by a copy of its own
+    constexpr u32 kBigLight = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256);
+    const bool ride = c->merge_light && (num_mask & kBigLight) != 0;
+    struct Unstage {
+        speck_config* c;
+        ~Unstage() { c->stage_off_src = nullptr, c->stage_off_dst = nullptr, c->stage_off_n = 0; }
+    } unstage{c};
+    if (ride) {
+        c->stage_off_src = sc.offsets;
+        c->stage_off_dst = c_ro;
+        c->stage_off_n = m + 1;
+    } else
+        HIP_TRY(hipMemcpyAsync(c_ro, sc.offsets, (size_t(m) + 1) * sizeof(u32), hipMemcpyDeviceToDevice, s));
     t->allocC = st.lap();
     t->loadBalanceNumeric = 0.f;
 

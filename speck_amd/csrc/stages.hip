@@ -911,7 +911,7 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     const u32* __restrict__ row_col_min, const u32* __restrict__ row_col_max,
     RowRec* __restrict__ recs, ClassifyParams cp, u64 exact_nnz, u64 expect_g, u32 expect_g_rows,
     DeviceStats* __restrict__ host_mirror, const u32* __restrict__ pred_off, u32* __restrict__ pred_off_out,
-    u32* __restrict__ pred_tile_out, bool pred_fold_esc)
+    u32* __restrict__ pred_tile_out, bool pred_fold_esc, u32* __restrict__ dev_ticket, u32* __restrict__ host_ticket)
 {
     constexpr int NW = kScanThreads / 64;
     __shared__ Fold s_fold;
@@ -948,13 +948,6 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
         // ... and its per-row plan / bucket arrays for exactly that many NUM_G rows
         if (expect_g_rows != ~0u && s_fold.total[NUM_G] != expect_g_rows) st->capacity_miss = 1;
         publish_bins(st->num, s_fold, s_bytes, num_cls ? cp.num_allowed : 0xFFFFFFFFu, st);
-        // everything the host needs is final here: write it straight into pinned host memory
-        // instead of a copy node at the end of the launch sequence
-        if (host_mirror) {
-            const u64* src = reinterpret_cast<const u64*>(st);
-            u64* dst = reinterpret_cast<u64*>(host_mirror);
-            for (u32 i = 0; i < sizeof(DeviceStats) / 8; ++i) dst[i] = src[i];
-        }
     }
     // what a replay of this call may take for granted and verify (launch.hpp, kPredTileWords): where my tile's rows
     // of every class go, how many there are -- in the shape the REPLAY classifies (its register-class rows are
@@ -982,6 +975,24 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
     for (int i = 0; i < ITEMS; ++i) tsum += c[i];
     u32 total;
     const u32 excl = block_exclusive_scan<kScanThreads>(tsum, s_scan, &total);
+    // EAGER call: everything the host needs to allocate C and size the numeric launches is final once block 0 has
+    // folded -- nothing a later block of this kernel does changes the statistics block.  The first wave of block 0
+    // mirrors it into pinned host memory and stores the call's ticket NOW (behind the barrier of the scan above: the
+    // fields thread 0 has just written are visible to the wave), instead of a done_kernel behind this kernel: the host
+    // has the numeric launches queued by the time the last block is through (-10 us per eager multiply).
+    if (host_mirror && blockIdx.x == 0 && wid == 0) {
+        const u64* src = reinterpret_cast<const u64*>(st);
+        u64* dst = reinterpret_cast<u64*>(host_mirror);
+        for (u32 i = lane; i < sizeof(DeviceStats) / 8; i += 64)
+            __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the mirror is written before the ticket
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const u32 t = *dev_ticket + 1u;
+            *dev_ticket = t;
+            __hip_atomic_store(host_ticket, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     u32 run = (u32)s_fold.sum_prefix + excl;
     u32 off[ITEMS];
 #pragma unroll
@@ -1373,7 +1384,7 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
                  const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
                  RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
                  DeviceStats* host_mirror, u64 expect_g, u32 expect_g_rows, const u32* pred_off, u32* pred_off_out,
-                 u32* pred_tile_out, bool pred_fold_esc)
+                 u32* pred_tile_out, bool pred_fold_esc, u32* dev_ticket, u32* host_ticket)
 {
     const u32 tiles = scan_tiles(m);
     auto go = [&](auto items) {
@@ -1384,7 +1395,7 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
         hipLaunchKernelGGL(num_apply_kernel<I>, dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, st,
                            partials, tiles, (const u8*)num_cls, a_ro, row_ops,
                            row_col_min, row_col_max, recs, cp, exact_nnz, expect_g, expect_g_rows, host_mirror, pred_off,
-                           pred_off_out, num_cls ? pred_tile_out : nullptr, pred_fold_esc);
+                           pred_off_out, num_cls ? pred_tile_out : nullptr, pred_fold_esc, dev_ticket, host_ticket);
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;
