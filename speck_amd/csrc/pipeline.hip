@@ -189,6 +189,7 @@ struct speck_config {
     u32* h_verify_dev = nullptr;
     u32* d_vticket = nullptr;
     u32 vticket_expected = 0;
+    bool validate_in_flight = false; // the input check of an eager call is running on vstream (begin_validate)
     GraphKey arena_key;              // what the per-row / per-entry metadata in the arena (b_sl, row arrays, symbolic records,
     bool arena_key_valid = false;    //   class table) was last written for -- by a multiply that COMPLETED
     bool replay_uncaptured = false;  // option replay_uncaptured (debugging): enqueue the sequence instead of launching its graph
@@ -1028,6 +1029,29 @@ int wait_verifier(speck_config* c, bool* changed)
     return SPECK_OK;
 }
 
+// The input check of an eager call, beside it on the verifier's stream (stages.hip: validate_b_kernel).
+int begin_validate(speck_config* c, const speck_dcsr* B)
+{
+    __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
+    launch_validate_b(c->vstream, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, B->nnz, c->h_verify_dev);
+    launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
+    HIP_TRY(hipGetLastError());
+    c->validate_in_flight = true;
+    return SPECK_OK;
+}
+// ... its verdict (waits for the check if it is still running: it is not, by the time anybody asks)
+int finish_validate(speck_config* c, bool* b_invalid)
+{
+    *b_invalid = false;
+    if (!c->validate_in_flight) return SPECK_OK;
+    c->validate_in_flight = false;
+    bool any = false;
+    const int rc = wait_verifier(c, &any);
+    if (rc != SPECK_OK) return rc;
+    *b_invalid = (__atomic_load_n(c->h_verify, __ATOMIC_ACQUIRE) & 4u) != 0;
+    return SPECK_OK;
+}
+
 template <typename T>
 int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, speck_dcsr* C,
                   speck_timings* t)
@@ -1232,6 +1256,23 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // (a row in any other class raises capacity_miss: publish_bins), grids from its counts, its scratch pool and
     // numeric-first window (checked by the scatter / numeric-first kernels).  Saves the first of the two read-backs --
     // a ticket, a spin and the launch latency behind it, ~15 us of a 170 us multiply.
+    // The input check -- B's rows strictly ascending and in range: one coalesced pass over B.col_ids -- runs BESIDE the
+    // call on the verifier's stream (it rode in the analysis launch until round 4 and cost that launch 13 us); its
+    // verdict is looked at with the statistics of the scan, before anything of C is written.  Until then the kernels
+    // stay inside their tables and windows whatever B holds.  A's column ids are checked -- and clamped -- by the analysis.
+    struct ValidateGuard {  // (no way out of this call leaves the check running: the next call reuses its verdict word)
+        speck_config* c;
+        ~ValidateGuard()
+        {
+            bool ignored;
+            (void)finish_validate(c, &ignored);
+        }
+    } validate_guard{c};
+    if (c->validate_inputs) {
+        rc = begin_validate(c, B);
+        if (rc != SPECK_OK) return fail(rc);
+    }
+    auto b_is_invalid = [&](bool* bad) { return finish_validate(c, bad); };
     bool speculated = false;
     u32 spec_counts[kMaxClasses];
     if (c->eager_speculate && c->spec_valid && c->spec_rows_a == A->rows && c->spec_rows_b == B->rows &&
@@ -1245,38 +1286,31 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         for (int k = 0; k < kMaxClasses; ++k)
             if ((kSymLightMask >> k & 1u) && !spec_counts[k]) spec_counts[k] = 256;
         mask |= kSymLightMask;
-        c->check_epoch = c->validate_inputs ? (++c->epoch_counter ? c->epoch_counter : ++c->epoch_counter) : 0u;
         rc = enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, mask, kAllNum, true, &tm, spec_counts,
                            early_stats ? c->h_stats_dev : nullptr, ~0ull, ~0u, 3u, c->nf_cap_entries,
                            keep_pred ? &c->pred : nullptr, fold_esc, false);
         if (rc == SPECK_OK) rc = early_stats ? await_scan_stats(c, s) : read_stats(c, s);
-        c->check_epoch = 0;
         if (rc != SPECK_OK) return fail(rc);
         if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
-        if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
+        bool b_bad = false;
+        rc = b_is_invalid(&b_bad);
+        if (rc != SPECK_OK) return fail(rc);
+        if (b_bad) return fail(SPECK_ERR_UNSORTED);
         speculated = !c->h_stats->capacity_miss;
         ++(speculated ? c->eager_spec_hits : c->eager_spec_misses);
         c->last.eager_speculated = speculated ? 1 : -1;
     }
     if (!speculated) {
-    // analysis + binning, and in the same launch the input check: B's rows strictly ascending and in range (one
-    // coalesced pass by extra workgroups of the analysis kernel; A's column ids are checked -- and clamped -- by the
-    // analysis itself).  The verdict is the call's epoch in a word block 0 of that kernel does not zero.
-    c->check_epoch = c->validate_inputs ? (++c->epoch_counter ? c->epoch_counter : ++c->epoch_counter) : 0u;
-    struct EpochOff {
-        speck_config* c;
-        ~EpochOff() { c->check_epoch = 0; }
-    } epoch_off{c};
+    // analysis + binning
     rc = front(1u);
     if (rc != SPECK_OK) return fail(rc);
     if (c->cp.nf_min_ops || c->cp.gh_per_window) {
         // numeric-first rows (and the global key sets of SYM_GH rows) need their scratch pool before the
-        // symbolic phase: one more read-back -- which also stops an invalid input before any kernel walks B's rows
+        // symbolic phase: one more read-back
         // (the replayed sequence has none: the pool of the previous identical call is checked on the device)
         rc = read_stats(c, s);
         if (rc != SPECK_OK) return fail(rc);
         if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
-        if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
         // No room (or no budget) for the pool: first the global key sets go (those rows take the multi-window
         // bitmap, which needs no memory), then the numeric-first rows (they take the two-phase path) -- for this
         // config from now on; the rows are classified again.
@@ -1305,7 +1339,10 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     rc = early_stats ? await_scan_stats(c, s) : read_stats(c, s);
     if (rc != SPECK_OK) return fail(rc);
     if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
-    if (c->h_stats->b_invalid) return fail(SPECK_ERR_UNSORTED);
+    bool b_bad = false;
+    rc = b_is_invalid(&b_bad);
+    if (rc != SPECK_OK) return fail(rc);
+    if (b_bad) return fail(SPECK_ERR_UNSORTED);
     }  // !speculated
     t->countProducts = 0.f;
     t->loadBalanceCounting = 0.f;

@@ -1285,6 +1285,36 @@ __global__ __launch_bounds__(64) void done_kernel(u32* __restrict__ dev_ticket, 
         __hip_atomic_store(host_ticket, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// The input check of B (validate_b_slice) as a kernel of its own, for the verifier's stream: an eager call launches it
+// first and looks at the verdict -- bit 2 of the pinned word -- when it reads back the statistics of its scan, long after
+// this kernel is through; nothing of C is written before that (riding in the analysis launch it cost that launch 13 us).
+__global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__ b_ro, const u32* __restrict__ b_col, u32 b_rows,
+                                                          u32 b_cols, u32* __restrict__ verdict)
+{
+    const u32 e_first = b_ro[0], e_last = b_ro[b_rows];
+    bool bad = e_last < e_first;
+    for (u64 i = u64(blockIdx.x) * 256 + threadIdx.x; e_first + i < e_last; i += u64(gridDim.x) * 256) {
+        const u32 e = e_first + (u32)i;
+        const u32 c = b_col[e];
+        if (c >= b_cols) bad = true;
+        if (e + 1 < e_last && b_col[e + 1] <= c) {
+            u32 lo = 0, hi = b_rows;  // first row whose offset is >= e + 1
+            while (lo < hi) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                if (b_ro[mid] < e + 1) lo = mid + 1; else hi = mid;
+            }
+            if (b_ro[lo] != e + 1) bad = true;
+        }
+    }
+    if (__ballot(bad) != 0 && lane_id() == 0) __hip_atomic_fetch_or(verdict, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, u64 b_nnz, u32* verdict)
+{
+    if (b_rows == 0) return;
+    const u32 want = cdiv(b_nnz ? b_nnz : 1, 256 * 4);
+    hipLaunchKernelGGL(validate_b_kernel, dim3(want > 2048u ? 2048u : want), dim3(256), 0, s, b_ro, b_col, b_rows, b_cols, verdict);
+}
+
 // ... and the ticket of the verifier's stream (launch_verifier): the kernel boundary in front of it orders the verifier's
 // verdict (system-scope atomics on pinned memory) before the ticket
 __global__ __launch_bounds__(64) void ticket_kernel(u32* __restrict__ dev_ticket, u32* __restrict__ host_ticket)
