@@ -5,7 +5,7 @@ sources under ``speck_amd/csrc``); this package is only the thin ctypes mirror o
 reference's host interface used by the tests and the benchmark harness.
 """
 from .api import (  # noqa: F401
-    SpeckError, Timings, dCSR, spECKConfig, HostCSR, MultiplyspECK, analysis, symbolic,
+    SpeckError, Timings, dCSR, spECKConfig, HostCSR, MultiplyspECK, BoundMultiply, analysis, symbolic,
     partition_rows, compare, compare_bounded, transpose, gen_matrix, load_matrix, load_mtx, store_mtx, load_hicsr,
     store_hicsr, lib_path,
 )

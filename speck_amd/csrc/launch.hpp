@@ -176,6 +176,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& A, cons
 u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block);
 // resident-set multiples a class grid may reach before its workgroups start striding over rows
 void set_grid_rounds(u32 block_classes, u32 subwave_classes);
+void set_spill_big_grid(u32 blocks);  // workgroups of the NUM_G launch that reduces the oversized buckets
 void set_tiny_threads(int threads);  // workgroup size of the merged small-row numeric launch (64 / 128 / 256)
 
 // LDS bytes a class needs (for occupancy-aware grid sizing and DESIGN.md tables)

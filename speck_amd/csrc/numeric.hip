@@ -1312,6 +1312,8 @@ static void launch_num_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
                        dim3(THREADS), lds, s, A, B, w, c_col, c_val, cls);
 }
 
+static u32 g_spill_big_grid = 256;
+void set_spill_big_grid(u32 blocks) { g_spill_big_grid = blocks ? blocks : 256u; }
 static int g_tiny_threads = 256;
 void set_tiny_threads(int t) { g_tiny_threads = (t == 64 || t == 128) ? t : 256; }
 
@@ -1499,7 +1501,10 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             //  that misses the 2/3 mark by a few entries would pay dozens of them over its column span)
             auto kr_big = num_spill_reduce_kernel<T, kNumB8KCap, kB8KW1, 512, kNumB2KMaxNnz, kNumB8KCap * 85 / 100, true>;
             set_dyn_lds(kr_big, lds);
-            hipLaunchKernelGGL(kr_big, dim3(2048), dim3(512), lds, s, w, cls);
+            // (its workgroups stride over the list of oversized buckets, which only the device knows -- usually a handful.
+            //  Each needs 106 KiB of LDS just to find that out: a grid of 2048 queued behind the NUM_B8K launches of the
+            //  same phase for 0.3-0.5 ms on the webbase stand-in; option spill_big_grid)
+            hipLaunchKernelGGL(kr_big, dim3(g_spill_big_grid), dim3(512), lds, s, w, cls);
             hipLaunchKernelGGL((num_spill_copy_kernel<T>), dim3(rows, 32), dim3(256), 0, s, w, c_col, c_val, cls);
             break;
         }

@@ -1597,6 +1597,9 @@ int speck_config_create(int device, speck_config** out)
     for (int i = 0; i < kMaxClasses; ++i) {
         hipStream_t s;
         hipEvent_t e;
+        // (a HIGH-priority stream for the NUM_G chain -- seven short kernels that queue for LDS behind the long rows of
+        //  the other launches -- was tried in round 4: the webbase stand-in lost 5 %, and the mere existence of such a
+        //  stream cost the scircuit stand-in, which never uses it, 55 %: 0.088 -> 0.138 ms.  Not done.)
         HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->aux.push_back(s);
@@ -1814,6 +1817,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     }
     else if (n == "grid_rounds_sub") {
         set_grid_rounds(0, (u32)value);
+        drop_graph(c);
+    }
+    else if (n == "spill_big_grid") {
+        set_spill_big_grid((u32)value);
         drop_graph(c);
     }
     else if (n == "tiny_threads") {
