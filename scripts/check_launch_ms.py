@@ -3,6 +3,9 @@
 
     python scripts/check_launch_ms.py profiles/r04_bench_scircuit.json profiles/r04_bench_scircuit_kernel_stats.csv [tol=0.05]
 
+(the LINE of the plain run against the TRACE of the same command under rocprofv3: a line printed under the profiler
+carries ~5 us of profiler overhead in every HIP-event duration)
+
 bench.py times the launches of the replayed sequence in an untimed pre-pass (HIP events on the launch's own stream);
 `rocprofv3 --kernel-trace --stats` of the same command averages every dispatch of a kernel.  The kernels of the replayed
 sequence carry names of their own (sym_light_fused_kernel; num_light_kernel<T, false>: no register-class bodies;
@@ -15,12 +18,13 @@ import sys
 KERNEL_OF = {  # bench launch name -> kernel name in the trace (fp64 legs)
     "fused_light": "sym_light_fused_kernel<double>",
     "light": "num_light_kernel<double, false>",
-    "numeric_first": "nf_dense_kernel<double, 256>",
+    "numeric_first": "nf_dense_kernel<double, 256, true>",
 }
 
 
 def main():
-    line = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    # (the bench line: the last line of the file that is a JSON object -- the profiler logs behind it)
+    line = json.loads([ln for ln in open(sys.argv[1]).read().splitlines() if ln.startswith("{")][-1])
     stats = {r["kernel"]: r for r in csv.DictReader(open(sys.argv[2]))}
     tol = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
     bad = 0

@@ -27,9 +27,6 @@ for w in $WORKLOADS; do
   rocprofv3 --kernel-trace --stats -d gpurun_out/_p_$w/trace -o r -- $BENCH --workload $w \
       > $OUT/${ROUND}_bench_${w}_under_rocprof.log 2>&1
   python scripts/rocpd_summary.py $(find gpurun_out/_p_$w/trace -name "*.db" | head -1) $OUT/${ROUND}_bench_${w}_kernel_stats.csv > /dev/null
-  # the launch durations of the line that run printed against the trace of the same process (<= 5 %)
-  python scripts/check_launch_ms.py $OUT/${ROUND}_bench_${w}_under_rocprof.log $OUT/${ROUND}_bench_${w}_kernel_stats.csv \
-      > $OUT/${ROUND}_launch_ms_check_${w}.txt 2>&1 || echo "$w: launch ms differ from the trace" >> $OUT/${ROUND}_launch_ms_check_${w}.txt
   i=0
   CSVS=""
   for p in "${PASSES[@]}"; do

@@ -15,7 +15,7 @@ import re
 import sys
 
 KEYS = [
-    (r"nf_dense_kernel", "num_numeric_first"), (r"nf_copy_kernel", "num_nfcopy"),
+    (r"nf_dense_kernel<\w+, \d+, false>", "num_numeric_first_eager"), (r"nf_dense_kernel", "num_numeric_first"), (r"nf_copy_kernel", "num_nfcopy"),
     # (round 4: the light launch of a fused replay carries its own name -- no register-class bodies -- and so does the
     #  analysis of a sequence that only verifies; bench.py's "light" is the replay's launch)
     (r"num_light_kernel<\w+, true>", "num_light_eager"), (r"num_light_kernel", "num_light"), (r"num_tiny_kernel", "num_tiny"),

@@ -11,6 +11,11 @@ cp $OUT/counters.json $OUT/traffic.json profiles/   # the bench lines read the c
 for w in scircuit mac_econ cant webbase uniform; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline --no-config5 --no-configs 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_$w.json
 done
+# the launch durations of the plain lines against the traces of the same commands under rocprofv3 (<= 5 %)
+for w in scircuit mac_econ cant webbase; do
+  python scripts/check_launch_ms.py $OUT/${ROUND}_bench_$w.json $OUT/${ROUND}_bench_${w}_kernel_stats.csv > $OUT/${ROUND}_launch_ms_check_$w.txt 2>&1 \
+      || echo "$w: launch ms differ from the trace by more than 5 %" >> $OUT/${ROUND}_launch_ms_check_$w.txt
+done
 timeout 900 python bench.py 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_default.json
 timeout 300 python scripts/multiwindow_time.py 2>&1 | grep windows > $OUT/${ROUND}_multiwindow_now.txt
 python - <<'PY'

@@ -582,7 +582,9 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
 // ordered scatter of the analysis) and counted.  After the scan NUM_NFCOPY moves it to its place in C.
 // For banded / FEM inputs (cant: every row) the whole symbolic walk -- as long as the numeric one --
 // turns into one copy of C.  (The reference always runs both phases; new functionality.)
-template <typename T, int THREADS>
+// (DIRECT: the launch of a replayed sequence that places the rows straight into C -- a template parameter only so that
+//  the kernel carries another NAME than the eager launch in a trace; the code is the same)
+template <typename T, int THREADS, bool DIRECT = false>
 __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                            u32* __restrict__ counts, u32 wcols)
 {
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
     u32* scratch = stage + 2 * THREADS;
     RowMeta<T> meta{stage, stage + THREADS, m_av, scratch + THREADS / 64 + 2};
     static_assert(THREADS >= kNumD1Cols / 32, "bitmap + prefix fit the staging area");
-    const bool direct = w.nf_pred_off != nullptr;  // replayed sequence: rows go straight to C (RowWork)
+    const bool direct = DIRECT;  // replayed sequence: rows go straight to C (RowWork::nf_pred_off)
     u32* __restrict__ o_col = direct ? w.nf_direct_col : w.nf_col;
     T* __restrict__ o_val = static_cast<T*>(direct ? w.nf_direct_val : w.nf_val);
     const RowSlice rs = row_slice(w.st->sym.count[SYM_NF], blockIdx.x, gridDim.x, 1u, 0u, (w.xcd_aware & 2u) != 0);
@@ -1393,6 +1395,12 @@ void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& Av, const 
     wcols = wcols < 256u ? 256u : (wcols > kNumD1Cols ? kNumD1Cols : (wcols + 255u) & ~255u);
     const u32 lds = (wcols + 256) * (u32)sizeof(Acc<T>) + wcols +
                     (2 * 256 + 256 / 64 + 2 + win_words<Block<256>>() + 3) / 4 * 16;
+    if (w.nf_pred_off) {
+        set_dyn_lds((nf_dense_kernel<T, 256, true>), lds);
+        SPECK_LAUNCH_TIMED((nf_dense_kernel<T, 256, true>), dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, e0,
+                           e1, src, Av.row_offsets, w, counts, wcols);
+        return;
+    }
     set_dyn_lds((nf_dense_kernel<T, 256>), lds);
     SPECK_LAUNCH_TIMED((nf_dense_kernel<T, 256>), dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, e0, e1,
                        src, Av.row_offsets, w, counts, wcols);

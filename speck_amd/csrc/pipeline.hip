@@ -1115,12 +1115,15 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             c->arena_key_valid = false;
             Timing tm;
             size_t ev_num_end = 0;
-            rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, &tm, &ev_num_end);
-            if (rc != SPECK_OK) return rc;
+            // (the verifier FIRST here: enqueuing the launches one by one with events around them takes the host longer
+            //  than the first of them runs -- launched behind them the verifier would run beside the LAST launch, not
+            //  beside the first as it does next to the graph)
             if (plan.overlap) {
                 rc = launch_verifier(c, A, B, sc);
                 if (rc != SPECK_OK) return rc;
             }
+            rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, &tm, &ev_num_end);
+            if (rc != SPECK_OK) return rc;
             HIP_TRY(hipStreamSynchronize(s));
             c->ticket_expected = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE);
             bool changed = false;
