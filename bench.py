@@ -304,11 +304,11 @@ def profile_prepass(job, split, merged, prof_steps=5):
     cfg.profile_kernels(1)
     # the 256-thread numeric classes run as ONE launch ("light": num_light_kernel), or with option split_light=1
     # as two ("light": the big-LDS classes, "tiny": num_tiny_kernel); the other classes launch separately
-    LIGHT, TINY = ("dense4k", "block2k", "wave512", "wave256"), ("r64", "r32", "wave128", "g16", "g8", "direct")
+    LIGHT, TINY = ("dense4k", "block2k", "wave512", "wave256"), ("r64", "r32", "wave128", "g16", "g8", "g4", "direct")
     if not split:
         LIGHT, TINY = LIGHT + TINY, ()
-    SYM_LIGHT = ("bitmap256k", "block4k", "wave1k", "wave256", "r64", "r32", "wave128", "g16", "g8")
-    ESC = ("g8", "g16", "r32", "r64")   # the register classes: finished in the symbolic phase of a fused replay
+    SYM_LIGHT = ("bitmap256k", "block4k", "wave1k", "wave256", "r64", "r32", "wave128", "g16", "g8", "g4")
+    ESC = ("g4", "g8", "g16", "r32", "r64")   # the register classes: finished in the symbolic phase of a fused replay
     kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny", "numeric_first", "fused_light"]}
     sym_ms = num_ms = 0.0
     fused = False

@@ -50,7 +50,8 @@ enum SymClass : u8 {
     SYM_R32 = 12,   // 32 lanes per row (two rows per wave): <= 128 products from <= 32 entries of A, columns sorted in
                     //   registers (esc_wide.hpp) -- no key set
     SYM_R64 = 13,   // a wave per row: <= 256 products from <= 64 entries of A, sorted in registers
-    SYM_CLASSES = 14,
+    SYM_G4 = 14,    // 4 lanes per row (16 rows per wave): <= 16 products from <= 4 entries of A, sorted in registers
+    SYM_CLASSES = 15,
     SYM_NONE = 0xFF  // resolved by the analysis kernel itself (empty / single-entry A rows)
 };
 // Numeric classes: chosen from the EXACT nnz of the C row (symbolic result).
@@ -72,7 +73,9 @@ enum NumClass : u8 {
     NUM_R32 = 12,    // 32 lanes per row: <= 128 products from <= 32 entries of A, column range < 2^25 -- expand / sort /
                      //   compress in registers (esc_wide.hpp), whatever the nnz
     NUM_R64 = 13,    // a wave per row: <= 256 products from <= 64 entries, column range < 2^24
-    NUM_CLASSES = 14,
+    NUM_G4 = 14,     // 4 lanes per row: <= 16 products from <= 4 entries of A -- the smallest register class (more than half
+                     //   of the rows of the mac_econ stand-in): twice the rows per wave-iteration of NUM_G8, a 16-element network
+    NUM_CLASSES = 15,
     NUM_NONE = 0xFF
 };
 
@@ -121,6 +124,7 @@ __host__ __device__ inline u32 table_bits(u32 nnz, u32 pct)
 }
 constexpr u32 kNumG8Cap = 32, kNumG8MaxNnz = max_nnz_of(32, SPECK_LOAD_TINY_PCT);
 constexpr u32 kNumEscMaxOps = 32, kNumEscMaxLen = 8;  // NUM_G8 / SYM_G8 = the register-resident classes (esc.hpp)
+constexpr u32 kNumEsc4MaxOps = 16, kNumEsc4MaxLen = 4;     // NUM_G4 / SYM_G4
 constexpr u32 kNumEsc16MaxOps = 64, kNumEsc16MaxLen = 16;  // NUM_G16 / SYM_G16: 16 lanes; columns < 2^26 (ClassifyParams::esc16)
 // the WIDE register classes (esc_wide.hpp): the sort key packs (column - first reachable column of the row) with the
 // product number into 32 bits -- a condition on the row's column RANGE (analysis), not on cols(B)
@@ -146,6 +150,7 @@ struct ClassifyParams {
     u32 num_w256;           // rows of 86..170 nnz: 32 lanes per row (else they join NUM_W512)
     u32 esc16;              // cols(B) <= 2^26: the 16-lane register class may pack (column, product number) into 32 bits
     u32 esc32, esc64;       // the wide register classes (32 / 64 lanes per row, 128 / 256 products)
+    u32 esc4;               // the 4-lane register class (with num_g8 / sym_g8: it is carved out of their rows)
     u32 esc_fused;          // replayed sequence with direct placement: the rows of the register classes are finished
                             //   in the symbolic phase (esc_rows.hpp) -- the numeric phase only accounts for them
     u32 num_g8;             // rows of <= kNumG8MaxNnz entries: 8 lanes per row (else they join NUM_G16)
@@ -200,6 +205,7 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
     if (ops == 0 || len_a <= 1) return SYM_NONE;
     if (is_numeric_first(len_a, ops, cmin, cmax, p)) return SYM_NF;
     // at most 32 products from at most 8 entries of A: sorted in registers (esc.hpp)
+    if (p.sym_g8 && p.esc4 && ops <= kNumEsc4MaxOps && len_a <= kNumEsc4MaxLen) return SYM_G4;
     if (p.sym_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return SYM_G8;
     if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return SYM_G16;  // 16 lanes, 64 products
     if (is_esc32(len_a, ops, cmin, cmax, p)) return SYM_R32;                             // 32 lanes, 128 products
@@ -232,6 +238,7 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     // at most 32 products from at most 8 entries of A: expand / sort / compress in registers (esc.hpp), whatever
     // the nnz; the hash classes take the rest by nnz
     // (num_g8 and sym_g8 are switched together: a fused row must be a register-class row in BOTH phases)
+    if (p.num_g8 && p.esc4 && ops <= kNumEsc4MaxOps && len_a <= kNumEsc4MaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G4;
     if (p.num_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G8;
     if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G16;
     if (is_esc32(len_a, ops, cmin, cmax, p)) return p.esc_fused ? NUM_NFCOPY : NUM_R32;

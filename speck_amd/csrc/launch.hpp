@@ -123,16 +123,17 @@ struct ClassHint {
 };
 constexpr ClassHint kNoHint{0xFFFFFFFFu, 0xFFFFFFFFu};
 struct ClassGrid {
-    u32 first[12];
-    ClassHint hint[11];
+    u32 first[13];
+    ClassHint hint[12];
 };
 constexpr u32 kSymLightMask = (1u << SYM_BM1) | (1u << SYM_B4K) | (1u << SYM_W1K) | (1u << SYM_W256) | (1u << SYM_G16) |
-                              (1u << SYM_G8) | (1u << SYM_W128) | (1u << SYM_R32) | (1u << SYM_R64);
+                              (1u << SYM_G8) | (1u << SYM_W128) | (1u << SYM_R32) | (1u << SYM_R64) | (1u << SYM_G4);
 constexpr u32 kNumLightMask = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256) | (1u << NUM_W128) |
-                              (1u << NUM_G16) | (1u << NUM_G8) | (1u << NUM_DIRECT) | (1u << NUM_R32) | (1u << NUM_R64);
+                              (1u << NUM_G16) | (1u << NUM_G8) | (1u << NUM_DIRECT) | (1u << NUM_R32) | (1u << NUM_R64) |
+                              (1u << NUM_G4);
 // the register classes (esc.hpp, esc_wide.hpp): their rows are finished in the symbolic phase of a fused replay
-constexpr u32 kNumEscMask = (1u << NUM_G8) | (1u << NUM_G16) | (1u << NUM_R32) | (1u << NUM_R64);
-constexpr u32 kSymEscMask = (1u << SYM_G8) | (1u << SYM_G16) | (1u << SYM_R32) | (1u << SYM_R64);
+constexpr u32 kNumEscMask = (1u << NUM_G4) | (1u << NUM_G8) | (1u << NUM_G16) | (1u << NUM_R32) | (1u << NUM_R64);
+constexpr u32 kSymEscMask = (1u << SYM_G4) | (1u << SYM_G8) | (1u << SYM_G16) | (1u << SYM_R32) | (1u << SYM_R64);
 
 // One launch for all 256-thread classes in `mask`.  counts_hint[cls] sizes each class' block range
 // (the kernels read the real counts on the device and stride, so a stale hint only costs speed).

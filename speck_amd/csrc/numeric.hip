@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    // launch order (ClassGrid slots): D1, B2K, W512, W256, R64, R32, W128, G16, G8, DIRECT
+    // launch order (ClassGrid slots): D1, B2K, W512, W256, R64, R32, W128, G16, G8, G4, DIRECT
     // (every body starts with open_list: its first record is requested from the hinted list position while the
     //  device-side table and the capacity_miss flag are still on their way)
     if (b < cg.first[1])
@@ -807,10 +807,13 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     } else if (b < cg.first[9]) {
         if constexpr (WITH_ESC)
             num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
-    } else if (b < cg.first[10])
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
+    } else if (b < cg.first[10]) {
+        if constexpr (WITH_ESC)
+            num_esc_body<T, 4, 256>(smem, src, w, c_col, c_val, NUM_G4, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
+    } else if (b < cg.first[11])
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[10], cg.first[11] - cg.first[10], cg.hint[10]);
     else  // the staged row offsets of an eager call -> C.row_offsets (RowWork::off_src)
-        for (u32 i = (b - cg.first[10]) * 256u + threadIdx.x; i < w.off_n; i += (cg.first[11] - cg.first[10]) * 256u)
+        for (u32 i = (b - cg.first[11]) * 256u + threadIdx.x; i < w.off_n; i += (cg.first[12] - cg.first[11]) * 256u)
             w.off_dst[i] = w.off_src[i];
 }
 
@@ -836,8 +839,10 @@ __global__ __launch_bounds__(TT) void num_tiny_kernel(ProductSrc<T> src, const u
         num_esc_body<T, 16, TT>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
     else if (b < cg.first[9])
         num_esc_body<T, 8, TT>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
+    else if (b < cg.first[10])
+        num_esc_body<T, 4, TT>(smem, src, w, c_col, c_val, NUM_G4, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
     else
-        num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
+        num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[10], cg.first[11] - cg.first[10], cg.hint[10]);
 }
 
 // ------------------------------------------------------------------ NUM_G
@@ -1273,6 +1278,7 @@ u32 numeric_lds_bytes_t(int cls)
 {
     switch (cls) {
         case NUM_DIRECT: return num_direct_lds<T, 256>();
+        case NUM_G4: return 64 * num_esc_group_lds<T, 4>();
         case NUM_G8: return 32 * num_esc_group_lds<T, 8>();
         case NUM_G16: return 16 * num_esc_group_lds<T, 16>();
         case NUM_R32: return 8 * num_escw_group_lds<T, 32>();
@@ -1324,9 +1330,9 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
                           const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count, bool exact,
                           hipEvent_t e0, hipEvent_t e1)
 {
-    constexpr int NS = 10;
-    static const int slots[NS] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W256, NUM_R64, NUM_R32, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
-    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 8, 16, 32, 256};
+    constexpr int NS = 11;
+    static const int slots[NS] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W256, NUM_R64, NUM_R32, NUM_W128, NUM_G16, NUM_G8, NUM_G4, NUM_DIRECT};
+    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 8, 16, 32, 64, 256};
     bool tiny_only = true;
     for (int k = 0; k < 4; ++k)
         if ((mask >> slots[k] & 1u) && counts_hint[slots[k]]) tiny_only = false;
@@ -1422,6 +1428,10 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                                dim3(TH), lds, s, A, B, w, c_col, c_val);
             break;
         }
+        case NUM_G4:
+            hipLaunchKernelGGL((num_esc_kernel<T, 4>), dim3(grid_for(count, lds, 256, cu_count, 64)), dim3(256), lds, s, A, B,
+                               w, c_col, c_val, cls);
+            break;
         case NUM_G8:
             hipLaunchKernelGGL((num_esc_kernel<T, 8>), dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B,
                                w, c_col, c_val, cls);

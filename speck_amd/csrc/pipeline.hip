@@ -524,9 +524,9 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
 
 // isolated cost per row of every class (ns, MI355X, scripts/class_times.py on the four stand-ins)
 constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 50000.f, 0.1f, 0.4f,
-                                             0.4f, 0.8f, 0.f, 0.f};
+                                             0.4f, 0.8f, 0.05f, 0.f};
 constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 2.5f, 1.5f, 0.2f,
-                                             0.6f, 1.2f, 0.f, 0.f};
+                                             0.6f, 1.2f, 0.1f, 0.f};
 constexpr u32 kAllSym = (1u << SYM_CLASSES) - 1u;
 constexpr u32 kAllNum = (1u << NUM_CLASSES) - 1u;
 
@@ -599,7 +599,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
     const u32* hint = sym_hint ? sym_hint : all_m;
     static const int merged[7] = {SYM_GH, SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, kLightBig, kLightTiny};
     static const int separate[SYM_CLASSES] = {SYM_GH,  SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF,  SYM_B4K, SYM_BM1,
-                                              SYM_W1K, SYM_W256, SYM_R64, SYM_R32, SYM_W128, SYM_G16, SYM_G8};
+                                              SYM_W1K, SYM_W256, SYM_R64, SYM_R32, SYM_W128, SYM_G16, SYM_G8, SYM_G4};
     // the launch's LDS size is the largest need among its classes and caps the waves per CU of all of
     // them: the 256-thread classes go in two launches, the big-LDS ones apart (split_light); the
     // first runs on a side stream next to the second
@@ -675,7 +675,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     const u32* hint = counts ? counts : all_m;
     static const int merged[6] = {NUM_G, NUM_D2, NUM_B8K, NUM_NFCOPY, kLightBig, kLightTiny};
     static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K, NUM_B2K, NUM_W256, NUM_NFCOPY, NUM_D1,
-                                              NUM_W512, NUM_R64, NUM_R32, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
+                                              NUM_W512, NUM_R64, NUM_R32, NUM_W128, NUM_G16, NUM_G8, NUM_G4, NUM_DIRECT};
     constexpr u32 kBigPart = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256);
     bool split_num = c->split_light;
     if (split_num && counts) {
@@ -785,7 +785,7 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
                (c->concurrent_classes ? 1u : 0u);
     k.num[7] ^= reinterpret_cast<u64>(s);
     k.num[5] |= u64(c->cp.nf_min_ops) << 8;
-    k.num[5] |= (u64(c->cp.esc32) << 40) | (u64(c->cp.esc64) << 41) | (u64(c->cp.esc16) << 42);
+    k.num[5] |= (u64(c->cp.esc32) << 40) | (u64(c->cp.esc64) << 41) | (u64(c->cp.esc16) << 42) | (u64(c->cp.esc4) << 43);
     k.num[4] |= u64(c->cp.gh_per_window) << 32;  // C->nnz fits 32 bits
     return k;
 }
@@ -1639,6 +1639,10 @@ int speck_config_create(int device, speck_config** out)
                               // scircuit stand-in 5 %, 1024 leaves the boundary rows of the cant one a launch of their own)
     c->cp.gh_per_window = 8192;  // global key set for rows with fewer products per 1 Mi-column bitmap window (0 = off)
     c->cp.esc16 = 1;       // rows of <= 64 products from <= 16 entries: 16 lanes per row, in registers (esc.hpp)
+    c->cp.esc4 = 0;        // rows of <= 16 products from <= 4 entries: 4 lanes per row, carved out of the 8-lane class.  OFF:
+                           //   measured round 4 -- webbase stand-in -1.5 % time, but mac_econ +2 % (its fused launch 52.4 ->
+                           //   56.0 us although 55 % of its 8-lane rows qualify) and scircuit +1 %: splitting the list of small
+                           //   rows in two costs the B-row locality of neighbouring rows more than the half-size network saves
     c->cp.esc32 = 1;       // rows of <= 128 products from <= 32 entries: 32 lanes per row, in registers (esc_wide.hpp)
     c->cp.esc64 = 1;       // rows of <= 256 products from <= 64 entries: a wave per row, in registers
     c->cp.num_g8 = 1;      // rows of <= 32 products from <= 8 entries: 8 lanes per row, in registers
@@ -1779,8 +1783,8 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         drop_graph(c);
         c->last_key_valid = false;
     }
-    else if (n == "esc32" || n == "esc64") {
-        (n == "esc32" ? c->cp.esc32 : c->cp.esc64) = value != 0;
+    else if (n == "esc32" || n == "esc64" || n == "esc4") {
+        (n == "esc32" ? c->cp.esc32 : (n == "esc64" ? c->cp.esc64 : c->cp.esc4)) = value != 0;
         drop_graph(c);
         c->last_key_valid = false;
     }

@@ -956,8 +956,12 @@ __global__ __launch_bounds__(kScanThreads) void num_apply_kernel(
         const PartialArrays pa(parts, nb);
         auto shaped = [&](auto&& get, u32 k) -> u32 {
             if (!pred_fold_esc) return get(k);
-            if (k == NUM_G8 || k == NUM_G16 || k == NUM_R32 || k == NUM_R64) return 0u;
-            return k == NUM_NFCOPY ? get(NUM_NFCOPY) + get(NUM_G8) + get(NUM_G16) + get(NUM_R32) + get(NUM_R64) : get(k);
+            if (kNumEscMask >> k & 1u) return 0u;
+            if (k != NUM_NFCOPY) return get(k);
+            u32 sum = get(NUM_NFCOPY);
+            for (u32 q = 0; q < kMaxClasses; ++q)
+                if (kNumEscMask >> q & 1u) sum += get(q);
+            return sum;
         };
         const u32 k = threadIdx.x;
         u32 pos = shaped([&](u32 q) { return s_fold.prefix[q]; }, k);

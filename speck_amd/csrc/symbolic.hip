@@ -109,7 +109,9 @@ __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductS
         const u32 before = (u32)__popcll(g.ballot(nonempty) & ((1ull << gl) - 1ull));
         if (nonempty) s_off[before] = sl.x - (incl - sl.y);
         u64 ends;
-        if constexpr (L == 8) {
+        if constexpr (L == 4) {
+            ends = esc_quad_or((nonempty && incl < 16u) ? (1u << incl) : 0u);
+        } else if constexpr (L == 8) {
             ends = esc_group_or((nonempty && incl < 32u) ? (1u << incl) : 0u);
         } else {
             const u64 bit = (nonempty && incl < 64u) ? (1ull << incl) : 0ull;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    // launch order (ClassGrid slots): BM1, B4K, W1K, W256, R64, R32, W128, G16, G8
+    // launch order (ClassGrid slots): BM1, B4K, W1K, W256, R64, R32, W128, G16, G8, G4
     if (b < cg.first[1])
         sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], cg.hint[0]);
     else if (b < cg.first[2])
@@ -352,8 +354,10 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
         sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
     else if (b < cg.first[8])
         sym_esc_body<16, 256>(smem, src, w, counts, SYM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
-    else
+    else if (b < cg.first[9])
         sym_esc_body<8, 256>(smem, src, w, counts, SYM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
+    else
+        sym_esc_body<4, 256>(smem, src, w, counts, SYM_G4, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
 }
 
 // The light launch of a REPLAYED sequence: the rows of the two register classes are finished here -- products
@@ -386,14 +390,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     else if (b < cg.first[8])
         num_esc_body<T, 16, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G16,
                                        b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7], counts);
-    else
+    else if (b < cg.first[9])
         num_esc_body<T, 8, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G8,
                                       b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8], counts);
+    else
+        num_esc_body<T, 4, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G4,
+                                      b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9], counts);
 }
 
 u32 symbolic_lds_bytes(int cls)
 {
     switch (cls) {
+        case SYM_G4: return 64 * sym_esc_group_lds<4>();
         case SYM_G8: return 32 * sym_esc_group_lds<8>();
         case SYM_G16: return 16 * sym_esc_group_lds<16>();
         case SYM_R32: return 8 * sym_escw_group_lds<32>();
@@ -464,11 +472,12 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
                            u32* counts, int cu_count, bool exact, u32 fused_vsize, const void* a_val,
                            const void* b_val, hipEvent_t e0, hipEvent_t e1)
 {
-    constexpr int NS = 9;
-    static const int slots[NS] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_R64, SYM_R32, SYM_W128, SYM_G16, SYM_G8};
-    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 16, 16, 32};
+    constexpr int NS = 10;
+    static const int slots[NS] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_R64, SYM_R32, SYM_W128, SYM_G16, SYM_G8, SYM_G4};
+    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 16, 16, 32, 64};
     const bool fused = fused_vsize != 0 && (mask & kSymEscMask) != 0;
     auto class_lds = [&](int cls) -> u32 {
+        if (fused && cls == SYM_G4) return 64 * (fused_vsize == 8 ? num_esc_group_lds<double, 4>() : num_esc_group_lds<float, 4>());
         if (fused && cls == SYM_G8) return 32 * (fused_vsize == 8 ? num_esc_group_lds<double, 8>() : num_esc_group_lds<float, 8>());
         if (fused && cls == SYM_G16) return 16 * (fused_vsize == 8 ? num_esc_group_lds<double, 16>() : num_esc_group_lds<float, 16>());
         if (fused && cls == SYM_R32) return 8 * (fused_vsize == 8 ? num_escw_group_lds<double, 32>() : num_escw_group_lds<float, 32>());
@@ -517,6 +526,10 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
     const u32* B = a_ro;
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
+        case SYM_G4:
+            hipLaunchKernelGGL(sym_esc_kernel<4>, dim3(grid_for(count, lds, 256, cu_count, 64)), dim3(256), lds, s, A, B, w,
+                               counts, cls);
+            break;
         case SYM_G8:
             hipLaunchKernelGGL(sym_esc_kernel<8>, dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B, w,
                                counts, cls);
