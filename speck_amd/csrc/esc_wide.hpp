@@ -383,7 +383,7 @@ __device__ __forceinline__ void sym_escw_body(unsigned char* smem, const Product
             heads += (col[r] != kEscInvalid && col[r] != before_col) ? 1u : 0u;
         }
         heads = g.reduce_add(heads, nullptr);
-        if (gl == 0) counts[rec.row] = heads;
+        if (gl == 0) store_row_count(w, counts, rec.row, heads);
         wave_lds_fence();  // the next row overwrites the offsets
         idx += stride;
     }

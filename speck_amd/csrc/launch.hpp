@@ -111,7 +111,21 @@ struct RowWork {
     const u32* off_src;
     u32* off_dst;
     u32 off_n;
+    // Replayed sequence WITHOUT a scan kernel (ReplayPlan::skip_scan): every kernel that produces a row's nnz compares it
+    // with the room the previous identical call gave the row (nf_pred_off) -- if every row keeps its length, every offset,
+    // class and record of the numeric phase is what that call's scan left in the arena.
+    u32 verify_counts;
 };
+
+#ifdef __HIPCC__
+// nnz of a row of C, as a symbolic kernel found it (see RowWork::verify_counts)
+__device__ __forceinline__ void store_row_count(const RowWork& w, u32* __restrict__ counts, u32 row, u32 cnt)
+{
+    counts[row] = cnt;
+    if (w.verify_counts && cnt != w.nf_pred_off[row + 1] - w.nf_pred_off[row])
+        const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
+}
+#endif
 
 // Block ranges of the classes inside a merged ("light") launch: class slot k owns the blocks
 // [first[k], first[k+1]).

@@ -67,6 +67,8 @@ struct ReplayPlan {
     u32 num_mask, launch_mask;
     u32 num_counts[kMaxClasses];
     bool direct, fused, pred_scan, pred_sym;
+    bool skip_scan;  // ... and so does every kernel that produces a row's nnz (RowWork::verify_counts): no scan kernel -- the
+                     //   numeric launches read the records, offsets and class table the previous replay's scan left
     bool overlap;  // the analysis only VERIFIES what the previous identical call left in the arena, on a stream of its
                    //   own beside the symbolic / scan / numeric launches (which read that: DESIGN.md 4.3)
     // ... and everything else of "the last eager call" the launches are sized from: a sequence that is enqueued anew at
@@ -181,6 +183,10 @@ struct speck_config {
     bool graph_pred_sym = false;     // ... and has no scatter kernel
     ReplayPlan graph_plan{};
     bool exec_dirty = false;         // other launches went onto the pipeline stream since graph_exec was last launched
+    bool skip_scan = true;           // option skip_scan: a replayed sequence that follows a replay of itself has no scan kernel
+    bool capture_skip_scan = false;  // set while such a sequence is being enqueued
+    bool arena_from_replay = false;  // the arena (numeric records, class table, statistics) was last written by a completed
+                                     //   REPLAY of arena_key's problem: the layout a sequence without a scan reads
     bool overlap_analysis = true;    // option overlap_analysis: a replayed sequence runs its analysis as a verifier beside it
     bool capture_overlap = false;    // set while such a sequence is being enqueued
     bool graph_overlap = false;      // the captured sequence does so
@@ -380,6 +386,7 @@ RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill,
     w.off_src = symbolic_phase ? nullptr : c->stage_off_src;
     w.off_dst = symbolic_phase ? nullptr : c->stage_off_dst;
     w.off_n = symbolic_phase ? 0u : c->stage_off_n;
+    w.verify_counts = c->capture_skip_scan ? 1u : 0u;
     return w;
 }
 
@@ -645,7 +652,10 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
         tm->ev_scan = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
-    if (c->capture_pred_scan)
+    if (c->capture_skip_scan) {
+        // no scan: every row's nnz was compared with the previous call's where it was produced (store_row_count, the
+        // fused register-class bodies, the numeric-first kernel); the numeric launches read what that call's scan left
+    } else if (c->capture_pred_scan)
         launch_scan_predicted(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                               sc.recs, c->d_stats, cp, c->gpred.off, c->gpred.num_tile, c->gpred.stats,
                               (c->capture_pred_sym && !c->capture_overlap) ? sc.partials : nullptr, c->capture_overlap);
@@ -823,7 +833,7 @@ int snapshot_prediction(speck_config* c, hipStream_t s, const ReplayPlan& p)
     return SPECK_OK;
 }
 
-ReplayPlan plan_replay(const speck_config* c)
+ReplayPlan plan_replay(const speck_config* c, bool arena_replay_ok = false)
 {
     // (The replayed sequence classifies exactly like the eager one.  Round 2 re-classified an under-filled NUM_B8K
     //  class into NUM_B2K at a load of 0.85 here; since the workgroup classes take rows up to that load in every
@@ -870,6 +880,13 @@ ReplayPlan plan_replay(const speck_config* c)
     // ... and then nothing downstream needs what the analysis WRITES any more: the previous identical call left all of it
     // in the arena.  The analysis becomes a verifier beside the sequence (its own stream, joined in front of the ticket).
     p.overlap = c->overlap_analysis && p.pred_sym && c->vstream != nullptr;
+    // ... and when the arena was last written by a replay of THIS sequence, its scan has nothing left to do either: the
+    // offsets, classes and records it would produce are a function of the rows' nnz and of the analysis' quantities --
+    // all verified where they are produced.  C.row_offsets is still rewritten in every call (from the sequence's copy of
+    // the offsets, by extra workgroups of the numeric light launch: needs that launch).
+    constexpr u32 kBigLight = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256);
+    p.skip_scan = c->skip_scan && arena_replay_ok && p.overlap && p.fused && p.direct && c->merge_light && !c->split_light &&
+                  (p.launch_mask & kBigLight) != 0;
     return p;
 }
 
@@ -885,6 +902,12 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
     c->capture_pred_scan = p.pred_scan;
     c->capture_pred_sym = p.pred_sym;
     c->capture_overlap = p.overlap;
+    c->capture_skip_scan = p.skip_scan;
+    if (p.skip_scan) {  // C.row_offsets <- the sequence's own copy of the offsets (numeric light launch)
+        c->stage_off_src = c->gpred.off;
+        c->stage_off_dst = C->row_offsets;
+        c->stage_off_n = (u32)A->rows + 1u;
+    }
     c->capture_c_col = C->col_ids;
     c->capture_c_val = C->data;
     struct Reset {
@@ -893,6 +916,8 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
         ~Reset()
         {
             c->capture_direct = c->capture_fused = c->capture_pred_scan = c->capture_pred_sym = c->capture_overlap = false;
+            if (c->capture_skip_scan) c->stage_off_src = nullptr, c->stage_off_dst = nullptr, c->stage_off_n = 0;
+            c->capture_skip_scan = false;
             c->nf_wcols = wcols;
         }
     } reset{c, c->nf_wcols};
@@ -921,10 +946,10 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
 // Capture the sequence into one graph, specialised to `key`.
 template <typename T>
 int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
-                  const speck_dcsr* C, const Scratch& sc, const GraphKey& key)
+                  const speck_dcsr* C, const Scratch& sc, const GraphKey& key, bool arena_replay_ok = false)
 {
     drop_graph(c);
-    ReplayPlan plan = plan_replay(c);
+    ReplayPlan plan = plan_replay(c, arena_replay_ok);
     if (snapshot_prediction(c, s, plan) != SPECK_OK) {  // no room for the sequence's own copy: predict nothing
         c->pred_valid = c->pred_tiles_valid = false;
         plan = plan_replay(c);
@@ -1105,13 +1130,14 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         if (c->last_key_valid && c->last_key == key) {
             c->exec_dirty = true;
             if (c->graph_valid && !(c->graph_key == key)) drop_graph(c);  // (its copy of the prediction is rewritten below)
-            ReplayPlan plan = plan_replay(c);
+            const bool arena_mine = c->arena_key_valid && c->arena_key == key;
+            ReplayPlan plan = plan_replay(c, arena_mine && c->arena_from_replay);
             if (snapshot_prediction(c, s, plan) != SPECK_OK) {
                 c->pred_valid = c->pred_tiles_valid = false;
                 plan = plan_replay(c);
             }
             // (a verifying analysis needs the metadata of THIS problem in the arena)
-            if (!(c->arena_key_valid && c->arena_key == key)) plan.overlap = false;
+            if (!arena_mine) plan.overlap = plan.skip_scan = false;
             c->arena_key_valid = false;
             Timing tm;
             size_t ev_num_end = 0;
@@ -1134,12 +1160,13 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             if (!changed && !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 c->arena_key = key;
                 c->arena_key_valid = true;
+                c->arena_from_replay = true;
                 publish_counts(c);
                 publish_kernel_times(c, tm, ev_num_end);
                 c->last.replayed = 0;  // (not served by the graph: graph_replays does not count it)
                 c->last.nf_direct = plan.direct ? 1 : 0;
                 c->last.esc_fused = plan.fused ? 1 : 0;
-                c->last.pred_stages = (plan.pred_scan ? 1 : 0) | (plan.pred_sym ? 2 : 0) | (plan.overlap ? 4 : 0);
+                c->last.pred_stages = (plan.pred_scan ? 1 : 0) | (plan.pred_sym ? 2 : 0) | (plan.overlap ? 4 : 0) | (plan.skip_scan ? 8 : 0);
                 return finish_complete();
             }
         }
@@ -1147,8 +1174,13 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     if (c->use_graph && c_ready && !c->profile_kernels && !t->measureAll) {
         const GraphKey key = make_key<T>(c, A, B, C, s);
         bool have = c->graph_valid && c->graph_key == key;
+        const bool replay_layout = c->arena_key_valid && c->arena_key == key && c->arena_from_replay;
         if (!have && c->last_key_valid && c->last_key == key)
-            have = capture_graph<T>(c, s, A, B, C, sc, key) == SPECK_OK;
+            have = capture_graph<T>(c, s, A, B, C, sc, key, replay_layout) == SPECK_OK;
+        // the sequence has replayed once: from now on it needs no scan kernel (captured anew, once)
+        else if (have && !c->graph_plan.skip_scan && replay_layout && c->last_key_valid && c->last_key == key &&
+                 plan_replay(c, true).skip_scan)
+            have = capture_graph<T>(c, s, A, B, C, sc, key, true) == SPECK_OK;
         if (have && c->exec_dirty && !(c->replay_uncaptured || c->use_user_stream)) {
             // (see below) a fresh executable for a graph that other launches have passed; no executable: eager path
             if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -1174,12 +1206,12 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             // same sequence runs with a writing analysis in front instead -- enqueued, not from the graph -- and leaves
             // the arena as the next replay needs it.
             const bool arena_ok = c->arena_key_valid && c->arena_key == key;
-            bool overlapped = c->graph_overlap;
+            bool overlapped = c->graph_overlap, skipped = c->graph_plan.skip_scan;
             c->arena_key_valid = false;  // (until this call has completed)
-            if (c->graph_overlap && !arena_ok) {
+            if ((c->graph_overlap && !arena_ok) || (c->graph_plan.skip_scan && !replay_layout)) {
                 ReplayPlan p2 = c->graph_plan;
-                p2.overlap = false;
-                overlapped = false;
+                p2.overlap = p2.skip_scan = false;
+                overlapped = skipped = false;
                 c->exec_dirty = true;
                 rc = enqueue_replay<T>(c, s, A, B, C, sc, p2, nullptr, nullptr);
                 if (rc != SPECK_OK) return rc;
@@ -1205,12 +1237,13 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             if (!changed && !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 c->arena_key = key;
                 c->arena_key_valid = true;
+                c->arena_from_replay = true;
                 ++c->graph_replays;
                 publish_counts(c);
                 c->last.replayed = 1;
                 c->last.nf_direct = c->graph_direct ? 1 : 0;
                 c->last.esc_fused = c->graph_fused ? 1 : 0;
-                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0) | (c->graph_pred_sym ? 2 : 0) | (overlapped ? 4 : 0);
+                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0) | (c->graph_pred_sym ? 2 : 0) | (overlapped ? 4 : 0) | (skipped ? 8 : 0);
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -1503,6 +1536,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     c->last_key_valid = true;
     c->arena_key = c->last_key;
     c->arena_key_valid = true;
+    c->arena_from_replay = false;
     c->spec_valid = true;
     c->spec_rows_a = A->rows;
     c->spec_rows_b = B->rows;
@@ -1745,6 +1779,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->last_key_valid = false;
     }
     else if (n == "eager_speculate") c->eager_speculate = value != 0;
+    else if (n == "skip_scan") {
+        c->skip_scan = value != 0;
+        drop_graph(c);
+    }
     else if (n == "overlap_analysis") {
         c->overlap_analysis = value != 0;
         drop_graph(c);

@@ -66,7 +66,7 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
                                     cnt += set_insert_batch<CAP>(tab, c, n);
                                 });
         cnt = g.reduce_add(cnt, scratch);
-        if (g.lane == 0) counts[rec.row] = cnt;
+        if (g.lane == 0) store_row_count(w, counts, rec.row, cnt);
         g.sync();
         idx += stride;
     }
@@ -134,7 +134,7 @@ __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductS
             heads += (col[r] != kEscInvalid && col[r] != before_col) ? 1u : 0u;
         }
         heads = g.reduce_add(heads, nullptr);
-        if (gl == 0) counts[rec.row] = heads;
+        if (gl == 0) store_row_count(w, counts, rec.row, heads);
         wave_lds_fence();  // the next row overwrites the offsets
         idx += stride;
     }
@@ -194,7 +194,7 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
             if (!multi) break;
         }
         total = g.reduce_add(total, scratch);
-        if (threadIdx.x == 0) counts[rec.row] = total;
+        if (threadIdx.x == 0) store_row_count(w, counts, rec.row, total);
     }
 }
 
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kGhThreads) void sym_global_hash_kernel(ProductSrc<
                                     cnt += gh_insert_batch(tab, shift, slots - 1u, c, n);
                                 });
         cnt = g.reduce_add(cnt, scratch);
-        if (threadIdx.x == 0) counts[rec.row] = cnt;
+        if (threadIdx.x == 0) store_row_count(w, counts, rec.row, cnt);
         __syncthreads();
     }
 }

@@ -58,7 +58,7 @@ import contextlib
 @contextlib.contextmanager
 def options(cfg, **kv):
     """Library options for the duration of a block (restored to the given defaults afterwards)."""
-    defaults = {"esc32": 1, "esc64": 1, "esc4": 0}
+    defaults = {"esc32": 1, "esc64": 1, "esc4": 0, "skip_scan": 1}
     for k, v in kv.items():
         cfg.set_option(k, v)
     try:
@@ -825,6 +825,92 @@ def test_replay_detects_changed_inputs_under_the_same_pointers(cfg):
     for _ in range(3):
         sa.MultiplyspECK(dA, dA, dC, cfg)
     _assert_matches_oracle(dC, A2, A2)
+
+
+def test_sequence_without_a_scan_verifies_every_row_length(cfg):
+    """From its second replay on a sequence has no scan kernel (speck_stats::pred_stages bit 3): the analysis beside it
+    verifies the structure-derived quantities, and every kernel that produces a row's nnz compares it with the room the
+    previous identical call gave the row.  B's column ids change IN PLACE so that (a) a register-class row, (b) a
+    hash-class row keeps its products but loses / gains distinct columns -- nothing the analysis looks at changes (row
+    lengths of B, first and last column of every B row) -- and the call must come back with the new product; C.row_offsets
+    is rewritten by every replay (scribbled over in between); values changed in place keep the sequence."""
+    import ctypes as C_
+    L = _lib.load()
+    rng = np.random.default_rng(77)
+    kb, n = 3000, 50000
+    # B rows of 6 entries: first and last column fixed per row, the four in between movable
+    first = rng.integers(0, 1000, size=kb)
+    last = first + 40000 + rng.integers(0, 5000, size=kb)
+    mid = np.sort(first[:, None] + 1 + rng.integers(0, 30000, size=(kb, 4)), axis=1)
+    for i in range(kb):
+        while len(set(mid[i])) < 4:
+            mid[i] = np.sort(first[i] + 1 + rng.integers(0, 30000, size=4))
+    bc = np.concatenate([first[:, None], mid, last[:, None]], axis=1)
+    B = po.HostCSR(kb, n, np.arange(kb + 1, dtype=np.uint32) * 6, bc.reshape(-1).astype(np.uint32), 0.5 + rng.random(kb * 6))
+    lens = np.concatenate([rng.integers(2, 6, size=2500), rng.integers(60, 90, size=300)])      # 12..30 and 360..540 products
+    ro = np.zeros(lens.size + 1, dtype=np.uint32)
+    ro[1:] = np.cumsum(lens)
+    acol = np.concatenate([np.sort(rng.choice(kb, size=k, replace=False)) for k in lens]).astype(np.uint32)
+    A = po.HostCSR(lens.size, kb, ro, acol, 0.5 + rng.random(acol.size))
+    dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR()
+    for _ in range(5):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    st = cfg.last_stats()
+    assert st["replayed"] and st["pred_stages"] == 15 and st["esc_fused"], st["pred_stages"]
+    assert st["num_bin_rows"]["wave512"] + st["num_bin_rows"]["block2k"] > 0 and st["num_bin_rows"]["nfcopy"] >= 2500
+    _assert_matches_oracle(dC, A, B)
+    # C.row_offsets scribbled over: the next replay rewrites it
+    junk = np.full(dC.rows + 1, 0x7FFFFFF0, dtype=np.uint32)
+    assert L.speck_dcsr_update(C_.byref(dC._c), junk.ctypes.data, None, None, 8) == 0
+    replays = st["graph_replays"]
+    sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["graph_replays"] == replays + 1
+    _assert_matches_oracle(dC, A, B)
+
+    def moved(used):
+        """One B row referenced by the row of A takes a column another referenced B row already holds (same first /
+        last column, same length): the row of C loses a distinct column."""
+        bc2 = bc.copy()
+        for u0 in used:
+            for u1 in used:
+                x = bc[u1, 1]
+                if u0 != u1 and bc[u0, 0] < x < bc[u0, 2] and x != bc[u0, 1]:
+                    bc2[u0, 1] = x
+                    return po.HostCSR(kb, n, B.row_offsets, bc2.reshape(-1).astype(np.uint32), B.data)
+        raise AssertionError("no movable column in this row")
+
+    small_row, big_row = 7, 2500 + 11        # a register-class row of A, a hash-class row of A
+    for row in (small_row, big_row):
+        used = A.col_ids[A.row_offsets[row]:A.row_offsets[row + 1]]
+        B2 = moved(used)
+        R2, _ = po.spgemm(A, B2)
+        misses = cfg.last_stats()["numeric_reruns"]
+        assert L.speck_dcsr_update(C_.byref(dB._c), None, np.ascontiguousarray(B2.col_ids).ctypes.data, None, 8) == 0
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+        got = dC.to_host()
+        assert got.nnz == R2.nnz and (got.row_offsets == R2.row_offsets).all() and (got.col_ids == R2.col_ids).all()
+        changed = (np.diff(R2.row_offsets.astype(np.int64)) != np.diff(po.spgemm(A, B)[0].row_offsets.astype(np.int64))).any()
+        assert changed and cfg.last_stats()["numeric_reruns"] == misses + 1   # a row length differs: the sequence objected
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["pred_stages"] == 15
+        _assert_matches_oracle(dC, A, B2)
+        assert L.speck_dcsr_update(C_.byref(dB._c), None, np.ascontiguousarray(B.col_ids).ctypes.data, None, 8) == 0
+        for _ in range(5):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        _assert_matches_oracle(dC, A, B)
+    # values only: the sequence stays
+    misses = cfg.last_stats()["numeric_reruns"]
+    A3 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data * -2.0)
+    assert L.speck_dcsr_update(C_.byref(dA._c), None, None, np.ascontiguousarray(A3.data).ctypes.data, 8) == 0
+    sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["numeric_reruns"] == misses and cfg.last_stats()["pred_stages"] == 15
+    _assert_matches_oracle(dC, A3, B)
+    with options(cfg, skip_scan=0):
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["pred_stages"] == 7
+        _assert_matches_oracle(dC, A3, B)
 
 
 def test_replay_detects_numeric_first_rows_wider_than_the_captured_window(cfg):
