@@ -309,6 +309,7 @@ def profile_prepass(job, split, merged, prof_steps=5):
         LIGHT, TINY = LIGHT + TINY, ()
     SYM_LIGHT = ("bitmap256k", "block4k", "wave1k", "wave256", "r64", "r32", "wave128", "g16", "g8", "g4")
     ESC = ("g4", "g8", "g16", "r32", "r64")   # the register classes: finished in the symbolic phase of a fused replay
+    job.step()   # (the first replayed call still has a scan kernel: what is timed below is the sequence from its second replay on)
     kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny", "numeric_first", "fused_light"]}
     sym_ms = num_ms = 0.0
     fused = False
