@@ -136,9 +136,11 @@ struct ClassHint {
     u32 off, cnt;
 };
 constexpr ClassHint kNoHint{0xFFFFFFFFu, 0xFFFFFFFFu};
+// (Round 4: the merged kernels no longer carry a ClassHint per class -- measured +-0 when they were added, and with ten
+//  class bodies in one kernel their 24 kernel-argument words were what pushed the fused light launch into spilling 90
+//  scalar registers: 50.4 -> 43.7 us on the scircuit stand-in without them.  The stand-alone class kernels never had any.)
 struct ClassGrid {
     u32 first[13];
-    ClassHint hint[12];
 };
 constexpr u32 kSymLightMask = (1u << SYM_BM1) | (1u << SYM_B4K) | (1u << SYM_W1K) | (1u << SYM_W256) | (1u << SYM_G16) |
                               (1u << SYM_G8) | (1u << SYM_W128) | (1u << SYM_R32) | (1u << SYM_R64) | (1u << SYM_G4);

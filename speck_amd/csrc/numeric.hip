@@ -782,36 +782,36 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     // (every body starts with open_list: its first record is requested from the hinted list position while the
     //  device-side table and the capacity_miss flag are still on their way)
     if (b < cg.first[1])
-        num_dense_body<T, kNumD1Win, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0], cg.hint[0]);
+        num_dense_body<T, kNumD1Win, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0], kNoHint);
     else if (b < cg.first[2])
         num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256>(
-            smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1], cg.hint[1]);
+            smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1], kNoHint);
     else if (b < cg.first[3])
         num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
-            smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2], cg.hint[2]);
+            smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2], kNoHint);
     else if (b < cg.first[4])
         num_hash_body<SubWave<32>, T, kNumW256Cap, kW256W1, kNumW256MaxNnz, SORT_BITMAP, 256>(
-            smem, src, w, c_col, c_val, NUM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.hint[3]);
+            smem, src, w, c_col, c_val, NUM_W256, b - cg.first[3], cg.first[4] - cg.first[3], kNoHint);
     else if (b < cg.first[5]) {
         if constexpr (WITH_ESC)
-            num_escw_body<T, 64, 256>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
+            num_escw_body<T, 64, 256>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], kNoHint);
     } else if (b < cg.first[6]) {
         if constexpr (WITH_ESC)
-            num_escw_body<T, 32, 256>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+            num_escw_body<T, 32, 256>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], kNoHint);
     } else if (b < cg.first[7])
         num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], kNoHint);
     else if (b < cg.first[8]) {
         if constexpr (WITH_ESC)
-            num_esc_body<T, 16, 256>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
+            num_esc_body<T, 16, 256>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], kNoHint);
     } else if (b < cg.first[9]) {
         if constexpr (WITH_ESC)
-            num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
+            num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], kNoHint);
     } else if (b < cg.first[10]) {
         if constexpr (WITH_ESC)
-            num_esc_body<T, 4, 256>(smem, src, w, c_col, c_val, NUM_G4, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
+            num_esc_body<T, 4, 256>(smem, src, w, c_col, c_val, NUM_G4, b - cg.first[9], cg.first[10] - cg.first[9], kNoHint);
     } else if (b < cg.first[11])
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[10], cg.first[11] - cg.first[10], cg.hint[10]);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[10], cg.first[11] - cg.first[10], kNoHint);
     else  // the staged row offsets of an eager call -> C.row_offsets (RowWork::off_src)
         for (u32 i = (b - cg.first[11]) * 256u + threadIdx.x; i < w.off_n; i += (cg.first[12] - cg.first[11]) * 256u)
             w.off_dst[i] = w.off_src[i];
@@ -829,20 +829,20 @@ __global__ __launch_bounds__(TT) void num_tiny_kernel(ProductSrc<T> src, const u
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
     if (b < cg.first[5])
-        num_escw_body<T, 64, TT>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
+        num_escw_body<T, 64, TT>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], kNoHint);
     else if (b < cg.first[6])
-        num_escw_body<T, 32, TT>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+        num_escw_body<T, 32, TT>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], kNoHint);
     else if (b < cg.first[7])
         num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, TT>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], kNoHint);
     else if (b < cg.first[8])
-        num_esc_body<T, 16, TT>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
+        num_esc_body<T, 16, TT>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], kNoHint);
     else if (b < cg.first[9])
-        num_esc_body<T, 8, TT>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
+        num_esc_body<T, 8, TT>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], kNoHint);
     else if (b < cg.first[10])
-        num_esc_body<T, 4, TT>(smem, src, w, c_col, c_val, NUM_G4, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
+        num_esc_body<T, 4, TT>(smem, src, w, c_col, c_val, NUM_G4, b - cg.first[9], cg.first[10] - cg.first[9], kNoHint);
     else
-        num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[10], cg.first[11] - cg.first[10], cg.hint[10]);
+        num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[10], cg.first[11] - cg.first[10], kNoHint);
 }
 
 // ------------------------------------------------------------------ NUM_G
@@ -1358,13 +1358,7 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
         if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);  // (nothing to time: an empty interval)
         return;
     }
-    for (int k = 0; k < NS; ++k) {
-        cg.hint[k] = kNoHint;
-        if (!exact) continue;
-        u32 off = 0;  // class lists follow each other in class order (publish_bins)
-        for (int c = 0; c < slots[k]; ++c) off += counts_hint[c];
-        cg.hint[k] = ClassHint{off, counts_hint[slots[k]]};
-    }
+    (void)exact;  // (list positions are no longer handed to the merged kernels: launch.hpp, ClassGrid)
     const ProductSrc<T> src{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
     // ... + the workgroups that move the staged row offsets (only the big kernel carries them)
     cg.first[NS + 1] = cg.first[NS];

@@ -339,32 +339,32 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     const u32 b = blockIdx.x;
     // launch order (ClassGrid slots): BM1, B4K, W1K, W256, R64, R32, W128, G16, G8, G4
     if (b < cg.first[1])
-        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], cg.hint[0]);
+        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], kNoHint);
     else if (b < cg.first[2])
-        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], cg.hint[1]);
+        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], kNoHint);
     else if (b < cg.first[3])
-        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], cg.hint[2]);
+        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], kNoHint);
     else if (b < cg.first[4])
-        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.hint[3]);
+        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], kNoHint);
     else if (b < cg.first[5])
-        sym_escw_body<64, 256>(smem, src, w, counts, SYM_R64, b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4]);
+        sym_escw_body<64, 256>(smem, src, w, counts, SYM_R64, b - cg.first[4], cg.first[5] - cg.first[4], kNoHint);
     else if (b < cg.first[6])
-        sym_escw_body<32, 256>(smem, src, w, counts, SYM_R32, b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5]);
+        sym_escw_body<32, 256>(smem, src, w, counts, SYM_R32, b - cg.first[5], cg.first[6] - cg.first[5], kNoHint);
     else if (b < cg.first[7])
-        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], kNoHint);
     else if (b < cg.first[8])
-        sym_esc_body<16, 256>(smem, src, w, counts, SYM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7]);
+        sym_esc_body<16, 256>(smem, src, w, counts, SYM_G16, b - cg.first[7], cg.first[8] - cg.first[7], kNoHint);
     else if (b < cg.first[9])
-        sym_esc_body<8, 256>(smem, src, w, counts, SYM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8]);
+        sym_esc_body<8, 256>(smem, src, w, counts, SYM_G8, b - cg.first[8], cg.first[9] - cg.first[8], kNoHint);
     else
-        sym_esc_body<4, 256>(smem, src, w, counts, SYM_G4, b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9]);
+        sym_esc_body<4, 256>(smem, src, w, counts, SYM_G4, b - cg.first[9], cg.first[10] - cg.first[9], kNoHint);
 }
 
 // The light launch of a REPLAYED sequence: the rows of the two register classes are finished here -- products
 // expanded, sorted, summed and written to the place the previous identical call gave the row in C (num_esc_body,
 // FUSED) -- instead of being counted now and walked again in the numeric phase.  The other classes count as above.
 template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void sym_light_fused_kernel(ProductSrc<T> nsrc, const u32* a_ro, RowWork w,
+__global__ __launch_bounds__(256) void sym_light_fused_kernel(ProductSrc<T> nsrc, const u32* a_ro, RowWork w,
                                                               u32* __restrict__ counts, ClassGrid cg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -372,30 +372,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const ProductSrc<float> src{nsrc.b_sl, nullptr, nsrc.b_col, nullptr, nsrc.w_sl};
     const u32 b = blockIdx.x;
     if (b < cg.first[1])
-        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], cg.hint[0]);
+        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], kNoHint);
     else if (b < cg.first[2])
-        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], cg.hint[1]);
+        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], kNoHint);
     else if (b < cg.first[3])
-        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], cg.hint[2]);
+        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], kNoHint);
     else if (b < cg.first[4])
-        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.hint[3]);
+        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], kNoHint);
     else if (b < cg.first[5])
         num_escw_body<T, 64, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_R64,
-                                        b - cg.first[4], cg.first[5] - cg.first[4], cg.hint[4], counts);
+                                        b - cg.first[4], cg.first[5] - cg.first[4], kNoHint, counts);
     else if (b < cg.first[6])
         num_escw_body<T, 32, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_R32,
-                                        b - cg.first[5], cg.first[6] - cg.first[5], cg.hint[5], counts);
+                                        b - cg.first[5], cg.first[6] - cg.first[5], kNoHint, counts);
     else if (b < cg.first[7])
-        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.hint[6]);
+        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], kNoHint);
     else if (b < cg.first[8])
         num_esc_body<T, 16, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G16,
-                                       b - cg.first[7], cg.first[8] - cg.first[7], cg.hint[7], counts);
+                                       b - cg.first[7], cg.first[8] - cg.first[7], kNoHint, counts);
     else if (b < cg.first[9])
         num_esc_body<T, 8, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G8,
-                                      b - cg.first[8], cg.first[9] - cg.first[8], cg.hint[8], counts);
+                                      b - cg.first[8], cg.first[9] - cg.first[8], kNoHint, counts);
     else
         num_esc_body<T, 4, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G4,
-                                      b - cg.first[9], cg.first[10] - cg.first[9], cg.hint[9], counts);
+                                      b - cg.first[9], cg.first[10] - cg.first[9], kNoHint, counts);
 }
 
 u32 symbolic_lds_bytes(int cls)
@@ -496,13 +496,7 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
         if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);  // (nothing to time: an empty interval)
         return;
     }
-    for (int k = 0; k < NS; ++k) {
-        cg.hint[k] = kNoHint;
-        if (!exact) continue;
-        u32 off = 0;  // class lists follow each other in class order (publish_bins)
-        for (int c = 0; c < slots[k]; ++c) off += counts_hint[c];
-        cg.hint[k] = ClassHint{off, counts_hint[slots[k]]};
-    }
+    (void)exact;  // (list positions are no longer handed to the merged kernels: launch.hpp, ClassGrid)
     if (fused && fused_vsize == 8) {
         const ProductSrc<double> nsrc{b_sl, static_cast<const double*>(a_val), b_col, static_cast<const double*>(b_val), w.w_sl};
         SPECK_LAUNCH_TIMED((sym_light_fused_kernel<double>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, nsrc, a_ro, w, counts, cg);
