@@ -879,7 +879,9 @@ ReplayPlan plan_replay(const speck_config* c, bool arena_replay_ok = false)
                  (!(c->last_sym_mask >> SYM_NF & 1u) || p.direct);
     // ... and then nothing downstream needs what the analysis WRITES any more: the previous identical call left all of it
     // in the arena.  The analysis becomes a verifier beside the sequence (its own stream, joined in front of the ticket).
-    p.overlap = c->overlap_analysis && p.pred_sym && c->vstream != nullptr;
+    // (on the library's own pipeline stream only: beside a CALLER's stream the verifier would not be ordered behind the
+    //  work that produces the inputs there)
+    p.overlap = c->overlap_analysis && p.pred_sym && c->vstream != nullptr && !c->use_user_stream;
     // ... and when the arena was last written by a replay of THIS sequence, its scan has nothing left to do either: the
     // offsets, classes and records it would produce are a function of the rows' nnz and of the analysis' quantities --
     // all verified where they are produced.  C.row_offsets is still rewritten in every call (from the sequence's copy of
@@ -1062,6 +1064,11 @@ int wait_verifier(speck_config* c, bool* changed)
 int begin_validate(speck_config* c, const speck_dcsr* B)
 {
     __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
+    if (c->use_user_stream) {
+        // the caller's stream may still be producing B: the check goes behind what is queued there now
+        HIP_TRY(hipEventRecord(c->fork, c->user_stream));
+        HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
+    }
     launch_validate_b(c->vstream, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, B->nnz, c->h_verify_dev);
     launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
     HIP_TRY(hipGetLastError());

@@ -913,6 +913,63 @@ def test_sequence_without_a_scan_verifies_every_row_length(cfg):
         _assert_matches_oracle(dC, A3, B)
 
 
+def test_call_on_a_callers_stream_sees_what_that_stream_produced(cfg):
+    """speck_config_set_stream: the multiply is ordered behind the work queued on the caller's stream.  B's column ids
+    are written BY that stream (a copy behind a long-running kernel) -- until then the buffer holds descending rows (an
+    invalid matrix) resp. another valid matrix.  The kernels the library runs on streams of its own (the input check of
+    an eager call, the structure verifier of a replayed sequence) must not look at B before the copy: (a) the first,
+    eager call must not reject B, (b) the replayed sequence must multiply with the new B."""
+    import torch
+    rng = np.random.default_rng(31)
+    A = fast_random_csr(4000, 3000, 5, 1)
+    B = fast_random_csr(3000, 6000, 6, 2)
+    lens = np.diff(B.row_offsets.astype(np.int64))
+    # the same rows, descending: every row longer than one entry is invalid
+    bad = np.concatenate([B.col_ids[B.row_offsets[i]:B.row_offsets[i + 1]][::-1] for i in range(B.rows)])
+    # another valid B of the same structure-derived quantities (row lengths, first / last column of every row)
+    other = B.col_ids.copy()
+    moved = 0
+    for i in range(B.rows):
+        lo, hi = B.row_offsets[i], B.row_offsets[i + 1]
+        if hi - lo >= 3 and B.col_ids[lo + 2] - B.col_ids[lo] >= 3:
+            c = B.col_ids[lo] + 1 if B.col_ids[lo + 1] != B.col_ids[lo] + 1 else B.col_ids[lo] + 2
+            other[lo + 1] = c
+            moved += 1
+    assert moved > 1000 and (lens > 1).sum() > 1000
+    B2 = po.HostCSR(B.rows, B.cols, B.row_offsets, other, B.data)
+    dev = torch.device("cuda:0")
+    t_ro = torch.from_numpy(B.row_offsets.view(np.int32)).to(dev)
+    t_ci = torch.from_numpy(bad.view(np.int32).copy()).to(dev)
+    t_va = torch.from_numpy(B.data).to(dev)
+    t_good = torch.from_numpy(B.col_ids.view(np.int32).copy()).to(dev)
+    t_other = torch.from_numpy(other.view(np.int32).copy()).to(dev)
+    dB = sa.dCSR.from_device(B.rows, B.cols, B.nnz, t_ro.data_ptr(), t_ci.data_ptr(), t_va.data_ptr(),
+                             keep=(t_ro, t_ci, t_va), host_row_offsets=B.row_offsets)
+    dA, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream(device=dev)
+    cfg.set_stream(s.cuda_stream)
+    try:
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(200_000_000)        # ~0.1 s: whatever does not wait for the stream runs long before the copy
+            t_ci.copy_(t_good, non_blocking=True)
+        sa.MultiplyspECK(dA, dB, dC, cfg)         # (a)
+        s.synchronize()
+        _assert_matches_oracle(dC, A, B)
+        for _ in range(5):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["replayed"]
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(200_000_000)
+            t_ci.copy_(t_other, non_blocking=True)
+        sa.MultiplyspECK(dA, dB, dC, cfg)         # (b)
+        s.synchronize()
+        _assert_matches_oracle(dC, A, B2)
+    finally:
+        cfg.set_stream(None)
+        torch.cuda.synchronize()
+
+
 def test_replay_detects_numeric_first_rows_wider_than_the_captured_window(cfg):
     """The numeric-first kernel's LDS window is as wide as the widest such row of the call the sequence was
     captured from (512 columns here).  B changes in place to rows spread over 3500 columns (still
