@@ -28,13 +28,13 @@ def main():
     A = sa.gen_matrix(wl, 1.0, 1)
     dA = sa.dCSR.from_host(A)
     dC = sa.dCSR(np.float64)
-    buf = np.zeros(12 * 16, dtype=np.uint64)
+    buf = np.zeros(16 * 16, dtype=np.uint64)   # kMaxClasses x 16 phases
     sa.MultiplyspECK(dA, dA, dC, cfg)
     fn(buf.ctypes.data)
     sa.MultiplyspECK(dA, dA, dC, cfg)
     fn(buf.ctypes.data)
     st = cfg.last_stats()
-    t = buf.reshape(12, 16)
+    t = buf.reshape(16, 16)
     for ci, name in enumerate(sa.api.NUM_CLASS_NAMES):
         rows = st["num_bin_rows"][name]
         if rows == 0 or t[ci].sum() == 0:

@@ -1295,19 +1295,30 @@ __global__ __launch_bounds__(64) void done_kernel(u32* __restrict__ dev_ticket, 
 __global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__ b_ro, const u32* __restrict__ b_col, u32 b_rows,
                                                           u32 b_cols, u32* __restrict__ verdict)
 {
+    // four consecutive entries (and the one behind them) per lane and step, all five loads in flight together: the
+    // kernel runs beside the analysis of the call and should be gone before it competes with anything else
+    constexpr u32 E = 4;
     const u32 e_first = b_ro[0], e_last = b_ro[b_rows];
     bool bad = e_last < e_first;
-    for (u64 i = u64(blockIdx.x) * 256 + threadIdx.x; e_first + i < e_last; i += u64(gridDim.x) * 256) {
+    const u64 n = e_last > e_first ? u64(e_last - e_first) : 0;
+    for (u64 i = (u64(blockIdx.x) * 256 + threadIdx.x) * E; i < n; i += u64(gridDim.x) * 256 * E) {
         const u32 e = e_first + (u32)i;
-        const u32 c = b_col[e];
-        if (c >= b_cols) bad = true;
-        if (e + 1 < e_last && b_col[e + 1] <= c) {
-            u32 lo = 0, hi = b_rows;  // first row whose offset is >= e + 1
-            while (lo < hi) {
-                const u32 mid = lo + ((hi - lo) >> 1);
-                if (b_ro[mid] < e + 1) lo = mid + 1; else hi = mid;
+        u32 c[E + 1];
+#pragma unroll
+        for (u32 k = 0; k <= E; ++k) c[k] = i + k < n ? b_col[e + k] : 0xFFFFFFFFu;
+#pragma unroll
+        for (u32 k = 0; k < E; ++k) {
+            if (i + k >= n) continue;
+            if (c[k] >= b_cols) bad = true;
+            if (i + k + 1 < n && c[k + 1] <= c[k]) {  // not ascending: fine only where a row starts (almost never looked up)
+                const u32 at = e + k + 1;
+                u32 lo = 0, hi = b_rows;  // first row whose offset is >= at
+                while (lo < hi) {
+                    const u32 mid = lo + ((hi - lo) >> 1);
+                    if (b_ro[mid] < at) lo = mid + 1; else hi = mid;
+                }
+                if (b_ro[lo] != at) bad = true;
             }
-            if (b_ro[lo] != e + 1) bad = true;
         }
     }
     if (__ballot(bad) != 0 && lane_id() == 0) __hip_atomic_fetch_or(verdict, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
