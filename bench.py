@@ -313,10 +313,12 @@ def profile_prepass(job, split, merged, prof_steps=5):
     kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny", "numeric_first", "fused_light"]}
     sym_ms = num_ms = 0.0
     fused = False
+    self_verified = False   # pred_stages bit 4: no symbolic pass for the hash / dense rows (their numeric bodies verify the nnz)
     for _ in range(prof_steps):
         job.step()
         s = cfg.last_stats()
         fused = s["esc_fused"]
+        self_verified = bool(s["pred_stages"] & 16)
         for k in NUM_CLASS_NAMES:
             kernel_ms[k] += s["num_bin_ms"][k] / prof_steps
         kernel_ms["light"] += s["num_light_ms"] / prof_steps
@@ -344,7 +346,7 @@ def profile_prepass(job, split, merged, prof_steps=5):
     kernel_bytes["numeric_first"] = kernel_bytes.pop("nfcopy")
     if fused:
         kernel_bytes["fused_light"] = (sum(kernel_bytes.pop(k) for k in ESC) +
-                                       sum(st["sym_bin_bytes"][k] for k in SYM_LIGHT if k not in ESC))
+                                       (0 if self_verified else sum(st["sym_bin_bytes"][k] for k in SYM_LIGHT if k not in ESC)))
         for k in ESC:
             kernel_bytes[k] = 0
     if merged:
@@ -354,6 +356,7 @@ def profile_prepass(job, split, merged, prof_steps=5):
     cfg.set_option("profile_replay", 0)
     st["num_bin_bytes"] = kernel_bytes
     st["esc_fused"] = fused
+    st["self_verified"] = self_verified
     return st, kernel_ms, sym_ms, num_ms
 
 
@@ -458,7 +461,7 @@ def verify_last_output(env, job, A, mode):
     r0, r1 = job.bounds
     st = scfg.last_stats()
     info = {"mode": mode, "checked": "output of the last timed step", "replayed": st["replayed"],
-            "nf_direct": st["nf_direct"], "esc_fused": st["esc_fused"]}
+            "nf_direct": st["nf_direct"], "esc_fused": st["esc_fused"], "pred_stages": st["pred_stages"]}
     try:
         if mode == "oracle":
             got = sC.to_host()

@@ -115,6 +115,9 @@ struct RowWork {
     // with the room the previous identical call gave the row (nf_pred_off) -- if every row keeps its length, every offset,
     // class and record of the numeric phase is what that call's scan left in the arena.
     u32 verify_counts;
+    // ... and WITHOUT a symbolic pass for the rows of the hash / dense classes of the numeric light launch
+    // (ReplayPlan::num_verify): their numeric bodies check the nnz themselves (numeric.hip, VERIFY) -- one walk per row.
+    u32 verify_numeric;
 };
 
 #ifdef __HIPCC__

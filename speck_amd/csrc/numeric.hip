@@ -143,10 +143,13 @@ __device__ __forceinline__ void num_direct_body(unsigned char* smem, const Produ
 // loop is their largest single part.  `ckeys` may alias the keys of the table (all slots are in
 // registers before the first write); the values stay where they are and are fetched by slot number.
 // `cap_row` (a power of two, SIZE <= cap_row <= CAP) slots of the table are in use.
-template <class G, typename T, u32 CAP, u32 NMAX>
-__device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, const Acc<T>* vals,
-                                                 u32* ckeys, u8* cslot, u32 cap_row, u32 base,
-                                                 u32* __restrict__ c_col, T* __restrict__ c_val)
+// VERIFY (all three emitters; RowWork::verify_numeric): the row's room in C is what the previous identical call found
+// (`room`), not what a symbolic pass of this call counted -- nothing is stored at or beyond it, and the number of entries
+// the table holds NOW is returned for the caller to compare.
+template <class G, typename T, u32 CAP, u32 NMAX, bool VERIFY = false>
+__device__ __forceinline__ u32 emit_rank_sorted(const G& g, const u32* keys, const Acc<T>* vals,
+                                                u32* ckeys, u8* cslot, u32 cap_row, u32 base,
+                                                u32* __restrict__ c_col, T* __restrict__ c_val, u32 room = 0xFFFFFFFFu)
 {
     constexpr u32 OWN = CAP / G::SIZE;
     constexpr u32 EMAX = (NMAX + G::SIZE - 1) / G::SIZE;
@@ -165,11 +168,15 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
         const u64 mask = g.ballot(k[j] != kEmptyKey);
         if (k[j] != kEmptyKey) {
             const u32 pos = run + __popcll(mask & lt);
-            ckeys[pos] = k[j];
-            cslot[pos] = (u8)(j * G::SIZE + g.lane);
+            if (!VERIFY || pos < NMAX) {  // (more entries than the class holds: the replay is rejected anyway)
+                ckeys[pos] = k[j];
+                cslot[pos] = (u8)(j * G::SIZE + g.lane);
+            }
         }
         run += __popcll(mask);
     }
+    const u32 found = run;
+    if constexpr (VERIFY) run = min(run, NMAX);
     if (g.lane < 4) ckeys[run + g.lane] = kEmptyKey;  // pad the last uint4
     g.sync();
     u32 mk[EMAX], ms[EMAX], r[EMAX];
@@ -208,10 +215,11 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
     }
 #pragma unroll
     for (u32 e = 0; e < EMAX; ++e)
-        if (mk[e] != kEmptyKey) {
+        if (mk[e] != kEmptyKey && (!VERIFY || r[e] < room)) {
             c_col[base + r[e]] = mk[e];
             c_val[base + r[e]] = (T)vals[ms[e]];
         }
+    return found;
 }
 
 // Narrow rows of the rank-sort classes: the reachable column range fits ONE bitmap word per lane of the
@@ -219,10 +227,10 @@ __device__ __forceinline__ void emit_rank_sorted(const G& g, const u32* keys, co
 // group scan of the word popcounts, one 8-byte LDS read + popcount per key -- ~60 wave instructions where
 // the compare loop above takes 150-400.  `bm` (SIZE words) may alias the table's keys, `bp` (SIZE uint2)
 // the A-row staging area.
-template <class G, typename T, u32 CAP>
-__device__ __forceinline__ void emit_narrow_sorted(const G& g, const u32* keys, const Acc<T>* vals, u32* bm,
-                                                   uint2* bp, u32 cap_row, u32 cmin, u32 base,
-                                                   u32* __restrict__ c_col, T* __restrict__ c_val)
+template <class G, typename T, u32 CAP, bool VERIFY = false>
+__device__ __forceinline__ u32 emit_narrow_sorted(const G& g, const u32* keys, const Acc<T>* vals, u32* bm,
+                                                  uint2* bp, u32 cap_row, u32 cmin, u32 base,
+                                                  u32* __restrict__ c_col, T* __restrict__ c_val, u32 room = 0xFFFFFFFFu)
 {
     constexpr u32 OWN = CAP / G::SIZE;
     u32 k[OWN];
@@ -234,10 +242,18 @@ __device__ __forceinline__ void emit_narrow_sorted(const G& g, const u32* keys, 
     g.sync();
     bm[g.lane] = 0;
     g.sync();
+    u32 outside = 0;  // (VERIFY: keys beyond the column range the records hold -- the structure has changed)
 #pragma unroll
     for (u32 j = 0; j < OWN; ++j)
         if (k[j] != kEmptyKey) {
             const u32 d = k[j] - cmin;
+            if constexpr (VERIFY) {
+                if (d >= G::SIZE * 32u) {
+                    k[j] = kEmptyKey;
+                    outside = 1;
+                    continue;
+                }
+            }
             atomicOr(&bm[d >> 5], 1u << (d & 31));
         }
     g.sync();
@@ -252,18 +268,21 @@ __device__ __forceinline__ void emit_narrow_sorted(const G& g, const u32* keys, 
             const u32 d = k[j] - cmin;
             const uint2 e = bp[d >> 5];
             const u32 r = e.y + (u32)__popc(e.x & ((1u << (d & 31)) - 1u));
+            if (VERIFY && r >= room) continue;
             c_col[base + r] = k[j];
             c_val[base + r] = (T)vals[j * G::SIZE + g.lane];
         }
+    if constexpr (VERIFY) return g.ballot(outside != 0) ? 0xFFFFFFFFu : total;
+    return total;
 }
 
 // Two-level bitmap sort (see the header comment).  S: LDS scratch of max(2*W1, 2*NMAX) words;
 // it may alias the table (slots are loaded into registers first).
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, bool STAGE = G::kIsBlock>
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, bool STAGE = G::kIsBlock, bool VERIFY = false>
 __device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, u32* keys, Acc<T>* vals, u32* S,
                                                    u32* scan_scratch, u32 cap_row, u32 cmin, u32 cmax,
                                                    u32 base, u32* __restrict__ c_col,
-                                                   T* __restrict__ c_val, int cls = 0)
+                                                   T* __restrict__ c_val, int cls = 0, u32 room = 0xFFFFFFFFu)
 {
     u32* const st_keys = keys;       // staging of the sorted window (STAGE): the table's own arrays
     Acc<T>* const st_vals = vals;
@@ -338,6 +357,7 @@ __device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, u32* keys, Acc<T>*
                 if (k[j] != kEmptyKey && d < ncols) {
                     const uint2 e = mx[brank[j]];
                     const u32 r = emitted + e.y + __popc(e.x & ((1u << (d & 31)) - 1u));
+                    if (VERIFY && r >= room) continue;
                     c_col[base + r] = k[j];
                     c_val[base + r] = (T)v[j];
                 }
@@ -367,7 +387,8 @@ __device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, u32* keys, Acc<T>*
                     st_vals[r[j]] = v[j];
                 }
             g.sync();
-            for (u32 i = g.lane; i < total; i += G::SIZE) {
+            const u32 fits = VERIFY ? min(total, room - min(room, emitted)) : total;
+            for (u32 i = g.lane; i < fits; i += G::SIZE) {
                 c_col[base + emitted + i] = st_keys[i];
                 c_val[base + emitted + i] = (T)st_vals[i];
             }
@@ -381,6 +402,7 @@ __device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, u32* keys, Acc<T>*
 
 // ------------------------------------------------------------------ hash kernels
 enum SortMode { SORT_RANK = 0, SORT_BITMAP = 1 };
+
 
 template <class G, int THREADS>
 constexpr u32 scan_scratch_words()
@@ -398,7 +420,11 @@ constexpr u32 num_group_lds()
 
 // Rows of the class with nnz <= NLO or nnz > NMAX are skipped: a class may be served by two
 // launches with differently sized tables (NUM_B8K below).
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0>
+// VERIFY: the launch of a replayed sequence that has NO symbolic pass for these rows (RowWork::verify_numeric): the record's
+// nnz -- table size, room in C -- is what the previous identical call found.  The body stays inside the table (bounded
+// probing) and inside the row's room whatever B holds now, counts what the table ends up with and raises capacity_miss if
+// that is not the nnz it was given: the host then takes the eager path, as after any other rejected replay.
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0, bool VERIFY = false>
 __device__ __forceinline__ void num_hash_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                               u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
                                               u32 bidx, u32 nblk, ClassHint hint = kNoHint)
@@ -447,27 +473,33 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         }
         g.sync();
         PHASE_MARK(0);
+        bool gave_up = false;
         for_each_product<true>(g, src, rec.a0, rec.a1, meta, scan_scratch,
                                [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
                                    Acc<T> pa[kBatch];
 #pragma unroll
                                    for (int u = 0; u < kBatch; ++u) pa[u] = p[u];
-                                   table_accumulate_batch(keys, vals, bits, c, pa, n);
+                                   gave_up |= table_accumulate_batch<Acc<T>, VERIFY>(keys, vals, bits, c, pa, n);
                                }, cls);
         PHASE_MARK(1);
+        u32 found;
         if constexpr (MODE == SORT_RANK) {
             // scratch: the compacted keys over the table's keys, their slot numbers over the A-row staging
             // the groups of a wave take the same sort (no wave ever runs both)
             const bool narrow = __ballot(u64(rec.cmax) - rec.cmin >= u64(G::SIZE) * 32) == 0;
             if (narrow)
-                emit_narrow_sorted<G, T, CAP>(g, keys, vals, keys, reinterpret_cast<uint2*>(m_av), cap_row, rec.cmin,
-                                              rec.base, c_col, c_val);
+                found = emit_narrow_sorted<G, T, CAP, VERIFY>(g, keys, vals, keys, reinterpret_cast<uint2*>(m_av), cap_row,
+                                                              rec.cmin, rec.base, c_col, c_val, rec.nnz);
             else
-                emit_rank_sorted<G, T, CAP, NMAX>(g, keys, vals, keys, reinterpret_cast<u8*>(m_av), cap_row, rec.base,
-                                                  c_col, c_val);
+                found = emit_rank_sorted<G, T, CAP, NMAX, VERIFY>(g, keys, vals, keys, reinterpret_cast<u8*>(m_av), cap_row,
+                                                                  rec.base, c_col, c_val, rec.nnz);
         } else {
-            emit_bitmap_sorted<G, T, CAP, W1, NMAX>(g, keys, vals, S, scan_scratch, cap_row, rec.cmin,
-                                                    rec.cmax, rec.base, c_col, c_val, cls);
+            found = emit_bitmap_sorted<G, T, CAP, W1, NMAX, G::kIsBlock, VERIFY>(g, keys, vals, S, scan_scratch, cap_row, rec.cmin,
+                                                                                 rec.cmax, rec.base, c_col, c_val, cls, rec.nnz);
+        }
+        if constexpr (VERIFY) {
+            // (any lane: a key that found no slot, or a table that holds another number of entries than the row was given)
+            if (gave_up || found != rec.nnz) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
         }
         g.sync();
         PHASE_MARK(2);
@@ -485,7 +517,8 @@ constexpr u32 num_dense_lds()
            (2 * (WCOLS / 32) + 2 * THREADS + THREADS / 64 + 2 + win_words<Block<THREADS>>() + 3) / 4 * 16;
 }
 
-template <typename T, u32 WCOLS, int THREADS>
+// (VERIFY: as num_hash_body -- nothing is stored beyond the row's room, the distinct columns found are compared with it)
+template <typename T, u32 WCOLS, int THREADS, bool VERIFY = false>
 __device__ __forceinline__ void num_dense_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                                u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
                                                u32 bidx, u32 nblk, ClassHint hint = kNoHint)
@@ -549,8 +582,10 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
                     while (word) {
                         const u32 d = i * 32u + (u32)__builtin_ctz(word);
                         word &= word - 1u;
-                        c_col[rec.base + r] = wbase + d;
-                        c_val[rec.base + r] = (T)vals[d];
+                        if (!VERIFY || r < rec.nnz) {
+                            c_col[rec.base + r] = wbase + d;
+                            c_val[rec.base + r] = (T)vals[d];
+                        }
                         vals[d] = 0;
                         ++r;
                     }
@@ -560,8 +595,10 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
                     const u32 word = bm[d >> 5];
                     if (word & (1u << (d & 31))) {
                         const u32 r = emitted + pref[d >> 5] + __popc(word & ((1u << (d & 31)) - 1u));
-                        c_col[rec.base + r] = wbase + d;
-                        c_val[rec.base + r] = (T)vals[d];
+                        if (!VERIFY || r < rec.nnz) {
+                            c_col[rec.base + r] = wbase + d;
+                            c_val[rec.base + r] = (T)vals[d];
+                        }
                         vals[d] = 0;
                     }
                 }
@@ -571,6 +608,9 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
             emitted += total;
             __syncthreads();
             if (!multi) break;
+        }
+        if constexpr (VERIFY) {
+            if (emitted != rec.nnz) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
         }
     }
 }
@@ -770,7 +810,9 @@ constexpr u32 kB8KW1 = 2048;  // 2 Mi columns per sort window
 // WITH_ESC = false: the launch of a sequence whose register-class rows are finished in its symbolic phase (fused
 // replay) -- those bodies are not even compiled in, and the kernel carries another NAME than the launch of an eager
 // call, so that a kernel trace tells the two apart (profiles/: per-kernel averages of the replayed sequence alone).
-template <typename T, bool WITH_ESC = true>
+// VERIFY = true: the launch of a sequence without a symbolic pass for its rows (RowWork::verify_numeric): every body checks
+// the row's nnz itself (num_hash_body / num_dense_body; the scaled copies of NUM_DIRECT hold what the analysis verifies).
+template <typename T, bool WITH_ESC = true, bool VERIFY = false>
 __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                         u32* __restrict__ c_col, T* __restrict__ c_val,
                                                         ClassGrid cg)
@@ -782,15 +824,15 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     // (every body starts with open_list: its first record is requested from the hinted list position while the
     //  device-side table and the capacity_miss flag are still on their way)
     if (b < cg.first[1])
-        num_dense_body<T, kNumD1Win, 256>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0], kNoHint);
+        num_dense_body<T, kNumD1Win, 256, VERIFY>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0], kNoHint);
     else if (b < cg.first[2])
-        num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256>(
+        num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256, 0, VERIFY>(
             smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1], kNoHint);
     else if (b < cg.first[3])
-        num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256>(
+        num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256, 0, VERIFY>(
             smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2], kNoHint);
     else if (b < cg.first[4])
-        num_hash_body<SubWave<32>, T, kNumW256Cap, kW256W1, kNumW256MaxNnz, SORT_BITMAP, 256>(
+        num_hash_body<SubWave<32>, T, kNumW256Cap, kW256W1, kNumW256MaxNnz, SORT_BITMAP, 256, 0, VERIFY>(
             smem, src, w, c_col, c_val, NUM_W256, b - cg.first[3], cg.first[4] - cg.first[3], kNoHint);
     else if (b < cg.first[5]) {
         if constexpr (WITH_ESC)
@@ -799,7 +841,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
         if constexpr (WITH_ESC)
             num_escw_body<T, 32, 256>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], kNoHint);
     } else if (b < cg.first[7])
-        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
+        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256, 0, VERIFY>(
             smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], kNoHint);
     else if (b < cg.first[8]) {
         if constexpr (WITH_ESC)
@@ -1338,6 +1380,7 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
         if ((mask >> slots[k] & 1u) && counts_hint[slots[k]]) tiny_only = false;
     // the small classes alone run in workgroups of g_tiny_threads threads (their groups never meet at a barrier
     // except in the scaled-copy class, whose chunk is the workgroup)
+    if (w.verify_numeric) tiny_only = false;  // (only the big kernel has verifying bodies)
     const int threads = tiny_only ? g_tiny_threads : 256;
     const u32 div = 256u / (u32)threads;
     auto class_lds = [&](int cls) -> u32 {
@@ -1366,7 +1409,11 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
     bool with_esc = false;  // (a class of the mask without rows has no blocks: its body is never entered)
     for (int k = 0; k < NS; ++k)
         if ((kNumEscMask >> slots[k] & 1u) && cg.first[k + 1] != cg.first[k]) with_esc = true;
-    if (!tiny_only && with_esc)
+    if (w.verify_numeric)  // (pipeline.hip plans such a sequence only when this launch has workgroup / wave classes and no
+                           //  register-class rows of its own)
+        SPECK_LAUNCH_TIMED((num_light_kernel<T, false, true>), dim3(cg.first[NS + 1]), dim3(256), lds, s, e0, e1, src,
+                           Av.row_offsets, w, c_col, c_val, cg);
+    else if (!tiny_only && with_esc)
         SPECK_LAUNCH_TIMED((num_light_kernel<T, true>), dim3(cg.first[NS + 1]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
     else if (!tiny_only)

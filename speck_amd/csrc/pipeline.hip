@@ -69,6 +69,8 @@ struct ReplayPlan {
     bool direct, fused, pred_scan, pred_sym;
     bool skip_scan;  // ... and so does every kernel that produces a row's nnz (RowWork::verify_counts): no scan kernel -- the
                      //   numeric launches read the records, offsets and class table the previous replay's scan left
+    bool num_verify;  // ... and no symbolic pass for the rows of the hash / dense classes: the numeric light launch verifies
+                      //   their nnz itself (RowWork::verify_numeric) -- the symbolic phase is the register-class rows alone
     bool overlap;  // the analysis only VERIFIES what the previous identical call left in the arena, on a stream of its
                    //   own beside the symbolic / scan / numeric launches (which read that: DESIGN.md 4.3)
     // ... and everything else of "the last eager call" the launches are sized from: a sequence that is enqueued anew at
@@ -185,6 +187,8 @@ struct speck_config {
     bool exec_dirty = false;         // other launches went onto the pipeline stream since graph_exec was last launched
     bool skip_scan = true;           // option skip_scan: a replayed sequence that follows a replay of itself has no scan kernel
     bool capture_skip_scan = false;  // set while such a sequence is being enqueued
+    int num_verify = 1;              // option num_verify (0: never, 1: when it pays, 2: whenever possible): ... and no symbolic pass for its hash / dense rows (ReplayPlan::num_verify)
+    bool capture_num_verify = false;
     bool arena_from_replay = false;  // the arena (numeric records, class table, statistics) was last written by a completed
                                      //   REPLAY of arena_key's problem: the layout a sequence without a scan reads
     bool overlap_analysis = true;    // option overlap_analysis: a replayed sequence runs its analysis as a verifier beside it
@@ -378,7 +382,7 @@ RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill,
     w.nf_col = static_cast<u32*>(c->nfpool);
     w.nf_val = c->nfpool ? static_cast<unsigned char*>(c->nfpool) + Carver::need(c->nf_cap_entries, 4) : nullptr;
     w.nf_cap = c->nfpool ? c->nf_cap_entries : 0;
-    w.nf_pred_off = c->capture_direct ? c->gpred.off : nullptr;
+    w.nf_pred_off = (c->capture_direct || c->capture_skip_scan) ? c->gpred.off : nullptr;
     w.nf_direct_col = c->capture_direct ? c->capture_c_col : nullptr;
     w.nf_direct_val = c->capture_direct ? c->capture_c_val : nullptr;
     w.w_sl = sc.w_sl;
@@ -387,6 +391,7 @@ RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill,
     w.off_dst = symbolic_phase ? nullptr : c->stage_off_dst;
     w.off_n = symbolic_phase ? 0u : c->stage_off_n;
     w.verify_counts = c->capture_skip_scan ? 1u : 0u;
+    w.verify_numeric = c->capture_num_verify ? 1u : 0u;
     return w;
 }
 
@@ -891,8 +896,28 @@ ReplayPlan plan_replay(const speck_config* c, bool arena_replay_ok = false)
     //  join of that phase would be followed by the fork of the numeric phase with no kernel in between, and a captured
     //  graph of that shape crashed the host inside the runtime every second run -- webbase stand-in, round 4; the same
     //  sequence enqueued launch by launch did not.  Those sequences keep their scan: it is 3 % of their multiply.)
-    p.skip_scan = c->skip_scan && arena_replay_ok && p.overlap && p.fused && p.direct && c->merge_light && !c->split_light &&
+    // (... or has no rows that are finished early at all: every row then goes through the numeric light launch)
+    const bool early_ok = (p.fused && p.direct) || (p.num_mask & (kEscNum | (1u << NUM_NFCOPY))) == 0;
+    p.skip_scan = c->skip_scan && arena_replay_ok && p.overlap && early_ok && c->merge_light && !c->split_light &&
                   (p.launch_mask & kBigLight) != 0 && (p.sym_mask & ~kSymLightMask) == 0;
+    // In such a sequence the symbolic pass of a hash / dense row has ONE reader left: the comparison of its count with the
+    // previous call's.  The numeric bodies of the light launch can make that comparison themselves -- they count what
+    // their table holds before they sort it -- if they stay inside a table that was sized by a nnz that may no longer
+    // hold (bounded probing) and inside the row's room in C (numeric.hip, VERIFY).  Then those rows are walked ONCE, as
+    // the register-class rows are: the symbolic phase of the sequence is the fused launch of the register classes alone
+    // (nothing at all for an input without such rows).  Only when every numeric launch is the light one: the workgroup
+    // classes with launches of their own (NUM_B8K, NUM_D2, NUM_G) have no verifying form.
+    // And only when it pays: the verifying bodies cost the numeric light launch 5-15 % (one more compare in its probing
+    // loop, the hottest loop of the library), while the symbolic pass of a FEW hash rows beside many register-class rows
+    // hides inside the fused launch (scircuit / mac_econ stand-ins: that launch got 1.5 us shorter, the numeric one 3 us
+    // longer).  So: when the hash / dense rows are what the symbolic launch spends its time on (isolated per-row costs,
+    // as for the stream forks) -- the nlpkkt stand-in, whose symbolic launch was a third of its multiply: 26.4 -> 19.4 ms.
+    // (option num_verify = 2: whenever possible)
+    float us_hash = 0.f, us_esc = 0.f;
+    for (int k = 0; k < kMaxClasses; ++k)
+        ((kSymEscMask >> k & 1u) ? us_esc : us_hash) += p.sym_counts[k] * kSymNsPerRow[k] * 1e-3f;
+    p.num_verify = c->num_verify && p.skip_scan && (p.launch_mask & ~kNumLightMask) == 0 &&
+                   (p.fused || !(p.launch_mask & kEscNum)) && (c->num_verify >= 2 || us_hash > us_esc);
     return p;
 }
 
@@ -909,6 +934,7 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
     c->capture_pred_sym = p.pred_sym;
     c->capture_overlap = p.overlap;
     c->capture_skip_scan = p.skip_scan;
+    c->capture_num_verify = p.num_verify;
     if (p.skip_scan) {  // C.row_offsets <- the sequence's own copy of the offsets (numeric light launch)
         c->stage_off_src = c->gpred.off;
         c->stage_off_dst = C->row_offsets;
@@ -923,13 +949,22 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
         {
             c->capture_direct = c->capture_fused = c->capture_pred_scan = c->capture_pred_sym = c->capture_overlap = false;
             if (c->capture_skip_scan) c->stage_off_src = nullptr, c->stage_off_dst = nullptr, c->stage_off_n = 0;
-            c->capture_skip_scan = false;
+            c->capture_skip_scan = c->capture_num_verify = false;
             c->nf_wcols = wcols;
         }
     } reset{c, c->nf_wcols};
     c->nf_wcols = p.nf_wcols;
-    int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, p.sym_mask,
-                           p.num_mask, true, tm, p.sym_counts, nullptr,
+    // (num_verify: the symbolic phase is the register classes alone -- the plan keeps every class, for the form of the
+    //  sequence that runs when the arena is not this problem's)
+    u32 sym_mask = p.sym_mask, sym_counts[kMaxClasses];
+    std::memcpy(sym_counts, p.sym_counts, sizeof(sym_counts));
+    if (p.num_verify) {
+        sym_mask &= kSymEscMask;
+        for (int k = 0; k < kMaxClasses; ++k)
+            if (!(kSymEscMask >> k & 1u)) sym_counts[k] = 0;
+    }
+    int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, sym_mask,
+                           p.num_mask, true, tm, sym_counts, nullptr,
                            p.g_products, p.num_counts[NUM_G], 3u, p.nf_cap_entries);
     if (rc != SPECK_OK) return rc;
     if (tm) {
@@ -1148,7 +1183,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 plan = plan_replay(c);
             }
             // (a verifying analysis needs the metadata of THIS problem in the arena)
-            if (!arena_mine) plan.overlap = plan.skip_scan = false;
+            if (!arena_mine) plan.overlap = plan.skip_scan = plan.num_verify = false;
             c->arena_key_valid = false;
             Timing tm;
             size_t ev_num_end = 0;
@@ -1185,7 +1220,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->last.replayed = 0;  // (not served by the graph: graph_replays does not count it)
                 c->last.nf_direct = plan.direct ? 1 : 0;
                 c->last.esc_fused = plan.fused ? 1 : 0;
-                c->last.pred_stages = (plan.pred_scan ? 1 : 0) | (plan.pred_sym ? 2 : 0) | (plan.overlap ? 4 : 0) | (plan.skip_scan ? 8 : 0);
+                c->last.pred_stages = (plan.pred_scan ? 1 : 0) | (plan.pred_sym ? 2 : 0) | (plan.overlap ? 4 : 0) | (plan.skip_scan ? 8 : 0) |
+                                      (plan.num_verify ? 16 : 0);
                 return finish_complete();
             }
         }
@@ -1226,10 +1262,11 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             // the arena as the next replay needs it.
             const bool arena_ok = c->arena_key_valid && c->arena_key == key;
             bool overlapped = c->graph_overlap, skipped = c->graph_plan.skip_scan;
+            const bool self_verified = c->graph_plan.num_verify;
             c->arena_key_valid = false;  // (until this call has completed)
             if ((c->graph_overlap && !arena_ok) || (c->graph_plan.skip_scan && !replay_layout)) {
                 ReplayPlan p2 = c->graph_plan;
-                p2.overlap = p2.skip_scan = false;
+                p2.overlap = p2.skip_scan = p2.num_verify = false;
                 overlapped = skipped = false;
                 c->exec_dirty = true;
                 rc = enqueue_replay<T>(c, s, A, B, C, sc, p2, nullptr, nullptr);
@@ -1262,7 +1299,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->last.replayed = 1;
                 c->last.nf_direct = c->graph_direct ? 1 : 0;
                 c->last.esc_fused = c->graph_fused ? 1 : 0;
-                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0) | (c->graph_pred_sym ? 2 : 0) | (overlapped ? 4 : 0) | (skipped ? 8 : 0);
+                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0) | (c->graph_pred_sym ? 2 : 0) | (overlapped ? 4 : 0) | (skipped ? 8 : 0) |
+                                      ((skipped && self_verified) ? 16 : 0);
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -1798,6 +1836,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->last_key_valid = false;
     }
     else if (n == "eager_speculate") c->eager_speculate = value != 0;
+    else if (n == "num_verify") {
+        c->num_verify = (int)value;
+        drop_graph(c);
+    }
     else if (n == "skip_scan") {
         c->skip_scan = value != 0;
         drop_graph(c);

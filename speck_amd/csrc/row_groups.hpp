@@ -572,12 +572,22 @@ __device__ __forceinline__ u32 set_insert_batch(u32* tab, const u32 (&key)[kBatc
 
 // The table of a row uses the first 2^bits slots of the class' arrays (bits chosen per row from
 // its exact nnz: every later pass over the slots costs LDS and VALU issue per SLOT, not per key).
-template <typename T>
-__device__ __forceinline__ void table_accumulate_batch(u32* keys, T* vals, u32 bits, const u32 (&key)[kBatch],
+// BOUNDED (numeric launches of a sequence that verifies the row lengths itself, RowWork::verify_numeric): the table is
+// sized from the nnz the PREVIOUS identical call found -- if the row has more distinct columns now, a key may find
+// neither itself nor a free slot.  From its second probe on a key walks home, home + step, home + 2 step, ... (odd step,
+// power-of-two table): every slot once, then `home` again -- a key that comes back there has seen the whole table and gives
+// up (its product is dropped; the caller rejects the replay).  The retry loop is the hottest loop of these kernels (every
+// batch of a wave enters it, for the longest chain among its lanes): the bound costs it one compare.  (Measured and
+// dropped: a trip counter with a break, per lane or per wave on the ballot of pending lanes -- the loop doubled in
+// instructions and the launch took 20-30 % longer.)
+// Returns true if any key of this lane gave up.
+template <typename T, bool BOUNDED = false>
+__device__ __forceinline__ bool table_accumulate_batch(u32* keys, T* vals, u32 bits, const u32 (&key)[kBatch],
                                                        const T (&prod)[kBatch], u32 nvalid)
 {
     const u32 mask = (1u << bits) - 1u;
     u32 slot[kBatch], old[kBatch];
+    bool gave_up = false;
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
         slot[u] = (key[u] * 0x9E3779B1u) >> (32u - bits);
@@ -589,15 +599,29 @@ __device__ __forceinline__ void table_accumulate_batch(u32* keys, T* vals, u32 b
         if ((u32)u >= nvalid) continue;
         if (old[u] != kEmptyKey && old[u] != key[u]) {
             const u32 step = probe_step(key[u], 32u - bits);
-            u32 inc = kFirstProbeInc ? kFirstProbeInc : step;
-            do {
-                slot[u] = (slot[u] + inc) & mask;
-                inc = step;
+            if constexpr (BOUNDED) {
+                slot[u] = (slot[u] + (kFirstProbeInc ? kFirstProbeInc : step)) & mask;
                 old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
-            } while (old[u] != kEmptyKey && old[u] != key[u]);
+                if (old[u] != kEmptyKey && old[u] != key[u]) {
+                    const u32 home = slot[u];
+                    do {
+                        slot[u] = (slot[u] + step) & mask;
+                        old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
+                    } while (old[u] != kEmptyKey && old[u] != key[u] && slot[u] != home);
+                }
+            } else {
+                u32 inc = kFirstProbeInc ? kFirstProbeInc : step;
+                do {
+                    slot[u] = (slot[u] + inc) & mask;
+                    inc = step;
+                    old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
+                } while (old[u] != kEmptyKey && old[u] != key[u]);
+            }
         }
-        atomicAdd(&vals[slot[u]], prod[u]);
+        if (!BOUNDED || old[u] == kEmptyKey || old[u] == key[u]) atomicAdd(&vals[slot[u]], prod[u]);
+        else gave_up = true;
     }
+    return gave_up;
 }
 
 // Bitmap marks of a batch of products: neighbouring lanes hold neighbouring columns of one B row, i.e. mostly

@@ -30,6 +30,15 @@ def cfg():
     c.cleanup()
 
 
+@pytest.fixture
+def verify_always(cfg):
+    """option num_verify = 2: a sequence without a scan drops the symbolic pass of its hash / dense rows whenever it can
+    (default 1: only when those rows are what the symbolic launch spends its time on)."""
+    cfg.set_option("num_verify", 2)
+    yield
+    cfg.set_option("num_verify", 1)
+
+
 def to_sa(h):
     return sa.HostCSR(h.rows, h.cols, h.row_offsets, h.col_ids, h.data)
 
@@ -827,7 +836,7 @@ def test_replay_detects_changed_inputs_under_the_same_pointers(cfg):
     _assert_matches_oracle(dC, A2, A2)
 
 
-def test_sequence_without_a_scan_verifies_every_row_length(cfg):
+def test_sequence_without_a_scan_verifies_every_row_length(cfg, verify_always):
     """From its second replay on a sequence has no scan kernel (speck_stats::pred_stages bit 3): the analysis beside it
     verifies the structure-derived quantities, and every kernel that produces a row's nnz compares it with the room the
     previous identical call gave the row.  B's column ids change IN PLACE so that (a) a register-class row, (b) a
@@ -856,7 +865,8 @@ def test_sequence_without_a_scan_verifies_every_row_length(cfg):
     for _ in range(5):
         sa.MultiplyspECK(dA, dB, dC, cfg)
     st = cfg.last_stats()
-    assert st["replayed"] and st["pred_stages"] == 15 and st["esc_fused"], st["pred_stages"]
+    # (bit 4: and no symbolic pass for the hash-class rows either -- their numeric bodies compare the nnz themselves)
+    assert st["replayed"] and st["pred_stages"] == 31 and st["esc_fused"], st["pred_stages"]
     assert st["num_bin_rows"]["wave512"] + st["num_bin_rows"]["block2k"] > 0 and st["num_bin_rows"]["nfcopy"] >= 2500
     _assert_matches_oracle(dC, A, B)
     # C.row_offsets scribbled over: the next replay rewrites it
@@ -893,7 +903,7 @@ def test_sequence_without_a_scan_verifies_every_row_length(cfg):
         assert changed and cfg.last_stats()["numeric_reruns"] == misses + 1   # a row length differs: the sequence objected
         for _ in range(4):
             sa.MultiplyspECK(dA, dB, dC, cfg)
-        assert cfg.last_stats()["pred_stages"] == 15
+        assert cfg.last_stats()["pred_stages"] == 31
         _assert_matches_oracle(dC, A, B2)
         assert L.speck_dcsr_update(C_.byref(dB._c), None, np.ascontiguousarray(B.col_ids).ctypes.data, None, 8) == 0
         for _ in range(5):
@@ -904,13 +914,133 @@ def test_sequence_without_a_scan_verifies_every_row_length(cfg):
     A3 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data * -2.0)
     assert L.speck_dcsr_update(C_.byref(dA._c), None, None, np.ascontiguousarray(A3.data).ctypes.data, 8) == 0
     sa.MultiplyspECK(dA, dB, dC, cfg)
-    assert cfg.last_stats()["numeric_reruns"] == misses and cfg.last_stats()["pred_stages"] == 15
+    assert cfg.last_stats()["numeric_reruns"] == misses and cfg.last_stats()["pred_stages"] == 31
     _assert_matches_oracle(dC, A3, B)
+    cfg.set_option("num_verify", 0)      # the symbolic pass of the hash-class rows back in the sequence
+    for _ in range(4):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["pred_stages"] == 15
+    _assert_matches_oracle(dC, A3, B)
+    cfg.set_option("num_verify", 2)
     with options(cfg, skip_scan=0):
         for _ in range(4):
             sa.MultiplyspECK(dA, dB, dC, cfg)
         assert cfg.last_stats()["pred_stages"] == 7
         _assert_matches_oracle(dC, A3, B)
+
+
+def _collapsing_problem(rng, n_small, big_lens, same_cols, span, kb=4000, n=60000):
+    """B rows of 6 entries: first and last column the same for a whole group of 200 / 400 B rows, the four in between drawn from
+    a pool of `same_cols` columns of the group.  A big row of A references B rows of ONE group: its row of C has
+    2 + (at most) same_cols entries, far fewer than products.  `B2` = the same B with the middle columns of every row drawn
+    from the whole span instead (same row lengths, same first / last column: nothing the analysis looks at changes) -- every
+    such row of C grows several-fold."""
+    group = 400 if max(big_lens) > 190 else 200
+    first = np.repeat(rng.integers(0, 500, size=kb // group), group)
+    last = first + span + 10
+    mid = np.zeros((kb, 4), dtype=np.int64)
+    mid2 = np.zeros((kb, 4), dtype=np.int64)
+    for g0 in range(0, kb, group):
+        pool = np.sort(rng.choice(np.arange(first[g0] + 1, first[g0] + span), size=same_cols, replace=False))
+        for i in range(g0, g0 + group):
+            mid[i] = np.sort(rng.choice(pool, size=4, replace=False))
+            mid2[i] = np.sort(first[g0] + 1 + rng.choice(span - 1, size=4, replace=False))
+
+    def mk(m):
+        bc = np.concatenate([first[:, None], m, last[:, None]], axis=1)
+        assert (np.diff(bc, axis=1) > 0).all()
+        return po.HostCSR(kb, n, np.arange(kb + 1, dtype=np.uint32) * 6, bc.reshape(-1).astype(np.uint32), 0.5 + rng.random(kb * 6))
+    B = mk(mid)
+    # (+ 20 rows of 60 entries from anywhere: ~250 distinct columns each, whatever B's middle columns are -- the sequence
+    #  keeps a wave-class row, which a sequence without a scan needs: its launch rewrites C.row_offsets)
+    n_wide = 20
+    lens = np.concatenate([rng.integers(2, 6, size=n_small), np.full(n_wide, 60), np.asarray(big_lens)])
+    ro = np.zeros(lens.size + 1, dtype=np.uint32)
+    ro[1:] = np.cumsum(lens)
+    cols = []
+    for i, k in enumerate(lens):
+        if i < n_small + n_wide:
+            cols.append(np.sort(rng.choice(kb, size=k, replace=False)))
+        else:
+            g0 = int(rng.integers(0, kb // group)) * group
+            cols.append(g0 + np.sort(rng.choice(group, size=k, replace=False)))
+    A = po.HostCSR(lens.size, kb, ro, np.concatenate(cols).astype(np.uint32), 0.5 + rng.random(int(ro[-1])))
+    B2 = po.HostCSR(kb, n, B.row_offsets, mk(mid2).col_ids, B.data)
+    return A, B, B2
+
+
+@pytest.mark.parametrize("big_lens,same_cols,span", [
+    ([70] * 60, 20, 30000),                  # 420 products, 22 entries: 64-slot tables of the rank-sort class -> 280 distinct
+    ([110] * 30 + [190] * 30, 150, 30000),   # 152 entries of 660 / 1140 products: 256-slot tables -> 440 / 760 distinct
+    ([190] * 40, 300, 30000),                # 302 entries: 512-slot tables -> 760 distinct
+    ([300] * 40, 400, 30000),                # 402 entries: 512 slots of a workgroup table -> 1 200 distinct
+    ([150] * 40, 1000, 3000),                # a narrow column range, well filled: the dense-window class (numeric-first rows
+                                             #   off): no table to outgrow -- 450 entries become 550, beyond the row's room
+])
+def test_numeric_bodies_survive_a_table_sized_by_a_stale_nnz(cfg, verify_always, big_lens, same_cols, span):
+    """A sequence without a symbolic pass (pred_stages bit 4) sizes the hash table of a row from the nnz the PREVIOUS
+    identical call found.  B's column ids change in place so that such rows have several times as many distinct columns as
+    their table has slots: the numeric bodies must stay inside the table (bounded probing) and inside the row's room in C,
+    say so (capacity_miss), and the call must come back with the new product; then the other way round (tables far too
+    large, rows shrink)."""
+    import ctypes as C_
+    L = _lib.load()
+    rng = np.random.default_rng(123 + same_cols)
+    A, B, B2 = _collapsing_problem(rng, 2000, big_lens, same_cols, span)
+    R, _ = po.spgemm(A, B)
+    R2, _ = po.spgemm(A, B2)
+    big = slice(2020, None)
+    grow = np.diff(R2.row_offsets.astype(np.int64))[big] / np.diff(R.row_offsets.astype(np.int64))[big]
+    assert grow.min() > (2.0 if span >= 4096 else 1.1), grow.min()
+    dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR()
+    if span < 4096:   # (such rows would be numeric-first rows: finished in the symbolic phase, which then stays)
+        cfg.set_option("nf_min_ops", 0)
+    try:
+        _stale_nnz_rounds(cfg, L, C_, A, B, B2, dA, dB, dC, span < 4096)
+    finally:
+        cfg.set_option("nf_min_ops", 512)
+
+
+def _stale_nnz_rounds(cfg, L, C_, A, B, B2, dA, dB, dC, dense):
+    for _ in range(5):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    st = cfg.last_stats()
+    assert st["replayed"] and st["pred_stages"] == 31, st["pred_stages"]
+    assert not dense or st["num_bin_rows"]["dense4k"] >= 40, st["num_bin_rows"]
+    _assert_matches_oracle(dC, A, B)
+    for Bnow in (B2, B, B2):
+        misses = cfg.last_stats()["numeric_reruns"]
+        assert L.speck_dcsr_update(C_.byref(dB._c), None, np.ascontiguousarray(Bnow.col_ids).ctypes.data, None, 8) == 0
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["numeric_reruns"] == misses + 1
+        _assert_matches_oracle(dC, A, Bnow)
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["pred_stages"] == 31
+        _assert_matches_oracle(dC, A, Bnow)
+
+
+def test_sequence_of_an_input_without_register_class_rows_is_one_numeric_launch(cfg):
+    """nlpkkt-like rows (hundreds of products each, no register-class row, no numeric-first row): from its second replay on
+    the sequence has no scan and no symbolic launch at all -- the numeric light launch verifies every row length."""
+    A = to_po(sa.gen_matrix("nlpkkt", 0.004, 3, signed=True))
+    dA, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR()
+    for _ in range(5):
+        sa.MultiplyspECK(dA, dA, dC, cfg)
+    st = cfg.last_stats()
+    esc = sum(st["num_bin_rows"][k] for k in ("g4", "g8", "g16", "r32", "r64") if k in st["num_bin_rows"])
+    if esc == 0 and st["num_bin_rows"]["nfcopy"] == 0:
+        assert st["replayed"] and st["pred_stages"] == 31 and not st["esc_fused"], st["pred_stages"]
+    else:
+        assert st["replayed"] and (st["pred_stages"] & 7) == 7
+    _assert_matches_oracle(dC, A, A)
+    # new values in place: the sequence stays and the product follows
+    A2 = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data * -0.5)
+    assert _lib.load().speck_dcsr_update(ctypes.byref(dA._c), None, None, np.ascontiguousarray(A2.data).ctypes.data, 8) == 0
+    misses = st["numeric_reruns"]
+    sa.MultiplyspECK(dA, dA, dC, cfg)
+    assert cfg.last_stats()["numeric_reruns"] == misses
+    _assert_matches_oracle(dC, A2, A2)
 
 
 def test_call_on_a_callers_stream_sees_what_that_stream_produced(cfg):
