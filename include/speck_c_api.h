@@ -85,7 +85,10 @@ typedef struct speck_stats {
                                                   *    decisions instead of folding them again: bit 0 the row-offset scan +
                                                   *    numeric binning (one kernel), bit 1 the symbolic binning (inside the
                                                   *    analysis kernel), bit 2 the analysis itself (a verifier on its own
-                                                  *    stream beside the sequence) -- DESIGN.md 4.3 */
+                                                  *    stream beside the sequence), bit 3 no scan kernel at all (every row's
+                                                  *    nnz compared where it is produced), bit 4 no symbolic pass for the hash
+                                                  *    / dense rows either (their numeric bodies verify the nnz themselves:
+                                                  *    option num_verify) -- DESIGN.md 4.3 */
     int32_t eager_speculated;                    /* an EAGER call that ran analysis .. scan as one batch sized from the previous
                                                   * eager call on the config (one read-back instead of two; option
                                                   * eager_speculate): 1 = its device-side checks held, -1 = they did not and

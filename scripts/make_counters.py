@@ -18,7 +18,10 @@ KEYS = [
     (r"nf_dense_kernel<\w+, \d+, false>", "num_numeric_first_eager"), (r"nf_dense_kernel", "num_numeric_first"), (r"nf_copy_kernel", "num_nfcopy"),
     # (round 4: the light launch of a fused replay carries its own name -- no register-class bodies -- and so does the
     #  analysis of a sequence that only verifies; bench.py's "light" is the replay's launch)
-    (r"num_light_kernel<\w+, true>", "num_light_eager"), (r"num_light_kernel", "num_light"), (r"num_tiny_kernel", "num_tiny"),
+    #  ... and a third one when its bodies verify the row lengths themselves: <T, false, true>; that sequence's FIRST replay
+    #  still runs <T, false, false>, listed apart then -- see main)
+    (r"num_light_kernel<\w+, true", "num_light_eager"), (r"num_light_kernel<\w+, false, true>", "num_light"),
+    (r"num_light_kernel", "num_light_plain"), (r"num_tiny_kernel", "num_tiny"),
     (r"analysis_kernel<\d+, \d+u, true>", "analysis_verify"),
     (r"sym_light_fused_kernel", "sym_light_fused"), (r"sym_light_kernel", "sym_light"),
     (r"num_hash_kernel<Block<512>", "num_block8k"), (r"num_hash_kernel<Block<256>", "num_block2k"),
@@ -54,9 +57,12 @@ def main():
     src = os.path.basename(out_csv).split("_")[0]
     traffic["_source"] = f"profiles/{src}_pmc_*_counters.csv"
     counters["_source"] = f"profiles/{src}_pmc_*_counters.csv"
+    verifying = any(re.search(r"num_light_kernel<\w+, false, true>", k) for k in table)
     for k in table:
         for pat, key in KEYS:
             if re.search(pat, k):
+                if key == "num_light_plain":
+                    key = "num_light_first_replay" if verifying else "num_light"
                 if "FETCH_SIZE" in table[k] or "WRITE_SIZE" in table[k]:
                     traffic[f"{workload}:{key}"] = int((2 * table[k].get("FETCH_SIZE", 0.0) + table[k].get("WRITE_SIZE", 0.0)) * 1024)
                 counters[f"{workload}:{key}"] = {c: round(v) for c, v in table[k].items()}

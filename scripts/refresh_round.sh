@@ -6,13 +6,13 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export PYTHONPATH=$PWD
 OUT=gpurun_out/profiles
 mkdir -p $OUT
-bash scripts/collect_counters.sh $ROUND "scircuit mac_econ cant webbase" > $OUT/collect.log 2>&1
+bash scripts/collect_counters.sh $ROUND "scircuit mac_econ cant webbase nlpkkt" > $OUT/collect.log 2>&1
 cp $OUT/counters.json $OUT/traffic.json profiles/   # the bench lines read the ceilings of THIS round's passes
-for w in scircuit mac_econ cant webbase uniform; do
+for w in scircuit mac_econ cant webbase uniform nlpkkt; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline --no-config5 --no-configs 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_$w.json
 done
 # the launch durations of the plain lines against the traces of the same commands under rocprofv3 (<= 5 %)
-for w in scircuit mac_econ cant webbase; do
+for w in scircuit mac_econ cant webbase nlpkkt; do
   python scripts/check_launch_ms.py $OUT/${ROUND}_bench_$w.json $OUT/${ROUND}_bench_${w}_kernel_stats.csv > $OUT/${ROUND}_launch_ms_check_$w.txt 2>&1 \
       || echo "$w: launch ms differ from the trace by more than 5 %" >> $OUT/${ROUND}_launch_ms_check_$w.txt
 done

@@ -763,25 +763,25 @@ __global__ __launch_bounds__(THREADS) void num_direct_kernel(ProductSrc<T> src, 
     num_direct_body<T, THREADS>(smem, src, w, c_col, c_val, blockIdx.x, gridDim.x);
 }
 
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0>
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0, bool VERIFY = false>
 __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                            u32* __restrict__ c_col,
                                                            T* __restrict__ c_val, int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
-    num_hash_body<G, T, CAP, W1, NMAX, MODE, THREADS, NLO>(smem, src, w, c_col, c_val, cls, blockIdx.x,
-                                                           gridDim.x);
+    num_hash_body<G, T, CAP, W1, NMAX, MODE, THREADS, NLO, VERIFY>(smem, src, w, c_col, c_val, cls, blockIdx.x,
+                                                                   gridDim.x);
 }
 
-template <typename T, u32 WCOLS, int THREADS>
+template <typename T, u32 WCOLS, int THREADS, bool VERIFY = false>
 __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                             u32* __restrict__ c_col,
                                                             T* __restrict__ c_val, int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
-    num_dense_body<T, WCOLS, THREADS>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
+    num_dense_body<T, WCOLS, THREADS, VERIFY>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
 }
 
 template <typename T, u32 L>
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_count_kernel(ProductS
                                 [&](const u32(&c)[kBatch], const T(&)[kBatch], u32 n) {
 #pragma unroll
                                     for (int u = 0; u < kBatch; ++u)
-                                        if ((u32)u < n) atomicAdd(&hist[(c[u] - rec.cmin) >> pl.shift], 1u);
+                                        if ((u32)u < n) atomicAdd(&hist[min((c[u] - rec.cmin) >> pl.shift, pl.nf - 1u)], 1u);
                                 }, cls);
         for (u32 f = threadIdx.x; f < pl.nf; f += kGWalkThreads)
             if (hist[f]) atomicAdd(&w.spill.fcount[pl.fbase + f], hist[f]);
@@ -1135,7 +1135,8 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(Produc
                                     [&](const u32(&c)[kBatch], const T(&)[kBatch], u32 n) {
 #pragma unroll
                                         for (int u = 0; u < kBatch; ++u)
-                                            if ((u32)u < n) atomicAdd(&hist[cell2b[(c[u] - rec.cmin) >> pl.shift]], 1u);
+                                            if ((u32)u < n)
+                                                atomicAdd(&hist[cell2b[min((c[u] - rec.cmin) >> pl.shift, pl.nf - 1u)]], 1u);
                                     }, cls);
             // (b) one reservation per touched bucket; hist becomes the chunk-local fill count
             for (u32 b = threadIdx.x; b < pl.nb; b += kGWalkThreads) {
@@ -1153,7 +1154,7 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(Produc
 #pragma unroll
                                        for (int u = 0; u < kBatch; ++u)
                                            if ((u32)u < n) {
-                                               const u32 b = cell2b[(c[u] - rec.cmin) >> pl.shift];
+                                               const u32 b = cell2b[min((c[u] - rec.cmin) >> pl.shift, pl.nf - 1u)];
                                                const u64 pos = pl.pbase + lbase[b] + atomicAdd(&hist[b], 1u);
                                                pcol[pos] = c[u];
                                                pval[pos] = p[u];
@@ -1236,7 +1237,9 @@ __global__ __launch_bounds__(THREADS) void num_spill_reduce_kernel(RowWork w, in
                             ++nv;
                         }
                     }
-                    table_accumulate_batch(keys, vals, bits, c, p, nv);
+                    // (bounded: a bucket's table is sized by its products and its column span -- a column outside the range
+                    //  the row's record holds, clamped into the last cell above, is not covered by that span)
+                    (void)table_accumulate_batch<Acc<T>, true>(keys, vals, bits, c, p, nv);
                 }
                 __syncthreads();
                 distinct = emit_bitmap_sorted<G, T, CAP, W1, N_HI>(g, keys, vals, S, scratch, cap_row, c_lo, c_hi,
@@ -1305,10 +1308,19 @@ __global__ __launch_bounds__(256) void num_spill_copy_kernel(RowWork w, u32* __r
             before = g.reduce_add(before, s_red);
             const u64 s0 = w.spill.bstart[pl.bbase + b];
             const size_t dst = size_t(rec.base) + before;
-            for (u32 i = threadIdx.x; i < n; i += 256) {
+            // (a sequence without a symbolic pass: the row's room is what the previous identical call found -- nothing
+            //  beyond it; the workgroup of the row's last bucket with entries compares the total below)
+            const u32 fits = w.verify_numeric ? min(n, rec.nnz - min(rec.nnz, before)) : n;
+            for (u32 i = threadIdx.x; i < fits; i += 256) {
                 c_col[dst + i] = ocol[s0 + i];
                 c_val[dst + i] = oval[s0 + i];
             }
+        }
+        if (w.verify_numeric && blockIdx.y == 0) {  // (uniform) the entries the buckets of the row hold NOW against its room
+            u32 total = 0;
+            for (u32 j = threadIdx.x; j < pl.nb; j += 256) total += w.spill.dcount[pl.bbase + j];
+            total = g.reduce_add(total, s_red);
+            if (threadIdx.x == 0 && total != rec.nnz) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
         }
     }
 }
@@ -1351,11 +1363,11 @@ static void set_dyn_lds(K kernel, u32 bytes)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0>
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0, bool VERIFY = false>
 static void launch_num_hash(hipStream_t s, int cls, u32 count, const ProductSrc<T>& A, const u32* B,
                             const RowWork& w, u32* c_col, T* c_val, int cu_count)
 {
-    auto k = num_hash_kernel<G, T, CAP, W1, NMAX, MODE, THREADS, NLO>;
+    auto k = num_hash_kernel<G, T, CAP, W1, NMAX, MODE, THREADS, NLO, VERIFY>;
     const u32 lds = (THREADS / G::SIZE) * num_group_lds<G, T, CAP, THREADS>();
     set_dyn_lds(k, lds);
     hipLaunchKernelGGL(k, dim3(grid_for(count, lds, THREADS, cu_count, THREADS / G::SIZE)),
@@ -1509,6 +1521,18 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             // two launches over the class: the rows of the lower half fit a half-size table, whose
             // workgroups run two per CU (the full table owns 106 of a CU's 160 KiB)
             // (a handful of rows cannot fill the CUs anyway: one launch, one row's latency less)
+            if (w.verify_numeric) {  // (a sequence without a symbolic pass: the verifying forms of the same launches)
+                if (count * 2 < (u32)cu_count) {
+                    launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, 0, true>(
+                        s, cls, count, A, B, w, c_col, c_val, cu_count);
+                    break;
+                }
+                launch_num_hash<Block<512>, T, kNumB8KCap / 2, kB8KW1, kNumB8KHalfMaxNnz, SORT_BITMAP, 512, 0, true>(
+                    s, cls, count, A, B, w, c_col, c_val, cu_count);
+                launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KHalfMaxNnz, true>(
+                    s, cls, count, A, B, w, c_col, c_val, cu_count);
+                break;
+            }
             if (count * 2 < (u32)cu_count) {
                 launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512>(
                     s, cls, count, A, B, w, c_col, c_val, cu_count);
@@ -1527,6 +1551,13 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             break;
         }
         case NUM_D2: {
+            if (w.verify_numeric) {
+                auto kv = num_dense_kernel<T, kNumD2Cols, 1024, true>;
+                set_dyn_lds(kv, lds);
+                hipLaunchKernelGGL(kv, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,
+                                   w, c_col, c_val, cls);
+                break;
+            }
             auto k = num_dense_kernel<T, kNumD2Cols, 1024>;
             set_dyn_lds(k, lds);
             hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,

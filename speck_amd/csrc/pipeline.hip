@@ -892,32 +892,34 @@ ReplayPlan plan_replay(const speck_config* c, bool arena_replay_ok = false)
     // all verified where they are produced.  C.row_offsets is still rewritten in every call (from the sequence's copy of
     // the offsets, by extra workgroups of the numeric light launch: needs that launch).
     constexpr u32 kBigLight = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256);
-    // (Only for sequences whose symbolic phase is the ONE light launch: with heavy symbolic classes on side streams the
-    //  join of that phase would be followed by the fork of the numeric phase with no kernel in between, and a captured
-    //  graph of that shape crashed the host inside the runtime every second run -- webbase stand-in, round 4; the same
-    //  sequence enqueued launch by launch did not.  Those sequences keep their scan: it is 3 % of their multiply.)
     // (... or has no rows that are finished early at all: every row then goes through the numeric light launch)
     const bool early_ok = (p.fused && p.direct) || (p.num_mask & (kEscNum | (1u << NUM_NFCOPY))) == 0;
-    p.skip_scan = c->skip_scan && arena_replay_ok && p.overlap && early_ok && c->merge_light && !c->split_light &&
-                  (p.launch_mask & kBigLight) != 0 && (p.sym_mask & ~kSymLightMask) == 0;
     // In such a sequence the symbolic pass of a hash / dense row has ONE reader left: the comparison of its count with the
-    // previous call's.  The numeric bodies of the light launch can make that comparison themselves -- they count what
-    // their table holds before they sort it -- if they stay inside a table that was sized by a nnz that may no longer
-    // hold (bounded probing) and inside the row's room in C (numeric.hip, VERIFY).  Then those rows are walked ONCE, as
-    // the register-class rows are: the symbolic phase of the sequence is the fused launch of the register classes alone
-    // (nothing at all for an input without such rows).  Only when every numeric launch is the light one: the workgroup
-    // classes with launches of their own (NUM_B8K, NUM_D2, NUM_G) have no verifying form.
-    // And only when it pays: the verifying bodies cost the numeric light launch 5-15 % (one more compare in its probing
-    // loop, the hottest loop of the library), while the symbolic pass of a FEW hash rows beside many register-class rows
-    // hides inside the fused launch (scircuit / mac_econ stand-ins: that launch got 1.5 us shorter, the numeric one 3 us
-    // longer).  So: when the hash / dense rows are what the symbolic launch spends its time on (isolated per-row costs,
-    // as for the stream forks) -- the nlpkkt stand-in, whose symbolic launch was a third of its multiply: 26.4 -> 19.4 ms.
+    // previous call's.  The numeric bodies can make that comparison themselves -- they count what their table holds before
+    // they sort it -- if they stay inside a table that was sized by a nnz that may no longer hold (bounded probing) and
+    // inside the row's room in C (numeric.hip, VERIFY; the spill chain of NUM_G sizes everything from what it counts in
+    // the same call and compares in its copy kernel).  Then those rows are walked ONCE, as the register-class rows are: the
+    // symbolic phase of the sequence is the fused launch of the register classes alone (nothing at all for an input
+    // without such rows) -- and the heavy symbolic classes that kept a sequence from dropping its scan (below) are gone.
+    // Only when it PAYS: the verifying bodies cost the numeric light launch 5-15 % (one more compare in its probing loop,
+    // the hottest loop of the library), while the symbolic pass of a FEW hash rows beside many register-class rows hides
+    // inside the fused launch (scircuit / mac_econ stand-ins: that launch got 1.5 us shorter, the numeric one 3 us
+    // longer).  So: when the hash / dense rows are what the symbolic phase spends its time on (isolated per-row costs, as
+    // for the stream forks) -- the nlpkkt stand-in, whose symbolic launch was a third of its multiply: 26.4 -> 19.4 ms.
     // (option num_verify = 2: whenever possible)
     float us_hash = 0.f, us_esc = 0.f;
     for (int k = 0; k < kMaxClasses; ++k)
         ((kSymEscMask >> k & 1u) ? us_esc : us_hash) += p.sym_counts[k] * kSymNsPerRow[k] * 1e-3f;
-    p.num_verify = c->num_verify && p.skip_scan && (p.launch_mask & ~kNumLightMask) == 0 &&
-                   (p.fused || !(p.launch_mask & kEscNum)) && (c->num_verify >= 2 || us_hash > us_esc);
+    const bool want_verify = c->num_verify && (p.fused || !(p.launch_mask & kEscNum)) && !(p.sym_mask >> SYM_NF & 1u) &&
+                             (c->num_verify >= 2 || us_hash > us_esc);
+    const u32 eff_sym = want_verify ? (p.sym_mask & kSymEscMask) : p.sym_mask;
+    // (Only for sequences whose symbolic phase is the ONE light launch: with heavy symbolic classes on side streams the
+    //  join of that phase would be followed by the fork of the numeric phase with no kernel in between, and a captured
+    //  graph of that shape crashed the host inside the runtime every second run -- webbase stand-in, round 4; the same
+    //  sequence enqueued launch by launch did not.  Those sequences keep their scan: it is 3 % of their multiply.)
+    p.skip_scan = c->skip_scan && arena_replay_ok && p.overlap && early_ok && c->merge_light && !c->split_light &&
+                  (p.launch_mask & kBigLight) != 0 && (eff_sym & ~kSymLightMask) == 0;
+    p.num_verify = want_verify && p.skip_scan;
     return p;
 }
 
@@ -1195,6 +1197,13 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             //  synchronisation the first launch of the sequence measured ~5 % longer than its average in a kernel trace)
             rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, nullptr, nullptr);
             if (rc != SPECK_OK) return rc;
+            // (... and the verifier not before the TIMED sequence starts: with launches of milliseconds -- nlpkkt stand-in --
+            //  the host has both sequences enqueued long before the first has run, and the verifier would spend itself
+            //  beside the untimed one: the timed light launch measured 16.9 ms against 18.7 in a trace of the graph)
+            if (plan.overlap) {
+                HIP_TRY(hipEventRecord(c->fork, s));
+                HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
+            }
             rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, &tm, &ev_num_end);
             if (rc != SPECK_OK) return rc;
             // (BEHIND the sequence, as the graph path does: launched in front of it the verifier ran beside the first launch
