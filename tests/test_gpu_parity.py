@@ -1642,6 +1642,21 @@ def test_randomised_structure_changes_under_the_same_pointers():
     assert "failures: 0" in r.stdout and "replayed=1" in r.stdout
 
 
+def test_randomised_changes_meet_sequences_without_a_symbolic_pass():
+    """The same tool, every chosen problem multiplied four times in a row (STRESS_REPEAT): the later calls of such a run are
+    replays without a scan and -- option num_verify = 2 -- without a symbolic pass for the hash / dense rows, and the next
+    in-place change of values or structure meets THAT sequence.  Its numeric bodies must notice what the analysis beside
+    it does not look at (row lengths of C) and survive what it has not looked at yet."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "stress_gpu.py")
+    env = dict(os.environ, STRESS_REPEAT="4")
+    r = subprocess.run([sys.executable, tool, "120", "7101", "interleave=3", "num_verify=2"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "failures: 0" in r.stdout and r.stdout.count("pred=31") >= 10
+
+
 def test_a_captured_sequence_owns_its_prediction(cfg):
     """A replayed sequence verifies (and places rows by) what the previous identical call decided.  That prediction
     belongs to the sequence: an eager multiply of OTHER matrices on the same config in between -- more rows, other

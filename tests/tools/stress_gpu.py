@@ -122,13 +122,17 @@ def interleaved(cfg, rng, steps, alive):
         if it == int(os.environ.get("STRESS_UNCAPTURED_AT", "-1")):   # this step: the launches of the replay, uncaptured
             cfg.set_option("profile_replay", 1)
             cfg.profile_kernels(1)
-        sa.MultiplyspECK(p["dA"], p["dB"], p["dC"], cfg)
-        p["calls"] += 1
-        got = p["dC"].to_host()
-        R, ab = p["R"], p["ab"]
-        tol = 1e-12 if p["dtype"] == np.float64 else 4.0 * 2.0 ** -23
-        ok = got.nnz == R.nnz and (got.row_offsets == R.row_offsets).all() and (got.col_ids == R.col_ids).all() and \
-            bool((np.abs(got.data.astype(np.float64) - R.data.astype(np.float64)) <= tol * ab + 1e-300).all())
+        ok = True
+        # (STRESS_REPEAT=K: the chosen problem K times in a row -- the later calls of a run are replays without a scan and,
+        #  option num_verify, without a symbolic pass, and the NEXT in-place change of that problem meets such a sequence)
+        for _ in range(int(os.environ.get("STRESS_REPEAT", "1"))):
+            sa.MultiplyspECK(p["dA"], p["dB"], p["dC"], cfg)
+            p["calls"] += 1
+            got = p["dC"].to_host()
+            R, ab = p["R"], p["ab"]
+            tol = 1e-12 if p["dtype"] == np.float64 else 4.0 * 2.0 ** -23
+            ok = ok and got.nnz == R.nnz and (got.row_offsets == R.row_offsets).all() and (got.col_ids == R.col_ids).all() and \
+                bool((np.abs(got.data.astype(np.float64) - R.data.astype(np.float64)) <= tol * ab + 1e-300).all())
         st = cfg.last_stats()
         bad += 0 if ok else 1
         print(f"{it:4d} {'ok ' if ok else 'BAD'} problem {j} call {p['calls']} replayed={int(st['replayed'])} "
