@@ -12,3 +12,5 @@ run single_d 300 4004 use_graph=0
 run turns_a 1500 4101 interleave=4
 run turns_b 1500 4102 interleave=3 esc64=0
 run turns_c 1000 4103 interleave=5 nf_min_ops=1
+STRESS_REPEAT=4 run repeat_a 500 7101 interleave=3 num_verify=2
+STRESS_REPEAT=4 run repeat_b 400 7103 interleave=3

@@ -69,6 +69,7 @@ struct ReplayPlan {
     bool direct, fused, pred_scan, pred_sym;
     bool skip_scan;  // ... and so does every kernel that produces a row's nnz (RowWork::verify_counts): no scan kernel -- the
                      //   numeric launches read the records, offsets and class table the previous replay's scan left
+    bool uncaptured;  // the launches of this sequence are enqueued at every call instead of captured into a graph (below)
     bool num_verify;  // ... and no symbolic pass for the rows of the hash / dense classes: the numeric light launch verifies
                       //   their nnz itself (RowWork::verify_numeric) -- the symbolic phase is the register-class rows alone
     bool overlap;  // the analysis only VERIFIES what the previous identical call left in the arena, on a stream of its
@@ -189,6 +190,7 @@ struct speck_config {
     bool capture_skip_scan = false;  // set while such a sequence is being enqueued
     int num_verify = 1;              // option num_verify (0: never, 1: when it pays, 2: whenever possible): ... and no symbolic pass for its hash / dense rows (ReplayPlan::num_verify)
     bool capture_num_verify = false;
+    bool capture_forked = false;     // option capture_forked (ReplayPlan::uncaptured)
     bool arena_from_replay = false;  // the arena (numeric records, class table, statistics) was last written by a completed
                                      //   REPLAY of arena_key's problem: the layout a sequence without a scan reads
     bool overlap_analysis = true;    // option overlap_analysis: a replayed sequence runs its analysis as a verifier beside it
@@ -920,6 +922,13 @@ ReplayPlan plan_replay(const speck_config* c, bool arena_replay_ok = false)
     p.skip_scan = c->skip_scan && arena_replay_ok && p.overlap && early_ok && c->merge_light && !c->split_light &&
                   (p.launch_mask & kBigLight) != 0 && (eff_sym & ~kSymLightMask) == 0;
     p.num_verify = want_verify && p.skip_scan;
+    // A sequence without a scan whose numeric phase FORKS (heavy classes on side streams: webbase stand-in) is not
+    // captured: the executable graph of that sequence crashed the host inside the runtime in every second process that had
+    // multiplied other problems on the config before (scripts/repro_standins.py; a segmentation fault inside
+    // hipGraphLaunch / instantiate, not in any kernel -- the same family as the join / fork shape above), while the same
+    // launches enqueued one by one at every call never did (ten processes).  That costs such a multiply 1-2 %
+    // (0.88 -> 0.89 ms) of the 16 % the missing symbolic phase gave it.  (option capture_forked = 1: capture anyway)
+    p.uncaptured = p.skip_scan && (p.launch_mask & ~(kNumLightMask | (1u << NUM_NFCOPY))) != 0 && !c->capture_forked;
     return p;
 }
 
@@ -1003,7 +1012,7 @@ int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const spe
     c->graph_pred_scan = plan.pred_scan;
     c->graph_pred_sym = plan.pred_sym;
     c->graph_overlap = plan.overlap;
-    if (c->use_user_stream || c->replay_uncaptured) {
+    if (c->use_user_stream || c->replay_uncaptured || plan.uncaptured) {
         // the launches of this sequence are enqueued one by one at every call (multiply_impl): only the plan and the
         // sequence's copy of the prediction are kept -- a caller's stream is never put into capture mode
         c->graph_key = key;
@@ -1200,7 +1209,10 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             // (... and the verifier not before the TIMED sequence starts: with launches of milliseconds -- nlpkkt stand-in --
             //  the host has both sequences enqueued long before the first has run, and the verifier would spend itself
             //  beside the untimed one: the timed light launch measured 16.9 ms against 18.7 in a trace of the graph)
-            if (plan.overlap) {
+            //  (only then: beside a sequence of tens of microseconds the host launches the verifier ~30 us AFTER the graph,
+            //   and a verifier that starts WITH the timed sequence made its first launch 5 % longer than a trace of the
+            //   graph shows it -- scircuit stand-in 45.5 against 43.2 us)
+            if (plan.overlap && c->last_eager_stats.sum_products >= (1ull << 29)) {
                 HIP_TRY(hipEventRecord(c->fork, s));
                 HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
             }
@@ -1245,7 +1257,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         else if (have && !c->graph_plan.skip_scan && replay_layout && c->last_key_valid && c->last_key == key &&
                  plan_replay(c, true).skip_scan)
             have = capture_graph<T>(c, s, A, B, C, sc, key, true) == SPECK_OK;
-        if (have && c->exec_dirty && !(c->replay_uncaptured || c->use_user_stream)) {
+        if (have && c->exec_dirty && !(c->replay_uncaptured || c->use_user_stream || c->graph_plan.uncaptured)) {
             // (see below) a fresh executable for a graph that other launches have passed; no executable: eager path
             if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
             c->graph_exec = nullptr;
@@ -1280,7 +1292,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->exec_dirty = true;
                 rc = enqueue_replay<T>(c, s, A, B, C, sc, p2, nullptr, nullptr);
                 if (rc != SPECK_OK) return rc;
-            } else if (c->replay_uncaptured || c->use_user_stream) {
+            } else if (c->replay_uncaptured || c->use_user_stream || c->graph_plan.uncaptured) {
                 rc = enqueue_replay<T>(c, s, A, B, C, sc, c->graph_plan, nullptr, nullptr);
                 if (rc != SPECK_OK) return rc;
             } else {
@@ -1845,6 +1857,10 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->last_key_valid = false;
     }
     else if (n == "eager_speculate") c->eager_speculate = value != 0;
+    else if (n == "capture_forked") {
+        c->capture_forked = value != 0;
+        drop_graph(c);
+    }
     else if (n == "num_verify") {
         c->num_verify = (int)value;
         drop_graph(c);

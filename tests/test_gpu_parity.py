@@ -1657,6 +1657,21 @@ def test_randomised_changes_meet_sequences_without_a_symbolic_pass():
     assert "failures: 0" in r.stdout and r.stdout.count("pred=31") >= 10
 
 
+def test_standins_take_turns_on_one_config_in_fresh_processes():
+    """scripts/repro_standins.py: the scircuit, mac_econ, cant and webbase stand-ins, seven multiplies each, on ONE config of
+    a fresh process.  A captured graph of the webbase sequence without a scan (its numeric phase forks onto side streams)
+    ended such a process with a segmentation fault inside the runtime -- every SECOND process, never inside this test
+    module's long-lived one -- so that sequence is enqueued launch by launch instead (ReplayPlan::uncaptured); four
+    processes in a row here."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "repro_standins.py")
+    for _ in range(4):
+        r = subprocess.run([sys.executable, tool, "webbase"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "webbase ok 31" in r.stdout and r.stdout.rstrip().endswith("done"), \
+            (r.returncode, r.stdout[-500:], r.stderr[-800:])
+
+
 def test_a_captured_sequence_owns_its_prediction(cfg):
     """A replayed sequence verifies (and places rows by) what the previous identical call decided.  That prediction
     belongs to the sequence: an eager multiply of OTHER matrices on the same config in between -- more rows, other
