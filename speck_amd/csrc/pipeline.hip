@@ -191,6 +191,7 @@ struct speck_config {
     int num_verify = 1;              // option num_verify (0: never, 1: when it pays, 2: whenever possible): ... and no symbolic pass for its hash / dense rows (ReplayPlan::num_verify)
     bool capture_num_verify = false;
     bool capture_forked = false;     // option capture_forked (ReplayPlan::uncaptured)
+    bool gate_verifier = false;      // profiled pre-pass: the verifier's stream waits for the symbolic phase of the timed sequence
     bool arena_from_replay = false;  // the arena (numeric records, class table, statistics) was last written by a completed
                                      //   REPLAY of arena_key's problem: the layout a sequence without a scan reads
     bool overlap_analysis = true;    // option overlap_analysis: a replayed sequence runs its analysis as a verifier beside it
@@ -978,6 +979,10 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
                            p.num_mask, true, tm, sym_counts, nullptr,
                            p.g_products, p.num_counts[NUM_G], 3u, p.nf_cap_entries);
     if (rc != SPECK_OK) return rc;
+    if (tm && c->gate_verifier) {  // (profiled pre-pass of a long sequence: the verifier's stream starts here, multiply_impl)
+        HIP_TRY(hipEventRecord(c->fork, s));
+        HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
+    }
     if (tm) {
         tm->ev_num = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -1212,11 +1217,11 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             //  (only then: beside a sequence of tens of microseconds the host launches the verifier ~30 us AFTER the graph,
             //   and a verifier that starts WITH the timed sequence made its first launch 5 % longer than a trace of the
             //   graph shows it -- scircuit stand-in 45.5 against 43.2 us)
-            if (plan.overlap && c->last_eager_stats.sum_products >= (1ull << 29)) {
-                HIP_TRY(hipEventRecord(c->fork, s));
-                HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
-            }
+            //  (... and behind the symbolic phase of the timed sequence: next to the graph the host launches the verifier ~30 us
+            //   after the graph -- the short fused launch of such an input is through by then)
+            c->gate_verifier = plan.overlap && c->last_eager_stats.sum_products >= (1ull << 29);
             rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, &tm, &ev_num_end);
+            c->gate_verifier = false;
             if (rc != SPECK_OK) return rc;
             // (BEHIND the sequence, as the graph path does: launched in front of it the verifier ran beside the first launch
             //  of the sequence from its start and made that launch ~2 us longer than it is inside the graph -- the launch
