@@ -1340,6 +1340,15 @@ __global__ __launch_bounds__(64) void ticket_kernel(u32* __restrict__ dev_ticket
         __hip_atomic_store(host_ticket, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// One wave that does nothing for `us` microseconds (constant 100 MHz counter): the profiled pre-pass of a long sequence
+// puts it in front of the verifier, which the host launches ~30 us behind a replayed graph (pipeline.hip, gate_verifier)
+__global__ __launch_bounds__(64) void delay_kernel(u32 ticks)
+{
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+void launch_delay(hipStream_t s, u32 us) { hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, us * 100u); }
+
 void launch_ticket(hipStream_t s, u32* dev_ticket, u32* host_ticket)
 {
     hipLaunchKernelGGL(ticket_kernel, dim3(1), dim3(64), 0, s, dev_ticket, host_ticket);
