@@ -927,8 +927,9 @@ ReplayPlan plan_replay(const speck_config* c, bool arena_replay_ok = false)
     // captured: the executable graph of that sequence crashed the host inside the runtime in every second process that had
     // multiplied other problems on the config before (scripts/repro_standins.py; a segmentation fault inside
     // hipGraphLaunch / instantiate, not in any kernel -- the same family as the join / fork shape above), while the same
-    // launches enqueued one by one at every call never did (ten processes).  That costs such a multiply 1-2 %
-    // (0.88 -> 0.89 ms) of the 16 % the missing symbolic phase gave it.  (option capture_forked = 1: capture anyway)
+    // launches enqueued one by one at every call never did (eight processes in a row, and the four of
+    // tests/test_gpu_parity.py::test_standins_take_turns_on_one_config_in_fresh_processes).  It costs such a multiply
+    // nothing measurable (webbase stand-in 0.874-0.882 ms either way).  (option capture_forked = 1: capture anyway)
     p.uncaptured = p.skip_scan && (p.launch_mask & ~(kNumLightMask | (1u << NUM_NFCOPY))) != 0 && !c->capture_forked;
     return p;
 }
