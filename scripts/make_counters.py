@@ -22,7 +22,8 @@ KEYS = [
     #  still runs <T, false, false>, listed apart then -- see main)
     (r"num_light_kernel<\w+, true", "num_light_eager"), (r"num_light_kernel<\w+, false, true>", "num_light"),
     (r"num_light_kernel", "num_light_plain"), (r"num_tiny_kernel", "num_tiny"),
-    (r"analysis_kernel<\d+, \d+u, true>", "analysis_verify"),
+    (r"analysis_kernel<\d+, \d+u, true>", "analysis_verify"), (r"verify_inputs_kernel", "verify_inputs"),
+    (r"snapshot_inputs_kernel", "snapshot_inputs"),
     (r"sym_light_fused_kernel", "sym_light_fused"), (r"sym_light_kernel", "sym_light"),
     (r"num_hash_kernel<Block<512>", "num_block8k"), (r"num_hash_kernel<Block<256>", "num_block2k"),
     (r"num_dense_kernel<\w+, 16384u", "num_dense16k"),

@@ -27,6 +27,13 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 // (the kernel also copies the statistics block into its pinned mirror, before the ticket)
 void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceStats* st, DeviceStats* host_mirror);
 void launch_ticket(hipStream_t s, u32* dev_ticket, u32* host_ticket);  // the ticket alone
+// the inputs the analysis depends on, kept (by every call whose analysis WRITES the arena) and compared (by the verifier of
+// a replayed sequence): stages.hip.  b_snap: 3 * b_rows + 1 words
+void launch_snapshot_inputs(hipStream_t s, const u32* a_ro, const u32* a_col, u32* a_col_copy, u64 nnz_a, const u32* b_ro,
+                            const u32* b_col, u32 b_rows, u32* b_snap);
+void launch_verify_inputs(hipStream_t s, const u32* a_ro, const u32* a_ro_copy, u32 m, const u32* a_col,
+                          const u32* a_col_copy, u64 nnz_a, const u32* b_ro, const u32* b_col, u32 b_rows, const u32* b_snap,
+                          u32* verdict);
 void launch_delay(hipStream_t s, u32 us);                               // a wave that idles for `us` microseconds
 // B's rows strictly ascending and in range (eager path): bit 2 of *verdict (pinned) on a violation
 void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, u64 b_nnz, u32* verdict);

@@ -191,6 +191,15 @@ struct speck_config {
     int num_verify = 1;              // option num_verify (0: never, 1: when it pays, 2: whenever possible): ... and no symbolic pass for its hash / dense rows (ReplayPlan::num_verify)
     bool capture_num_verify = false;
     bool capture_forked = false;     // option capture_forked (ReplayPlan::uncaptured)
+    // The inputs the analysis depends on as the last WRITING analysis saw them (stages.hip, launch_snapshot_inputs): A's
+    // column ids | B's row offsets | first and last column id of every row of B.  The verifier of a replayed sequence
+    // compares the inputs with this copy instead of recomputing the analysis (option verify_inputs); grow-only, and like
+    // the arena it belongs to whoever ran a writing analysis last (snap_for_arena travels with arena_key).
+    u32* snap = nullptr;
+    size_t snap_words = 0, snap_a_words = 0;
+    bool verify_inputs = true;
+    bool snap_taken = false;         // this call has taken the snapshot already (eager: beside the call, begin_validate)
+    bool snap_for_arena = false;     // the snapshot was taken with the analysis that wrote the arena's metadata
     bool gate_verifier = false;      // profiled pre-pass: the verifier's stream waits for the symbolic phase of the timed sequence
     bool arena_from_replay = false;  // the arena (numeric records, class table, statistics) was last written by a completed
                                      //   REPLAY of arena_key's problem: the layout a sequence without a scan reads
@@ -251,6 +260,27 @@ int ensure_arena(speck_config* c, size_t bytes)
     HIP_TRY(hipMalloc(&c->arena, want));
     c->arena_bytes = want;
     return SPECK_OK;
+}
+
+// room for the input snapshot of a problem (no room: the verifier recomputes the analysis instead)
+void ensure_snap(speck_config* c, u64 nnz_a, u64 b_rows)
+{
+    const size_t a_words = (size_t(nnz_a) + 63) & ~size_t(63), need = a_words + 3 * size_t(b_rows) + 1;
+    if (need > c->snap_words) {
+        if (c->snap) (void)hipFree(c->snap);
+        c->snap = nullptr;
+        c->snap_words = 0;
+        c->snap_for_arena = false;
+        const size_t want = need + need / 8;
+        if (hipMalloc(reinterpret_cast<void**>(&c->snap), want * sizeof(u32)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->snap = nullptr;
+            return;
+        }
+        c->snap_words = want;
+    }
+    if (c->snap_a_words != a_words) c->snap_for_arena = false;  // (another layout: whatever it holds is not this problem's)
+    c->snap_a_words = a_words;
 }
 
 struct Carver {
@@ -600,6 +630,12 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
                         c->d_stats, cp, sc.b_sl, between, sc.nf_off, expect_nf, (u32)B->rows,
                         pred_out ? pred_out->sym_block : nullptr, c->capture_pred_sym ? c->gpred.sym_block : nullptr,
                         c->gpred.stats, (u32)B->cols, B->nnz, c->check_epoch, sc.a_ro_copy);
+        if (!c->capture_overlap) {  // (a writing analysis: the inputs it went with, for the verifier of later replays)
+            if (c->snap && !c->snap_taken)
+                launch_snapshot_inputs(s, A->row_offsets, A->col_ids, c->snap, A->nnz, B->row_offsets, B->col_ids, (u32)B->rows,
+                                       c->snap + c->snap_a_words);
+            c->snap_for_arena = c->snap != nullptr;
+        }
         if (timed) {
             tm->ev_analysis_end = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -1088,6 +1124,14 @@ void publish_kernel_times(speck_config* c, const Timing& tm, size_t ev_num_end)
 int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, const Scratch& sc)
 {
     __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
+    if (c->verify_inputs && c->snap && c->snap_for_arena) {
+        // the arena's metadata is a function of inputs that are still what the writing analysis saw: four streams compared
+        launch_verify_inputs(c->vstream, A->row_offsets, sc.a_ro_copy, (u32)A->rows, A->col_ids, c->snap, A->nnz, B->row_offsets,
+                             B->col_ids, (u32)B->rows, c->snap + c->snap_a_words, c->h_verify_dev);
+        launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
+        HIP_TRY(hipGetLastError());
+        return SPECK_OK;
+    }
     ClassifyParams cp = c->cp;
     cp.sym_allowed = cp.num_allowed = 0xFFFFFFFFu;
     cp.esc16 = (c->cp.esc16 && B->cols <= (1ull << 26)) ? 1u : 0u;  // (as enqueue_front classifies)
@@ -1117,7 +1161,7 @@ int wait_verifier(speck_config* c, bool* changed)
 }
 
 // The input check of an eager call, beside it on the verifier's stream (stages.hip: validate_b_kernel).
-int begin_validate(speck_config* c, const speck_dcsr* B)
+int begin_validate(speck_config* c, const speck_dcsr* A, const speck_dcsr* B)
 {
     __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
     if (c->use_user_stream) {
@@ -1126,6 +1170,13 @@ int begin_validate(speck_config* c, const speck_dcsr* B)
         HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
     }
     launch_validate_b(c->vstream, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, B->nnz, c->h_verify_dev);
+    // (... and the snapshot of the inputs this call's analysis goes with, off the call's critical path: the call does not
+    //  return before this stream's ticket -- ValidateGuard -- so the caller cannot change the inputs under it)
+    if (c->snap && A->rows) {
+        launch_snapshot_inputs(c->vstream, A->row_offsets, A->col_ids, c->snap, A->nnz, B->row_offsets, B->col_ids, (u32)B->rows,
+                               c->snap + c->snap_a_words);
+        c->snap_taken = true;
+    }
     launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
     HIP_TRY(hipGetLastError());
     c->validate_in_flight = true;
@@ -1185,6 +1236,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
     Scratch sc = carve(c, m, A->nnz);
+    c->snap_taken = false;
+    if (c->verify_inputs && c->overlap_analysis && c->use_graph) ensure_snap(c, A->nnz, B->rows);
 
     // ------------------------------------------------------------------ replay path
     // Same buffers as a previous call, C already allocated for the expected nnz: replay the
@@ -1393,7 +1446,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         }
     } validate_guard{c};
     if (c->validate_inputs) {
-        rc = begin_validate(c, B);
+        rc = begin_validate(c, A, B);
         if (rc != SPECK_OK) return fail(rc);
     }
     auto b_is_invalid = [&](bool* bad) { return finish_validate(c, bad); };
@@ -1795,6 +1848,7 @@ int speck_config_destroy(speck_config* c)
     if (c->h_verify) (void)hipHostFree(c->h_verify);
     if (c->d_vticket) (void)hipFree(c->d_vticket);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->snap) (void)hipFree(c->snap);
     if (c->gpool) (void)hipFree(c->gpool);
     if (c->nfpool) (void)hipFree(c->nfpool);
     if (c->pred.buf) (void)hipFree(c->pred.buf);
@@ -1869,6 +1923,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "eager_speculate") c->eager_speculate = value != 0;
     else if (n == "capture_forked") {
         c->capture_forked = value != 0;
+        drop_graph(c);
+    }
+    else if (n == "verify_inputs") {
+        c->verify_inputs = value != 0;
+        c->snap_for_arena = false;
         drop_graph(c);
     }
     else if (n == "num_verify") {

@@ -1340,6 +1340,92 @@ __global__ __launch_bounds__(64) void ticket_kernel(u32* __restrict__ dev_ticket
         __hip_atomic_store(host_ticket, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// ---- the inputs of the analysis, kept and compared (pipeline.hip: launch_verifier) ------------------------------------
+// Everything the analysis leaves in the arena is a function of A.row_offsets, A.col_ids, B.row_offsets and the first and
+// last column id of every row of B.  A replayed sequence whose analysis only VERIFIES (ReplayPlan::overlap) therefore does
+// not have to recompute that function and compare its results entry by entry -- a chain of gathers A.col -> B.rowptr ->
+// B.col per entry of A, 18 ms beside the numeric launch of the nlpkkt stand-in (4.5 ms alone) and a tenth of that launch's
+// bandwidth: it compares the INPUTS with the copy the last writing analysis went with -- four streams, no gather but the
+// two column ids per row of B.  b_snap: B.row_offsets [k + 1] | first, last column id per row [2 k].
+__global__ __launch_bounds__(256) void snapshot_inputs_kernel(const u32* __restrict__ a_ro, const u32* __restrict__ a_col,
+                                                               u32* __restrict__ a_col_copy, u64 nnz_a,
+                                                               const u32* __restrict__ b_ro, const u32* __restrict__ b_col,
+                                                               u32 b_rows, u32* __restrict__ b_snap)
+{
+    const u32 e_base = a_ro[0];  // (A may be a row-range view with absolute offsets)
+    const u64 tid = u64(blockIdx.x) * 256 + threadIdx.x, nthreads = u64(gridDim.x) * 256;
+    for (u64 i = tid; i < nnz_a; i += nthreads) a_col_copy[i] = a_col[e_base + i];
+    for (u64 r = tid; r <= b_rows; r += nthreads) {
+        const u32 lo = b_ro[r];
+        b_snap[r] = lo;
+        if (r < b_rows) {
+            const u32 hi = b_ro[r + 1];
+            b_snap[size_t(b_rows) + 1 + 2 * r] = hi > lo ? b_col[lo] : 0xFFFFFFFFu;
+            b_snap[size_t(b_rows) + 2 + 2 * r] = hi > lo ? b_col[hi - 1] : 0u;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void verify_inputs_kernel(const u32* __restrict__ a_ro, const u32* __restrict__ a_ro_copy,
+                                                             u32 m, const u32* __restrict__ a_col,
+                                                             const u32* __restrict__ a_col_copy, u64 nnz_a,
+                                                             const u32* __restrict__ b_ro, const u32* __restrict__ b_col,
+                                                             u32 b_rows, const u32* __restrict__ b_snap, u32* __restrict__ verdict)
+{
+    const u32 e_base = a_ro[0];
+    const u64 tid = u64(blockIdx.x) * 256 + threadIdx.x, nthreads = u64(gridDim.x) * 256;
+    bool bad = e_base != a_ro_copy[0];
+    for (u64 i = tid; i <= m; i += nthreads) bad |= a_ro[i] != a_ro_copy[i];
+    if (!bad) {  // (same first entry: the copies line up)
+        constexpr u32 U = 4;  // entries per thread and step, all loads in flight
+        for (u64 i0 = tid * U; i0 < nnz_a; i0 += nthreads * U) {
+            u32 x[U], y[U];
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) {
+                const u64 i = i0 + u;
+                x[u] = i < nnz_a ? a_col[e_base + i] : 0u;
+                y[u] = i < nnz_a ? a_col_copy[i] : 0u;
+            }
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) bad |= x[u] != y[u];
+        }
+    }
+    for (u64 r = tid; r <= b_rows; r += nthreads) {
+        const u32 lo = b_ro[r];
+        if (lo != b_snap[r]) {
+            bad = true;
+            continue;
+        }
+        if (r < b_rows) {
+            const u32 hi = b_ro[r + 1];
+            if (hi != b_snap[r + 1]) {  // (the offsets are the ones the snapshot was taken with: inside B's arrays)
+                bad = true;
+                continue;
+            }
+            const u32 first = hi > lo ? b_col[lo] : 0xFFFFFFFFu, last = hi > lo ? b_col[hi - 1] : 0u;
+            bad |= first != b_snap[size_t(b_rows) + 1 + 2 * r] || last != b_snap[size_t(b_rows) + 2 + 2 * r];
+        }
+    }
+    if (__ballot(bad) != 0 && lane_id() == 0) __hip_atomic_fetch_or(verdict, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static u32 input_blocks(u64 nnz_a, u32 b_rows)
+{
+    const u64 want = cdiv(std::max<u64>(nnz_a, b_rows) + 1, 256 * 8);
+    return (u32)std::min<u64>(std::max<u64>(want, 1), 4096);
+}
+void launch_snapshot_inputs(hipStream_t s, const u32* a_ro, const u32* a_col, u32* a_col_copy, u64 nnz_a, const u32* b_ro,
+                            const u32* b_col, u32 b_rows, u32* b_snap)
+{
+    hipLaunchKernelGGL(snapshot_inputs_kernel, dim3(input_blocks(nnz_a, b_rows)), dim3(256), 0, s, a_ro, a_col, a_col_copy,
+                       nnz_a, b_ro, b_col, b_rows, b_snap);
+}
+void launch_verify_inputs(hipStream_t s, const u32* a_ro, const u32* a_ro_copy, u32 m, const u32* a_col,
+                          const u32* a_col_copy, u64 nnz_a, const u32* b_ro, const u32* b_col, u32 b_rows, const u32* b_snap,
+                          u32* verdict)
+{
+    hipLaunchKernelGGL(verify_inputs_kernel, dim3(input_blocks(nnz_a, b_rows)), dim3(256), 0, s, a_ro, a_ro_copy, m, a_col,
+                       a_col_copy, nnz_a, b_ro, b_col, b_rows, b_snap, verdict);
+}
+
 // One wave that does nothing for `us` microseconds (constant 100 MHz counter): the profiled pre-pass of a long sequence
 // puts it in front of the verifier, which the host launches ~30 us behind a replayed graph (pipeline.hip, gate_verifier)
 __global__ __launch_bounds__(64) void delay_kernel(u32 ticks)

@@ -1672,6 +1672,95 @@ def test_standins_take_turns_on_one_config_in_fresh_processes():
             (r.returncode, r.stdout[-500:], r.stderr[-800:])
 
 
+def test_verifier_compares_the_inputs_of_the_analysis(cfg):
+    """The verifier beside a replayed sequence compares A.row_offsets, A.col_ids, B.row_offsets and the first / last column id
+    of every row of B with the copy the last writing analysis went with (option verify_inputs; before: it recomputed the
+    analysis).  Each of the four changes IN PLACE, one at a time, so that C changes or at least the metadata the kernels
+    read does: the replay must be rejected and the eager re-run deliver the new product; the next replays verify against
+    the NEW inputs.  verify_inputs = 0 (the recomputing verifier) must see the same."""
+    import ctypes as C_
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    A = to_po(sa.gen_matrix("scircuit", 0.05, 11, signed=True))
+    B = fast_random_csr(A.cols, 5000, 6, 12)
+    for vi in (1, 0):
+        cfg.set_option("verify_inputs", vi)
+        try:
+            dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR()
+            for _ in range(4):
+                sa.MultiplyspECK(dA, dB, dC, cfg)
+            assert cfg.last_stats()["replayed"] and cfg.last_stats()["pred_stages"] & 4
+            _assert_matches_oracle(dC, A, B)
+            A2, B2 = A, B
+
+            def step(newA, newB, what, must_miss=True):
+                misses = cfg.last_stats()["numeric_reruns"]
+                if newA is not A2:
+                    assert L.speck_dcsr_update(C_.byref(dA._c), np.ascontiguousarray(newA.row_offsets).ctypes.data,
+                                               np.ascontiguousarray(newA.col_ids).ctypes.data, None, 8) == 0
+                if newB is not B2:
+                    assert L.speck_dcsr_update(C_.byref(dB._c), np.ascontiguousarray(newB.row_offsets).ctypes.data,
+                                               np.ascontiguousarray(newB.col_ids).ctypes.data, None, 8) == 0
+                sa.MultiplyspECK(dA, dB, dC, cfg)
+                # (the comparing verifier objects to ANY change of what it looks at; the recomputing one only when a quantity
+                #  the kernels read comes out differently -- a first column that is not its row's minimum changes none)
+                assert cfg.last_stats()["numeric_reruns"] == misses + 1 or not must_miss, what
+                _assert_matches_oracle(dC, newA, newB)
+                for _ in range(3):
+                    sa.MultiplyspECK(dA, dB, dC, cfg)
+                assert cfg.last_stats()["replayed"], what
+                _assert_matches_oracle(dC, newA, newB)
+
+            def movable_boundary(M):
+                """A row r (>= 2 entries) whose last column id is below the first of row r + 1 (>= 1 entry): the boundary
+                can move one entry to the left and both rows stay ascending."""
+                ro = M.row_offsets.astype(np.int64)
+                lens = np.diff(ro)
+                ok = np.zeros(M.rows, dtype=bool)
+                idx = np.nonzero((lens[:-1] >= 2) & (lens[1:] >= 1))[0]
+                ok[idx] = M.col_ids[ro[idx + 1] - 1] < M.col_ids[ro[idx + 1]]
+                assert ok.any()
+                return int(np.argmax(ok))
+
+            # (a) one column id of A: the entry references another row of B
+            col = A2.col_ids.copy()
+            ro = A2.row_offsets.astype(np.int64)
+            done = False
+            for r in np.nonzero(np.diff(ro) >= 3)[0]:
+                e = int(ro[r]) + 1
+                if col[e + 1] - col[e - 1] >= 3:
+                    col[e] = col[e - 1] + 1 if col[e] != col[e - 1] + 1 else col[e - 1] + 2
+                    done = True
+                    break
+            assert done
+            A3 = po.HostCSR(A2.rows, A2.cols, A2.row_offsets, col, A2.data)
+            step(A3, B2, "A.col_ids")
+            A2 = A3
+            # (b) a row boundary of A moves by one entry (same nnz)
+            r = movable_boundary(A2)
+            ro = A2.row_offsets.copy()
+            ro[r + 1] -= 1
+            A3 = po.HostCSR(A2.rows, A2.cols, ro, A2.col_ids, A2.data)
+            step(A3, B2, "A.row_offsets")
+            A2 = A3
+            # (c) the first column id of a row of B that A references
+            bro = B2.row_offsets.astype(np.int64)
+            bcol = B2.col_ids.copy()
+            k = next(int(k) for k in np.unique(A2.col_ids) if bro[k + 1] - bro[k] >= 1 and bcol[bro[k]] > 0)
+            bcol[bro[k]] -= 1
+            B3 = po.HostCSR(B2.rows, B2.cols, B2.row_offsets, bcol, B2.data)
+            step(A2, B3, "first column of a row of B", must_miss=vi == 1)
+            B2 = B3
+            # (d) a row boundary of B moves by one entry
+            r = movable_boundary(B2)
+            bro = B2.row_offsets.copy()
+            bro[r + 1] -= 1
+            B3 = po.HostCSR(B2.rows, B2.cols, bro, B2.col_ids, B2.data)
+            step(A2, B3, "B.row_offsets", must_miss=vi == 1)
+        finally:
+            cfg.set_option("verify_inputs", 1)
+
+
 def test_a_captured_sequence_owns_its_prediction(cfg):
     """A replayed sequence verifies (and places rows by) what the previous identical call decided.  That prediction
     belongs to the sequence: an eager multiply of OTHER matrices on the same config in between -- more rows, other
