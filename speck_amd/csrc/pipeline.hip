@@ -198,8 +198,8 @@ struct speck_config {
     u32* snap = nullptr;
     size_t snap_words = 0, snap_a_words = 0;
     bool verify_inputs = true;
-    bool snap_taken = false;         // this call has taken the snapshot already (eager: beside the call, begin_validate)
-    bool snap_for_arena = false;     // the snapshot was taken with the analysis that wrote the arena's metadata
+    bool snap_pending = false;       // the verifier of the call in flight recomputes the analysis AND takes the copy
+    bool snap_for_arena = false;     // the copy holds the inputs the arena's metadata was derived from (and verified against)
     bool gate_verifier = false;      // profiled pre-pass: the verifier's stream waits for the symbolic phase of the timed sequence
     bool arena_from_replay = false;  // the arena (numeric records, class table, statistics) was last written by a completed
                                      //   REPLAY of arena_key's problem: the layout a sequence without a scan reads
@@ -630,12 +630,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
                         c->d_stats, cp, sc.b_sl, between, sc.nf_off, expect_nf, (u32)B->rows,
                         pred_out ? pred_out->sym_block : nullptr, c->capture_pred_sym ? c->gpred.sym_block : nullptr,
                         c->gpred.stats, (u32)B->cols, B->nnz, c->check_epoch, sc.a_ro_copy);
-        if (!c->capture_overlap) {  // (a writing analysis: the inputs it went with, for the verifier of later replays)
-            if (c->snap && !c->snap_taken)
-                launch_snapshot_inputs(s, A->row_offsets, A->col_ids, c->snap, A->nnz, B->row_offsets, B->col_ids, (u32)B->rows,
-                                       c->snap + c->snap_a_words);
-            c->snap_for_arena = c->snap != nullptr;
-        }
+        if (!c->capture_overlap) c->snap_for_arena = false;  // (a writing analysis: the copy of the inputs is not its)
         if (timed) {
             tm->ev_analysis_end = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -1140,6 +1135,14 @@ int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, c
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, sc.counts, sc.partials, sc.recs_sym,
                     c->d_stats, cp, sc.b_sl, nullptr, sc.nf_off, ~0ull, (u32)B->rows, nullptr, nullptr, nullptr,
                     (u32)B->cols, B->nnz, 0u, sc.a_ro_copy, c->h_verify_dev);
+    // ... and behind it the copy of the inputs it has just verified the arena against (they do not change while the call
+    // is in flight): the verifiers of the next replays compare with that.  (The FIRST replay of a problem pays the
+    // recomputing verifier once; the eager call that precedes it pays nothing.)
+    if (c->verify_inputs && c->snap) {
+        launch_snapshot_inputs(c->vstream, A->row_offsets, A->col_ids, c->snap, A->nnz, B->row_offsets, B->col_ids, (u32)B->rows,
+                               c->snap + c->snap_a_words);
+        c->snap_pending = true;
+    }
     launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -1161,7 +1164,7 @@ int wait_verifier(speck_config* c, bool* changed)
 }
 
 // The input check of an eager call, beside it on the verifier's stream (stages.hip: validate_b_kernel).
-int begin_validate(speck_config* c, const speck_dcsr* A, const speck_dcsr* B)
+int begin_validate(speck_config* c, const speck_dcsr* B)
 {
     __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
     if (c->use_user_stream) {
@@ -1170,13 +1173,6 @@ int begin_validate(speck_config* c, const speck_dcsr* A, const speck_dcsr* B)
         HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
     }
     launch_validate_b(c->vstream, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, B->nnz, c->h_verify_dev);
-    // (... and the snapshot of the inputs this call's analysis goes with, off the call's critical path: the call does not
-    //  return before this stream's ticket -- ValidateGuard -- so the caller cannot change the inputs under it)
-    if (c->snap && A->rows) {
-        launch_snapshot_inputs(c->vstream, A->row_offsets, A->col_ids, c->snap, A->nnz, B->row_offsets, B->col_ids, (u32)B->rows,
-                               c->snap + c->snap_a_words);
-        c->snap_taken = true;
-    }
     launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
     HIP_TRY(hipGetLastError());
     c->validate_in_flight = true;
@@ -1236,7 +1232,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
     Scratch sc = carve(c, m, A->nnz);
-    c->snap_taken = false;
+    c->snap_pending = false;
     if (c->verify_inputs && c->overlap_analysis && c->use_graph) ensure_snap(c, A->nnz, B->rows);
 
     // ------------------------------------------------------------------ replay path
@@ -1299,6 +1295,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->arena_key = key;
                 c->arena_key_valid = true;
                 c->arena_from_replay = true;
+                if (c->snap_pending) c->snap_for_arena = true;  // (the copy of the inputs this call's verifier took: launch_verifier)
                 publish_counts(c);
                 publish_kernel_times(c, tm, ev_num_end);
                 c->last.replayed = 0;  // (not served by the graph: graph_replays does not count it)
@@ -1378,6 +1375,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->arena_key = key;
                 c->arena_key_valid = true;
                 c->arena_from_replay = true;
+                if (c->snap_pending) c->snap_for_arena = true;  // (the copy of the inputs this call's verifier took: launch_verifier)
                 ++c->graph_replays;
                 publish_counts(c);
                 c->last.replayed = 1;
@@ -1446,7 +1444,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         }
     } validate_guard{c};
     if (c->validate_inputs) {
-        rc = begin_validate(c, A, B);
+        rc = begin_validate(c, B);
         if (rc != SPECK_OK) return fail(rc);
     }
     auto b_is_invalid = [&](bool* bad) { return finish_validate(c, bad); };
