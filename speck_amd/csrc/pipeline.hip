@@ -1443,10 +1443,14 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             (void)finish_validate(c, &ignored);
         }
     } validate_guard{c};
-    if (c->validate_inputs) {
-        rc = begin_validate(c, B);
-        if (rc != SPECK_OK) return fail(rc);
-    }
+    // (launched BEHIND the first batch of the call, not in front of it: two launches on another stream cost the host
+    //  5-10 us that the analysis -- the head of the call's critical path -- then starts later)
+    bool validate_started = false;
+    auto start_validate = [&]() -> int {
+        if (!c->validate_inputs || validate_started) return SPECK_OK;
+        validate_started = true;
+        return begin_validate(c, B);
+    };
     auto b_is_invalid = [&](bool* bad) { return finish_validate(c, bad); };
     bool speculated = false;
     u32 spec_counts[kMaxClasses];
@@ -1464,6 +1468,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         rc = enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, mask, kAllNum, true, &tm, spec_counts,
                            early_stats ? c->h_stats_dev : nullptr, ~0ull, ~0u, 3u, c->nf_cap_entries,
                            keep_pred ? &c->pred : nullptr, fold_esc, false);
+        if (rc == SPECK_OK) rc = start_validate();
         if (rc == SPECK_OK) rc = early_stats ? await_scan_stats(c, s) : read_stats(c, s);
         if (rc != SPECK_OK) return fail(rc);
         if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
@@ -1478,6 +1483,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     if (!speculated) {
     // analysis + binning
     rc = front(1u);
+    if (rc == SPECK_OK) rc = start_validate();
     if (rc != SPECK_OK) return fail(rc);
     if (c->cp.nf_min_ops || c->cp.gh_per_window) {
         // numeric-first rows (and the global key sets of SYM_GH rows) need their scratch pool before the
