@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -200,6 +201,7 @@ struct speck_config {
     bool verify_inputs = true;
     bool snap_pending = false;       // the verifier of the call in flight recomputes the analysis AND takes the copy
     bool snap_for_arena = false;     // the copy holds the inputs the arena's metadata was derived from (and verified against)
+    std::function<int()> after_analysis;  // set by an eager call for the duration of its first batch (multiply_impl)
     bool gate_verifier = false;      // profiled pre-pass: the verifier's stream waits for the symbolic phase of the timed sequence
     bool arena_from_replay = false;  // the arena (numeric records, class table, statistics) was last written by a completed
                                      //   REPLAY of arena_key's problem: the layout a sequence without a scan reads
@@ -631,6 +633,12 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
                         pred_out ? pred_out->sym_block : nullptr, c->capture_pred_sym ? c->gpred.sym_block : nullptr,
                         c->gpred.stats, (u32)B->cols, B->nnz, c->check_epoch, sc.a_ro_copy);
         if (!c->capture_overlap) c->snap_for_arena = false;  // (a writing analysis: the copy of the inputs is not its)
+        // (eager call: the input check of B goes onto its stream HERE -- behind the launch of the analysis, the head of
+        //  the call's critical path, and beside that latency-bound kernel rather than beside the symbolic launches)
+        if (c->after_analysis) {
+            const int hrc = c->after_analysis();
+            if (hrc != SPECK_OK) return hrc;
+        }
         if (timed) {
             tm->ev_analysis_end = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -1443,14 +1451,19 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             (void)finish_validate(c, &ignored);
         }
     } validate_guard{c};
-    // (launched BEHIND the first batch of the call, not in front of it: two launches on another stream cost the host
-    //  5-10 us that the analysis -- the head of the call's critical path -- then starts later)
+    // (launched BEHIND the analysis of the call, not in front of it: two launches on another stream cost the host
+    //  5-10 us that the analysis -- the head of the call's critical path -- then starts later; enqueue_front calls it)
     bool validate_started = false;
     auto start_validate = [&]() -> int {
         if (!c->validate_inputs || validate_started) return SPECK_OK;
         validate_started = true;
         return begin_validate(c, B);
     };
+    struct HookGuard {
+        speck_config* c;
+        ~HookGuard() { c->after_analysis = nullptr; }
+    } hook_guard{c};
+    c->after_analysis = start_validate;
     auto b_is_invalid = [&](bool* bad) { return finish_validate(c, bad); };
     bool speculated = false;
     u32 spec_counts[kMaxClasses];
@@ -1468,7 +1481,6 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         rc = enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, mask, kAllNum, true, &tm, spec_counts,
                            early_stats ? c->h_stats_dev : nullptr, ~0ull, ~0u, 3u, c->nf_cap_entries,
                            keep_pred ? &c->pred : nullptr, fold_esc, false);
-        if (rc == SPECK_OK) rc = start_validate();
         if (rc == SPECK_OK) rc = early_stats ? await_scan_stats(c, s) : read_stats(c, s);
         if (rc != SPECK_OK) return fail(rc);
         if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
@@ -1483,7 +1495,6 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     if (!speculated) {
     // analysis + binning
     rc = front(1u);
-    if (rc == SPECK_OK) rc = start_validate();
     if (rc != SPECK_OK) return fail(rc);
     if (c->cp.nf_min_ops || c->cp.gh_per_window) {
         // numeric-first rows (and the global key sets of SYM_GH rows) need their scratch pool before the
