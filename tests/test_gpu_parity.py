@@ -1020,6 +1020,51 @@ def _stale_nnz_rounds(cfg, L, C_, A, B, B2, dA, dB, dC, dense):
         _assert_matches_oracle(dC, A, Bnow)
 
 
+def test_previous_columns_of_c_are_checked_before_they_are_kept(cfg, verify_always):
+    """A sequence without a symbolic pass does not sort its hash rows: it looks the row's PREVIOUS column ids -- still in C --
+    up in the table and keeps them if they are the table's keys (numeric.hip, emit_by_previous).  C is the caller's buffer
+    between two calls: junk in it, two neighbouring column ids swapped (the same set, out of order), one column id twice --
+    none of them may survive: the replay objects, the eager path re-runs, the product is right and sorted."""
+    import ctypes as C_
+    L = _lib.load()
+    rng = np.random.default_rng(99)
+    A, B, _ = _collapsing_problem(rng, 2000, [110] * 30 + [190] * 30, 150, 30000)
+    dA, dB, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR()
+    for _ in range(5):
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+    assert cfg.last_stats()["replayed"] and cfg.last_stats()["pred_stages"] == 31
+    _assert_matches_oracle(dC, A, B)
+    good = dC.to_host()
+    ro = good.row_offsets.astype(np.int64)
+    row = 2020 + 7                                    # a hash-class row (152 entries)
+    lo, hi = int(ro[row]), int(ro[row + 1])
+    assert hi - lo > 100
+
+    def scribble(cols, must_object=True):
+        misses = cfg.last_stats()["numeric_reruns"]
+        assert L.speck_dcsr_update(C_.byref(dC._c), None, np.ascontiguousarray(cols).ctypes.data, None, 8) == 0
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["numeric_reruns"] == misses + (1 if must_object else 0)
+        _assert_matches_oracle(dC, A, B)
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["pred_stages"] == 31
+        _assert_matches_oracle(dC, A, B)
+
+    scribble(good.col_ids.copy(), must_object=False)             # what is there: kept
+    c = good.col_ids.copy()
+    c[lo + 10], c[lo + 11] = c[lo + 11], c[lo + 10]
+    scribble(c)                                                  # the same set, out of order
+    c = good.col_ids.copy()
+    c[lo + 20] = c[lo + 19]
+    scribble(c)                                                  # one column id twice (and one missing)
+    c = good.col_ids.copy()
+    c[lo + 5] += 1 if c[lo + 5] + 1 < c[lo + 6] else 0
+    if (c != good.col_ids).any():
+        scribble(c)                                              # a column id the row does not have
+    scribble(np.full(good.nnz, 0xFFFFFFF0, dtype=np.uint32))     # junk everywhere
+
+
 def test_sequence_of_an_input_without_register_class_rows_is_one_numeric_launch(cfg):
     """nlpkkt-like rows (hundreds of products each, no register-class row, no numeric-first row): from its second replay on
     the sequence has no scan and no symbolic launch at all -- the numeric light launch verifies every row length."""
@@ -1769,6 +1814,8 @@ def test_a_captured_sequence_owns_its_prediction(cfg):
     Bg = to_po(sa.gen_matrix("cant", 0.08, 8, signed=True))   # numeric-first rows, other sizes
     dA, dC = sa.dCSR.from_host(to_sa(A)), sa.dCSR()
     dB, dD = sa.dCSR.from_host(to_sa(Bg)), sa.dCSR()
+    sa.MultiplyspECK(dB, dB, dD, cfg)    # (the config's scratch arena is sized for the larger problem from the start: a
+    dD = sa.dCSR()                       #  grown arena is a new arena, and nothing captured against the old one survives)
     for _ in range(4):
         sa.MultiplyspECK(dA, dA, dC, cfg)
     st = cfg.last_stats()
