@@ -411,10 +411,12 @@ __device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, u32* keys, Acc<T>*
 #ifndef SPECK_EMIT_BY_PREVIOUS
 #define SPECK_EMIT_BY_PREVIOUS 1
 #endif
-template <class G, typename T, u32 CAP>
+// PF > 0: the previous column ids (and their left neighbours) were requested when the row was opened -- PF per lane, in
+// registers -- so that their round trip to memory runs beside the product walk instead of behind it.
+template <class G, typename T, u32 CAP, u32 PF = 0>
 __device__ __forceinline__ u32 emit_by_previous(const G& g, const u32* keys, const Acc<T>* vals, u32 cap_row, u32 bits,
                                                 u32 base, u32 nnz, const u32* c_col_prev, T* __restrict__ c_val,
-                                                u32* scratch)
+                                                u32* scratch, const u32* pf_col = nullptr, const u32* pf_left = nullptr)
 {
     constexpr u32 OWN = CAP / G::SIZE;
     u32 mine = 0;
@@ -425,9 +427,20 @@ __device__ __forceinline__ u32 emit_by_previous(const G& g, const u32* keys, con
     const bool go = cnt == nnz;  // (uniform for the group; both reductions stay outside the branch: DPP)
     const u32 mask = cap_row - 1u;
     u32 bad = 0;
-    for (u32 i = g.lane; go && i < nnz; i += G::SIZE) {
-        const u32 col = c_col_prev[size_t(base) + i];
-        if (i && c_col_prev[size_t(base) + i - 1] >= col) bad = 1;
+    u32 e = 0;
+    for (u32 i = g.lane; go && i < nnz; i += G::SIZE, ++e) {
+        u32 col, left;
+        if constexpr (PF > 0) {
+            // (e is a compile-time index after unrolling: PF <= 8)
+            col = 0, left = 0;
+#pragma unroll
+            for (u32 q = 0; q < PF; ++q)
+                if (q == e) col = pf_col[q], left = pf_left[q];
+        } else {
+            col = c_col_prev[size_t(base) + i];
+            left = i ? c_col_prev[size_t(base) + i - 1] : 0u;
+        }
+        if (i && left >= col) bad = 1;
         u32 slot = (col * 0x9E3779B1u) >> (32u - bits);
         u32 k = keys[slot];
         if (k != col && k != kEmptyKey) {
@@ -470,7 +483,12 @@ constexpr u32 num_group_lds()
 // nnz -- table size, room in C -- is what the previous identical call found.  The body stays inside the table (bounded
 // probing) and inside the row's room whatever B holds now, counts what the table ends up with and raises capacity_miss if
 // that is not the nnz it was given: the host then takes the eager path, as after any other rejected replay.
-template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0, bool VERIFY = false>
+// KEEP: the row's previous column ids are kept if they are the table's keys (emit_by_previous) instead of sorted again.
+// (Only in the verifying launches: measured for EVERY replayed sequence -- a symbolic pass gives the exact nnz, C holds the
+//  previous result there as well -- the latency-bound light launches of the short-row inputs did not gain: scircuit
+//  22.3 -> 23.1 us with the columns read at emit time, 22.2 -> 22.8 us with them requested when the row is opened.)
+template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0, bool VERIFY = false,
+          bool KEEP = VERIFY>
 __device__ __forceinline__ void num_hash_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                               u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
                                               u32 bidx, u32 nblk, ClassHint hint = kNoHint)
@@ -519,6 +537,17 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         }
         g.sync();
         PHASE_MARK(0);
+        // (KEEP: the row's previous column ids, requested now -- emit_by_previous)
+        constexpr u32 PF = (KEEP && SPECK_EMIT_BY_PREVIOUS && (NMAX + G::SIZE - 1) / G::SIZE <= 8) ? (NMAX + G::SIZE - 1) / G::SIZE : 0;
+        u32 pf_col[PF ? PF : 1], pf_left[PF ? PF : 1];
+        if constexpr (PF > 0) {
+#pragma unroll
+            for (u32 q = 0; q < PF; ++q) {
+                const u32 i = q * G::SIZE + g.lane;
+                pf_col[q] = i < rec.nnz ? c_col[size_t(rec.base) + i] : 0u;
+                pf_left[q] = (i && i < rec.nnz) ? c_col[size_t(rec.base) + i - 1] : 0u;
+            }
+        }
         bool gave_up = false;
         for_each_product<true>(g, src, rec.a0, rec.a1, meta, scan_scratch,
                                [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
@@ -529,9 +558,10 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
                                }, cls);
         PHASE_MARK(1);
         u32 found;
-        if constexpr (VERIFY && SPECK_EMIT_BY_PREVIOUS) {
+        if constexpr (KEEP && SPECK_EMIT_BY_PREVIOUS) {
             g.sync();
-            found = emit_by_previous<G, T, CAP>(g, keys, vals, cap_row, bits, rec.base, rec.nnz, c_col, c_val, scan_scratch);
+            found = emit_by_previous<G, T, CAP, PF>(g, keys, vals, cap_row, bits, rec.base, rec.nnz, c_col, c_val, scan_scratch,
+                                                    pf_col, pf_left);
         } else if constexpr (MODE == SORT_RANK) {
             // scratch: the compacted keys over the table's keys, their slot numbers over the A-row staging
             // the groups of a wave take the same sort (no wave ever runs both)
@@ -546,8 +576,9 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
             found = emit_bitmap_sorted<G, T, CAP, W1, NMAX, G::kIsBlock, VERIFY>(g, keys, vals, S, scan_scratch, cap_row, rec.cmin,
                                                                                  rec.cmax, rec.base, c_col, c_val, cls, rec.nnz);
         }
-        if constexpr (VERIFY) {
-            // (any lane: a key that found no slot, or a table that holds another number of entries than the row was given)
+        if constexpr (VERIFY || (KEEP && SPECK_EMIT_BY_PREVIOUS)) {
+            // (any lane: a key that found no slot, a table that holds another number of entries than the row was given,
+            //  previous column ids that are not the table's keys)
             if (gave_up || found != rec.nnz) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
         }
         g.sync();
