@@ -408,6 +408,9 @@ __device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, u32* keys, Acc<T>*
 // columns strictly ascending and all of them found  <=>  the same set of columns: C.col_ids is right as it stands.  Anything
 // else (a caller that scribbled over C, a structure that changed) is a mismatch like any other: capacity_miss, eager re-run.
 // Returns the number of entries in the table, or 0xFFFFFFFF if a previous column is missing or out of order.
+#ifndef SPECK_PF_MAX
+#define SPECK_PF_MAX 14  // (the 8 Ki-table rows: 98 VGPRs with 14 + 14 prefetched ids, no sort registers; webbase -2.5 %)
+#endif
 #ifndef SPECK_EMIT_BY_PREVIOUS
 #define SPECK_EMIT_BY_PREVIOUS 1
 #endif
@@ -538,7 +541,7 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         g.sync();
         PHASE_MARK(0);
         // (KEEP: the row's previous column ids, requested now -- emit_by_previous)
-        constexpr u32 PF = (KEEP && SPECK_EMIT_BY_PREVIOUS && (NMAX + G::SIZE - 1) / G::SIZE <= 8) ? (NMAX + G::SIZE - 1) / G::SIZE : 0;
+        constexpr u32 PF = (KEEP && SPECK_EMIT_BY_PREVIOUS && (NMAX + G::SIZE - 1) / G::SIZE <= SPECK_PF_MAX) ? (NMAX + G::SIZE - 1) / G::SIZE : 0;
         u32 pf_col[PF ? PF : 1], pf_left[PF ? PF : 1];
         if constexpr (PF > 0) {
 #pragma unroll
