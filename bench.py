@@ -3,33 +3,32 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload scircuit|...] [--scaling weak|strong]
 
-One "step" = one complete MultiplyspECK call (analysis -> binning -> symbolic -> scan ->
-numeric, output matrix reused across steps exactly like the reference's benchmark loop,
-source/Executor.cpp:43-72) with A and B already resident in HBM.
+One "step" = one COMPLETE MultiplyspECK call with A and B resident in HBM and the output matrix reused across
+steps (the reference's benchmark loop, source/Executor.cpp:43-72): analysis -> binning -> symbolic -> scan ->
+allocation check -> numeric (+ in-kernel sort), every stage inside the timed region, as the reference runs them in
+every iteration (source/GPU/Multiply.cu:488-575, 835-1043).  `value` / `ms_per_step` are THAT call (library option
+use_graph = 0).  The structure-reuse mode of a repeated identical call (the replayed sequence) is
+reported beside it as `value_reuse` / `ms_reuse` at N = 1 and is never the metric.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): rows of A are sharded by the
-analysis pass' product counts, B is replicated, and every step has ONE exchange: the gatherv of
-the C shards to rank 0 over RCCL (speck_amd/sharding.py).  The exchange of step k is posted
-when its multiply ends and runs while step k+1 multiplies (two output matrices alternate; the
-timed region ends only when the last exchange has completed on every rank).
-  --scaling weak   (default) the matrix has N x the rows of the 1-GPU workload: per-GPU work fixed
-  --scaling strong the SAME matrix at every N (BASELINE.json configs[4]: nlpkkt160 at 1/2/4/8)
-`value` always includes the exchange; `multiply_only` is the same K steps with C left row-sharded.
-Unless --no-config5 is given the line also carries `config5`: a short strong-scaling measurement
-of the nlpkkt160 stand-in at this N (value with the exchange + multiply_only), so that the
-driver's `--gpus 1,2,4,8` sweep yields that curve without extra flags.
-At N = 1 the line also carries `configs`: every single-GPU configuration of BASELINE.json (scircuit, webbase,
-mac_econ, cant) with its own ms_per_step / eager_ms_per_step / value / roofline (--no-configs skips them).
+stdout carries ONE JSON line (<= 4 KB, no prose).  Everything else -- every launch with bytes / duration / ceilings,
+rows per class, the verification details of every leg -- goes to --detail (default bench_detail.json next to this
+file; scripts/check_launch_ms.py and the profiles/ regeneration read that).
 
-The output of the LAST timed step -- the replayed launch sequence -- is downloaded and checked (the reference
-compares after every iteration, source/Executor.cpp:51-55, 67-71): against the CPU oracle in full (indices
-bit-exact, values within 1e-12 * sum|a*b|), the nlpkkt leg through size-independent properties on the device
-plus the oracle on sampled row blocks (oracle/verify.py).  `verified` is false -- and the exit code non-zero --
-if any check fails (--no-verify skips them: `verified` is then null).
+N > 1 (torch.distributed.run, or started here when no launcher did): rows of A are sharded by the analysis pass'
+product counts, B is replicated, every step ends with ONE exchange: the gatherv of the C shards to rank 0
+(speck_gather_* of the C ABI over RCCL).  `value` includes the exchange, `multiply_only` is the same steps with C
+left row-sharded.  --scaling weak (default): N x the rows; --scaling strong: the same matrix at every N.
+Unless --no-config5 the line carries `config5`: the nlpkkt160 stand-in, strong scaling, at this N.
+At N = 1 the line carries `configs`: the other single-GPU configurations of BASELINE.json, one short object each.
 
-Inputs: $SPECK_MTX_DIR/<name>.mtx (scircuit, webbase-1M, mac_econ_fwd500, cant, nlpkkt160) is used
-when present ("data": "suitesparse"); SuiteSparse files do not exist offline, so the default is the
-stand-in of SURVEY.md 8d fitted to the original's n / nnz / P / nnz(C) ("data": "synthetic").
+The output of the LAST timed step is downloaded and checked (the reference compares after every iteration,
+source/Executor.cpp:51-55, 67-71): against the CPU oracle in full (indices bit-exact, values within
+1e-12 * sum|a*b|), the nlpkkt leg through size-independent properties on the device plus the oracle on sampled row
+blocks (oracle/verify.py).  `verified` is false -- and the exit code 3 -- if any check of any leg fails.
+
+Inputs: $SPECK_MTX_DIR/<name>.mtx (scircuit, webbase-1M, mac_econ_fwd500, cant, nlpkkt160) is used when present
+("data": "suitesparse"); SuiteSparse files do not exist offline, so the default is the stand-in of SURVEY.md 8d
+fitted to the original's n / nnz / P / nnz(C) ("data": "synthetic").
 """
 import argparse
 import json
@@ -54,11 +53,16 @@ L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XC
 # LDS atomic issue ceiling, wave-instructions per second for the whole chip: ds_add_f64 takes 20.6 cycles per
 # wave-instruction and CU (scripts/ubench/lds_atomics.hip); 256 CUs at 2.4 GHz
 LDS_ATOMIC_PEAK_GWPS = 256 * 2.4 / 20.6
+# VALU issue ceiling: a wave64 instruction occupies its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
+VALU_PEAK_GWPS = 256 * 4 * 2.4 / 4
 SUITESPARSE_FILES = {"scircuit": "scircuit", "webbase": "webbase-1M", "mac_econ": "mac_econ_fwd500",
                      "cant": "cant", "nlpkkt": "nlpkkt160"}
-# numeric launches as bench.py names them -> key in profiles/traffic.json (scripts/make_traffic.py)
-TRAFFIC_KEYS = {"light": "num_light", "tiny": "num_tiny", "fused_light": "sym_light_fused", "block8k": "num_block8k", "dense16k": "num_dense16k",
-                "global": "num_global", "numeric_first": "num_numeric_first"}
+# numeric launches of the COMPLETE call as bench.py names them -> key in profiles/{traffic,counters}.json
+# (scripts/make_counters.py; the kernels of the reuse mode carry names of their own and other keys)
+COUNTER_KEYS = {"light": "num_light", "numeric_first": "num_numeric_first", "nfcopy": "num_nfcopy", "block8k": "num_block8k",
+                "dense16k": "num_dense16k", "global": "num_global_reduce"}
+# the classes of the merged 256-thread numeric launch (num_light_kernel)
+LIGHT = ("dense4k", "block2k", "wave512", "wave256", "r64", "r32", "wave128", "g16", "g8", "g4", "direct")
 
 
 class _DevArray:
@@ -93,7 +97,7 @@ def load_workload(workload, scale, seed, mtx=None):
     if path:
         return sa.load_matrix(path, write_cache=False), "suitesparse", os.path.basename(path)
     A = sa.gen_matrix(workload, scale, seed, signed=True)
-    return A, "synthetic", f"{workload}-like A*A (SURVEY 8d stand-in, fitted to n/nnz/P/nnzC)"
+    return A, "synthetic", f"{workload}-like A*A (SURVEY 8d stand-in)"
 
 
 class Env:
@@ -214,8 +218,8 @@ class Job:
         else:
             self.mine = self.dA
         self.gather = gather and env.world > 1
-        # N > 1: two output matrices (each with its own config: a captured launch sequence is tied to
-        # the buffers it writes) alternate, so that a shard can be sent while the next one is computed
+        # N > 1: two output matrices (each with its own config) alternate, so that a shard can be sent while the
+        # next one is computed
         self.slots = [(self.cfg, sa.dCSR(A.data.dtype))]
         if self.gather:
             self.slots.append((env.new_config(), sa.dCSR(A.data.dtype)))
@@ -224,7 +228,9 @@ class Job:
         self.last = None  # (config, output matrix) of the last step
         self.bounds = (0, A.rows) if env.world == 1 else (bounds[env.rank], bounds[env.rank + 1])
 
-    def set_graph(self, on):
+    def set_reuse(self, on):
+        """on: a repeated identical call may run the structure-reuse sequence (library option use_graph);
+        off: every call is the complete pipeline."""
         for scfg, _ in self.slots:
             scfg.set_option("use_graph", int(on))
 
@@ -286,106 +292,74 @@ class Job:
             scfg.cleanup()
 
 
-def profile_prepass(job, split, merged, prof_steps=5):
-    """Untimed steps with HIP events, each recorded on the stream the launch runs on.  One eager call collects the
-    algorithmic bytes per class; then the launches of the REPLAYED sequence -- the one the timed region replays as
-    a graph -- run uncaptured (library option profile_replay) with events around every launch, then with events
-    around the phases only."""
+def profile_prepass(job, prof_steps=5):
+    """Untimed COMPLETE calls with HIP events, each recorded on the stream the launch runs on (the light launches and
+    the numeric-first one carry kernel-exact begin / end stamps).  One call collects the algorithmic bytes per class;
+    prof_steps calls with events around every launch; prof_steps calls with one event pair per phase only."""
     cfg = job.cfg
+    job.step()                           # (allocates C; the next calls are sized from this one like the timed ones)
     cfg.profile_kernels(1)
-    cfg.set_option("collect_bytes", 1)   # per-class algorithmic bytes: one call is enough
+    cfg.set_option("collect_bytes", 1)   # per-class algorithmic bytes (SURVEY 8d, per row): one call is enough
     job.step()
     torch.cuda.synchronize()
     st = cfg.last_stats()
     cfg.set_option("collect_bytes", 0)
-    cfg.profile_kernels(0)
-    job.step()                           # (an eager call without the byte model: what the replay is specialised to)
-    cfg.set_option("profile_replay", 1)
-    cfg.profile_kernels(1)
-    # the 256-thread numeric classes run as ONE launch ("light": num_light_kernel), or with option split_light=1
-    # as two ("light": the big-LDS classes, "tiny": num_tiny_kernel); the other classes launch separately
-    LIGHT, TINY = ("dense4k", "block2k", "wave512", "wave256"), ("r64", "r32", "wave128", "g16", "g8", "g4", "direct")
-    if not split:
-        LIGHT, TINY = LIGHT + TINY, ()
-    SYM_LIGHT = ("bitmap256k", "block4k", "wave1k", "wave256", "r64", "r32", "wave128", "g16", "g8", "g4")
-    ESC = ("g4", "g8", "g16", "r32", "r64")   # the register classes: finished in the symbolic phase of a fused replay
-    job.step()   # (the first replayed call still has a scan kernel: what is timed below is the sequence from its second replay on)
-    kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "tiny", "numeric_first", "fused_light"]}
-    sym_ms = num_ms = 0.0
-    fused = False
-    self_verified = False   # pred_stages bit 4: no symbolic pass for the hash / dense rows (their numeric bodies verify the nnz)
+    kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "numeric_first"]}
+    stage_ms = {"analysis_binning": 0.0, "scan": 0.0, "sym_light": 0.0}
     for _ in range(prof_steps):
         job.step()
         s = cfg.last_stats()
-        fused = s["esc_fused"]
-        self_verified = bool(s["pred_stages"] & 16)
         for k in NUM_CLASS_NAMES:
             kernel_ms[k] += s["num_bin_ms"][k] / prof_steps
-        kernel_ms["light"] += s["num_light_ms"] / prof_steps
-        kernel_ms["tiny"] += s["num_tiny_ms"] / prof_steps
-        # numeric-first rows: their NUMERIC kernel runs inside the symbolic phase (DESIGN.md 4.5); it is
-        # accounted as a numeric launch, the symbolic phase is what remains
-        nf = s["sym_bin_ms"]["numeric_first"] if s["sym_bin_rows"]["numeric_first"] else 0.0
-        kernel_ms["numeric_first"] += nf / prof_steps
-        # ... and so is the symbolic light launch of a sequence that finishes the rows of the register classes
-        # in it (DESIGN.md 4.6): it moves their numeric bytes, plus the symbolic bytes of its other classes
-        if fused:
-            kernel_ms["fused_light"] += (s["sym_light_ms"] + s["sym_tiny_ms"]) / prof_steps
-    # the phases, timed WITHOUT an event between their class launches (mode 2: one event pair per phase; an
-    # event record between two launches of a phase costs each a few us the replayed sequence does not pay)
+        kernel_ms["light"] += (s["num_light_ms"] + s["num_tiny_ms"]) / prof_steps
+        # numeric-first rows: their NUMERIC kernel runs inside the symbolic phase (DESIGN.md 4.5) -- a numeric launch
+        if s["sym_bin_rows"]["numeric_first"]:
+            kernel_ms["numeric_first"] += s["sym_bin_ms"]["numeric_first"] / prof_steps
+        stage_ms["analysis_binning"] += s["analysis_ms"] / prof_steps
+        stage_ms["scan"] += s["scan_ms"] / prof_steps
+        stage_ms["sym_light"] += (s["sym_light_ms"] + s["sym_tiny_ms"]) / prof_steps
+    # the phases, WITHOUT an event between their class launches (mode 2: one event pair per phase)
     cfg.profile_kernels(2)
-    in_sym_ms = kernel_ms["numeric_first"] + kernel_ms["fused_light"]
+    sym_ms = num_ms = 0.0
     for _ in range(prof_steps):
         job.step()
         s = cfg.last_stats()
-        sym_ms += (s["analysis_ms"] + s["scan_ms"] + max(s["sym_phase_ms"] - in_sym_ms, 0.0)) / prof_steps
-        num_ms += (s["num_phase_ms"] + in_sym_ms) / prof_steps
-    kernel_bytes = dict(st["num_bin_bytes"])
-    # the algorithmic bytes of the numeric-first rows belong to the launch that computes them; the
-    # copy of the finished rows into C is extra traffic outside the model (listed by time only)
-    kernel_bytes["numeric_first"] = kernel_bytes.pop("nfcopy")
-    if fused:
-        kernel_bytes["fused_light"] = (sum(kernel_bytes.pop(k) for k in ESC) +
-                                       (0 if self_verified else sum(st["sym_bin_bytes"][k] for k in SYM_LIGHT if k not in ESC)))
-        for k in ESC:
-            kernel_bytes[k] = 0
-    if merged:
-        kernel_bytes["light"] = sum(kernel_bytes.pop(k) for k in LIGHT)
-        kernel_bytes["tiny"] = sum(kernel_bytes.pop(k) for k in TINY)
+        # symbolic = analysis + binning + symbolic launches + scan (the reference's countProducts + loadBalanceCounting
+        # + globalMapsCounting + spGEMMCounting, SURVEY 8d); the numeric-first kernel is numeric work inside it
+        sym_ms += (s["analysis_ms"] + s["sym_phase_ms"] + s["scan_ms"] - kernel_ms["numeric_first"]) / prof_steps
+        num_ms += (s["num_phase_ms"] + kernel_ms["numeric_first"]) / prof_steps
     cfg.profile_kernels(0)
-    cfg.set_option("profile_replay", 0)
+    kernel_bytes = dict(st["num_bin_bytes"])
+    # the algorithmic bytes of the numeric-first rows belong to the launch that computes them; the copy of the
+    # finished rows into C is extra traffic outside the model (listed by time only)
+    kernel_bytes["numeric_first"] = kernel_bytes.pop("nfcopy")
+    kernel_bytes["light"] = sum(kernel_bytes.pop(k) for k in LIGHT)
     st["num_bin_bytes"] = kernel_bytes
-    st["esc_fused"] = fused
-    st["self_verified"] = self_verified
-    return st, kernel_ms, sym_ms, num_ms
+    return st, kernel_ms, stage_ms, sym_ms, num_ms
 
 
 def ceilings_for(counters, workload, launch_name, ms):
     """Secondary ceilings of one launch from the committed rocprofv3 --pmc passes of the same command
     (profiles/counters.json; NOT measured in this run -- only the duration is): HBM-side bytes, L1 -> L2 requests,
-    LDS atomic wave-instructions, VALU issue."""
-    c = counters.get(f"{workload}:{TRAFFIC_KEYS.get(launch_name, 'num_' + launch_name)}")
+    LDS atomic wave-instructions, VALU wave-instructions -- each as a fraction of its peak over `ms`.  A fraction
+    above 1 means counters and duration do not belong together: dropped (None), never printed."""
+    c = counters.get(f"{workload}:{COUNTER_KEYS.get(launch_name, 'num_' + launch_name)}")
     if not c or ms <= 0:
         return None
     sec = ms * 1e-3
     out = {}
     if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
         hbm = (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024
-        out["hbm_measured_GBps"] = round(hbm / sec / 1e9, 1)
-        out["hbm_measured_frac"] = round(hbm / sec / 1e9 / HBM_PEAK_GBS, 4)
+        out["hbm_measured_frac"] = hbm / sec / 1e9 / HBM_PEAK_GBS
     if "TCP_TCC_READ_REQ_sum" in c:
         l2 = (c.get("TCP_TCC_READ_REQ_sum", 0) + c.get("TCP_TCC_WRITE_REQ_sum", 0)) * 64
-        out["l2_GBps"] = round(l2 / sec / 1e9, 1)
-        out["l2_frac"] = round(l2 / sec / 1e9 / L2_PEAK_GBS, 4)
+        out["l2_frac"] = l2 / sec / 1e9 / L2_PEAK_GBS
     if "SQ_INSTS_LDS_ATOMIC" in c:
-        g = c["SQ_INSTS_LDS_ATOMIC"] / sec / 1e9
-        out["lds_atomic_Gwaveinst_per_s"] = round(g, 3)
-        out["lds_atomic_frac"] = round(g / LDS_ATOMIC_PEAK_GWPS, 4)
-    if c.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in c:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, SQ_BUSY_CYCLES per SE: report the raw ratio
-        # per SIMD-cycle as the guide's VALUBusy does (4 SIMDs per CU)
-        out["valu_insts_per_launch"] = int(c.get("SQ_INSTS_VALU", 0))
-    if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"]:
+        out["lds_atomic_frac"] = c["SQ_INSTS_LDS_ATOMIC"] / sec / 1e9 / LDS_ATOMIC_PEAK_GWPS
+    if "SQ_INSTS_VALU" in c:
+        out["valu_frac"] = c["SQ_INSTS_VALU"] / sec / 1e9 / VALU_PEAK_GWPS
+    out = {k: (round(v, 4) if v <= 1.0 else None) for k, v in out.items()}
+    if c.get("SQ_LDS_IDX_ACTIVE"):
         out["lds_bank_conflict_ratio"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 3)
     return out or None
 
@@ -395,10 +369,16 @@ def b_num_bytes(rows, nnz_a, products, nnz_c, vsize=8):
     return 4 * (rows + 1) + (4 + vsize) * nnz_a + 8 * nnz_a + (4 + vsize) * products + 4 * (rows + 1) + (4 + vsize) * nnz_c
 
 
-def roofline_block(workload, st, kernel_ms, num_ms, b_num=None):
-    """Every numeric launch with its algorithmic bytes, duration and fraction of the HBM peak; the
-    headline `kernel` is the launch with the LONGEST duration (it bounds the phase), `largest` the one
-    that moves the most algorithmic bytes."""
+def _load_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    return json.load(open(p)) if os.path.exists(p) else {}
+
+
+def roofline_blocks(workload, st, kernel_ms, num_ms, b_num):
+    """(compact object for the line, full object for the detail file).  Every numeric launch of the complete call with
+    its algorithmic bytes (SURVEY 8d's per-row model summed over the rows of its classes, computed on the device),
+    its duration and the fraction of the HBM peak; the line's kernel is the launch with the LONGEST duration (it
+    bounds the phase).  `bound` = the measured ceiling with the highest fraction of its peak."""
     launches = []
     for name, b in st["num_bin_bytes"].items():
         ms = kernel_ms.get(name, 0.0)
@@ -409,66 +389,50 @@ def roofline_block(workload, st, kernel_ms, num_ms, b_num=None):
                          "frac": round(gbs / HBM_PEAK_GBS, 4)})
     launches.sort(key=lambda x: -x["ms"])
     if not launches:
-        return None
-    traffic_tab, tsrc = {}, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        traffic_tab = json.load(open(tpath))
-        tsrc = traffic_tab.get("_source")
-    counters, csrc = {}, None
-    cpath = os.path.join(ROOT, "profiles", "counters.json")
-    if os.path.exists(cpath):
-        counters = json.load(open(cpath))
-        csrc = counters.get("_source")
+        return None, None
+    traffic_tab, counters = _load_json("traffic.json"), _load_json("counters.json")
     for x in launches:
         x["ceilings"] = ceilings_for(counters, workload, x["name"], x["ms"])
-    dom, big = launches[0], max(launches, key=lambda x: x["bytes"])
-    traffic = traffic_tab.get(f"{workload}:{TRAFFIC_KEYS.get(dom['name'], 'num_' + dom['name'])}")
-    total_bytes = sum(x["bytes"] for x in launches)
-    return {
-        "bound": "hbm", "kernel": f"numeric:{dom['name']}", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
-        "traffic_source": (tsrc or "profiles/traffic.json") + " (separate rocprofv3 --pmc passes of the same "
-                          "command, (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch; not measured in this run)"
-        if traffic is not None else None,
-        "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": dom["ms"],
-        "selected_by": "longest numeric launch (HIP events on the launch's own stream)",
-        "timed_with": "HIP events of the launches of the replayed sequence, run uncaptured on the pipeline's own streams "
-                      "(library option profile_replay) in an untimed pre-pass of the same process; the light launches "
-                      "and the numeric-first launch carry their own begin / end stamps (hipExtLaunchKernelGGL), the other "
-                      "launches are bracketed by two event records",
-        "largest": {"kernel": f"numeric:{big['name']}", "bytes": big["bytes"], "ms": big["ms"], "frac": big["frac"]},
-        # the PHASE by SURVEY 8(d)'s B_num alone (the north star's ">= 40 % on the numeric phase"); the launches above may
-        # carry more: a fused light launch also moves the symbolic bytes of the classes it only counts
-        "numeric_phase_frac": round((b_num if b_num else total_bytes) / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
-        "numeric_phase_bytes": int(b_num if b_num else total_bytes),
-        "numeric_phase_ms": round(num_ms, 5),
-        "numeric_phase_frac_by_launch_bytes": round(total_bytes / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
-        "ceilings": dom["ceilings"],
-        "ceilings_source": ((csrc or "profiles/counters.json") + ": separate rocprofv3 --pmc passes of the same command "
-                            "(counts per launch) over the duration measured in this run; peaks: HBM 8 TB/s, L2 34.5 TB/s "
-                            "(MI355X_MICROARCH.md), LDS atomics 29.8 G wave-instructions/s (ds_add_f64 microbenchmark)")
-        if dom["ceilings"] else None,
-        "launches": launches,
+        x["traffic"] = traffic_tab.get(f"{workload}:{COUNTER_KEYS.get(x['name'], 'num_' + x['name'])}")
+    dom = launches[0]
+    ceil = dom["ceilings"] or {}
+    named = {"hbm": ceil.get("hbm_measured_frac"), "l2": ceil.get("l2_frac"), "lds_atomic": ceil.get("lds_atomic_frac"),
+             "valu": ceil.get("valu_frac")}
+    named = {k: v for k, v in named.items() if v is not None}
+    bound = max(named, key=named.get) if named else "hbm"
+    phase_frac = round(b_num / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)
+    compact = {
+        "bound": bound, "kernel": f"numeric:{dom['name']}", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": dom["frac"], "traffic": dom["traffic"], "bytes": dom["bytes"], "avg_launch_ms": dom["ms"],
+        "hbm_measured_frac": ceil.get("hbm_measured_frac"), "l2_frac": ceil.get("l2_frac"),
+        "lds_atomic_frac": ceil.get("lds_atomic_frac"), "valu_frac": ceil.get("valu_frac"),
+        "numeric_phase_frac": phase_frac,
     }
+    full = dict(compact, launches=launches, numeric_phase_bytes=int(b_num), numeric_phase_ms=round(num_ms, 5),
+                counters_source=counters.get("_source"), traffic_source=traffic_tab.get("_source"),
+                peaks={"hbm_GBps": HBM_PEAK_GBS, "l2_GBps": L2_PEAK_GBS, "lds_atomic_Gwaveinst_per_s": round(LDS_ATOMIC_PEAK_GWPS, 2),
+                       "valu_Gwaveinst_per_s": VALU_PEAK_GWPS})
+    return compact, full
 
 
-def verify_last_output(env, job, A, mode):
+def verify_last_output(env, job, A, mode, cache):
     """Check the output matrix of the last step of `job` (this rank's row shard).  mode "oracle": the whole
-    shard against the CPU oracle; "properties": device-side properties + the oracle on sampled row blocks."""
+    shard against the CPU oracle; "properties": device-side properties + the oracle on sampled row blocks.
+    `cache` keeps the oracle's product between the two checks of a leg (complete call, reuse mode)."""
     from oracle import verify as ov
     scfg, sC = job.last
     r0, r1 = job.bounds
     st = scfg.last_stats()
-    info = {"mode": mode, "checked": "output of the last timed step", "replayed": st["replayed"],
-            "nf_direct": st["nf_direct"], "esc_fused": st["esc_fused"], "pred_stages": st["pred_stages"]}
+    info = {"mode": mode, "replayed": st["replayed"], "pred_stages": st["pred_stages"], "eager_speculated": st["eager_speculated"]}
     try:
         if mode == "oracle":
             got = sC.to_host()
             from oracle import pyoracle as po
-            H = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data)
-            ok, d = ov.compare_with_oracle(H.row_slice(r0, r1) if (r0, r1) != (0, A.rows) else H, H,
-                                           got.row_offsets, got.col_ids, got.data)
+            if "ref" not in cache:
+                H = po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data)
+                cache["ref"] = po.spgemm_f64_of(H.row_slice(r0, r1) if (r0, r1) != (0, A.rows) else H, H)
+            ok, d = ov.compare_with_reference(cache["ref"], got.row_offsets, got.col_ids, got.data,
+                                              ov.TOL32 if A.data.dtype == np.float32 else ov.TOL64)
         else:
             ro, col, val = shard_tensors(sC)
             ok, d = ov.device_properties(torch, job.t_ro, job.t_col, job.t_val, r0, r1, ro, col, val, A.cols)
@@ -480,32 +444,32 @@ def verify_last_output(env, job, A, mode):
         ok = False
         info["error"] = repr(e)
     info["ok"] = bool(ok)
+    info["ok_all_ranks"] = env.sum_over_ranks(0 if ok else 1)[0] == 0
     return info
 
 
-def measure(env, A, steps, warmup, gather, profile, verify=None, eager=False):
-    """Returns (result dict on every rank)."""
+def measure(env, A, steps, warmup, gather, profile, verify=None, reuse=False):
+    """One leg.  Returns a result dict on every rank: the COMPLETE call timed (`ms_per_step`), and with `reuse` the
+    structure-reuse mode of the same repeated call beside it (`ms_reuse`)."""
     job = Job(env, A, gather)
+    job.set_reuse(False)
     out = {}
     if profile:
-        merged = not any(n == "merge_light" and v == "0" for n, v in env.opts)
-        split = any(n == "split_light" and v == "1" for n, v in env.opts)
-        st, kernel_ms, sym_ms, num_ms = profile_prepass(job, split, merged)
-        out.update(st=st, kernel_ms=kernel_ms, sym_ms=sym_ms, num_ms=num_ms)
+        st, kernel_ms, stage_ms, sym_ms, num_ms = profile_prepass(job)
+        out.update(st=st, kernel_ms=kernel_ms, stage_ms=stage_ms, sym_ms=sym_ms, num_ms=num_ms)
     else:
         job.step()
         out["st"] = job.cfg.last_stats()
     P_local, nnzc_local = out["st"]["sum_products"], out["st"]["nnz_c"]
-    for _ in range(max(warmup, 2 * len(job.slots) + 2)):  # every slot reaches its replayed sequence
+    for _ in range(max(warmup, len(job.slots) + 1)):
         job.step()
     elapsed = job.timed(steps)
-    out["replays"] = job.cfg.last_stats()["graph_replays"]
+    out["speculated"] = job.cfg.last_stats()["eager_speculated"]
+    cache = {}
     out["verify"] = None
     if verify:
         job.drain()
-        out["verify"] = verify_last_output(env, job, A, verify)
-        bad = 0 if out["verify"]["ok"] else 1
-        out["verify"]["ok_all_ranks"] = env.sum_over_ranks(bad)[0] == 0
+        out["verify"] = verify_last_output(env, job, A, verify, cache)
     out["P"], out["nnzC"] = env.sum_over_ranks(P_local, nnzc_local)
     # the floor the exchange puts under a step at N > 1: every peer -> root transfer rides ONE xGMI link, so a step
     # cannot be shorter than the largest peer shard (row counts + column ids + values) over that link's peak
@@ -517,7 +481,6 @@ def measure(env, A, steps, warmup, gather, profile, verify=None, eager=False):
         dist.all_reduce(t)
         peers = [int(x) for i, x in enumerate(t.tolist()) if i != 0]
         out["exchange_floor_ms"] = round(max(peers) / XGMI_LINK_GBS / 1e9 * 1e3, 4) if peers else 0.0
-    out["elapsed"] = elapsed
     out["ms_per_step"] = elapsed * 1e3 / steps
     out["gflops"] = 2.0 * out["P"] / (elapsed / steps) / 1e9
     # N > 1, reported next to `value` (never instead of it): the same K steps without the exchange,
@@ -525,44 +488,53 @@ def measure(env, A, steps, warmup, gather, profile, verify=None, eager=False):
     out["multiply_only"] = None
     if job.gather:
         e2 = job.timed(steps, exchange=False)
-        out["multiply_only"] = {"value": round(2.0 * out["P"] / (e2 / steps) / 1e9, 3), "unit": "GFLOP/s",
-                                "ms_per_step": round(e2 * 1e3 / steps, 4),
-                                "note": "same steps without the gatherv (C left row-sharded); not the job metric"}
-    # the same steps WITHOUT the replayed graph: what a caller pays whose structure changes from call to call
-    out["eager_ms_per_step"] = None
-    if eager:
-        job.set_graph(False)
-        job.step(exchange=False)
+        out["multiply_only"] = {"value": round(2.0 * out["P"] / (e2 / steps) / 1e9, 3), "ms_per_step": round(e2 * 1e3 / steps, 4)}
+    # the structure-reuse mode of the same repeated call: reported beside the metric, never as it
+    out["ms_reuse"] = out["verify_reuse"] = None
+    out["replays"] = 0
+    if reuse:
+        job.set_reuse(True)
+        for _ in range(6):               # (capture, first replay, the sequence without a scan from the second replay on)
+            job.step(exchange=False)
         e3 = job.timed(steps, exchange=False)
-        out["eager_ms_per_step"] = e3 * 1e3 / steps
-        job.set_graph(True)
+        out["ms_reuse"] = e3 * 1e3 / steps
+        out["replays"] = job.cfg.last_stats()["graph_replays"]
+        if verify:
+            out["verify_reuse"] = verify_last_output(env, job, A, verify, cache)
     job.close()
     return out
 
 
-def config_entry(env, workload, wl_name, data_label, A, res, steps):
-    """One single-GPU configuration as an object of `configs` (and the body of the headline)."""
+def leg_ok(res):
+    checks = [v["ok_all_ranks"] for v in (res["verify"], res["verify_reuse"]) if v]
+    return all(checks) if checks else None
+
+
+def config_objects(workload, wl_name, data_label, A, res, steps):
+    """(short object for the line, full object for the detail file) of one single-GPU leg."""
     st = res["st"]
     vsize = 4 if A.data.dtype == np.float32 else 8
-    # (the committed counter passes are fp64 runs: an fp32 leg finds none under its own key)
-    roof = roofline_block(workload if vsize == 8 else workload + "_f32", st, res["kernel_ms"], res["num_ms"], b_num_bytes(A.rows, A.nnz, res["P"], res["nnzC"], vsize))
-    eager_ms = res["eager_ms_per_step"]
-    return {
-        "workload": wl_name, "name": workload, "data": data_label, "dtype": "f32" if vsize == 4 else "f64",
-        "rows": A.rows, "nnzA": A.nnz,
-        "products": res["P"], "nnzC": res["nnzC"], "steps": steps,
-        "ms_per_step": round(res["ms_per_step"], 4),
-        "eager_ms_per_step": round(eager_ms, 4) if eager_ms else None,
-        "value": round(res["gflops"], 3), "unit": "GFLOP/s",
-        "value_eager": round(2.0 * res["P"] / (eager_ms * 1e-3) / 1e9, 3) if eager_ms else None,
-        "phases_ms": {"symbolic": round(res["sym_ms"], 4), "numeric": round(res["num_ms"], 4)},
-        "roofline": roof,
-        "kernels_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items() if v > 0},
-        "rows_per_class": {k: v for k, v in st["num_bin_rows"].items() if v},
-        "graph_replays": res["replays"],
-        "verified": res["verify"]["ok_all_ranks"] if res["verify"] else None,
-        "verify": res["verify"],
+    key = workload if vsize == 8 else workload + "_f32"
+    compact_roof, full_roof = roofline_blocks(key, st, res["kernel_ms"], res["num_ms"],
+                                              b_num_bytes(A.rows, A.nnz, res["P"], res["nnzC"], vsize))
+    ms, ms_reuse = res["ms_per_step"], res["ms_reuse"]
+    short = {
+        "name": workload, "dtype": "f32" if vsize == 4 else "f64", "ms_per_step": round(ms, 4),
+        "ms_reuse": round(ms_reuse, 4) if ms_reuse else None, "value": round(res["gflops"], 2),
+        "value_reuse": round(2.0 * res["P"] / (ms_reuse * 1e-3) / 1e9, 2) if ms_reuse else None,
+        "roofline_frac": compact_roof["frac"] if compact_roof else None,
+        "numeric_phase_frac": compact_roof["numeric_phase_frac"] if compact_roof else None,
+        "bound": compact_roof["bound"] if compact_roof else None, "verified": leg_ok(res),
     }
+    full = dict(short, workload=wl_name, data=data_label, rows=A.rows, nnzA=A.nnz, products=res["P"], nnzC=res["nnzC"],
+                steps=steps, phases_ms={"symbolic": round(res["sym_ms"], 4), "numeric": round(res["num_ms"], 4)},
+                stages_ms={k: round(v, 5) for k, v in res["stage_ms"].items()}, roofline=full_roof,
+                kernels_ms={k: round(v, 5) for k, v in res["kernel_ms"].items() if v > 0},
+                rows_per_class={k: v for k, v in st["num_bin_rows"].items() if v},
+                sym_rows_per_class={k: v for k, v in st["sym_bin_rows"].items() if v},
+                eager_speculated=res["speculated"], graph_replays=res["replays"], verify=res["verify"],
+                verify_reuse=res["verify_reuse"])
+    return short, full, compact_roof
 
 
 def main():
@@ -571,6 +543,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="scircuit")
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64", help="value type of the headline workload")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=1)
@@ -583,19 +556,24 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the other single-GPU configurations")
     ap.add_argument("--no-verify", action="store_true", help="do not check the output of the last timed step")
     ap.add_argument("--no-f32", action="store_true", help="N=1: skip the fp32 legs (mac_econ, cant)")
+    ap.add_argument("--no-reuse", action="store_true", help="N=1: skip the structure-reuse mode beside the metric")
     ap.add_argument("--configs-steps", type=int, default=20)
     ap.add_argument("--config5-scale", type=float, default=1.0)
     ap.add_argument("--config5-steps", type=int, default=5)
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="file for everything the line omits")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (tuning)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     env = Env(args)
     n_gpus, rank = env.world, env.rank
+    reuse = n_gpus == 1 and not args.no_reuse
 
     # ---- workload (same on every rank: deterministic generator / same file, B replicated)
     scale = args.scale * (n_gpus if args.scaling == "weak" else 1)
     A, data_label, wl_name = load_workload(args.workload, scale, args.seed, args.mtx)
+    if args.dtype == "f32":
+        A = sa.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data.astype(np.float32))
     if data_label == "suitesparse" and args.scaling == "weak" and n_gpus > 1:
         args.scaling = "strong"  # a file has one size
     assert A.rows == A.cols, "A*A needs a square matrix (use the transpose for rectangular inputs)"
@@ -606,109 +584,79 @@ def main():
         return "properties" if (w == "nlpkkt" and A_.rows > 2_000_000) or A_.nnz > 40_000_000 else "oracle"
 
     res = measure(env, A, args.steps, args.warmup, gather=not args.no_gather, profile=True,
-                  verify=verify_mode(args.workload, A), eager=n_gpus == 1)
+                  verify=verify_mode(args.workload, A), reuse=reuse)
     verdicts = []
-
-    out = None
+    out, detail = None, {}
     if rank == 0:
-        head = config_entry(env, args.workload, wl_name, data_label, A, res, args.steps)
+        short, full, roof = config_objects(args.workload, wl_name, data_label, A, res, args.steps)
+        detail["headline"] = full
         out = {
             "metric": "SpGEMM GFLOP/s (2*flops_intermediate/s), A*A",
-            "value": head["value"],
-            "unit": "GFLOP/s",
-            "n_gpus": n_gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"],
-            "eager_ms_per_step": head["eager_ms_per_step"],
-            "value_eager": head["value_eager"],
-            "value_eager_note": "the same steps with the replay off (option use_graph = 0): what a caller pays whose "
-                                "structure changes from call to call; `value` is the reference's benchmark loop "
-                                "(source/Executor.cpp:59-72: same buffers every iteration), served by the replayed sequence",
-            "higher_is_better": True,
-            "scaling": args.scaling,
-            "vs_baseline": None,
-            "dtype": "f64",
+            "value": short["value"], "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": short["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": short["dtype"],
             "data": data_label if not env.shared_gpu else data_label + " (ranks share one GPU, gloo: plumbing check only)",
-            "config": {
-                "workload": wl_name, "rows": A.rows, "nnzA": A.nnz, "products": res["P"],
-                "nnzC": res["nnzC"], "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",
-                "gather": bool(n_gpus > 1 and not args.no_gather),
-                "exchange_floor_ms": res["exchange_floor_ms"],
-                "exchange_floor_note": ("largest peer shard (4 B per row + 12 B per entry of C) over one 153 GB/s xGMI link: "
-                                        "`value` includes the gatherv and cannot beat it; the >= 6x row-sharded speed-up of "
-                                        "the north star is a statement about `multiply_only`") if n_gpus > 1 else None,
-                "exchange_note": env.exchange_note,
-                "exchange": (f"pipelined gatherv to rank 0 ({env.exchange}: " +
-                             ("speck_gather_* of the C ABI, " + ("host-staged transport" if env.shared_gpu else "RCCL")
-                              if env.exchange == "native" else "torch.distributed") + ")")
-                if n_gpus > 1 and not args.no_gather else None,
-            },
+            "config": {"workload": wl_name, "rows": A.rows, "nnzA": A.nnz, "products": res["P"], "nnzC": res["nnzC"],
+                       "parallelism": f"rows{n_gpus}" if n_gpus > 1 else "single",
+                       "timed_call": "complete (analysis+binning+symbolic+scan+numeric+sort)"},
+            "value_reuse": short["value_reuse"], "ms_reuse": short["ms_reuse"],
             "verified": None,
-            "verify": head["verify"],
-            "parity": "oracle- and rocSPARSE-pinned (reference ships no golden vectors): indices bit-exact, "
-                      "|c - c_ref| <= 1e-12 * sum|a*b| per entry",
-            "phases_ms": dict(head["phases_ms"],
-                              note="untimed profiled pre-pass (the launches of the replayed sequence, uncaptured), one "
-                                   "HIP event pair per phase; symbolic = analysis + binning + symbolic launches + scan, "
-                                   "numeric = the launches of the symbolic phase that finish rows (numeric-first rows; "
-                                   "the light launch when it finishes the register-class rows) + fork to join of the "
-                                   "numeric launches"),
-            "roofline": head["roofline"],
-            "kernels_ms": head["kernels_ms"],
-            "rows_per_class": head["rows_per_class"],
-            "graph_replays": res["replays"],
+            "phases_ms": full["phases_ms"],
+            "roofline": roof,
         }
-        if res["multiply_only"] is not None:
+        if n_gpus > 1:
+            out["config"].update(gather=not args.no_gather, exchange_floor_ms=res["exchange_floor_ms"],
+                                 exchange=(env.exchange + (":hostmem" if env.shared_gpu else ":rccl") if env.exchange == "native"
+                                           else "torch") if not args.no_gather else None)
+            if env.exchange_note:
+                detail["exchange_note"] = out["config"]["exchange_note"] = env.exchange_note[:160]
             out["multiply_only"] = res["multiply_only"]
-        verdicts.append(head["verified"])
+        verdicts.append(short["verified"])
     del res
 
-    # ---- N = 1: every single-GPU configuration of BASELINE.json (configs[1..3]) in the same line
+    # ---- N = 1: every other single-GPU configuration of BASELINE.json (configs[1..3]), one short object each
     if n_gpus == 1 and not args.no_configs:
-        entries = []
+        entries, full_entries = [], []
         for w in ("scircuit", "webbase", "mac_econ", "cant"):
-            if w == args.workload and args.scale == 1.0 and not args.mtx:
-                entries.append(head)
+            if w == args.workload and args.scale == 1.0 and not args.mtx and args.dtype == "f64":
                 continue
             Aw, label_w, name_w = load_workload(w, 1.0, args.seed)
-            rw = measure(env, Aw, args.configs_steps, 3, gather=False, profile=True, verify=verify_mode(w, Aw),
-                         eager=True)
-            entries.append(config_entry(env, w, name_w, label_w, Aw, rw, args.configs_steps))
-            verdicts.append(entries[-1]["verified"])
+            rw = measure(env, Aw, args.configs_steps, 3, gather=False, profile=True, verify=verify_mode(w, Aw), reuse=reuse)
+            s, f, _ = config_objects(w, name_w, label_w, Aw, rw, args.configs_steps)
+            entries.append(s)
+            full_entries.append(f)
+            verdicts.append(s["verified"])
             del Aw, rw
-        out["configs"] = entries
-        # the <float, ...> instantiation (source/GPU/Multiply.cu:1130) on the two mid-density inputs: 8-byte table
-        # entries / 8 bytes per product in the byte model; checked against the product in fp64 (4 eps32 * sum|a*b|)
+        # the <float, ...> instantiation (source/GPU/Multiply.cu:1130) on the two mid-density inputs: 8 bytes per
+        # product in the byte model; checked against the product in fp64 (4 eps32 * sum|a*b|)
         if not args.no_f32:
-            f32 = []
             for w in ("mac_econ", "cant"):
                 Aw, label_w, name_w = load_workload(w, 1.0, args.seed)
                 Aw = sa.HostCSR(Aw.rows, Aw.cols, Aw.row_offsets, Aw.col_ids, Aw.data.astype(np.float32))
-                rw = measure(env, Aw, args.configs_steps, 3, gather=False, profile=True, verify=verify_mode(w, Aw),
-                             eager=True)
-                f32.append(config_entry(env, w, name_w + " (fp32 values)", label_w, Aw, rw, args.configs_steps))
-                verdicts.append(f32[-1]["verified"])
+                rw = measure(env, Aw, args.configs_steps, 3, gather=False, profile=True, verify=verify_mode(w, Aw), reuse=reuse)
+                s, f, _ = config_objects(w, name_w + " (fp32 values)", label_w, Aw, rw, args.configs_steps)
+                entries.append(s)
+                full_entries.append(f)
+                verdicts.append(s["verified"])
                 del Aw, rw
-            out["configs_f32"] = f32
+        out["configs"] = entries
+        detail["configs"] = full_entries
 
     # ---- BASELINE.json configs[4]: the nlpkkt160 stand-in, STRONG scaling, at this N
     if not args.no_config5 and not (args.workload == "nlpkkt" and args.scaling == "strong"):
         A5, label5, name5 = load_workload("nlpkkt", args.config5_scale, args.seed)
         r5 = measure(env, A5, args.config5_steps, 2, gather=not args.no_gather, profile=False,
-                     verify=verify_mode("nlpkkt", A5))
+                     verify=verify_mode("nlpkkt", A5), reuse=reuse)
         if rank == 0:
             out["config5"] = {
-                "workload": name5, "data": label5, "scaling": "strong", "n_gpus": n_gpus, "rows": A5.rows,
-                "nnzA": A5.nnz, "products": r5["P"], "nnzC": r5["nnzC"], "steps": args.config5_steps,
-                "value": round(r5["gflops"], 3), "unit": "GFLOP/s", "ms_per_step": round(r5["ms_per_step"], 4),
-                "multiply_only": r5["multiply_only"] if r5["multiply_only"] is not None else
-                {"value": round(r5["gflops"], 3), "unit": "GFLOP/s", "ms_per_step": round(r5["ms_per_step"], 4),
-                 "note": "N = 1: nothing to exchange"},
-                "exchange_floor_ms": r5["exchange_floor_ms"],
-                "verified": r5["verify"]["ok_all_ranks"] if r5["verify"] else None,
-                "verify": r5["verify"],
+                "name": "nlpkkt", "scaling": "strong", "n_gpus": n_gpus, "rows": A5.rows, "products": r5["P"],
+                "steps": args.config5_steps, "value": round(r5["gflops"], 2), "ms_per_step": round(r5["ms_per_step"], 4),
+                "value_reuse": round(2.0 * r5["P"] / (r5["ms_reuse"] * 1e-3) / 1e9, 2) if r5["ms_reuse"] else None,
+                "ms_reuse": round(r5["ms_reuse"], 4) if r5["ms_reuse"] else None,
+                "multiply_only": r5["multiply_only"], "exchange_floor_ms": r5["exchange_floor_ms"], "verified": leg_ok(r5),
             }
+            detail["config5"] = dict(out["config5"], workload=name5, data=label5, nnzA=A5.nnz, nnzC=r5["nnzC"],
+                                     verify=r5["verify"], verify_reuse=r5["verify_reuse"])
             verdicts.append(out["config5"]["verified"])
         del A5, r5
 
@@ -717,7 +665,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(A, out["config"]["products"])
         checked = [v for v in verdicts if v is not None]
         out["verified"] = all(checked) if checked else None
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out, separators=(",", ":"))
+        detail["line"] = out
+        detail["line_bytes"] = len(line)
+        try:
+            with open(args.detail, "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {args.detail}: {e}", file=sys.stderr)
+        print(line, flush=True)
     failed = rank == 0 and out["verified"] is False
     if env.comm is not None:
         env.comm.close()

@@ -1,7 +1,7 @@
 """Result checks shared by tests/ and bench.py (TEST INFRASTRUCTURE ONLY, like everything under oracle/).
 
 The reference compares the product after every iteration of its benchmark loop (source/Executor.cpp:51-55,
-67-71, against cuSPARSE); here the output of the LAST timed step -- the replayed launch sequence -- is compared
+67-71, against cuSPARSE); here the output of the LAST timed step (of the complete call, and of the structure-reuse mode beside it) is compared
 with the CPU oracle: row_offsets and col_ids bit-exact, values |c - c_ref| <= tol * sum|a*b| per entry.
 Inputs too large for the oracle in seconds (the full-size nlpkkt stand-in) are checked through size-independent
 properties on the device (row offsets consistent, every row strictly ascending and in range, row sums
@@ -22,12 +22,9 @@ def _as_po(A):
     return A if isinstance(A, po.HostCSR) else po.HostCSR(A.rows, A.cols, A.row_offsets, A.col_ids, A.data)
 
 
-def compare_with_oracle(A, B, got_ro, got_col, got_val, tol=None, threads=0):
-    """Full comparison.  Returns (ok, detail dict).  fp32 inputs are compared with their product in fp64 (TOL32)."""
-    A, B = _as_po(A), _as_po(B)
-    if tol is None:
-        tol = TOL32 if A.data.dtype == np.float32 else TOL64
-    R, ab = po.spgemm_f64_of(A, B, threads=threads)
+def compare_with_reference(ref, got_ro, got_col, got_val, tol):
+    """`ref` = (R, ab): the oracle's product and its per-entry sum|a*b| (pyoracle.spgemm_f64_of).  Returns (ok, detail)."""
+    R, ab = ref
     d = {"oracle_nnz": int(R.nnz), "got_nnz": int(len(got_col)), "tol": tol}
     if len(got_col) != R.nnz or len(got_ro) != len(R.row_offsets):
         return False, dict(d, why="nnz / rows differ")
@@ -40,6 +37,14 @@ def compare_with_oracle(A, B, got_ro, got_col, got_val, tol=None, threads=0):
     worst = float(np.max(err / bound)) if err.size else 0.0
     d["max_err_over_bound"] = round(worst, 4)
     return bool(worst <= 1.0), d
+
+
+def compare_with_oracle(A, B, got_ro, got_col, got_val, tol=None, threads=0):
+    """Full comparison.  Returns (ok, detail dict).  fp32 inputs are compared with their product in fp64 (TOL32)."""
+    A, B = _as_po(A), _as_po(B)
+    if tol is None:
+        tol = TOL32 if A.data.dtype == np.float32 else TOL64
+    return compare_with_reference(po.spgemm_f64_of(A, B, threads=threads), got_ro, got_col, got_val, tol)
 
 
 def _row_ids(torch, ro, nnz):

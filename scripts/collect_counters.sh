@@ -2,9 +2,10 @@
 # Regenerates the rocprofv3 evidence of a round under gpurun_out/profiles/ (copy the summaries into profiles/):
 #   kernel-trace + stats of the default bench command per workload, and SEPARATE --pmc passes (kernel-trace only,
 #   as gpurun requires): FETCH_SIZE | WRITE_SIZE | SQ / LDS | TCP.
-# usage (GPU box): bash scripts/collect_counters.sh r03 "scircuit mac_econ cant webbase"
+# usage (GPU box): bash scripts/collect_counters.sh r05 "scircuit mac_econ cant webbase mac_econ_f32"
+#   (a workload named <w>_f32 runs `bench.py --workload <w> --dtype f32`; its counters land under the key <w>_f32)
 set -u
-ROUND=${1:-r03}
+ROUND=${1:-r05}
 WORKLOADS=${2:-"scircuit mac_econ cant webbase"}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -21,17 +22,20 @@ PASSES=(
  "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_TA_BUSY_sum"
  "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
 )
-BENCH="python bench.py --no-cpu-baseline --no-config5 --no-configs --no-verify"
 for w in $WORKLOADS; do
+  base=${w%_f32}
+  BENCH="python bench.py --no-cpu-baseline --no-config5 --no-configs --no-verify --workload $base --detail gpurun_out/_p_$w/detail.json"
+  if [ "$base" != "$w" ]; then BENCH="$BENCH --dtype f32"; fi
   rm -rf gpurun_out/_p_$w
-  rocprofv3 --kernel-trace --stats -d gpurun_out/_p_$w/trace -o r -- $BENCH --workload $w \
+  mkdir -p gpurun_out/_p_$w
+  rocprofv3 --kernel-trace --stats -d gpurun_out/_p_$w/trace -o r -- $BENCH \
       > $OUT/${ROUND}_bench_${w}_under_rocprof.log 2>&1
   python scripts/rocpd_summary.py $(find gpurun_out/_p_$w/trace -name "*.db" | head -1) $OUT/${ROUND}_bench_${w}_kernel_stats.csv > /dev/null
   i=0
   CSVS=""
   for p in "${PASSES[@]}"; do
     i=$((i+1))
-    timeout 600 rocprofv3 --kernel-trace --pmc $p -d gpurun_out/_p_$w/pass$i -o r -- $BENCH --workload $w --steps 5 --warmup 2 \
+    timeout 600 rocprofv3 --kernel-trace --pmc $p -d gpurun_out/_p_$w/pass$i -o r -- $BENCH --steps 5 --warmup 2 \
         > gpurun_out/_p_$w/pass$i.log 2>&1
     db=$(find gpurun_out/_p_$w/pass$i -name "*.db" | head -n 1)
     if [ -n "$db" ]; then python scripts/rocpd_pmc.py $db gpurun_out/_p_$w/pass$i.csv > /dev/null; CSVS="$CSVS gpurun_out/_p_$w/pass$i.csv"

@@ -1468,7 +1468,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     bool speculated = false;
     u32 spec_counts[kMaxClasses];
     if (c->eager_speculate && c->spec_valid && c->spec_rows_a == A->rows && c->spec_rows_b == B->rows &&
-        (c->cp.nf_min_ops || c->cp.gh_per_window) && !c->profile_kernels) {
+        (c->cp.nf_min_ops || c->cp.gh_per_window)) {
         u32 mask = 0;
         for (int k = 0; k < kMaxClasses; ++k) {
             spec_counts[k] = c->last_sym_counts[k] ? c->last_sym_counts[k] + c->last_sym_counts[k] / 4 + 64 : 0;
@@ -2025,7 +2025,15 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
         c->max_side_streams = (u32)value;
         drop_graph(c);
     }
-    else if (n == "use_graph") c->use_graph = value != 0;
+    else if (n == "use_graph") {
+        // (an eager call leaves a prediction behind only for a config that may replay: the call that follows the switch
+        //  is a complete one)
+        if (c->use_graph != (value != 0)) {
+            drop_graph(c);
+            c->last_key_valid = false;
+        }
+        c->use_graph = value != 0;
+    }
     else if (n == "grid_rounds_block") {
         set_grid_rounds((u32)value, 0);
         drop_graph(c);

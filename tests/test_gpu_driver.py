@@ -73,53 +73,105 @@ def test_driver_individual_times_table(tmp_path):
         assert vals[k] > 0, (k, vals)
 
 
-def test_bench_two_ranks_share_the_gpu():
+def _bench_line(out):
+    """The ONE JSON line bench.py prints: <= 4 KB, the driver's contract fields, no prose."""
+    import json
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    assert len(lines[0]) <= 4096, len(lines[0])
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "verified", "phases_ms", "roofline"):
+        assert k in d, k
+    assert d["config"]["timed_call"].startswith("complete")
+    return d
+
+
+def test_bench_two_ranks_share_the_gpu(tmp_path):
     """Plumbing of bench.py's N > 1 path (row shards, two alternating output matrices, pipelined
     gatherv) with both ranks on GPU 0 and gloo instead of RCCL -- not a measurement."""
     import json
     import sys
     env = dict(os.environ, SPECK_BENCH_SHARED_GPU="1")
     port = 29600 + os.getpid() % 300
+    detail = tmp_path / "detail.json"
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                        "--scale", "0.25", "--config5-scale", "0.004", "--config5-steps", "3"],
+                        "--scale", "0.25", "--config5-scale", "0.004", "--config5-steps", "3", "--detail", str(detail)],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-2000:]
-    line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    d = _bench_line(out)
     assert d["n_gpus"] == 2 and d["config"]["gather"] and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["graph_replays"] > 0 and d["config"]["parallelism"] == "rows2"
-    assert d["multiply_only"]["value"] > 0
+    assert d["config"]["parallelism"] == "rows2" and d["config"]["exchange"] == "native:hostmem"
+    assert d["multiply_only"]["value"] > 0 and d["config"]["exchange_floor_ms"] > 0
     # every rank checked its row shard of the last step against the oracle
-    assert d["verified"] is True and d["verify"]["ok_all_ranks"] and d["verify"]["mode"] == "oracle"
+    full = json.load(open(detail))
+    assert d["verified"] is True and full["headline"]["verify"]["ok_all_ranks"] and full["headline"]["verify"]["mode"] == "oracle"
+    # (N > 1: every step is the complete call -- the structure-reuse mode is an N = 1 side figure)
+    assert d["value_reuse"] is None and full["headline"]["verify"]["replayed"] is False
     # the BASELINE.json configs[4] leg: nlpkkt stand-in, strong scaling, with and without the exchange
     c5 = d["config5"]
     assert c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["value"] > 0 and c5["multiply_only"]["value"] > 0
     assert c5["verified"] is True
 
 
-def test_bench_launches_its_own_ranks_when_called_without_a_launcher():
+def test_bench_launches_its_own_ranks_when_called_without_a_launcher(tmp_path):
     """`python bench.py --gpus N` as the driver calls it -- no torch.distributed.run in front: bench.py starts the N
-    ranks itself and rank 0 prints the line with n_gpus = N.  On a box with fewer GPUs it refuses (exit code 2, no
-    line) instead of printing a one-GPU number, unless the ranks may share GPU 0 (plumbing check)."""
-    import json
+    ranks itself and rank 0 prints the (one, compact) line with n_gpus = N.  On a box with fewer GPUs it refuses (exit
+    code 2, no line) instead of printing a one-GPU number, unless the ranks may share GPU 0 (plumbing check)."""
     import sys
     import torch
     base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--scale", "0.1",
-           "--no-config5", "--no-cpu-baseline"]
+           "--no-config5", "--no-cpu-baseline", "--detail", str(tmp_path / "detail.json")]
     p = subprocess.run(cmd, cwd=ROOT, env=dict(base, SPECK_BENCH_SHARED_GPU="1"), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-2000:]
-    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    d = _bench_line(out)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "rows2" and d["verified"] is True
     assert d["config"]["exchange_floor_ms"] > 0 and d["multiply_only"]["value"] > 0
     if torch.cuda.device_count() < 2:
         p = subprocess.run(cmd, cwd=ROOT, env=base, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert p.returncode == 2 and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_bench_default_line_is_compact_and_times_the_complete_call(tmp_path):
+    """The N = 1 line as the driver parses it (small scale here): `value` is the COMPLETE call -- every stage inside the
+    timed region, so its symbolic phase is not a few microseconds of verifier --, the structure-reuse mode of the repeated
+    call stands beside it as `value_reuse`, every other configuration is one short object, the nlpkkt leg carries the
+    same pair, and everything else is in the detail file."""
+    import json
+    import sys
+    detail = tmp_path / "detail.json"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--configs-steps", "3",
+                        "--config5-scale", "0.01", "--config5-steps", "2", "--no-cpu-baseline", "--detail", str(detail)],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    d = _bench_line(out)
+    assert d["n_gpus"] == 1 and d["verified"] is True and d["dtype"] == "f64"
+    assert d["ms_reuse"] < d["ms_per_step"] and d["value_reuse"] > d["value"] > 0
+    full = json.load(open(detail))
+    head = full["headline"]
+    # the timed call ran the symbolic launches: its symbolic phase is longer than the symbolic light launch alone
+    assert d["phases_ms"]["symbolic"] > head["stages_ms"]["sym_light"] > 0.005
+    assert head["verify"]["replayed"] is False and head["verify_reuse"]["replayed"] is True
+    r = d["roofline"]
+    assert r["kernel"].startswith("numeric:") and 0 < r["frac"] <= 1 and r["avg_launch_ms"] > 0 and r["bytes"] > 0
+    for k in ("hbm_measured_frac", "l2_frac", "lds_atomic_frac", "valu_frac"):
+        assert r[k] is None or 0 <= r[k] <= 1, (k, r[k])     # a ceiling above 1 is not evidence: never printed
+    names = [c["name"] + ":" + c["dtype"] for c in d["configs"]]
+    assert names == ["webbase:f64", "mac_econ:f64", "cant:f64", "mac_econ:f32", "cant:f32"]
+    for c in d["configs"]:
+        assert set(c) == {"name", "dtype", "ms_per_step", "ms_reuse", "value", "value_reuse", "roofline_frac",
+                          "numeric_phase_frac", "bound", "verified"}
+        assert c["verified"] is True and c["ms_per_step"] > 0 and c["ms_reuse"] > 0
+    c5 = d["config5"]
+    assert c5["verified"] is True and c5["ms_per_step"] > 0 and c5["ms_reuse"] > 0 and c5["value_reuse"] > 0
+    assert full["line_bytes"] <= 4096 and len(full["headline"]["roofline"]["launches"]) >= 1
 
 
 def test_bench_falls_back_to_the_torch_exchange_when_the_native_one_fails_its_self_test():
@@ -136,7 +188,7 @@ def test_bench_falls_back_to_the_torch_exchange_when_the_native_one_fails_its_se
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-2000:]
-    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    d = _bench_line(out)
     assert d["n_gpus"] == 2 and d["verified"] is True and d["value"] > 0
     assert "torch" in d["config"]["exchange"] and "fell back" in d["config"]["exchange_note"]
 
@@ -157,7 +209,7 @@ def test_bench_strong_scaling_mode_two_ranks_share_the_gpu():
                            cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         out = p.stdout.decode()
         assert p.returncode == 0, out[-2000:]
-        d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+        d = _bench_line(out)
         assert d["scaling"] == "strong" and d["n_gpus"] == n and d["value"] > 0 and "config5" not in d
         assert d["verified"] is True
         sizes[n] = (d["config"]["rows"], d["config"]["products"], d["config"]["nnzC"])
@@ -224,14 +276,15 @@ def test_bench_reads_a_symmetric_suitesparse_file(tmp_path):
     n_diag = int((A.col_ids == rows_of).sum())
     env = dict(os.environ, SPECK_MTX_DIR=str(tmp_path))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "nlpkkt", "--scaling", "strong",
-                        "--steps", "3", "--warmup", "2", "--no-configs", "--no-cpu-baseline"],
+                        "--steps", "3", "--warmup", "2", "--no-configs", "--no-cpu-baseline", "--detail",
+                        str(tmp_path / "detail.json")],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-2000:]
-    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    d = _bench_line(out)
     assert d["data"] == "suitesparse" and d["config"]["rows"] == A.rows
     assert d["config"]["nnzA"] == 2 * n_lower - n_diag
-    assert d["verified"] is True and d["verify"]["mode"] == "oracle"
+    assert d["verified"] is True and json.load(open(tmp_path / "detail.json"))["headline"]["verify"]["mode"] == "oracle"
 
 
 def test_symmetric_file_with_both_triangles_is_rejected_end_to_end(tmp_path):
