@@ -62,7 +62,7 @@ SUITESPARSE_FILES = {"scircuit": "scircuit", "webbase": "webbase-1M", "mac_econ"
 COUNTER_KEYS = {"light": "num_light", "numeric_first": "num_numeric_first", "nfcopy": "num_nfcopy", "block8k": "num_block8k",
                 "dense16k": "num_dense16k", "global": "num_global_reduce"}
 # the classes of the merged 256-thread numeric launch (num_light_kernel)
-LIGHT = ("dense4k", "block2k", "wave512", "wave256", "r64", "r32", "wave128", "g16", "g8", "g4", "direct")
+LIGHT = ("dense4k", "block2k", "wave512", "wave256", "r64", "r32", "wave128", "g16", "g8", "direct")
 
 
 class _DevArray:

@@ -16,9 +16,9 @@ from . import _lib
 from ._lib import CStats, CTimings, DCsr, NUM_NUM_BINS, NUM_SYM_BINS
 
 SYM_CLASS_NAMES = ["g16", "wave256", "wave1k", "block4k", "block16k", "block32k", "bitmap256k", "bitmap1m",
-                   "numeric_first", "global_hash", "g8", "wave128", "r32", "r64", "g4"]
+                   "numeric_first", "global_hash", "g8", "wave128", "r32", "r64"]
 NUM_CLASS_NAMES = ["direct", "g16", "wave128", "wave512", "block2k", "block8k", "dense4k", "dense16k", "global",
-                   "wave256", "nfcopy", "g8", "r32", "r64", "g4"]
+                   "wave256", "nfcopy", "g8", "r32", "r64"]
 
 
 class SpeckError(RuntimeError):

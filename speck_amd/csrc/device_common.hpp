@@ -50,8 +50,7 @@ enum SymClass : u8 {
     SYM_R32 = 12,   // 32 lanes per row (two rows per wave): <= 128 products from <= 32 entries of A, columns sorted in
                     //   registers (esc_wide.hpp) -- no key set
     SYM_R64 = 13,   // a wave per row: <= 256 products from <= 64 entries of A, sorted in registers
-    SYM_G4 = 14,    // 4 lanes per row (16 rows per wave): <= 16 products from <= 4 entries of A, sorted in registers
-    SYM_CLASSES = 15,
+    SYM_CLASSES = 14,
     SYM_NONE = 0xFF  // resolved by the analysis kernel itself (empty / single-entry A rows)
 };
 // Numeric classes: chosen from the EXACT nnz of the C row (symbolic result).
@@ -73,9 +72,7 @@ enum NumClass : u8 {
     NUM_R32 = 12,    // 32 lanes per row: <= 128 products from <= 32 entries of A, column range < 2^25 -- expand / sort /
                      //   compress in registers (esc_wide.hpp), whatever the nnz
     NUM_R64 = 13,    // a wave per row: <= 256 products from <= 64 entries, column range < 2^24
-    NUM_G4 = 14,     // 4 lanes per row: <= 16 products from <= 4 entries of A -- the smallest register class (more than half
-                     //   of the rows of the mac_econ stand-in): twice the rows per wave-iteration of NUM_G8, a 16-element network
-    NUM_CLASSES = 15,
+    NUM_CLASSES = 14,
     NUM_NONE = 0xFF
 };
 
@@ -124,7 +121,6 @@ __host__ __device__ inline u32 table_bits(u32 nnz, u32 pct)
 }
 constexpr u32 kNumG8Cap = 32, kNumG8MaxNnz = max_nnz_of(32, SPECK_LOAD_TINY_PCT);
 constexpr u32 kNumEscMaxOps = 32, kNumEscMaxLen = 8;  // NUM_G8 / SYM_G8 = the register-resident classes (esc.hpp)
-constexpr u32 kNumEsc4MaxOps = 16, kNumEsc4MaxLen = 4;     // NUM_G4 / SYM_G4
 constexpr u32 kNumEsc16MaxOps = 64, kNumEsc16MaxLen = 16;  // NUM_G16 / SYM_G16: 16 lanes; columns < 2^26 (ClassifyParams::esc16)
 // the WIDE register classes (esc_wide.hpp): the sort key packs (column - first reachable column of the row) with the
 // product number into 32 bits -- a condition on the row's column RANGE (analysis), not on cols(B)
@@ -150,7 +146,6 @@ struct ClassifyParams {
     u32 num_w256;           // rows of 86..170 nnz: 32 lanes per row (else they join NUM_W512)
     u32 esc16;              // cols(B) <= 2^26: the 16-lane register class may pack (column, product number) into 32 bits
     u32 esc32, esc64;       // the wide register classes (32 / 64 lanes per row, 128 / 256 products)
-    u32 esc4;               // the 4-lane register class (with num_g8 / sym_g8: it is carved out of their rows)
     u32 esc_fused;          // replayed sequence with direct placement: the rows of the register classes are finished
                             //   in the symbolic phase (esc_rows.hpp) -- the numeric phase only accounts for them
     u32 num_g8;             // rows of <= kNumG8MaxNnz entries: 8 lanes per row (else they join NUM_G16)
@@ -205,7 +200,6 @@ __host__ __device__ inline u8 classify_symbolic(u32 len_a, u32 ops, u32 cmin, u3
     if (ops == 0 || len_a <= 1) return SYM_NONE;
     if (is_numeric_first(len_a, ops, cmin, cmax, p)) return SYM_NF;
     // at most 32 products from at most 8 entries of A: sorted in registers (esc.hpp)
-    if (p.sym_g8 && p.esc4 && ops <= kNumEsc4MaxOps && len_a <= kNumEsc4MaxLen) return SYM_G4;
     if (p.sym_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return SYM_G8;
     if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return SYM_G16;  // 16 lanes, 64 products
     if (is_esc32(len_a, ops, cmin, cmax, p)) return SYM_R32;                             // 32 lanes, 128 products
@@ -238,7 +232,6 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     // at most 32 products from at most 8 entries of A: expand / sort / compress in registers (esc.hpp), whatever
     // the nnz; the hash classes take the rest by nnz
     // (num_g8 and sym_g8 are switched together: a fused row must be a register-class row in BOTH phases)
-    if (p.num_g8 && p.esc4 && ops <= kNumEsc4MaxOps && len_a <= kNumEsc4MaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G4;
     if (p.num_g8 && ops <= kNumEscMaxOps && len_a <= kNumEscMaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G8;
     if (p.esc16 && ops <= kNumEsc16MaxOps && len_a <= kNumEsc16MaxLen) return p.esc_fused ? NUM_NFCOPY : NUM_G16;
     if (is_esc32(len_a, ops, cmin, cmax, p)) return p.esc_fused ? NUM_NFCOPY : NUM_R32;
@@ -292,14 +285,13 @@ struct DeviceStats {
     u32 b_invalid;           // a row of B is not strictly ascending / holds a column >= cols (eager path)
     u32 nf_max_range;        // widest column range among the SYM_NF rows (sizes the LDS window of their kernel)
     u32 a_invalid;           // a column id of A is >= rows(B) (the analysis clamps it, so nothing reads out of bounds)
-    u32 b_bad_epoch;         // LAST word, never zeroed by the analysis kernel: the validation blocks of that kernel store
-                             //   the call's epoch here when a row of B is not strictly ascending / in range (they run
-                             //   next to the block that zeroes the rest, so the verdict is a value no other call wrote)
+    u32 chain_error;         // a workgroup of the analysis / scan waited in vain for the workgroups before it (chain.hpp)
 };
 static_assert(sizeof(DeviceStats) % 8 == 0, "mirrored to the host in 8-byte words");
 
-// One row of work as the class kernels see it: written in class order by the scatter kernels,
-// read with a single 32-byte load (the next row's record is fetched while the current one runs).
+// One row of work as the class kernels see it: ONE 32-byte load per row, from the row's place in its class list
+// (launch.hpp, class_rec_at: written by the analysis for the symbolic phase, by the scan for the numeric one); a class
+// kernel requests the record of its next row while the current one runs.
 struct __attribute__((aligned(32))) RowRec {
     u32 a0, a1;      // bounds of the A row (absolute offsets into A.col_ids / A.data)
     u32 base;        // first entry of the C row (numeric phase)
@@ -308,41 +300,6 @@ struct __attribute__((aligned(32))) RowRec {
     u32 ops;         // intermediate products of the row
     u32 row;         // row of A / C
 };
-// What every analysis / scan block leaves behind for the blocks of the scatter kernel that follows
-// (plain stores: ~12 ns per same-line global atomic would otherwise dominate these kernels).
-// Stored as a structure of arrays over the blocks -- every scatter block folds ALL partials, and with
-// one record per block that was ~130 KB of strided reads per workgroup (the fold was most of the
-// 16-22 us these kernels took on the 200 k-row stand-ins).  BlockPartial only sizes the allocation.
-struct BlockPartial {
-    u64 products;
-    u32 max_val;
-    u32 pad;
-    u32 count[kMaxClasses];
-    u64 bytes[kMaxClasses];
-    u64 g_ops;  // numeric phase: products of the block's NUM_G rows (sizes the spill pool)
-    u64 pad2[2];
-};  // (g_ops doubles as the scratch entries of the block's SYM_NF rows in the symbolic phase)
-struct PartialArrays {
-    u64* products;  // [cap]   analysis: products of the block's rows; scan: nnz of the tile
-    u64* g_ops;     // [cap]
-    u64* bytes;     // [kMaxClasses][cap]  (only with ClassifyParams::want_bytes)
-    u32* count;     // [kMaxClasses][cap]  rows per class
-    u32* max_val;   // [cap]
-    u32* aux_max;   // [cap]   analysis: widest column range among the block's SYM_NF rows
-    u32 cap;
-    __host__ __device__ PartialArrays(BlockPartial* base, u32 blocks)
-    {
-        cap = (blocks + 1u) & ~1u;
-        products = reinterpret_cast<u64*>(base);
-        g_ops = products + cap;
-        bytes = g_ops + cap;
-        count = reinterpret_cast<u32*>(bytes + size_t(kMaxClasses) * cap);
-        max_val = count + size_t(kMaxClasses) * cap;
-        aux_max = max_val + cap;
-    }
-};
-static_assert(sizeof(BlockPartial) >= 8 + 8 + 8 * kMaxClasses + 4 * kMaxClasses + 4 + 4 + 8, "PartialArrays fits");
-
 #ifdef __HIPCC__
 // ---- wave64 primitives ---------------------------------------------------------
 __device__ __forceinline__ u32 lane_id() { return __lane_id(); }

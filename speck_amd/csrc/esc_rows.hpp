@@ -36,7 +36,7 @@ constexpr u32 num_esc_group_lds()
 template <typename T, u32 L, int THREADS, bool FUSED = false>
 __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                              u32* __restrict__ c_col, T* __restrict__ c_val, int cls, u32 bidx,
-                                             u32 nblk, ClassHint hint = kNoHint, u32* __restrict__ counts = nullptr)
+                                             u32 nblk, u32 hint = kNoCount, u32* __restrict__ counts = nullptr)
 {
     static_assert(L == 4 || L == 8 || L == 16, "4, 8 or 16 lanes per row");
     using G = SubWave<L>;
@@ -48,16 +48,12 @@ __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductS
     Acc<T>* s_vals = reinterpret_cast<Acc<T>*>(mine);     // [4 L] products by number
     Acc<T>* s_av = s_vals + NP;                           // [L]   a_ik of the j-th non-empty entry
     u32* s_off = reinterpret_cast<u32*>(s_av + L);        // [L]   its B-row start minus its first product number
-    const ListHead head = open_list<FUSED>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
-    if (head.miss) return;  // (FUSED too: the records of a block whose rows changed are not written by a predicted binning)
-    const RowRec* recs = head.recs;
-    u32 idx = head.rs.idx;
-    const u32 stride = head.rs.stride, count = head.rs.end;
-    RowRec next = head.next;
+    RowCursor cur = open_list<FUSED>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
+    // (a replayed sequence that an earlier kernel has declared void walks nothing)
+    if (cur.miss) return;
     const u32 gl = g.lane;
-    while (idx < count) {
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + stride < count) next = recs[idx + stride];
+    while (cur.more()) {
+        const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         u32 place = rec.base, place_len = 0;
         if constexpr (FUSED) {
             place = w.nf_pred_off[rec.row];
@@ -189,7 +185,6 @@ __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductS
                 ++pos;
             }
         wave_lds_fence();  // the next row overwrites the staging and the products
-        idx += stride;
     }
 }
 

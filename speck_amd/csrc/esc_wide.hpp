@@ -178,7 +178,7 @@ constexpr u32 sym_escw_group_lds()
 template <typename T, u32 L, int THREADS, bool FUSED = false>
 __device__ __forceinline__ void num_escw_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                               u32* __restrict__ c_col, T* __restrict__ c_val, int cls, u32 bidx,
-                                              u32 nblk, ClassHint hint = kNoHint, u32* __restrict__ counts = nullptr)
+                                              u32 nblk, u32 hint = kNoCount, u32* __restrict__ counts = nullptr)
 {
     static_assert(L == 32 || L == 64, "32 or 64 lanes per row");
     using G = SubWave<L>;
@@ -192,16 +192,12 @@ __device__ __forceinline__ void num_escw_body(unsigned char* smem, const Product
     Acc<T>* s_av = s_vals + NP;                           // [L]   a_ik of the j-th non-empty entry
     u32* s_off = reinterpret_cast<u32*>(s_av + L);        // [L]   its B-row start minus its first product number
     const EscEnds<L> ends{reinterpret_cast<uint2*>(s_off + L)};
-    const ListHead head = open_list<FUSED>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
-    if (head.miss) return;
-    const RowRec* recs = head.recs;
-    u32 idx = head.rs.idx;
-    const u32 stride = head.rs.stride, count = head.rs.end;
-    RowRec next = head.next;
+    RowCursor cur = open_list<FUSED>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
+    // (a replayed sequence that an earlier kernel has declared void walks nothing)
+    if (cur.miss) return;
     const u32 gl = g.lane;
-    while (idx < count) {
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + stride < count) next = recs[idx + stride];
+    while (cur.more()) {
+        const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         u32 place = rec.base, place_len = 0;
         if constexpr (FUSED) {
             place = w.nf_pred_off[rec.row];
@@ -331,7 +327,6 @@ __device__ __forceinline__ void num_escw_body(unsigned char* smem, const Product
                 ++pos;
             }
         wave_lds_fence();  // the next row overwrites the staging and the products
-        idx += stride;
     }
 }
 
@@ -340,7 +335,7 @@ __device__ __forceinline__ void num_escw_body(unsigned char* smem, const Product
 template <u32 L, int THREADS>
 __device__ __forceinline__ void sym_escw_body(unsigned char* smem, const ProductSrc<float>& src, const RowWork& w,
                                               u32* __restrict__ counts, int cls, u32 bidx, u32 nblk,
-                                              ClassHint hint = kNoHint)
+                                              u32 hint = kNoCount)
 {
     static_assert(L == 32 || L == 64, "32 or 64 lanes per row");
     using G = SubWave<L>;
@@ -349,16 +344,12 @@ __device__ __forceinline__ void sym_escw_body(unsigned char* smem, const Product
     const u32 gid = threadIdx.x / L;
     u32* s_off = reinterpret_cast<u32*>(smem + gid * sym_escw_group_lds<L>());
     const EscEnds<L> ends{reinterpret_cast<uint2*>(s_off + L)};
-    const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
-    if (head.miss) return;
-    const RowRec* recs = head.recs;
-    u32 idx = head.rs.idx;
-    const u32 stride = head.rs.stride, count = head.rs.end;
-    RowRec next = head.next;
+    RowCursor cur = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
+    // (a replayed sequence that an earlier kernel has declared void walks nothing)
+    if (cur.miss) return;
     const u32 gl = g.lane;
-    while (idx < count) {
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + stride < count) next = recs[idx + stride];
+    while (cur.more()) {
+        const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         uint2 sl = make_uint2(0u, 0u);
         if (rec.a0 + gl < rec.a1) sl = src.b_sl[rec.a0 + gl];
         u32 total;
@@ -385,7 +376,6 @@ __device__ __forceinline__ void sym_escw_body(unsigned char* smem, const Product
         heads = g.reduce_add(heads, nullptr);
         if (gl == 0) store_row_count(w, counts, rec.row, heads);
         wave_lds_fence();  // the next row overwrites the offsets
-        idx += stride;
     }
 }
 

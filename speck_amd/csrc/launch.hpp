@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_ext.h>
 
+#include "chain.hpp"
 #include "device_common.hpp"
 
 namespace speck {
@@ -10,20 +11,37 @@ u32 analysis_blocks(u32 m);
 void set_analysis_wide_rows(u32 avg_len);  // analysis: 64 rows per wave when nnz(A) / rows(A) <= avg_len (0: never)
 u32 scan_tiles(u32 m);
 
-// analysis (+ stats fold + ordered scatter of the symbolic row records when sym_cls != nullptr)
-void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32* b_ro,
-                     const u32* b_col, u32 m, u64 nnz_a, u32* row_ops, u32* row_max_ops,
-                     u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
-                     BlockPartial* partials, RowRec* recs, DeviceStats* st, const ClassifyParams& cp,
-                     uint2* b_sl, hipEvent_t between = nullptr, u64* nf_off = nullptr,
-                     u64 expect_nf = ~0ull, u32 b_rows = ~0u, u32* pred_block_out = nullptr,
-                     const u32* pred_block = nullptr, const DeviceStats* pred_stats = nullptr, u32 b_cols = 0,
-                     u64 b_nnz = 0, u32 validate_epoch = 0 /* != 0: also check B's rows (DeviceStats::b_bad_epoch) */,
-                     u32* a_ro_copy = nullptr /* A's row offsets as this call saw them (a later VERIFY compares) */,
-                     u32* verdict = nullptr /* != nullptr: VERIFY -- compare everything with what is stored, write nothing but
-                                               this word (pinned host memory) on a difference: 1, | 2 for a bad column of A */);
+// ---- class lists: RECORDS at fixed places ------------------------------------------------------------------
+// One buffer of kListRegions x rows(A) records per phase.  Class c lives in region c / 2; the even class of a pair grows
+// up from the region's first record, the odd one down from its last -- together they hold at most rows(A) records.  So a
+// producer places a row knowing only how many rows of the class come BEFORE it (chain.hpp), and a class kernel reads the
+// record of list entry i with ONE load, from an address it knows before it has read a single device word.
+// (First form of round 5: row ids in the lists, records in row order -- 4 bytes per list entry instead of 32, but every
+//  row of every class kernel paid a dependent load: numeric light launch 52 -> 57 us on the scircuit stand-in, the
+//  669 k single-entry rows of the webbase stand-in +5 % on the whole multiply.)
+constexpr u32 kListRegions = (kMaxClasses + 1) / 2;
+__host__ __device__ inline size_t class_list_records(u32 m) { return size_t(kListRegions) * (m ? m : 1u); }
+__host__ __device__ __forceinline__ RowRec* class_rec_at(RowRec* lists, u32 m, u32 cls, u32 i)
+{
+    RowRec* region = lists + size_t(cls >> 1) * m;
+    return (cls & 1u) ? region + (m - 1u - i) : region + i;
+}
+__host__ __device__ __forceinline__ const RowRec* class_rec_at(const RowRec* lists, u32 m, u32 cls, u32 i)
+{
+    return class_rec_at(const_cast<RowRec*>(lists), m, cls, i);
+}
 
-// completion ticket of a replayed launch sequence (pinned host word the host spins on)
+// analysis + symbolic binning (ONE kernel, stages.hip).  sym_cls == nullptr: the per-row quantities and the totals only.
+// verdict != nullptr: VERIFY -- compare everything with what is stored, write nothing but this word (pinned host
+// memory) on a difference: 1, | 2 for a bad column of A.
+void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32* b_ro, const u32* b_col, u32 m, u64 nnz_a,
+                     u32* row_ops, u32* row_max_ops, u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
+                     RowRec* sym_recs, DeviceStats* st, const ClassifyParams& cp, uint2* b_sl, const Chain& chain,
+                     u64* nf_off = nullptr, u64 expect_nf = ~0ull, u32 b_rows = ~0u,
+                     u32* a_ro_copy = nullptr /* A's row offsets as this call saw them (a later VERIFY compares) */,
+                     u32* verdict = nullptr, u64* bytes_acc = nullptr /* [2][kMaxClasses], with cp.want_bytes */);
+
+// completion ticket of a launch sequence (pinned host word the host spins on)
 // (the kernel also copies the statistics block into its pinned mirror, before the ticket)
 void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceStats* st, DeviceStats* host_mirror);
 void launch_ticket(hipStream_t s, u32* dev_ticket, u32* host_ticket);  // the ticket alone
@@ -34,38 +52,19 @@ void launch_snapshot_inputs(hipStream_t s, const u32* a_ro, const u32* a_col, u3
 void launch_verify_inputs(hipStream_t s, const u32* a_ro, const u32* a_ro_copy, u32 m, const u32* a_col,
                           const u32* a_col_copy, u64 nnz_a, const u32* b_ro, const u32* b_col, u32 b_rows, const u32* b_snap,
                           u32* verdict);
-void launch_delay(hipStream_t s, u32 us);                               // a wave that idles for `us` microseconds
 // B's rows strictly ascending and in range (eager path): bit 2 of *verdict (pinned) on a violation
 void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, u64 b_nnz, u32* verdict);
+// staged row offsets -> C.row_offsets when no numeric light launch carries them (not if the sequence was declared void)
+void launch_copy_offsets(hipStream_t s, const u32* src, u32* dst, u32 n, const DeviceStats* st);
 
-// exclusive scan of the row counts into offsets_out (may alias counts; + numeric classification, stats fold,
-// ordered scatter of the numeric row records when num_cls != nullptr).  offsets_out is left as it was when a
-// check of the call fails (capacity_miss, invalid input, nnz overflow).
+// exclusive scan of the row counts into offsets_out + numeric classification, records and class lists (ONE kernel;
+// num_recs == nullptr: the offsets and nnz(C) only).  pred_off: the offsets a replayed sequence has placed rows by -- every
+// fresh offset must agree (capacity_miss).  host_mirror: the last tile mirrors the statistics and stores the ticket.
 void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro, const u32* row_ops,
-                 const u32* row_col_min, const u32* row_col_max, u8* num_cls, BlockPartial* partials,
-                 RowRec* recs, DeviceStats* st, const ClassifyParams& cp, u32 vsize, u64 exact_nnz,
-                 DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
-                 const u32* pred_off = nullptr, u32* pred_off_out = nullptr, u32* pred_tile_out = nullptr,
-                 bool pred_fold_esc = false, u32* dev_ticket = nullptr, u32* host_ticket = nullptr
-                 /* with host_mirror: block 0 mirrors the statistics and stores the ticket as soon as it has folded */);
-
-// What a call leaves behind for a replay of the SAME call to verify instead of recompute (pipeline.hip: Prediction):
-// per scan tile the position of its rows in every numeric class list, how many there are, and the products of its
-// NUM_G rows.  Layout of one tile: pos[kMaxClasses] | count[kMaxClasses] | g_ops (lo, hi).
-constexpr u32 kPredTileWords = 2 * kMaxClasses + 2;
-// ... and per analysis block the same for the symbolic class lists (+ the scratch entries of its numeric-first rows)
-constexpr u32 kPredBlockWords = 2 * kMaxClasses + 2;
-
-// The scan of a replayed sequence whose every row offset is predicted (pred_off) and whose tile tables are known
-// (pred_tile): ONE kernel, no fold over the tiles -- each tile scans its rows from its predicted base, compares
-// every fresh offset and its class histogram with the prediction (capacity_miss on any difference; nothing is then
-// written by that tile) and writes the row records at the predicted list positions.  The statistics the numeric
-// kernels and the host read are those of the predicted call (pred_stats), valid if no tile objects.
-void launch_scan_predicted(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro,
-                           const u32* row_ops, const u32* row_col_min, const u32* row_col_max, RowRec* recs,
-                           DeviceStats* st, const ClassifyParams& cp, const u32* pred_off, const u32* pred_tile,
-                           const DeviceStats* pred_stats, BlockPartial* analysis_partials = nullptr,
-                           bool totals_from_pred = false);
+                 const u32* row_col_min, const u32* row_col_max, RowRec* num_recs, DeviceStats* st,
+                 const ClassifyParams& cp, u32 vsize, u64 exact_nnz, const Chain& chain, DeviceStats* host_mirror = nullptr,
+                 u64 expect_g = ~0ull, u32 expect_g_rows = ~0u, const u32* pred_off = nullptr, u32* pred_off_out = nullptr,
+                 u32* dev_ticket = nullptr, u32* host_ticket = nullptr, u64* bytes_acc = nullptr);
 
 // Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
 // and two product pools (expanded by column bucket; reduced and sorted).
@@ -94,8 +93,9 @@ struct SpillBuffers {
 
 // Everything a symbolic / numeric kernel needs besides the matrices.
 struct RowWork {
-    const RowRec* recs;     // row records grouped by class (device)
-    const DeviceStats* st;  // offsets/counts live here (device)
+    const RowRec* recs;     // class lists of this phase: records (class_rec_at above)
+    u32 m;                  // rows(A): extent of a list region
+    const DeviceStats* st;  // class counts live here (device)
     const uint2* b_sl;      // per A entry (relative to the first entry of the A view): (start, length) of the
                             //   referenced B row, written by the analysis
     SpillBuffers spill;     // NUM_G class (all null when no row needs it)
@@ -113,9 +113,8 @@ struct RowWork {
     uint2* w_sl;            // per A entry: (start, length) of its B row INSIDE the current column window
                             //   (multi-window rows, row_groups.hpp WindowCursors); a row's entries belong to its workgroup
     u32 xcd_aware;          // class lists are walked in per-XCD contiguous slices (row_groups.hpp)
-    // Eager call: the scan staged the row offsets of C in scratch (C.row_offsets -- possibly the caller's reused buffer --
-    // is written only once nothing can fail any more); extra workgroups of the numeric light launch move them to C
-    // instead of a copy of its own in front of the launch (-8 us).  off_n = 0: nothing to move.
+    // The scan staged the row offsets of C in scratch (C.row_offsets -- possibly the caller's reused buffer -- is written
+    // only once nothing can fail any more); extra workgroups of the numeric light launch move them to C.  off_n = 0: nothing to move.
     const u32* off_src;
     u32* off_dst;
     u32 off_n;
@@ -138,33 +137,26 @@ __device__ __forceinline__ void store_row_count(const RowWork& w, u32* __restric
 }
 #endif
 
-// Block ranges of the classes inside a merged ("light") launch: class slot k owns the blocks
-// [first[k], first[k+1]).
-// Host-known position of a class list inside the record array (exact counts of the previous identical call, or
-// of a read-back of this one): lets a workgroup request its first record without waiting for the device-side
-// table -- the table is still what decides (a stale hint only costs the second request).  cnt = ~0: unknown.
-struct ClassHint {
-    u32 off, cnt;
-};
-constexpr ClassHint kNoHint{0xFFFFFFFFu, 0xFFFFFFFFu};
-// (Round 4: the merged kernels no longer carry a ClassHint per class -- measured +-0 when they were added, and with ten
-//  class bodies in one kernel their 24 kernel-argument words were what pushed the fused light launch into spilling 90
-//  scalar registers: 50.4 -> 43.7 us on the scircuit stand-in without them.  The stand-alone class kernels never had any.)
+// Block ranges of the classes inside a merged ("light") launch: class slot k owns the blocks [first[k], first[k+1]);
+// cnt[k] = the rows the host expects in the slot's class (exact when the structure is what it was at the last read-back /
+// in the previous call; ~0: unknown): a workgroup requests its first list entries by it BEFORE the device-side class
+// table has arrived -- the table decides, a stale hint costs one more round trip.
 struct ClassGrid {
     u32 first[13];
+    u32 cnt[12];
 };
+constexpr u32 kNoCount = 0xFFFFFFFFu;
 constexpr u32 kSymLightMask = (1u << SYM_BM1) | (1u << SYM_B4K) | (1u << SYM_W1K) | (1u << SYM_W256) | (1u << SYM_G16) |
-                              (1u << SYM_G8) | (1u << SYM_W128) | (1u << SYM_R32) | (1u << SYM_R64) | (1u << SYM_G4);
+                              (1u << SYM_G8) | (1u << SYM_W128) | (1u << SYM_R32) | (1u << SYM_R64);
 constexpr u32 kNumLightMask = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256) | (1u << NUM_W128) |
-                              (1u << NUM_G16) | (1u << NUM_G8) | (1u << NUM_DIRECT) | (1u << NUM_R32) | (1u << NUM_R64) |
-                              (1u << NUM_G4);
+                              (1u << NUM_G16) | (1u << NUM_G8) | (1u << NUM_DIRECT) | (1u << NUM_R32) | (1u << NUM_R64);
 // the register classes (esc.hpp, esc_wide.hpp): their rows are finished in the symbolic phase of a fused replay
-constexpr u32 kNumEscMask = (1u << NUM_G4) | (1u << NUM_G8) | (1u << NUM_G16) | (1u << NUM_R32) | (1u << NUM_R64);
-constexpr u32 kSymEscMask = (1u << SYM_G4) | (1u << SYM_G8) | (1u << SYM_G16) | (1u << SYM_R32) | (1u << SYM_R64);
+constexpr u32 kNumEscMask = (1u << NUM_G8) | (1u << NUM_G16) | (1u << NUM_R32) | (1u << NUM_R64);
+constexpr u32 kSymEscMask = (1u << SYM_G8) | (1u << SYM_G16) | (1u << SYM_R32) | (1u << SYM_R64);
 
 // One launch for all 256-thread classes in `mask`.  counts_hint[cls] sizes each class' block range
 // (the kernels read the real counts on the device and stride, so a stale hint only costs speed).
-// `exact`: counts_hint holds the exact rows of EVERY class (the kernels then get ClassHints).
+// `exact`: counts_hint holds the rows the host expects in EVERY class (ClassGrid::cnt).
 void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, const u32* a_ro,
                            const uint2* b_sl, const u32* b_col, const RowWork& w,
                            u32* counts, int cu_count, bool exact = false, u32 fused_vsize = 0,
@@ -177,7 +169,7 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
 
 // Launch the symbolic kernel of class `cls`.  `count` is an UPPER BOUND of the class' row count
 // (the rows of A): the grid depends only on it, the kernels read the real count from the
-// device-side stats block, so the launch sequence is static and can be captured in a hipGraph.
+// device-side stats block, so the launch sequence is static.
 void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const uint2* b_sl,
                      const u32* b_col, const RowWork& w, u32* counts, int cu_count);
 
@@ -205,7 +197,6 @@ u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block);
 // resident-set multiples a class grid may reach before its workgroups start striding over rows
 void set_grid_rounds(u32 block_classes, u32 subwave_classes);
 void set_spill_big_grid(u32 blocks);  // workgroups of the NUM_G launch that reduces the oversized buckets
-void set_tiny_threads(int threads);  // workgroup size of the merged small-row numeric launch (64 / 128 / 256)
 
 // LDS bytes a class needs (for occupancy-aware grid sizing and DESIGN.md tables)
 u32 symbolic_lds_bytes(int cls);

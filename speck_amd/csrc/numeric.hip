@@ -50,7 +50,7 @@ constexpr u32 num_direct_lds()
 template <typename T, int THREADS>
 __device__ __forceinline__ void num_direct_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                                 u32* __restrict__ c_col, T* __restrict__ c_val, u32 bidx,
-                                                u32 nblk, ClassHint hint = kNoHint)
+                                                u32 nblk, u32 hint = kNoCount)
 {
     using G = Block<THREADS>;
     const G g;
@@ -62,27 +62,26 @@ __device__ __forceinline__ void num_direct_body(unsigned char* smem, const Produ
     u32* win_all = scratch + THREADS / 64 + 2;
     const u32 l = lane_id();
     u32* win = win_all + (threadIdx.x >> 6) * kWinWords;
-    // (a thread per row of the chunk: the speculative first record of open_list is that of thread 0's row only,
-    //  so the records are requested here, from the hinted position, and re-requested if the table disagrees)
+    // (a thread per row of the chunk: with a host-known count the records of the first chunk are requested at once, next
+    //  to the device-side class table that confirms the count)
     const u32 miss = w.st->capacity_miss;
-    u32 off = w.st->num.offset[NUM_DIRECT], count = w.st->num.count[NUM_DIRECT];
-    RowSlice rs{};
+    const u32 count = min(w.st->num.count[NUM_DIRECT], w.m);
+    const bool hinted = hint != kNoCount && hint <= w.m;
+    RowSlice rs{0u, 0u, 1u};
     RowRec first_rec{};
-    const bool hinted = hint.cnt != 0xFFFFFFFFu;
     if (hinted) {
-        rs = row_slice(hint.cnt, bidx, nblk, THREADS, 0u, (w.xcd_aware & 1u) != 0);
-        if (rs.idx + threadIdx.x < rs.end) first_rec = (w.recs + hint.off)[rs.idx + threadIdx.x];
+        rs = row_slice(hint, bidx, nblk, THREADS, 0u, (w.xcd_aware & 1u) != 0);
+        if (rs.idx + threadIdx.x < rs.end) first_rec = *class_rec_at(w.recs, w.m, NUM_DIRECT, rs.idx + threadIdx.x);
     }
     if (miss) return;
-    const bool spec_ok = hinted && off == hint.off && count == hint.cnt;
-    const RowRec* recs = w.recs + off;
+    const bool spec_ok = hinted && count == hint;
     if (!spec_ok) rs = row_slice(count, bidx, nblk, THREADS, 0u, (w.xcd_aware & 1u) != 0);
     for (u32 first = rs.idx; first < rs.end; first += rs.stride) {
         const u32 cnt = min((u32)THREADS, rs.end - first);
         u32 len = 0, bs = 0, base = 0;
         T av = T(0);
         if (threadIdx.x < cnt) {
-            const RowRec rec = (spec_ok && first == rs.idx) ? first_rec : recs[first + threadIdx.x];
+            const RowRec rec = (spec_ok && first == rs.idx) ? first_rec : *class_rec_at(w.recs, w.m, NUM_DIRECT, first + threadIdx.x);
             len = rec.nnz;
             base = rec.base;
             av = src.a_val[rec.a0];
@@ -494,7 +493,7 @@ template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS,
           bool KEEP = VERIFY>
 __device__ __forceinline__ void num_hash_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                               u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
-                                              u32 bidx, u32 nblk, ClassHint hint = kNoHint)
+                                              u32 bidx, u32 nblk, u32 hint = kNoCount)
 {
     constexpr u32 NG = THREADS / G::SIZE;
     constexpr u32 kGroupBytes = num_group_lds<G, T, CAP, THREADS>();
@@ -514,18 +513,13 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     u32* scan_scratch = m_incl + 2 * G::SIZE;
     RowMeta<T> meta{m_incl, m_incl + G::SIZE, m_av, scan_scratch + scan_scratch_words<G, THREADS>()};
     u32* S = reinterpret_cast<u32*>(mine);
-    const ListHead head = open_list<false>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
-    if (head.miss) return;
-    const RowRec* recs = head.recs;
-    u32 idx = head.rs.idx;
-    const u32 stride = head.rs.stride, count = head.rs.end;
-    RowRec next = head.next;
-    while (idx < count) {
+    RowCursor cur = open_list<false>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
+    // (a replayed sequence that an earlier kernel has declared void walks nothing)
+    if (cur.miss) return;
+    while (cur.more()) {
         PHASE_BEGIN(cls);
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + stride < count) next = recs[idx + stride];
+        const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         if (rec.nnz <= NLO || rec.nnz > NMAX) {  // the other launch's row (uniform for the group)
-            idx += stride;
             continue;
         }
         // table of this row: the smallest power of two >= 1.5 nnz (load <= 2/3), at least one slot
@@ -586,7 +580,6 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         }
         g.sync();
         PHASE_MARK(2);
-        idx += stride;
     }
 }
 
@@ -604,7 +597,7 @@ constexpr u32 num_dense_lds()
 template <typename T, u32 WCOLS, int THREADS, bool VERIFY = false>
 __device__ __forceinline__ void num_dense_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                                u32* __restrict__ c_col, T* __restrict__ c_val, int cls,
-                                               u32 bidx, u32 nblk, ClassHint hint = kNoHint)
+                                               u32 bidx, u32 nblk, u32 hint = kNoCount)
 {
     constexpr u32 WORDS = WCOLS / 32;
     using G = Block<THREADS>;
@@ -615,17 +608,13 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
     u32* pref = bm + WORDS;
     u32* scratch = pref + WORDS + 2 * THREADS;
     RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av, scratch + THREADS / 64 + 2};
-    const ListHead head = open_list<false>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
-    if (head.miss) return;
-    const RowSlice rs = head.rs;
-    const RowRec* recs = head.recs;
-    RowRec next = head.next;
+    RowCursor cur = open_list<false>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
+    if (cur.miss) return;
     for (u32 i = threadIdx.x; i < WCOLS; i += THREADS) vals[i] = 0;
     for (u32 i = threadIdx.x; i < WORDS; i += THREADS) bm[i] = 0;
     __syncthreads();
-    for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
+    while (cur.more()) {
+        const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         u32 emitted = 0;
         // a row wider than one window: per-entry cursors, every B entry is read once (WindowCursors)
         const bool multi = u64(rec.cmax) - rec.cmin + 1 > WCOLS;
@@ -739,16 +728,12 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
     const bool direct = DIRECT;  // replayed sequence: rows go straight to C (RowWork::nf_pred_off)
     u32* __restrict__ o_col = direct ? w.nf_direct_col : w.nf_col;
     T* __restrict__ o_val = static_cast<T*>(direct ? w.nf_direct_val : w.nf_val);
-    const RowSlice rs = row_slice(w.st->sym.count[SYM_NF], blockIdx.x, gridDim.x, 1u, 0u, (w.xcd_aware & 2u) != 0);
-    const RowRec* recs = w.recs + w.st->sym.offset[SYM_NF];
-    RowRec next{};
-    if (rs.idx < rs.end) next = recs[rs.idx];
+    RowCursor cur = open_list<true>(w, SYM_NF, kNoCount, blockIdx.x, gridDim.x, 1u, 0u, (w.xcd_aware & 2u) != 0);
     for (u32 i = threadIdx.x; i < WCOLS; i += THREADS) vals[i] = 0;
     for (u32 i = threadIdx.x; i < WCOLS / 4; i += THREADS) flag_words[i] = 0;
     __syncthreads();
-    for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
+    while (cur.more()) {
+        const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         u64 slot = 0;
         u32 slot_len = 0;
         if (direct) {
@@ -814,14 +799,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void nf_copy_kernel(RowWork w, u32* __restrict__ c_col, T* __restrict__ c_val)
 {
     if (w.st->capacity_miss) return;
-    const u32 count = w.st->num.count[NUM_NFCOPY];
-    const RowRec* recs = w.recs + w.st->num.offset[NUM_NFCOPY];
+    const u32 count = min(w.st->num.count[NUM_NFCOPY], w.m);
     const u32* __restrict__ s_col = w.nf_col;
     const T* __restrict__ s_val = static_cast<const T*>(w.nf_val);
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
     for (u32 idx = wave; idx < count; idx += nwaves) {
-        const RowRec rec = recs[idx];
+        const RowRec rec = *class_rec_at(w.recs, w.m, NUM_NFCOPY, idx);
         const u64 slot = w.nf_off[rec.row];
         for (u32 j = lane; j < rec.nnz; j += 64) {
             c_col[size_t(rec.base) + j] = s_col[slot + j];
@@ -903,71 +887,66 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    // launch order (ClassGrid slots): D1, B2K, W512, W256, R64, R32, W128, G16, G8, G4, DIRECT
-    // (every body starts with open_list: its first record is requested from the hinted list position while the
+    // launch order (ClassGrid slots): D1, B2K, W512, W256, R64, R32, W128, G16, G8, DIRECT
+    // (every body starts with open_list: its first row ids are requested by the host-known count while the
     //  device-side table and the capacity_miss flag are still on their way)
     if (b < cg.first[1])
-        num_dense_body<T, kNumD1Win, 256, VERIFY>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0], kNoHint);
+        num_dense_body<T, kNumD1Win, 256, VERIFY>(smem, src, w, c_col, c_val, NUM_D1, b - cg.first[0], cg.first[1] - cg.first[0], cg.cnt[0]);
     else if (b < cg.first[2])
         num_hash_body<Block<256>, T, kNumB2KCap, kB2KW1, kNumB2KMaxNnz, SORT_BITMAP, 256, 0, VERIFY>(
-            smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1], kNoHint);
+            smem, src, w, c_col, c_val, NUM_B2K, b - cg.first[1], cg.first[2] - cg.first[1], cg.cnt[1]);
     else if (b < cg.first[3])
         num_hash_body<SubWave<64>, T, kNumW512Cap, kW512W1, kNumW512MaxNnz, SORT_BITMAP, 256, 0, VERIFY>(
-            smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2], kNoHint);
+            smem, src, w, c_col, c_val, NUM_W512, b - cg.first[2], cg.first[3] - cg.first[2], cg.cnt[2]);
     else if (b < cg.first[4])
         num_hash_body<SubWave<32>, T, kNumW256Cap, kW256W1, kNumW256MaxNnz, SORT_BITMAP, 256, 0, VERIFY>(
-            smem, src, w, c_col, c_val, NUM_W256, b - cg.first[3], cg.first[4] - cg.first[3], kNoHint);
+            smem, src, w, c_col, c_val, NUM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.cnt[3]);
     else if (b < cg.first[5]) {
         if constexpr (WITH_ESC)
-            num_escw_body<T, 64, 256>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], kNoHint);
+            num_escw_body<T, 64, 256>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], cg.cnt[4]);
     } else if (b < cg.first[6]) {
         if constexpr (WITH_ESC)
-            num_escw_body<T, 32, 256>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], kNoHint);
+            num_escw_body<T, 32, 256>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], cg.cnt[5]);
     } else if (b < cg.first[7])
         num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256, 0, VERIFY>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], kNoHint);
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.cnt[6]);
     else if (b < cg.first[8]) {
         if constexpr (WITH_ESC)
-            num_esc_body<T, 16, 256>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], kNoHint);
+            num_esc_body<T, 16, 256>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.cnt[7]);
     } else if (b < cg.first[9]) {
         if constexpr (WITH_ESC)
-            num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], kNoHint);
-    } else if (b < cg.first[10]) {
-        if constexpr (WITH_ESC)
-            num_esc_body<T, 4, 256>(smem, src, w, c_col, c_val, NUM_G4, b - cg.first[9], cg.first[10] - cg.first[9], kNoHint);
-    } else if (b < cg.first[11])
-        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[10], cg.first[11] - cg.first[10], kNoHint);
-    else  // the staged row offsets of an eager call -> C.row_offsets (RowWork::off_src)
-        for (u32 i = (b - cg.first[11]) * 256u + threadIdx.x; i < w.off_n; i += (cg.first[12] - cg.first[11]) * 256u)
+            num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.cnt[8]);
+    } else if (b < cg.first[10])
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[9], cg.first[10] - cg.first[9], cg.cnt[9]);
+    else if (!w.st->capacity_miss)  // the staged row offsets -> C.row_offsets (RowWork::off_src; not for a sequence declared void)
+        for (u32 i = (b - cg.first[10]) * 256u + threadIdx.x; i < w.off_n; i += (cg.first[11] - cg.first[10]) * 256u)
             w.off_dst[i] = w.off_src[i];
 }
 
-// The three smallest classes alone: the merged kernel above takes the register count of its
+// The small classes alone: the merged kernel above takes the register count of its
 // hungriest body (5 waves per SIMD); these bodies need 70 VGPRs, and a launch of their own
 // reaches 7 waves per SIMD -- what rows that are one short chain of dependent loads need.
-template <typename T, int TT>
-__global__ __launch_bounds__(TT) void num_tiny_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
-                                                      u32* __restrict__ c_col, T* __restrict__ c_val,
-                                                      ClassGrid cg)
+template <typename T>
+__global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
+                                                       u32* __restrict__ c_col, T* __restrict__ c_val,
+                                                       ClassGrid cg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
     if (b < cg.first[5])
-        num_escw_body<T, 64, TT>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], kNoHint);
+        num_escw_body<T, 64, 256>(smem, src, w, c_col, c_val, NUM_R64, b - cg.first[4], cg.first[5] - cg.first[4], cg.cnt[4]);
     else if (b < cg.first[6])
-        num_escw_body<T, 32, TT>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], kNoHint);
+        num_escw_body<T, 32, 256>(smem, src, w, c_col, c_val, NUM_R32, b - cg.first[5], cg.first[6] - cg.first[5], cg.cnt[5]);
     else if (b < cg.first[7])
-        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, TT>(
-            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], kNoHint);
+        num_hash_body<SubWave<32>, T, kNumW128Cap, 0, kNumW128MaxNnz, SORT_RANK, 256>(
+            smem, src, w, c_col, c_val, NUM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.cnt[6]);
     else if (b < cg.first[8])
-        num_esc_body<T, 16, TT>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], kNoHint);
+        num_esc_body<T, 16, 256>(smem, src, w, c_col, c_val, NUM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.cnt[7]);
     else if (b < cg.first[9])
-        num_esc_body<T, 8, TT>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], kNoHint);
-    else if (b < cg.first[10])
-        num_esc_body<T, 4, TT>(smem, src, w, c_col, c_val, NUM_G4, b - cg.first[9], cg.first[10] - cg.first[9], kNoHint);
+        num_esc_body<T, 8, 256>(smem, src, w, c_col, c_val, NUM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.cnt[8]);
     else
-        num_direct_body<T, TT>(smem, src, w, c_col, c_val, b - cg.first[10], cg.first[11] - cg.first[10], kNoHint);
+        num_direct_body<T, 256>(smem, src, w, c_col, c_val, b - cg.first[9], cg.first[10] - cg.first[9], cg.cnt[9]);
 }
 
 // ------------------------------------------------------------------ NUM_G
@@ -1003,8 +982,7 @@ __global__ __launch_bounds__(1024) void num_spill_plan_kernel(RowWork w, int cls
     __shared__ u64 s_run_p;
     __shared__ u32 s_run_b, s_run_f;
     if (w.st->capacity_miss) return;
-    const u32 count = w.st->num.count[cls];
-    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    const u32 count = min(w.st->num.count[cls], w.m);
     if (threadIdx.x == 0) {
         s_run_p = 0;
         s_run_b = 0;
@@ -1015,7 +993,7 @@ __global__ __launch_bounds__(1024) void num_spill_plan_kernel(RowWork w, int cls
         const u32 i = i0 + threadIdx.x;
         u32 ops = 0, nb = 0, nf = 0, shift = 0, unit = 1;
         if (i < count) {
-            const RowRec rec = recs[i];
+            const RowRec rec = *class_rec_at(w.recs, w.m, cls, i);
             ops = rec.ops;
             const u32 range_m1 = rec.cmax - rec.cmin;
             nb = (ops + kGBucketTarget - 1) / kGBucketTarget;
@@ -1088,10 +1066,9 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_count_kernel(ProductS
     RowMeta<T> meta{m_incl, m_incl + kGWalkThreads, nullptr, win};
     if (w.st->capacity_miss) return;
     src.rebase(a_ro);
-    const u32 count = w.st->num.count[cls];
-    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    const u32 count = min(w.st->num.count[cls], w.m);
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const RowRec rec = recs[idx];
+        const RowRec rec = *class_rec_at(w.recs, w.m, cls, idx);
         u32 lo, hi;
         if (!spill_slice(rec, lo, hi)) continue;
         const GRowPlan pl = w.spill.plan[idx];
@@ -1122,11 +1099,10 @@ __global__ __launch_bounds__(256) void num_spill_offsets_kernel(RowWork w, int c
     __shared__ u32 s_bc[kGMaxBuckets];  // products per bucket of the row (this workgroup owns them all)
     __shared__ u32 s_lo[kGMaxBuckets], s_hi[kGMaxBuckets];  // column span of every bucket
     if (w.st->capacity_miss) return;
-    const u32 count = w.st->num.count[cls];
-    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    const u32 count = min(w.st->num.count[cls], w.m);
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
         const GRowPlan pl = w.spill.plan[idx];
-        const RowRec rec = recs[idx];
+        const RowRec rec = *class_rec_at(w.recs, w.m, cls, idx);
         for (u32 b = threadIdx.x; b < pl.nb; b += 256) s_bc[b] = 0;
         __syncthreads();
         u32 run = 0;                 // products before the current chunk of cells
@@ -1200,10 +1176,9 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(Produc
     src.rebase(a_ro);
     u32* pcol = w.spill.pcol[0];
     T* pval = static_cast<T*>(w.spill.pval[0]);
-    const u32 count = w.st->num.count[cls];
-    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    const u32 count = min(w.st->num.count[cls], w.m);
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const RowRec rec = recs[idx];
+        const RowRec rec = *class_rec_at(w.recs, w.m, cls, idx);
         u32 lo, hi;
         if (!spill_slice(rec, lo, hi)) continue;
         const GRowPlan pl = w.spill.plan[idx];
@@ -1378,10 +1353,9 @@ __global__ __launch_bounds__(256) void num_spill_copy_kernel(RowWork w, u32* __r
     if (w.st->capacity_miss) return;
     const u32* ocol = w.spill.pcol[1];
     const T* oval = static_cast<const T*>(w.spill.pval[1]);
-    const u32 count = w.st->num.count[cls];
-    const RowRec* recs = w.recs + w.st->num.offset[cls];
+    const u32 count = min(w.st->num.count[cls], w.m);
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const RowRec rec = recs[idx];
+        const RowRec rec = *class_rec_at(w.recs, w.m, cls, idx);
         const GRowPlan pl = w.spill.plan[idx];
         for (u32 b = blockIdx.y; b < pl.nb; b += gridDim.y) {
             const u32 n = w.spill.dcount[pl.bbase + b];
@@ -1415,7 +1389,6 @@ u32 numeric_lds_bytes_t(int cls)
 {
     switch (cls) {
         case NUM_DIRECT: return num_direct_lds<T, 256>();
-        case NUM_G4: return 64 * num_esc_group_lds<T, 4>();
         case NUM_G8: return 32 * num_esc_group_lds<T, 8>();
         case NUM_G16: return 16 * num_esc_group_lds<T, 16>();
         case NUM_R32: return 8 * num_escw_group_lds<T, 32>();
@@ -1459,48 +1432,36 @@ static void launch_num_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
 
 static u32 g_spill_big_grid = 256;
 void set_spill_big_grid(u32 blocks) { g_spill_big_grid = blocks ? blocks : 256u; }
-static int g_tiny_threads = 256;
-void set_tiny_threads(int t) { g_tiny_threads = (t == 64 || t == 128) ? t : 256; }
 
 template <typename T>
 void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const CsrView<T>& Av,
                           const CsrView<T>& Bv, const RowWork& w, u32* c_col, T* c_val, int cu_count, bool exact,
                           hipEvent_t e0, hipEvent_t e1)
 {
-    constexpr int NS = 11;
-    static const int slots[NS] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W256, NUM_R64, NUM_R32, NUM_W128, NUM_G16, NUM_G8, NUM_G4, NUM_DIRECT};
-    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 8, 16, 32, 64, 256};
+    constexpr int NS = 10;
+    static const int slots[NS] = {NUM_D1, NUM_B2K, NUM_W512, NUM_W256, NUM_R64, NUM_R32, NUM_W128, NUM_G16, NUM_G8, NUM_DIRECT};
+    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 8, 16, 32, 256};
     bool tiny_only = true;
     for (int k = 0; k < 4; ++k)
         if ((mask >> slots[k] & 1u) && counts_hint[slots[k]]) tiny_only = false;
-    // the small classes alone run in workgroups of g_tiny_threads threads (their groups never meet at a barrier
-    // except in the scaled-copy class, whose chunk is the workgroup)
-    if (w.verify_numeric) tiny_only = false;  // (only the big kernel has verifying bodies)
-    const int threads = tiny_only ? g_tiny_threads : 256;
-    const u32 div = 256u / (u32)threads;
-    auto class_lds = [&](int cls) -> u32 {
-        if (!tiny_only) return numeric_lds_bytes_t<T>(cls);
-        if (cls != NUM_DIRECT) return numeric_lds_bytes_t<T>(cls) / div;
-        return threads == 64 ? num_direct_lds<T, 64>() : threads == 128 ? num_direct_lds<T, 128>() : num_direct_lds<T, 256>();
-    };
+    if (w.verify_numeric || w.off_n) tiny_only = false;  // (only the big kernel has verifying bodies / moves the offsets)
     u32 lds = 0;
     for (int k = 0; k < NS; ++k)
-        if (mask >> slots[k] & 1u) lds = lds > class_lds(slots[k]) ? lds : class_lds(slots[k]);
+        if (mask >> slots[k] & 1u) lds = std::max(lds, numeric_lds_bytes_t<T>(slots[k]));
     ClassGrid cg{};
     for (int k = 0; k < NS; ++k) {
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
-        const u32 rpb = rows_per_block[k] >= div ? rows_per_block[k] / div : 1u;
-        cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, threads, cu_count, rpb) : 0u);
+        cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
+        cg.cnt[k] = exact ? counts_hint[slots[k]] : kNoCount;
     }
-    if (cg.first[NS] == 0) {
-        if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);  // (nothing to time: an empty interval)
-        return;
-    }
-    (void)exact;  // (list positions are no longer handed to the merged kernels: launch.hpp, ClassGrid)
-    const ProductSrc<T> src{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
     // ... + the workgroups that move the staged row offsets (only the big kernel carries them)
     cg.first[NS + 1] = cg.first[NS];
     if (!tiny_only && w.off_n) cg.first[NS + 1] += std::min<u32>((w.off_n + 2047u) / 2048u, 512u);
+    if (cg.first[NS + 1] == 0) {
+        if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);  // (nothing to time: an empty interval)
+        return;
+    }
+    const ProductSrc<T> src{w.b_sl, Av.data, Bv.col_ids, Bv.data, w.w_sl};
     bool with_esc = false;  // (a class of the mask without rows has no blocks: its body is never entered)
     for (int k = 0; k < NS; ++k)
         if ((kNumEscMask >> slots[k] & 1u) && cg.first[k + 1] != cg.first[k]) with_esc = true;
@@ -1514,14 +1475,8 @@ void launch_numeric_light(hipStream_t s, const u32* counts_hint, u32 mask, const
     else if (!tiny_only)
         SPECK_LAUNCH_TIMED((num_light_kernel<T, false>), dim3(cg.first[NS + 1]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
-    else if (threads == 64)
-        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 64>), dim3(cg.first[NS]), dim3(64), lds, s, e0, e1, src, Av.row_offsets, w,
-                           c_col, c_val, cg);
-    else if (threads == 128)
-        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 128>), dim3(cg.first[NS]), dim3(128), lds, s, e0, e1, src, Av.row_offsets, w,
-                           c_col, c_val, cg);
     else
-        SPECK_LAUNCH_TIMED((num_tiny_kernel<T, 256>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
+        SPECK_LAUNCH_TIMED((num_tiny_kernel<T>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, src, Av.row_offsets, w,
                            c_col, c_val, cg);
 }
 
@@ -1564,10 +1519,6 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                                dim3(TH), lds, s, A, B, w, c_col, c_val);
             break;
         }
-        case NUM_G4:
-            hipLaunchKernelGGL((num_esc_kernel<T, 4>), dim3(grid_for(count, lds, 256, cu_count, 64)), dim3(256), lds, s, A, B,
-                               w, c_col, c_val, cls);
-            break;
         case NUM_G8:
             hipLaunchKernelGGL((num_esc_kernel<T, 8>), dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B,
                                w, c_col, c_val, cls);

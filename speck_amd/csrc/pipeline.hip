@@ -4,11 +4,12 @@
 //   * one grow-only scratch arena per config (the reference cudaMallocs/frees every
 //     scratch buffer inside each call, Multiply.cu:202-225,1056-1070)
 //   * the launch sequence is STATIC: every kernel takes its row list and counts from a
-//     device-side stats block and its grid depends only on rows(A), so
-//       - the eager path needs ONE blocking read-back (nnz(C), to allocate C) instead of the
-//         reference's 5-8, and
-//       - a repeated call with the same buffers (the benchmark loop, Executor.cpp:59-72)
-//         replays a captured hipGraph: one graph launch + one synchronisation per multiply.
+//     device-side stats block and its grid depends only on rows(A), so a call needs ONE read-back
+//     (nnz(C), to allocate C) instead of the reference's 5-8;
+//   * a repeated call with the same buffers (the benchmark loop, Executor.cpp:59-72) may REUSE the placement of the
+//     previous identical call (option use_graph -- the name is historical: the sequence is enqueued launch by launch,
+//     no executable graph since round 5) -- verified on the device, never trusted; the complete call is the default
+//     of every measurement (bench.py);
 //   * kernel classes run concurrently on separate streams between explicit fork/join events.
 #include <hip/hip_runtime.h>
 
@@ -47,18 +48,13 @@ struct GraphKey {
     }
 };
 
-// What an eager call leaves behind for a replay of the SAME call (same buffers, same sizes) to verify instead of
-// recompute: the row offsets of C, per scan tile / analysis block where its rows go in the class lists (launch.hpp,
-// kPredTileWords), and the final statistics block.  One device allocation, carved.  The config keeps two: `pred`,
-// rewritten by every eager call, and `gpred`, the snapshot a captured sequence owns -- an eager call on OTHER
-// buffers in between must not change what that sequence compares against (and writes by).
+// What a complete call leaves behind for a repeated identical call (same buffers, same sizes) to place rows by: the row
+// offsets of C -- the config's OWN copy (C.row_offsets is the caller's to overwrite).  The config keeps two: `pred`,
+// rewritten by every complete call, and `gpred`, the copy a reuse sequence owns -- a complete call on OTHER buffers in
+// between must not change what that sequence compares against (and writes by).
 struct Prediction {
-    void* buf = nullptr;
-    size_t bytes = 0;
-    u32* off = nullptr;        // [rows + 1]
-    u32* num_tile = nullptr;   // [scan_tiles(rows)][kPredTileWords]
-    u32* sym_block = nullptr;  // [analysis_blocks(rows)][kPredBlockWords]
-    DeviceStats* stats = nullptr;
+    u32* off = nullptr;  // [rows + 1]
+    size_t words = 0;
     u32 rows = 0;
 };
 
@@ -67,17 +63,15 @@ struct Prediction {
 struct ReplayPlan {
     u32 num_mask, launch_mask;
     u32 num_counts[kMaxClasses];
-    bool direct, fused, pred_scan, pred_sym;
-    bool skip_scan;  // ... and so does every kernel that produces a row's nnz (RowWork::verify_counts): no scan kernel -- the
-                     //   numeric launches read the records, offsets and class table the previous replay's scan left
-    bool uncaptured;  // the launches of this sequence are enqueued at every call instead of captured into a graph (below)
+    bool direct, fused;
+    bool skip_scan;  // every kernel that produces a row's nnz compares it with the previous call's (RowWork::verify_counts):
+                     //   no scan kernel -- the numeric launches read the records, lists and class table that call's scan left
     bool num_verify;  // ... and no symbolic pass for the rows of the hash / dense classes: the numeric light launch verifies
                       //   their nnz itself (RowWork::verify_numeric) -- the symbolic phase is the register-class rows alone
     bool overlap;  // the analysis only VERIFIES what the previous identical call left in the arena, on a stream of its
                    //   own beside the symbolic / scan / numeric launches (which read that: DESIGN.md 4.3)
-    // ... and everything else of "the last eager call" the launches are sized from: a sequence that is enqueued anew at
-    // every call (caller's stream, replay_uncaptured, profile_replay) must not pick up what a multiply of ANOTHER
-    // problem left in the config since (a captured graph has it baked in)
+    // ... and everything else of "the last complete call" the launches are sized from: the sequence is enqueued anew at
+    // every call and must not pick up what a multiply of ANOTHER problem left in the config since
     u32 sym_mask;
     u32 sym_counts[kMaxClasses];
     u64 g_products, nf_cap_entries;
@@ -101,41 +95,35 @@ struct speck_config {
     DeviceStats* d_stats = nullptr;
     DeviceStats* h_stats = nullptr;  // pinned, mapped
     DeviceStats* h_stats_dev = nullptr;  // device address of h_stats
-    u32* d_ticket = nullptr;             // completion ticket of the replayed sequence: device counter,
+    u32* d_ticket = nullptr;             // completion ticket of a launch sequence: device counter,
     u32* h_ticket = nullptr;             //   pinned host copy (the host spins on it),
     u32* h_ticket_dev = nullptr;         //   its device address
     u32 ticket_expected = 0;
     bool spin_wait = true;
+    void* chain_buf = nullptr;           // look-back chain of the analysis / scan kernels (chain.hpp)
+    u64 chain_launches = 0;              // ... launches that used it: the tag of the next one (next_chain)
+    u64* d_bytes = nullptr;              // [2][kMaxClasses] algorithmic bytes per class (option collect_bytes only)
     ClassifyParams cp{};
     int profile_kernels = 0;  // 1: HIP events around every launch; 2: around the phases only (no event between
-                              //    the class launches of a phase: their spans are what a replayed sequence sees)
-    bool profile_replay = false;  // option profile_replay: a profiled call that COULD be replayed runs the launches
-                                  //    of the replayed sequence (uncaptured) instead of the eager path
+                              //    the class launches of a phase)
     std::vector<hipEvent_t> kev;   // kernel event pool (timing)
     std::vector<hipStream_t> aux;  // one stream per kernel class: classes run concurrently
     std::vector<hipEvent_t> aux_done;
     hipEvent_t fork = nullptr;
-    bool eager_speculate = true;  // option eager_speculate: an eager call that follows another one on this config sizes
+    bool eager_speculate = true;  // option eager_speculate: a complete call that follows another one on this config sizes
                                   //   its symbolic phase (grids, launched classes, scratch pool, numeric-first window) from
                                   //   THAT call and runs analysis .. scan as one batch -- one read-back instead of two; the
                                   //   device checks every assumption (capacity_miss: the two-read-back sequence re-runs)
     bool spec_valid = false;      // such a call has completed (last_sym_* describe it)
     u64 spec_rows_a = 0, spec_rows_b = 0;
     int eager_spec_hits = 0, eager_spec_misses = 0;
-    const u32* stage_off_src = nullptr;  // eager call in flight: the staged row offsets ride to C in the numeric light
+    const u32* stage_off_src = nullptr;  // call in flight: the staged row offsets ride to C in the numeric light
     u32* stage_off_dst = nullptr;        //   launch (RowWork::off_src)
     u32 stage_off_n = 0;
-    bool validate_inputs = true;  // eager path: B's rows strictly ascending and in range
-    u32 epoch_counter = 0, check_epoch = 0;  // ... reported as the call's epoch (DeviceStats::b_bad_epoch); set while
-                                             //   an eager call that checks is in flight
+    bool validate_inputs = true;  // complete call: B's rows strictly ascending and in range
     bool concurrent_classes = true;
     u32 max_side_streams = 12;
-    float split_min_us = 10.f; // both parts of a light launch must be at least this long to be launched apart
     float fork_min_us = 60.f;  // estimated duration from which a class launch gets its own stream
-    bool merge_light = true;  // all 256-thread classes of a phase in one launch
-    bool split_light = false; // ... in two back-to-back launches, by LDS / register need (since the register classes
-                              //   sort without LDS tables the small rows are bound by their gathers, and ONE launch
-                              //   overlaps them with the latency-bound wave / workgroup rows: -5 % on every stand-in)
     u32 xcd_aware = 10;       // class lists walked in per-XCD contiguous slices: bit 0 sub-wave hash classes,
                               //   bit 1 dense-window / bitmap classes, bit 2 workgroup hash classes, bit 3 the
                               //   register classes (measured: +3.5 % on the cant stand-in for bit 1, -9 % time of
@@ -144,13 +132,11 @@ struct speck_config {
                               //   imbalance)
     u32 last_sym_counts[kMaxClasses] = {}, last_num_counts[kMaxClasses] = {};
 
-    // captured launch sequence of the last repeated call
+    // the reuse sequence of the last repeated call (name of the option: use_graph)
     bool use_graph = true;
     bool graph_valid = false;
     GraphKey graph_key;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    u32 last_sym_mask = 0, last_num_mask = 0;  // non-empty classes of the last eager call
+    u32 last_sym_mask = 0, last_num_mask = 0;  // non-empty classes of the last complete call
     u32 last_max_row_nnz = 0;                  // ... and its longest C row
     GraphKey last_key;                         // ... and what it ran on
     bool last_key_valid = false;
@@ -162,38 +148,23 @@ struct speck_config {
     u64 nf_cap_entries = 0;
     size_t nf_pool_max_bytes = 0;  // 0: half of the free device memory at allocation time
     int pool_fallbacks = 0;        // times a scratch-pool class was switched off because the pool did not fit
-    // direct placement of the numeric-first rows by a replayed sequence: the row offsets of the last eager call
-    // (the config's own copy -- C.row_offsets is the caller's to overwrite), and the C buffers of the capture
     Prediction pred, gpred;
-    DeviceStats last_eager_stats{};  // final statistics block of the last eager call (what `pred` goes with)
-    bool pred_valid = false;         // pred.off holds the offsets of the last eager call
-    bool pred_tiles_valid = false;   // ... and pred.num_tile its tile tables,
-    bool pred_fold_esc = false;      //     in the shape of a sequence that finishes the register-class rows early
-    bool pred_scan = true;           // option pred_scan: a replayed sequence scans with launch_scan_predicted
-    bool capture_pred_scan = false;  // set while such a sequence is being enqueued
-    bool pred_sym = true;            // option pred_sym: ... and bins its rows for the symbolic phase inside the analysis
-                                     //   kernel, at the list positions of the previous identical call (no scatter kernel)
-    bool capture_pred_sym = false;
+    DeviceStats last_eager_stats{};  // final statistics block of the last complete call (what `pred` goes with)
+    bool pred_valid = false;         // pred.off holds the offsets of the last complete call
     bool nf_direct = true;           // option nf_direct
-    bool capture_direct = false;     // set while a sequence with direct placement is being captured
+    bool capture_direct = false;     // set while a sequence with direct placement is being enqueued
     bool esc_fused = true;           // option esc_fused: such a sequence finishes the rows of the register classes in
                                      //   its symbolic phase
-    bool capture_fused = false;      // set while a sequence that does so is being captured
+    bool capture_fused = false;      // set while a sequence that does so is being enqueued
     u32* capture_c_col = nullptr;
     void* capture_c_val = nullptr;
-    bool graph_direct = false;       // the captured sequence places the numeric-first rows directly
-    bool graph_fused = false;        // ... and finishes the rows of the register classes in its symbolic phase
-    bool graph_pred_scan = false;    // ... and scans with the predicted kernel
-    bool graph_pred_sym = false;     // ... and has no scatter kernel
     ReplayPlan graph_plan{};
-    bool exec_dirty = false;         // other launches went onto the pipeline stream since graph_exec was last launched
-    bool skip_scan = true;           // option skip_scan: a replayed sequence that follows a replay of itself has no scan kernel
+    bool skip_scan = true;           // option skip_scan: a reuse sequence that follows a replay of itself has no scan kernel
     bool capture_skip_scan = false;  // set while such a sequence is being enqueued
     int num_verify = 1;              // option num_verify (0: never, 1: when it pays, 2: whenever possible): ... and no symbolic pass for its hash / dense rows (ReplayPlan::num_verify)
     bool capture_num_verify = false;
-    bool capture_forked = false;     // option capture_forked (ReplayPlan::uncaptured)
     // The inputs the analysis depends on as the last WRITING analysis saw them (stages.hip, launch_snapshot_inputs): A's
-    // column ids | B's row offsets | first and last column id of every row of B.  The verifier of a replayed sequence
+    // column ids | B's row offsets | first and last column id of every row of B.  The verifier of a reuse sequence
     // compares the inputs with this copy instead of recomputing the analysis (option verify_inputs); grow-only, and like
     // the arena it belongs to whoever ran a writing analysis last (snap_for_arena travels with arena_key).
     u32* snap = nullptr;
@@ -201,25 +172,23 @@ struct speck_config {
     bool verify_inputs = true;
     bool snap_pending = false;       // the verifier of the call in flight recomputes the analysis AND takes the copy
     bool snap_for_arena = false;     // the copy holds the inputs the arena's metadata was derived from (and verified against)
-    std::function<int()> after_analysis;  // set by an eager call for the duration of its first batch (multiply_impl)
-    bool gate_verifier = false;      // profiled pre-pass: the verifier's stream waits for the symbolic phase of the timed sequence
-    bool arena_from_replay = false;  // the arena (numeric records, class table, statistics) was last written by a completed
+    std::function<int()> after_analysis;  // set by a complete call for the duration of its first batch (multiply_impl)
+    bool arena_from_replay = false;  // the arena (numeric records, lists, class table, statistics) was last written by a completed
                                      //   REPLAY of arena_key's problem: the layout a sequence without a scan reads
-    bool overlap_analysis = true;    // option overlap_analysis: a replayed sequence runs its analysis as a verifier beside it
+    bool overlap_analysis = true;    // option overlap_analysis: a reuse sequence runs its analysis as a verifier beside it
     bool capture_overlap = false;    // set while such a sequence is being enqueued
-    bool graph_overlap = false;      // the captured sequence does so
     hipStream_t vstream = nullptr;   // the verifier's stream
     u32* h_verify = nullptr;         // its verdict (word 0) and its completion ticket (word 16): pinned, mapped
     u32* h_verify_dev = nullptr;
     u32* d_vticket = nullptr;
     u32 vticket_expected = 0;
-    bool validate_in_flight = false; // the input check of an eager call is running on vstream (begin_validate)
-    GraphKey arena_key;              // what the per-row / per-entry metadata in the arena (b_sl, row arrays, symbolic records,
+    bool verifier_in_flight = false; // a verifier / input check runs on vstream: drained on every way out of the call
+    bool validate_in_flight = false; // the input check of a complete call is running on vstream (begin_validate)
+    GraphKey arena_key;              // what the per-row / per-entry metadata in the arena (b_sl, row arrays, records, lists,
     bool arena_key_valid = false;    //   class table) was last written for -- by a multiply that COMPLETED
-    bool replay_uncaptured = false;  // option replay_uncaptured (debugging): enqueue the sequence instead of launching its graph
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
-    u64 last_g_products = 0;  // what the spill pools of the captured sequence were sized for
+    u64 last_g_products = 0;  // what the spill pools of the reuse sequence were sized for
     speck_stats last{};
 };
 
@@ -240,14 +209,7 @@ constexpr std::chrono::microseconds kSpinBudget{2000};
 
 hipStream_t main_stream(speck_config* c) { return c->use_user_stream ? c->user_stream : c->streams[0]; }
 
-void drop_graph(speck_config* c)
-{
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-    if (c->graph) (void)hipGraphDestroy(c->graph);
-    c->graph_exec = nullptr;
-    c->graph = nullptr;
-    c->graph_valid = false;
-}
+void drop_graph(speck_config* c) { c->graph_valid = false; }
 
 int ensure_arena(speck_config* c, size_t bytes)
 {
@@ -302,32 +264,26 @@ struct Carver {
 
 struct Scratch {
     u32 *row_ops, *row_max_ops, *row_col_min, *row_col_max;
-    RowRec* recs;  // one 32-byte record per row, grouped by (numeric) kernel class
-    RowRec* recs_sym;  // ... and by symbolic class: kept apart, so that the symbolic records of a call survive its scan
-                       //   (a replayed sequence whose analysis only verifies reads those of the previous identical call)
-    u8* cls;       // numeric class of every row
-    u8* cls_sym;   // symbolic class of every row
+    RowRec* sym_recs;  // one 32-byte record per row, in the list of its symbolic class (launch.hpp, class_rec_at)
+    RowRec* num_recs;  // ... of its numeric class: kept apart, so that the symbolic lists of a call survive its scan (a reuse
+                       //   sequence whose analysis only verifies reads those of the previous identical call)
+    u8* cls_sym;     // symbolic class of every row
     u32* a_ro_copy;  // A's row offsets as the analysis saw them
-    BlockPartial* partials;
     uint2* b_sl;  // per A entry: (start, length) of the referenced B row (written by the analysis)
     uint2* w_sl;  // per A entry: its B entries inside the current column window (multi-window rows)
     u64* nf_off;           // per row: scratch slot of a numeric-first row
     u32* counts;           // per row (+1): nnz of the C row, written by the symbolic kernels
-    u32* offsets;          // per row (+1): C.row_offsets of an eager call until C is known to be allocated
+    u32* offsets;          // per row (+1): C.row_offsets of a call until C is known to be allocated
 };
-
-u32 partial_blocks(u32 m) { return std::max(analysis_blocks(m), scan_tiles(m)) + 2; }  // + PartialArrays padding
 
 size_t scratch_bytes(u32 m, u64 nnz_a)
 {
     size_t b = 2 * Carver::need(nnz_a, 8);
     b += 4 * Carver::need(m, 4);
-    b += 2 * Carver::need(size_t(m) + 1, 4);
+    b += 3 * Carver::need(size_t(m) + 1, 4);
     b += Carver::need(m, 8);
-    b += 2 * Carver::need(m, sizeof(RowRec));
-    b += 2 * Carver::need(m, 1);
-    b += Carver::need(size_t(m) + 1, 4);
-    b += Carver::need(partial_blocks(m), sizeof(BlockPartial));
+    b += Carver::need(m, 1);
+    b += 2 * Carver::need(class_list_records(m), sizeof(RowRec));
     return b + 4096;
 }
 
@@ -338,42 +294,49 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
     s.b_sl = cv.take<uint2>(nnz_a);
     s.w_sl = cv.take<uint2>(nnz_a);
     s.nf_off = cv.take<u64>(m);
-    s.recs = cv.take<RowRec>(m);
-    s.recs_sym = cv.take<RowRec>(m);
     s.cls_sym = cv.take<u8>(m);
     s.a_ro_copy = cv.take<u32>(size_t(m) + 1);
     s.row_ops = cv.take<u32>(m);
     s.row_max_ops = cv.take<u32>(m);
     s.row_col_min = cv.take<u32>(m);
     s.row_col_max = cv.take<u32>(m);
-    s.cls = cv.take<u8>(m);
     s.counts = cv.take<u32>(size_t(m) + 1);
     s.offsets = cv.take<u32>(size_t(m) + 1);
-    s.partials = cv.take<BlockPartial>(partial_blocks(m));
+    s.sym_recs = cv.take<RowRec>(class_list_records(m));
+    s.num_recs = cv.take<RowRec>(class_list_records(m));
     return s;
 }
 
-// (re)allocate and carve a Prediction for `m` rows; false if the device has no room (the replay then predicts less)
+// The chain of the next analysis / scan launch on `s`: a tag of its own (chain.hpp); the buffers are cleared -- on the
+// stream, in front of the launch -- before a tag comes round again.
+int next_chain(speck_config* c, hipStream_t s, Chain* out)
+{
+    Chain ch;
+    ch.agg = static_cast<u64*>(c->chain_buf);
+    ch.sup = ch.agg + kChainAggWords;
+    ch.error = reinterpret_cast<u32*>(ch.sup + kChainSupWords);
+    if (c->chain_launches % kChainTags == 0 && c->chain_launches != 0)
+        HIP_TRY(hipMemsetAsync(c->chain_buf, 0, (kChainAggWords + kChainSupWords) * 8, s));
+    ch.tag = (u32)(c->chain_launches % kChainTags) + 1u;
+    ++c->chain_launches;
+    *out = ch;
+    return SPECK_OK;
+}
+
+// (re)allocate a Prediction for `m` rows; false if the device has no room (the reuse sequence then places nothing)
 bool ensure_pred(Prediction& p, u32 m)
 {
-    const size_t need = Carver::need(size_t(m) + 1, 4) + Carver::need(size_t(scan_tiles(m)) * kPredTileWords, 4) +
-                        Carver::need(size_t(analysis_blocks(m)) * kPredBlockWords, 4) +
-                        Carver::need(1, sizeof(DeviceStats));
-    if (need > p.bytes) {
-        if (p.buf) (void)hipFree(p.buf);
+    const size_t need = size_t(m) + 1;
+    if (need > p.words) {
+        if (p.off) (void)hipFree(p.off);
         p = Prediction{};
-        if (hipMalloc(&p.buf, need) != hipSuccess) {
+        if (hipMalloc(reinterpret_cast<void**>(&p.off), need * 4) != hipSuccess) {
             (void)hipGetLastError();
-            p.buf = nullptr;
+            p.off = nullptr;
             return false;
         }
-        p.bytes = need;
+        p.words = need;
     }
-    Carver cv(p.buf);
-    p.off = cv.take<u32>(size_t(m) + 1);
-    p.num_tile = cv.take<u32>(size_t(scan_tiles(m)) * kPredTileWords);
-    p.sym_block = cv.take<u32>(size_t(analysis_blocks(m)) * kPredBlockWords);
-    p.stats = cv.take<DeviceStats>(1);
     p.rows = m;
     return true;
 }
@@ -406,10 +369,11 @@ int ensure_nfpool(speck_config* c, u64 entries, size_t vsize)
     return SPECK_OK;
 }
 
-RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill, bool symbolic_phase = false)
+RowWork make_work(speck_config* c, const Scratch& sc, const SpillBuffers& spill, u32 m, bool symbolic_phase = false)
 {
     RowWork w{};
-    w.recs = symbolic_phase ? sc.recs_sym : sc.recs;
+    w.recs = symbolic_phase ? sc.sym_recs : sc.num_recs;
+    w.m = m;
     w.st = c->d_stats;
     w.b_sl = sc.b_sl;
     w.spill = spill;
@@ -485,28 +449,24 @@ struct ClassTiming {
     size_t ev;
 };
 
-// pseudo classes: the merged launches of the 256-thread classes -- the big-LDS ones and the small ones
-constexpr int kLightBig = -1, kLightTiny = -2;
+// pseudo class: the merged launch of the 256-thread classes of a phase
+constexpr int kLight = -1;
 
 template <typename LaunchFn>
-int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u32 mask, u32 big_mask,
-                u32 tiny_mask, const u32* counts, const float* ns_per_row, size_t* ev_idx,
-                std::vector<ClassTiming>* timing, int exact_cls, LaunchFn&& launch)
+int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u32 mask, u32 light_mask,
+                const u32* counts, const float* ns_per_row, size_t* ev_idx, std::vector<ClassTiming>* timing,
+                int exact_cls, LaunchFn&& launch)
 {
     bool forked = false;
     size_t used = 0;
-    auto active = [&](int cls) {
-        if (cls == kLightBig) return (mask & big_mask) != 0;
-        if (cls == kLightTiny) return (mask & tiny_mask) != 0;
-        return (mask >> cls & 1u) != 0;
-    };
+    auto active = [&](int cls) { return cls == kLight ? (mask & light_mask) != 0 : (mask >> cls & 1u) != 0; };
     // Estimated duration of an item from the host-known row counts of the previous identical call
     // (isolated per-row costs, scripts/class_times.py).  An item earns a side stream only when it is
-    // long enough to pay for the cross-queue dependency (~10-15 us per branch of a replayed graph):
+    // long enough to pay for the cross-queue dependency (~10-15 us per branch):
     // the scircuit / mac_econ stand-ins run fastest on ONE stream, the webbase one with four.
     auto est_us = [&](int cls) -> float {
-        if (!counts) return 1e9f;  // eager first call: counts unknown, keep every class apart
-        u32 m = cls == kLightBig ? (mask & big_mask) : cls == kLightTiny ? (mask & tiny_mask) : (1u << cls);
+        if (!counts) return 1e9f;  // first call: counts unknown, keep every class apart
+        const u32 m = cls == kLight ? (mask & light_mask) : (1u << cls);
         float us = 0.f;
         for (int k = 0; k < kMaxClasses; ++k)
             if (m >> k & 1u) us += counts[k] * ns_per_row[k] * 1e-3f;
@@ -526,20 +486,33 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
     if (n_big >= 2)
         for (int i = 0; i < n_order; ++i)
             if (active(order[i]) && est_us(order[i]) >= c->fork_min_us) last_active = i;
-    // at most `max_side_streams` branches: every cross-queue dependency of a replayed graph costs
-    // ~10 us, so further side items queue behind each other on the last side stream
+    // at most `max_side_streams` branches: further side items queue behind each other on the last side stream
     const size_t max_side = std::min<size_t>(c->aux.size(), c->max_side_streams);
     size_t touched = 0;  // side streams that carry work
-    for (int i = 0; i < n_order; ++i) {
+    // The HOST needs ~5 us per launch, and a phase of the webbase stand-in is a dozen of them (the spill chain alone is
+    // nine): the items are enqueued LONGEST FIRST -- in the fixed order of rounds 1-4 the two NUM_B8K launches, which end
+    // that phase, were enqueued 55 us after the scan's ticket, behind the short kernels of the spill chain.
+    int seq[kMaxClasses + 2];
+    int n_seq = 0;
+    for (int i = 0; i < n_order; ++i)
+        if (active(order[i])) seq[n_seq++] = i;
+    if (counts)
+        std::stable_sort(seq, seq + n_seq, [&](int a, int b) { return est_us(order[a]) > est_us(order[b]); });
+    auto on_side = [&](int i) {
+        return c->concurrent_classes && max_side > 0 && i != last_active && n_big >= 2 && est_us(order[i]) >= c->fork_min_us;
+    };
+    // (the fork is recorded in front of EVERYTHING the phase puts on the pipeline stream: a side item must not wait for
+    //  the pipeline stream's own item of the phase)
+    for (int q = 0; q < n_seq && !forked; ++q)
+        if (on_side(seq[q])) {
+            HIP_TRY(hipEventRecord(c->fork, s));
+            forked = true;
+        }
+    for (int q = 0; q < n_seq; ++q) {
+        const int i = seq[q];
         const int cls = order[i];
-        if (!active(cls)) continue;
         hipStream_t ks = s;
-        if (c->concurrent_classes && max_side > 0 && i != last_active && n_big >= 2 &&
-            est_us(cls) >= c->fork_min_us) {
-            if (!forked) {
-                HIP_TRY(hipEventRecord(c->fork, s));
-                forked = true;
-            }
+        if (on_side(i)) {
             const size_t slot = std::min(used, max_side - 1);
             ks = c->aux[slot];
             if (slot >= touched) {
@@ -551,7 +524,7 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
         const bool timed = c->profile_kernels == 1 && timing;
         // the light launches and the numeric-first one stamp their events themselves, with the kernel's own begin and
         // end (launch.hpp, SPECK_LAUNCH_TIMED); the others are bracketed by two event records
-        const bool exact = timed && (cls == kLightBig || cls == kLightTiny || cls == exact_cls);
+        const bool exact = timed && (cls == kLight || cls == exact_cls);
         hipEvent_t e0 = timed ? kernel_event(c, *ev_idx) : nullptr, e1 = timed ? kernel_event(c, *ev_idx + 1) : nullptr;
         if (timed && !exact) (void)hipEventRecord(e0, ks);
         launch(ks, cls, exact ? e0 : nullptr, exact ? e1 : nullptr);
@@ -571,9 +544,9 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
 
 // isolated cost per row of every class (ns, MI355X, scripts/class_times.py on the four stand-ins)
 constexpr float kSymNsPerRow[kMaxClasses] = {0.15f, 0.6f, 3.f, 5.f, 30.f, 1000.f, 8.5f, 1000.f, 12.f, 50000.f, 0.1f, 0.4f,
-                                             0.4f, 0.8f, 0.05f, 0.f};
+                                             0.4f, 0.8f, 0.f, 0.f};
 constexpr float kNumNsPerRow[kMaxClasses] = {0.1f, 0.3f, 2.f, 4.f, 12.f, 75.f, 12.f, 300.f, 1500.f, 2.5f, 1.5f, 0.2f,
-                                             0.6f, 1.2f, 0.1f, 0.f};
+                                             0.6f, 1.2f, 0.f, 0.f};
 constexpr u32 kAllSym = (1u << SYM_CLASSES) - 1u;
 constexpr u32 kAllNum = (1u << NUM_CLASSES) - 1u;
 
@@ -586,19 +559,19 @@ u32 mask_of(const u32* counts, int n)
 }
 
 struct Timing {
-    size_t ev = 0, ev_analysis = 0, ev_between = 0, ev_analysis_end = 0, ev_scan = 0, ev_num = 0;
+    size_t ev = 0, ev_analysis = 0, ev_analysis_end = 0, ev_scan = 0, ev_num = 0;
     std::vector<ClassTiming> sym, num;
 };
 
-// analysis -> symbolic classes -> scan + numeric classification.  Nothing here needs a host
-// decision: `sym_mask` only prunes kernels of classes known to be empty (eager path: all).
+// analysis (+ symbolic binning) -> symbolic classes -> scan (+ numeric binning).  Nothing here needs a host
+// decision: `sym_mask` only prunes kernels of classes known to be empty (first call: all).
 int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const speck_dcsr* B,
-                  const Scratch& sc, u32* offsets_out, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
+                  const Scratch& sc, u32 vsize, u64 exact_nnz, u32 sym_mask, u32 num_mask,
                   bool classify_numeric, Timing* tm, const u32* sym_hint = nullptr,
                   DeviceStats* host_mirror = nullptr, u64 expect_g = ~0ull, u32 expect_g_rows = ~0u,
                   u32 parts = 3 /* 1: analysis + binning, 2: symbolic launches + scan */, u64 expect_nf = ~0ull,
-                  const Prediction* pred_out = nullptr /* eager: what this call leaves for a replay */,
-                  bool pred_fold_esc = false, bool hint_exact = true /* sym_hint holds THIS call's counts (list positions) */)
+                  u32* pred_off_out = nullptr /* what this call leaves for a repeated one to place rows by */,
+                  bool hint_exact = true /* sym_hint holds THIS call's counts */)
 {
     const u32 m = (u32)A_in->rows;
     // A sequence whose analysis only verifies (capture_overlap) reads A's row offsets where the previous identical call
@@ -607,33 +580,31 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
     speck_dcsr a_stored = *A_in;
     if (c->capture_overlap) a_stored.row_offsets = sc.a_ro_copy;
     const speck_dcsr* const A = &a_stored;
-    u32* const c_ro = sc.counts;  // the symbolic kernels count into scratch; the scan writes offsets_out
+    u32* const c_ro = sc.counts;  // the symbolic kernels count into scratch; the scan writes sc.offsets
     ClassifyParams cp = c->cp;
     cp.sym_allowed = sym_mask;
     cp.num_allowed = num_mask;
     cp.esc16 = (c->cp.esc16 && B->cols <= (1ull << 26)) ? 1u : 0u;  // (column << 6 | product number) fits 32 bits
     cp.esc_fused = c->capture_fused ? 1u : 0u;
+    u64* const bytes = c->cp.want_bytes ? c->d_bytes : nullptr;
     const bool timed = c->profile_kernels && tm;
     if (parts & 1u) {
         if (timed) {
             tm->ev_analysis = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
         }
-        hipEvent_t between = nullptr;
-        if (timed) {
-            tm->ev_between = tm->ev;
-            between = kernel_event(c, tm->ev++);
+        // (capture_overlap: no analysis IN the sequence -- launch_verifier puts it on a stream of its own)
+        if (!c->capture_overlap) {
+            if (bytes) HIP_TRY(hipMemsetAsync(bytes, 0, 2 * kMaxClasses * sizeof(u64), s));
+            Chain chain;
+            const int crc = next_chain(c, s, &chain);
+            if (crc != SPECK_OK) return crc;
+            launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
+                            sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, c_ro, sc.sym_recs,
+                            c->d_stats, cp, sc.b_sl, chain, sc.nf_off, expect_nf, (u32)B->rows, sc.a_ro_copy, nullptr, bytes);
+            c->snap_for_arena = false;  // (a writing analysis: the copy of the inputs is not its)
         }
-        // (capture_overlap: no analysis IN the sequence -- launch_verifier puts it on a stream of its own, outside any
-        //  graph: a fork / join inside the captured graph cost ~25 us of cross-queue hand-offs, more than it hid)
-        if (!c->capture_overlap)
-        launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
-                        sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, c_ro, sc.partials, sc.recs_sym,
-                        c->d_stats, cp, sc.b_sl, between, sc.nf_off, expect_nf, (u32)B->rows,
-                        pred_out ? pred_out->sym_block : nullptr, c->capture_pred_sym ? c->gpred.sym_block : nullptr,
-                        c->gpred.stats, (u32)B->cols, B->nnz, c->check_epoch, sc.a_ro_copy);
-        if (!c->capture_overlap) c->snap_for_arena = false;  // (a writing analysis: the copy of the inputs is not its)
-        // (eager call: the input check of B goes onto its stream HERE -- behind the launch of the analysis, the head of
+        // (complete call: the input check of B goes onto its stream HERE -- behind the launch of the analysis, the head of
         //  the call's critical path, and beside that latency-bound kernel rather than beside the symbolic launches)
         if (c->after_analysis) {
             const int hrc = c->after_analysis();
@@ -646,39 +617,19 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
         HIP_TRY(hipGetLastError());
     }
     if (!(parts & 2u)) return SPECK_OK;
-    const RowWork w = make_work(c, sc, SpillBuffers{}, true);
+    const RowWork w = make_work(c, sc, SpillBuffers{}, m, true);
     // heaviest classes first: they have the longest tails
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;  // no host-known counts: size every class for rows(A)
     const u32* hint = sym_hint ? sym_hint : all_m;
-    static const int merged[7] = {SYM_GH, SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, kLightBig, kLightTiny};
-    static const int separate[SYM_CLASSES] = {SYM_GH,  SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF,  SYM_B4K, SYM_BM1,
-                                              SYM_W1K, SYM_W256, SYM_R64, SYM_R32, SYM_W128, SYM_G16, SYM_G8, SYM_G4};
-    // the launch's LDS size is the largest need among its classes and caps the waves per CU of all of
-    // them: the 256-thread classes go in two launches, the big-LDS ones apart (split_light); the
-    // first runs on a side stream next to the second
-    // ... unless one of the two parts is next to empty: then a second launch only adds a boundary
-    auto part_us = [](const u32* counts, const float* ns, u32 mask) {
-        float us = 0.f;
-        for (int k = 0; k < kMaxClasses; ++k)
-            if (mask >> k & 1u) us += counts[k] * ns[k] * 1e-3f;
-        return us;
-    };
-    bool split_sym = c->split_light;
-    if (split_sym && sym_hint)
-        split_sym = part_us(sym_hint, kSymNsPerRow, kSymLightMask & (1u << SYM_BM1)) >= c->split_min_us &&
-                    part_us(sym_hint, kSymNsPerRow, kSymLightMask & ~(1u << SYM_BM1)) >= c->split_min_us;
-    const u32 sym_big = split_sym ? (1u << SYM_BM1) : kSymLightMask;
-    int rc = run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 7 : (int)SYM_CLASSES, sym_mask,
-                         kSymLightMask & sym_big, kSymLightMask & ~sym_big, sym_hint, kSymNsPerRow,
-                         tm ? &tm->ev : nullptr, tm ? &tm->sym : nullptr, (int)SYM_NF,
+    static const int order[6] = {SYM_GH, SYM_BM2, SYM_B32K, SYM_B16K, SYM_NF, kLight};
+    int rc = run_classes(c, s, order, 6, sym_mask, kSymLightMask, sym_hint, kSymNsPerRow, tm ? &tm->ev : nullptr,
+                         tm ? &tm->sym : nullptr, (int)SYM_NF,
                          [&](hipStream_t ks, int cls, hipEvent_t e0, hipEvent_t e1) {
-                             if (cls == kLightBig || cls == kLightTiny) {
-                                 const u32 part = cls == kLightBig ? sym_big : ~sym_big;
-                                 launch_symbolic_light(ks, hint, sym_mask & kSymLightMask & part, A->row_offsets,
-                                                       sc.b_sl, B->col_ids, w, c_ro, c->sm,
-                                                       sym_hint != nullptr && hint_exact, c->capture_fused ? vsize : 0u, A->data,
-                                                       B->data, e0, e1);
+                             if (cls == kLight) {
+                                 launch_symbolic_light(ks, hint, sym_mask & kSymLightMask, A->row_offsets, sc.b_sl, B->col_ids, w,
+                                                       c_ro, c->sm, sym_hint != nullptr && hint_exact,
+                                                       c->capture_fused ? vsize : 0u, A->data, B->data, e0, e1);
                              } else if (cls == SYM_NF) {
                                  // the numeric dense-window kernel, in the symbolic phase (numeric.hip)
                                  if (vsize == 8) {
@@ -702,16 +653,15 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
     if (c->capture_skip_scan) {
         // no scan: every row's nnz was compared with the previous call's where it was produced (store_row_count, the
         // fused register-class bodies, the numeric-first kernel); the numeric launches read what that call's scan left
-    } else if (c->capture_pred_scan)
-        launch_scan_predicted(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
-                              sc.recs, c->d_stats, cp, c->gpred.off, c->gpred.num_tile, c->gpred.stats,
-                              (c->capture_pred_sym && !c->capture_overlap) ? sc.partials : nullptr, c->capture_overlap);
-    else
-        launch_scan(s, c_ro, offsets_out, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
-                    classify_numeric ? sc.cls : nullptr, sc.partials, sc.recs, c->d_stats, cp, vsize, exact_nnz,
-                    host_mirror, expect_g, expect_g_rows, c->capture_direct ? c->gpred.off : nullptr,
-                    pred_out ? pred_out->off : nullptr, pred_out ? pred_out->num_tile : nullptr, pred_fold_esc,
-                    host_mirror ? c->d_ticket : nullptr, host_mirror ? c->h_ticket_dev : nullptr);
+    } else {
+        Chain chain;
+        const int crc = next_chain(c, s, &chain);
+        if (crc != SPECK_OK) return crc;
+        launch_scan(s, c_ro, sc.offsets, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
+                    classify_numeric ? sc.num_recs : nullptr, c->d_stats, cp, vsize, exact_nnz, chain, host_mirror,
+                    expect_g, expect_g_rows, c->capture_direct ? c->gpred.off : nullptr, pred_off_out,
+                    host_mirror ? c->d_ticket : nullptr, host_mirror ? c->h_ticket_dev : nullptr, bytes);
+    }
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -719,42 +669,31 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
 
 template <typename T>
 int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
-                 const Scratch& sc, const u32* /*c_ro*/, u32* c_col, T* c_val, u32 num_mask,
+                 const Scratch& sc, u32* c_col, T* c_val, u32 num_mask,
                  const u32* counts /*host-known, or nullptr*/, Timing* tm)
 {
     const u32 m = (u32)A->rows;
     CsrView<T> Av{c->capture_overlap ? sc.a_ro_copy : A->row_offsets, A->col_ids, static_cast<const T*>(A->data), m, (u32)A->cols};
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
-    const RowWork w = make_work(c, sc, c->spill);
+    RowWork w = make_work(c, sc, c->spill, m);
+    // the staged offsets -> C.row_offsets: by extra workgroups of the numeric light launch when there is one, else by a
+    // (guarded) copy of its own
+    if (w.off_n && !(num_mask & kNumLightMask)) {
+        launch_copy_offsets(s, w.off_src, w.off_dst, w.off_n, c->d_stats);
+        w.off_n = 0;
+    }
     u32 all_m[kMaxClasses];
     for (auto& x : all_m) x = m;
     const u32* hint = counts ? counts : all_m;
-    static const int merged[6] = {NUM_G, NUM_D2, NUM_B8K, NUM_NFCOPY, kLightBig, kLightTiny};
-    static const int separate[NUM_CLASSES] = {NUM_G,  NUM_D2,   NUM_B8K, NUM_B2K, NUM_W256, NUM_NFCOPY, NUM_D1,
-                                              NUM_W512, NUM_R64, NUM_R32, NUM_W128, NUM_G16, NUM_G8, NUM_G4, NUM_DIRECT};
-    constexpr u32 kBigPart = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256);
-    bool split_num = c->split_light;
-    if (split_num && counts) {
-        auto part_us = [&](u32 mask) {
-            float us = 0.f;
-            for (int k = 0; k < kMaxClasses; ++k)
-                if (mask >> k & 1u) us += counts[k] * kNumNsPerRow[k] * 1e-3f;
-            return us;
-        };
-        split_num = part_us(kNumLightMask & kBigPart) >= c->split_min_us &&
-                    part_us(kNumLightMask & ~kBigPart) >= c->split_min_us;
-    }
-    const u32 num_big = split_num ? kBigPart : kNumLightMask;
-    return run_classes(c, s, c->merge_light ? merged : separate, c->merge_light ? 6 : (int)NUM_CLASSES, num_mask,
-                       kNumLightMask & num_big, kNumLightMask & ~num_big, counts, kNumNsPerRow,
-                       tm ? &tm->ev : nullptr, tm ? &tm->num : nullptr, -100,
+    static const int order[5] = {NUM_G, NUM_D2, NUM_B8K, NUM_NFCOPY, kLight};
+    return run_classes(c, s, order, 5, num_mask, kNumLightMask, counts, kNumNsPerRow, tm ? &tm->ev : nullptr,
+                       tm ? &tm->num : nullptr, -100,
                        [&](hipStream_t ks, int cls, hipEvent_t e0, hipEvent_t e1) {
-                           if (cls == kLightBig || cls == kLightTiny) {
-                               const u32 part = cls == kLightBig ? num_big : ~num_big;
-                               launch_numeric_light<T>(ks, hint, num_mask & kNumLightMask & part, Av, Bv, w, c_col,
-                                                       c_val, c->sm, counts != nullptr, e0, e1);
-                           } else
+                           if (cls == kLight)
+                               launch_numeric_light<T>(ks, hint, num_mask & kNumLightMask, Av, Bv, w, c_col, c_val, c->sm,
+                                                       counts != nullptr, e0, e1);
+                           else
                                launch_numeric<T>(ks, cls, hint[cls], Av, Bv, w, c_col, c_val, c->sm);
                        });
 }
@@ -781,8 +720,7 @@ int wait_ticket(speck_config* c, hipStream_t s)
 }
 
 // The statistics block of the call so far, on the host.  With the ticket: done_kernel mirrors the block into pinned
-// memory and the host spins (a copy + blocking synchronisation costs 10-20 us of wake-up latency, and the eager path
-// reads back twice).
+// memory and the host spins (a copy + blocking synchronisation costs 10-20 us of wake-up latency).
 int read_stats(speck_config* c, hipStream_t s)
 {
     if (c->spin_wait) {
@@ -793,35 +731,33 @@ int read_stats(speck_config* c, hipStream_t s)
         HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
-    // the input check of this (eager) call reports with the call's epoch
-    if (c->check_epoch && c->h_stats->b_bad_epoch == c->check_epoch) c->h_stats->b_invalid = 1;
-    return SPECK_OK;
+    return c->h_stats->chain_error ? SPECK_ERR_HIP : SPECK_OK;
 }
 
 // ... when the scan of the batch mirrors the block and stores the ticket itself (enqueue_front with a host mirror):
-// no done_kernel, the host has the statistics while the scan's last blocks are still running
+// no done_kernel, the host has the statistics while the scan's other tiles are still writing their rows
 int await_scan_stats(speck_config* c, hipStream_t s)
 {
     if (!c->spin_wait) return read_stats(c, s);
     const int rc = wait_ticket(c, s);
     if (rc != SPECK_OK) return rc;
-    if (c->check_epoch && c->h_stats->b_bad_epoch == c->check_epoch) c->h_stats->b_invalid = 1;
-    return SPECK_OK;
+    return c->h_stats->chain_error ? SPECK_ERR_HIP : SPECK_OK;
 }
 
-void publish_counts(speck_config* c)
+void publish_counts(speck_config* c, hipStream_t s)
 {
     c->last.sum_products = c->h_stats->sum_products;
     c->last.max_row_ops = c->h_stats->max_row_ops;
     c->last.nnz_c = c->h_stats->nnz_c;
     c->last.max_row_nnz_c = c->h_stats->max_row_nnz_c;
-    for (int i = 0; i < SPECK_NUM_SYM_BINS; ++i) {
-        c->last.sym_bin_rows[i] = c->h_stats->sym.count[i];
-        c->last.sym_bin_bytes[i] = c->h_stats->sym.bytes[i];
-    }
-    for (int i = 0; i < SPECK_NUM_NUM_BINS; ++i) {
-        c->last.num_bin_rows[i] = c->h_stats->num.count[i];
-        c->last.num_bin_bytes[i] = c->h_stats->num.bytes[i];
+    for (int i = 0; i < SPECK_NUM_SYM_BINS; ++i) c->last.sym_bin_rows[i] = c->h_stats->sym.count[i];
+    for (int i = 0; i < SPECK_NUM_NUM_BINS; ++i) c->last.num_bin_rows[i] = c->h_stats->num.count[i];
+    if (c->cp.want_bytes && c->d_bytes) {  // (profiling: the per-class byte model, summed by the analysis / scan kernels)
+        u64 b[2 * kMaxClasses] = {};
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(b, c->d_bytes, sizeof(b), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int i = 0; i < SPECK_NUM_SYM_BINS; ++i) c->last.sym_bin_bytes[i] = b[i];
+            for (int i = 0; i < SPECK_NUM_NUM_BINS; ++i) c->last.num_bin_bytes[i] = b[kMaxClasses + i];
+        }
     }
 }
 
@@ -842,49 +778,24 @@ GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, con
                (c->concurrent_classes ? 1u : 0u);
     k.num[7] ^= reinterpret_cast<u64>(s);
     k.num[5] |= u64(c->cp.nf_min_ops) << 8;
-    k.num[5] |= (u64(c->cp.esc32) << 40) | (u64(c->cp.esc64) << 41) | (u64(c->cp.esc16) << 42) | (u64(c->cp.esc4) << 43);
+    k.num[5] |= (u64(c->cp.esc32) << 40) | (u64(c->cp.esc64) << 41) | (u64(c->cp.esc16) << 42);
     k.num[4] |= u64(c->cp.gh_per_window) << 32;  // C->nnz fits 32 bits
     return k;
 }
 
-
-// The config's prediction (of the last eager call = this call: same key) becomes the sequence's own: device copy of
-// the arrays, and the statistics block of that call in the shape the sequence classifies in.
-int snapshot_prediction(speck_config* c, hipStream_t s, const ReplayPlan& p)
+// The config's copy of the row offsets (of the last complete call = this call: same key) becomes the sequence's own.
+int snapshot_prediction(speck_config* c, hipStream_t s)
 {
     if (!c->pred_valid) return SPECK_OK;
     if (!ensure_pred(c->gpred, c->pred.rows)) return SPECK_ERR_OOM;
-    HIP_TRY(hipMemcpyAsync(c->gpred.buf, c->pred.buf, std::min(c->pred.bytes, c->gpred.bytes), hipMemcpyDeviceToDevice, s));
-    // (the statistics of THAT call, kept by the eager path: the pinned mirror holds whatever ran last -- a replay of
-    //  another problem on this config, for instance)
-    DeviceStats ps = c->last_eager_stats;
-    ps.capacity_miss = 0;
-    std::memcpy(ps.num.count, p.num_counts, sizeof(ps.num.count));
-    u32 run = 0;
-    for (int k = 0; k < kMaxClasses; ++k) {
-        ps.num.offset[k] = run;
-        run += ps.num.count[k];
-    }
-    ps.num.offset[kMaxClasses] = run;
-    if (p.fused)
-        for (int k = 0; k < kMaxClasses; ++k)
-            if (kNumEscMask >> k & 1u) {
-                ps.num.bytes[NUM_NFCOPY] += ps.num.bytes[k];
-                ps.num.bytes[k] = 0;
-            }
-    // (a BLOCKING copy, behind the device-to-device one: `ps` is on the stack, and an asynchronous copy from pageable
-    //  memory makes the runtime lock those pages behind the caller's back -- a later copy of other pageable memory,
-    //  e.g. the caller downloading C, then ended in a GPU memory fault during the next replay: found by the stress run)
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipMemcpy(c->gpred.stats, &ps, sizeof(ps), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->gpred.off, c->pred.off, (size_t(c->pred.rows) + 1) * 4, hipMemcpyDeviceToDevice, s));
     return SPECK_OK;
 }
 
-ReplayPlan plan_replay(const speck_config* c, bool arena_replay_ok = false)
+// What a repeated identical call may take from the previous one (DESIGN.md 3, table of pred_stages bits).  FROZEN since
+// round 5: the complete call is what is measured; this mode is kept, tested, and not extended.
+ReplayPlan plan_replay(const speck_config* c, bool arena_mine, bool arena_replay_ok)
 {
-    // (The replayed sequence classifies exactly like the eager one.  Round 2 re-classified an under-filled NUM_B8K
-    //  class into NUM_B2K at a load of 0.85 here; since the workgroup classes take rows up to that load in every
-    //  call -- device_common.hpp, SPECK_LOAD_PCT -- there is nothing left to fold.)
     ReplayPlan p;
     p.num_mask = c->last_num_mask;
     std::memcpy(p.num_counts, c->last_num_counts, sizeof(p.num_counts));
@@ -893,16 +804,16 @@ ReplayPlan plan_replay(const speck_config* c, bool arena_replay_ok = false)
     p.g_products = c->last_g_products;
     p.nf_cap_entries = c->nf_cap_entries;
     p.nf_wcols = c->nf_wcols;
-    // Numeric-first rows: the eager call wrote them to scratch slots and copied them after the scan (nothing else
-    // knows where a row goes before the scan).  The replayed sequence knows where they WENT: it writes each row
+    // Numeric-first rows: a complete call writes them to scratch slots and copies them after the scan (nothing else
+    // knows where a row goes before the scan).  The reuse sequence knows where they WENT: it writes each row
     // straight to the offset the previous identical call gave it, provided its fresh nnz is the same, and the scan
-    // checks every fresh offset against that prediction -- no slot, no copy launch.
-    // The same knowledge lets the rows of the register classes (NUM_G8 / NUM_G16: products sorted in registers,
-    // nothing sized by the nnz) be finished in the SYMBOLIC phase: one walk of the row instead of two.  The numeric
-    // phase then accounts for them as rows that are already in place.
+    // checks every fresh offset against that -- no slot, no copy launch.
+    // The same knowledge lets the rows of the register classes (products sorted in registers, nothing sized by the
+    // nnz) be finished in the SYMBOLIC phase: one walk of the row instead of two.  The numeric phase then accounts for
+    // them as rows that are already in place.
     constexpr u32 kEscNum = kNumEscMask;
     p.fused = c->esc_fused && c->nf_direct && c->pred_valid && (p.num_mask & kEscNum) != 0 &&
-              c->cp.sym_g8 == c->cp.num_g8 && c->merge_light;  // (the fused body lives in the merged light launch)
+              c->cp.sym_g8 == c->cp.num_g8;
     if (p.fused) {
         for (int k = 0; k < kMaxClasses; ++k)
             if (kEscNum >> k & 1u) {
@@ -913,85 +824,50 @@ ReplayPlan plan_replay(const speck_config* c, bool arena_replay_ok = false)
     }
     p.direct = c->nf_direct && c->pred_valid && (p.num_mask >> NUM_NFCOPY & 1u);
     p.launch_mask = p.direct ? (p.num_mask & ~(1u << NUM_NFCOPY)) : p.num_mask;
-    // Every row offset predicted, every tile table known (in the shape this sequence classifies in): the scan is one
-    // kernel that verifies instead of two that fold (launch_scan_predicted).  Rows waiting for the copy launch need
-    // their records: not with those.
-    const bool shape_ok = c->pred_fold_esc == p.fused || !(c->last_num_mask & kEscNum);  // (no such rows: one shape)
-    p.pred_scan = c->pred_scan && c->pred_valid && c->pred_tiles_valid && shape_ok &&
-                  (p.direct || !(p.num_mask >> NUM_NFCOPY & 1u));
-    // ... and so is the symbolic binning, inside the analysis kernel (no scatter kernel, its totals folded by the
-    // predicted scan).  Rows that need a scratch slot from the scatter's prefix (global key sets; numeric-first rows
-    // that are not placed directly) keep the scatter kernel.
-    p.pred_sym = c->pred_sym && p.pred_scan && !(c->last_sym_mask >> SYM_GH & 1u) &&
-                 (!(c->last_sym_mask >> SYM_NF & 1u) || p.direct);
-    // ... and then nothing downstream needs what the analysis WRITES any more: the previous identical call left all of it
-    // in the arena.  The analysis becomes a verifier beside the sequence (its own stream, joined in front of the ticket).
+    // Nothing downstream needs what the analysis WRITES when the previous identical call left all of it in the arena:
+    // the analysis becomes a verifier beside the sequence (its own stream, its own ticket).
     // (on the library's own pipeline stream only: beside a CALLER's stream the verifier would not be ordered behind the
-    //  work that produces the inputs there)
-    p.overlap = c->overlap_analysis && p.pred_sym && c->vstream != nullptr && !c->use_user_stream;
+    //  work that produces the inputs there; rows that take a scratch slot keep the writing analysis)
+    p.overlap = c->overlap_analysis && arena_mine && c->pred_valid && c->vstream != nullptr && !c->use_user_stream &&
+                !(c->last_sym_mask >> SYM_GH & 1u) && (!(c->last_sym_mask >> SYM_NF & 1u) || p.direct) &&
+                (p.direct || !(p.num_mask >> NUM_NFCOPY & 1u));
     // ... and when the arena was last written by a replay of THIS sequence, its scan has nothing left to do either: the
-    // offsets, classes and records it would produce are a function of the rows' nnz and of the analysis' quantities --
-    // all verified where they are produced.  C.row_offsets is still rewritten in every call (from the sequence's copy of
-    // the offsets, by extra workgroups of the numeric light launch: needs that launch).
+    // offsets, classes, records and lists it would produce are a function of the rows' nnz and of the analysis' quantities
+    // -- all verified where they are produced.  C.row_offsets is still rewritten in every call (from the sequence's copy
+    // of the offsets, by extra workgroups of the numeric light launch: needs that launch).
     constexpr u32 kBigLight = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256);
     // (... or has no rows that are finished early at all: every row then goes through the numeric light launch)
     const bool early_ok = (p.fused && p.direct) || (p.num_mask & (kEscNum | (1u << NUM_NFCOPY))) == 0;
     // In such a sequence the symbolic pass of a hash / dense row has ONE reader left: the comparison of its count with the
-    // previous call's.  The numeric bodies can make that comparison themselves -- they count what their table holds before
-    // they sort it -- if they stay inside a table that was sized by a nnz that may no longer hold (bounded probing) and
-    // inside the row's room in C (numeric.hip, VERIFY; the spill chain of NUM_G sizes everything from what it counts in
-    // the same call and compares in its copy kernel).  Then those rows are walked ONCE, as the register-class rows are: the
-    // symbolic phase of the sequence is the fused launch of the register classes alone (nothing at all for an input
-    // without such rows) -- and the heavy symbolic classes that kept a sequence from dropping its scan (below) are gone.
-    // Only when it PAYS: the verifying bodies cost the numeric light launch 5-15 % (one more compare in its probing loop,
-    // the hottest loop of the library), while the symbolic pass of a FEW hash rows beside many register-class rows hides
-    // inside the fused launch (scircuit / mac_econ stand-ins: that launch got 1.5 us shorter, the numeric one 3 us
-    // longer).  So: when the hash / dense rows are what the symbolic phase spends its time on (isolated per-row costs, as
-    // for the stream forks) -- the nlpkkt stand-in, whose symbolic launch was a third of its multiply: 26.4 -> 19.4 ms.
-    // (option num_verify = 2: whenever possible)
+    // previous call's.  The numeric bodies can make that comparison themselves (numeric.hip, VERIFY) -- when it PAYS: the
+    // verifying bodies cost the numeric light launch 5-15 %, while the symbolic pass of a FEW hash rows beside many
+    // register-class rows hides inside the fused launch.  (option num_verify = 2: whenever possible)
     float us_hash = 0.f, us_esc = 0.f;
     for (int k = 0; k < kMaxClasses; ++k)
         ((kSymEscMask >> k & 1u) ? us_esc : us_hash) += p.sym_counts[k] * kSymNsPerRow[k] * 1e-3f;
     const bool want_verify = c->num_verify && (p.fused || !(p.launch_mask & kEscNum)) && !(p.sym_mask >> SYM_NF & 1u) &&
                              (c->num_verify >= 2 || us_hash > us_esc);
     const u32 eff_sym = want_verify ? (p.sym_mask & kSymEscMask) : p.sym_mask;
-    // (Only for sequences whose symbolic phase is the ONE light launch: with heavy symbolic classes on side streams the
-    //  join of that phase would be followed by the fork of the numeric phase with no kernel in between, and a captured
-    //  graph of that shape crashed the host inside the runtime every second run -- webbase stand-in, round 4; the same
-    //  sequence enqueued launch by launch did not.  Those sequences keep their scan: it is 3 % of their multiply.)
-    p.skip_scan = c->skip_scan && arena_replay_ok && p.overlap && early_ok && c->merge_light && !c->split_light &&
+    p.skip_scan = c->skip_scan && arena_replay_ok && p.overlap && early_ok &&
                   (p.launch_mask & kBigLight) != 0 && (eff_sym & ~kSymLightMask) == 0;
     p.num_verify = want_verify && p.skip_scan;
-    // A sequence without a scan whose numeric phase FORKS (heavy classes on side streams: webbase stand-in) is not
-    // captured: the executable graph of that sequence crashed the host inside the runtime in every second process that had
-    // multiplied other problems on the config before (scripts/repro_standins.py; a segmentation fault inside
-    // hipGraphLaunch / instantiate, not in any kernel -- the same family as the join / fork shape above), while the same
-    // launches enqueued one by one at every call never did (eight processes in a row, and the four of
-    // tests/test_gpu_parity.py::test_standins_take_turns_on_one_config_in_fresh_processes).  It costs such a multiply
-    // nothing measurable (webbase stand-in 0.874-0.882 ms either way).  (option capture_forked = 1: capture anyway)
-    p.uncaptured = p.skip_scan && (p.launch_mask & ~(kNumLightMask | (1u << NUM_NFCOPY))) != 0 && !c->capture_forked;
     return p;
 }
 
-// front + back + ticket of a replayed sequence, into a stream under capture -- or, with `tm`, straight onto the
-// stream with HIP events around the launches (speck_config_profile_kernels + option profile_replay: the launches
-// the replay consists of, timed one by one)
+// front + back + ticket of a reuse sequence, straight onto the stream (with `tm`: HIP events around the launches)
 template <typename T>
 int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B, const speck_dcsr* C,
                    const Scratch& sc, const ReplayPlan& p, Timing* tm, size_t* ev_num_end)
 {
     c->capture_fused = p.fused;
     c->capture_direct = p.direct;
-    c->capture_pred_scan = p.pred_scan;
-    c->capture_pred_sym = p.pred_sym;
     c->capture_overlap = p.overlap;
     c->capture_skip_scan = p.skip_scan;
     c->capture_num_verify = p.num_verify;
-    if (p.skip_scan) {  // C.row_offsets <- the sequence's own copy of the offsets (numeric light launch)
-        c->stage_off_src = c->gpred.off;
-        c->stage_off_dst = C->row_offsets;
-        c->stage_off_n = (u32)A->rows + 1u;
-    }
+    // C.row_offsets <- the staged offsets of this call's scan, or (no scan) the sequence's own copy of the offsets
+    c->stage_off_src = p.skip_scan ? c->gpred.off : sc.offsets;
+    c->stage_off_dst = C->row_offsets;
+    c->stage_off_n = (u32)A->rows + 1u;
     c->capture_c_col = C->col_ids;
     c->capture_c_val = C->data;
     struct Reset {
@@ -999,8 +875,8 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
         u32 wcols;
         ~Reset()
         {
-            c->capture_direct = c->capture_fused = c->capture_pred_scan = c->capture_pred_sym = c->capture_overlap = false;
-            if (c->capture_skip_scan) c->stage_off_src = nullptr, c->stage_off_dst = nullptr, c->stage_off_n = 0;
+            c->capture_direct = c->capture_fused = c->capture_overlap = false;
+            c->stage_off_src = nullptr, c->stage_off_dst = nullptr, c->stage_off_n = 0;
             c->capture_skip_scan = c->capture_num_verify = false;
             c->nf_wcols = wcols;
         }
@@ -1015,81 +891,21 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
         for (int k = 0; k < kMaxClasses; ++k)
             if (!(kSymEscMask >> k & 1u)) sym_counts[k] = 0;
     }
-    int rc = enqueue_front(c, s, A, B, sc, C->row_offsets, (u32)sizeof(T), C->nnz, sym_mask,
-                           p.num_mask, true, tm, sym_counts, nullptr,
+    int rc = enqueue_front(c, s, A, B, sc, (u32)sizeof(T), C->nnz, sym_mask, p.num_mask, true, tm, sym_counts, nullptr,
                            p.g_products, p.num_counts[NUM_G], 3u, p.nf_cap_entries);
     if (rc != SPECK_OK) return rc;
-    if (tm && c->gate_verifier) {  // (profiled pre-pass of a long sequence: the verifier's stream starts here, multiply_impl)
-        HIP_TRY(hipEventRecord(c->fork, s));
-        HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
-        // (... and a moment later, as next to the graph: a verifier dispatched TOGETHER with the numeric launch takes half of
-        //  the chip's wave slots before that launch's resident workgroups have them, and keeps them -- the nlpkkt stand-in's
-        //  light launch then measured 20.0 ms against 18.7 in a trace of the graph)
-        launch_delay(c->vstream, 30);
-    }
     if (tm) {
         tm->ev_num = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
-    rc = enqueue_back<T>(c, s, A, B, sc, C->row_offsets, C->col_ids, static_cast<T*>(C->data),
-                         p.launch_mask, p.num_counts, tm);
+    rc = enqueue_back<T>(c, s, A, B, sc, C->col_ids, static_cast<T*>(C->data), p.launch_mask, p.num_counts, tm);
     if (rc != SPECK_OK) return rc;
     if (tm) {
         *ev_num_end = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     }
-    // no copy node: the last kernel mirrors the (final) statistics block into pinned host memory, then stores
-    // the completion ticket
+    // the last kernel mirrors the (final) statistics block into pinned host memory, then stores the completion ticket
     launch_done(s, c->d_ticket, c->h_ticket_dev, c->d_stats, c->h_stats_dev);
-    return SPECK_OK;
-}
-
-// Capture the sequence into one graph, specialised to `key`.
-template <typename T>
-int capture_graph(speck_config* c, hipStream_t s, const speck_dcsr* A, const speck_dcsr* B,
-                  const speck_dcsr* C, const Scratch& sc, const GraphKey& key, bool arena_replay_ok = false)
-{
-    drop_graph(c);
-    ReplayPlan plan = plan_replay(c, arena_replay_ok);
-    if (snapshot_prediction(c, s, plan) != SPECK_OK) {  // no room for the sequence's own copy: predict nothing
-        c->pred_valid = c->pred_tiles_valid = false;
-        plan = plan_replay(c);
-    }
-    c->graph_plan = plan;
-    c->graph_direct = plan.direct;
-    c->graph_fused = plan.fused;
-    c->graph_pred_scan = plan.pred_scan;
-    c->graph_pred_sym = plan.pred_sym;
-    c->graph_overlap = plan.overlap;
-    if (c->use_user_stream || c->replay_uncaptured || plan.uncaptured) {
-        // the launches of this sequence are enqueued one by one at every call (multiply_impl): only the plan and the
-        // sequence's copy of the prediction are kept -- a caller's stream is never put into capture mode
-        c->graph_key = key;
-        c->graph_valid = true;
-        ++c->graph_captures;
-        return SPECK_OK;
-    }
-    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-    const int rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, nullptr, nullptr);
-    hipGraph_t g = nullptr;
-    hipError_t e2 = hipStreamEndCapture(s, &g);
-    if (rc != SPECK_OK || e2 != hipSuccess || !g) {
-        if (g) (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        return SPECK_ERR_HIP;
-    }
-    hipGraphExec_t ge = nullptr;
-    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) {
-        (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        return SPECK_ERR_HIP;
-    }
-    c->graph = g;
-    c->graph_exec = ge;
-    c->graph_key = key;
-    c->graph_valid = true;
-    c->exec_dirty = false;
-    ++c->graph_captures;
     return SPECK_OK;
 }
 
@@ -1103,30 +919,29 @@ void publish_kernel_times(speck_config* c, const Timing& tm, size_t ev_num_end)
     };
     (void)hipEventElapsedTime(&c->last.analysis_ms, c->kev[tm.ev_analysis], c->kev[tm.ev_analysis_end]);
     c->last.scan_ms = ms(tm.ev_scan);
-    // phases: end of the analysis launches -> start of the scan (all symbolic branches joined);
+    // phases: end of the analysis launch -> start of the scan (all symbolic branches joined);
     // before the first numeric launch -> after the last join
     (void)hipEventElapsedTime(&c->last.sym_phase_ms, c->kev[tm.ev_analysis_end], c->kev[tm.ev_scan]);
     (void)hipEventElapsedTime(&c->last.num_phase_ms, c->kev[tm.ev_num], c->kev[ev_num_end]);
     for (const auto& ct : tm.sym) {
-        if (ct.cls == kLightBig) c->last.sym_light_ms = ms(ct.ev);
-        else if (ct.cls == kLightTiny) c->last.sym_tiny_ms = ms(ct.ev);
+        if (ct.cls == kLight) c->last.sym_light_ms = ms(ct.ev);
         else c->last.sym_bin_ms[ct.cls] = ms(ct.ev);
     }
     for (const auto& ct : tm.num) {
-        if (ct.cls == kLightBig) c->last.num_light_ms = ms(ct.ev);
-        else if (ct.cls == kLightTiny) c->last.num_tiny_ms = ms(ct.ev);
+        if (ct.cls == kLight) c->last.num_light_ms = ms(ct.ev);
         else c->last.num_bin_ms[ct.cls] = ms(ct.ev);
     }
     c->last.kernel_events_valid = 1;
 }
 
-// The analysis of a replayed sequence as a VERIFIER (ReplayPlan::overlap): on its own stream, enqueued by the host
+// The analysis of a reuse sequence as a VERIFIER (ReplayPlan::overlap): on its own stream, enqueued by the host
 // right behind the sequence, so that it runs beside it.  It compares what it computes from A and B as they are now with
 // what the previous identical call left in the arena -- which is what the sequence's kernels read -- and reports to
 // pinned host memory.  wait_verifier: the verdict, once that stream is idle (it is, long before the sequence's ticket).
 int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, const Scratch& sc)
 {
     __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
+    c->verifier_in_flight = true;
     if (c->verify_inputs && c->snap && c->snap_for_arena) {
         // the arena's metadata is a function of inputs that are still what the writing analysis saw: four streams compared
         launch_verify_inputs(c->vstream, A->row_offsets, sc.a_ro_copy, (u32)A->rows, A->col_ids, c->snap, A->nnz, B->row_offsets,
@@ -1140,12 +955,10 @@ int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, c
     cp.esc16 = (c->cp.esc16 && B->cols <= (1ull << 26)) ? 1u : 0u;  // (as enqueue_front classifies)
     cp.esc_fused = 0;
     launch_analysis(c->vstream, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, (u32)A->rows, A->nnz, sc.row_ops,
-                    sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, sc.counts, sc.partials, sc.recs_sym,
-                    c->d_stats, cp, sc.b_sl, nullptr, sc.nf_off, ~0ull, (u32)B->rows, nullptr, nullptr, nullptr,
-                    (u32)B->cols, B->nnz, 0u, sc.a_ro_copy, c->h_verify_dev);
+                    sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, sc.counts, sc.sym_recs, c->d_stats, cp,
+                    sc.b_sl, Chain{}, sc.nf_off, ~0ull, (u32)B->rows, sc.a_ro_copy, c->h_verify_dev);
     // ... and behind it the copy of the inputs it has just verified the arena against (they do not change while the call
-    // is in flight): the verifiers of the next replays compare with that.  (The FIRST replay of a problem pays the
-    // recomputing verifier once; the eager call that precedes it pays nothing.)
+    // is in flight): the verifiers of the next replays compare with that.
     if (c->verify_inputs && c->snap) {
         launch_snapshot_inputs(c->vstream, A->row_offsets, A->col_ids, c->snap, A->nnz, B->row_offsets, B->col_ids, (u32)B->rows,
                                c->snap + c->snap_a_words);
@@ -1167,11 +980,26 @@ int wait_verifier(speck_config* c, bool* changed)
     }
     if (!seen) HIP_TRY(hipStreamSynchronize(c->vstream));
     c->vticket_expected = __atomic_load_n(c->h_verify + 16, __ATOMIC_ACQUIRE);
+    c->verifier_in_flight = false;
     *changed = __atomic_load_n(c->h_verify, __ATOMIC_ACQUIRE) != 0u;
     return SPECK_OK;
 }
+// No way out of a call leaves work on the verifier's stream: the next call zeroes the verdict word and counts tickets
+// (an early return between launch_verifier and wait_verifier let an orphaned verifier OR into the next
+// call's verdict).
+struct VerifierGuard {
+    speck_config* c;
+    ~VerifierGuard()
+    {
+        if (!c->verifier_in_flight) return;
+        (void)hipStreamSynchronize(c->vstream);
+        c->vticket_expected = __atomic_load_n(c->h_verify + 16, __ATOMIC_ACQUIRE);
+        c->verifier_in_flight = false;
+        c->validate_in_flight = false;
+    }
+};
 
-// The input check of an eager call, beside it on the verifier's stream (stages.hip: validate_b_kernel).
+// The input check of a complete call, beside it on the verifier's stream (stages.hip: validate_b_kernel).
 int begin_validate(speck_config* c, const speck_dcsr* B)
 {
     __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
@@ -1180,6 +1008,7 @@ int begin_validate(speck_config* c, const speck_dcsr* B)
         HIP_TRY(hipEventRecord(c->fork, c->user_stream));
         HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
     }
+    c->verifier_in_flight = true;
     launch_validate_b(c->vstream, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, B->nnz, c->h_verify_dev);
     launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
     HIP_TRY(hipGetLastError());
@@ -1242,155 +1071,61 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     Scratch sc = carve(c, m, A->nnz);
     c->snap_pending = false;
     if (c->verify_inputs && c->overlap_analysis && c->use_graph) ensure_snap(c, A->nnz, B->rows);
+    VerifierGuard verifier_guard{c};
 
-    // ------------------------------------------------------------------ replay path
-    // Same buffers as a previous call, C already allocated for the expected nnz: replay the
-    // captured launch sequence.  The device checks the two assumptions baked into it (nnz(C)
-    // unchanged, no row in a class that was pruned); on a miss the eager path below re-runs.
+    // ------------------------------------------------------------------ reuse path (option use_graph)
+    // Same buffers as the previous call, C already allocated for the expected nnz: the sequence that places rows where
+    // that call put them (plan_replay).  The device checks every assumption; on a miss the complete call below re-runs.
     const bool c_ready = C->rows == A->rows && C->row_offsets && C->col_ids && C->data && C->nnz > 0;
-    if (c->use_graph && c_ready && c->profile_kernels && c->profile_replay && !t->measureAll) {
-        // the launches a replay of this call consists of, straight onto the stream with events around them
-        const GraphKey key = make_key<T>(c, A, B, C, s);
-        if (c->last_key_valid && c->last_key == key) {
-            c->exec_dirty = true;
-            if (c->graph_valid && !(c->graph_key == key)) drop_graph(c);  // (its copy of the prediction is rewritten below)
-            const bool arena_mine = c->arena_key_valid && c->arena_key == key;
-            ReplayPlan plan = plan_replay(c, arena_mine && c->arena_from_replay);
-            if (snapshot_prediction(c, s, plan) != SPECK_OK) {
-                c->pred_valid = c->pred_tiles_valid = false;
-                plan = plan_replay(c);
-            }
-            // (a verifying analysis needs the metadata of THIS problem in the arena)
-            if (!arena_mine) plan.overlap = plan.skip_scan = plan.num_verify = false;
-            c->arena_key_valid = false;
-            Timing tm;
-            size_t ev_num_end = 0;
-            // (the verifier FIRST here: enqueuing the launches one by one with events around them takes the host longer
-            //  than the first of them runs -- launched behind them the verifier would run beside the LAST launch, not
-            //  beside the first as it does next to the graph)
-            // (the same sequence once WITHOUT events directly in front: the timed launches then start on a chip that is
-            //  busy and warm, as every replay of the graph behind another one does -- after the idle gap of a host-side
-            //  synchronisation the first launch of the sequence measured ~5 % longer than its average in a kernel trace)
-            rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, nullptr, nullptr);
-            if (rc != SPECK_OK) return rc;
-            // (... and the verifier not before the TIMED sequence starts: with launches of milliseconds -- nlpkkt stand-in --
-            //  the host has both sequences enqueued long before the first has run, and the verifier would spend itself
-            //  beside the untimed one: the timed light launch measured 16.9 ms against 18.7 in a trace of the graph)
-            //  (only then: beside a sequence of tens of microseconds the host launches the verifier ~30 us AFTER the graph,
-            //   and a verifier that starts WITH the timed sequence made its first launch 5 % longer than a trace of the
-            //   graph shows it -- scircuit stand-in 45.5 against 43.2 us)
-            //  (... and behind the symbolic phase of the timed sequence: next to the graph the host launches the verifier ~30 us
-            //   after the graph -- the short fused launch of such an input is through by then)
-            c->gate_verifier = plan.overlap && c->last_eager_stats.sum_products >= (1ull << 29);
-            rc = enqueue_replay<T>(c, s, A, B, C, sc, plan, &tm, &ev_num_end);
-            c->gate_verifier = false;
-            if (rc != SPECK_OK) return rc;
-            // (BEHIND the sequence, as the graph path does: launched in front of it the verifier ran beside the first launch
-            //  of the sequence from its start and made that launch ~2 us longer than it is inside the graph -- the launch
-            //  durations of this path are the ones the bench line and scripts/check_launch_ms.py quote)
-            if (plan.overlap) {
-                rc = launch_verifier(c, A, B, sc);
-                if (rc != SPECK_OK) return rc;
-            }
-            HIP_TRY(hipStreamSynchronize(s));
-            c->ticket_expected = __atomic_load_n(c->h_ticket, __ATOMIC_ACQUIRE);
-            bool changed = false;
-            if (plan.overlap) {
-                rc = wait_verifier(c, &changed);
-                if (rc != SPECK_OK) return rc;
-            }
-            if (!changed && !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
-                c->arena_key = key;
-                c->arena_key_valid = true;
-                c->arena_from_replay = true;
-                if (c->snap_pending) c->snap_for_arena = true;  // (the copy of the inputs this call's verifier took: launch_verifier)
-                publish_counts(c);
-                publish_kernel_times(c, tm, ev_num_end);
-                c->last.replayed = 0;  // (not served by the graph: graph_replays does not count it)
-                c->last.nf_direct = plan.direct ? 1 : 0;
-                c->last.esc_fused = plan.fused ? 1 : 0;
-                c->last.pred_stages = (plan.pred_scan ? 1 : 0) | (plan.pred_sym ? 2 : 0) | (plan.overlap ? 4 : 0) | (plan.skip_scan ? 8 : 0) |
-                                      (plan.num_verify ? 16 : 0);
-                return finish_complete();
-            }
-        }
-    }
     if (c->use_graph && c_ready && !c->profile_kernels && !t->measureAll) {
         const GraphKey key = make_key<T>(c, A, B, C, s);
+        const bool arena_mine = c->arena_key_valid && c->arena_key == key;
+        const bool replay_layout = arena_mine && c->arena_from_replay;
         bool have = c->graph_valid && c->graph_key == key;
-        const bool replay_layout = c->arena_key_valid && c->arena_key == key && c->arena_from_replay;
-        if (!have && c->last_key_valid && c->last_key == key)
-            have = capture_graph<T>(c, s, A, B, C, sc, key, replay_layout) == SPECK_OK;
-        // the sequence has replayed once: from now on it needs no scan kernel (captured anew, once)
-        else if (have && !c->graph_plan.skip_scan && replay_layout && c->last_key_valid && c->last_key == key &&
-                 plan_replay(c, true).skip_scan)
-            have = capture_graph<T>(c, s, A, B, C, sc, key, true) == SPECK_OK;
-        if (have && c->exec_dirty && !(c->replay_uncaptured || c->use_user_stream || c->graph_plan.uncaptured)) {
-            // (see below) a fresh executable for a graph that other launches have passed; no executable: eager path
-            if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-            c->graph_exec = nullptr;
-            if (hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                drop_graph(c);
-                have = false;
-            }
-            c->exec_dirty = false;
+        // a new sequence: behind a complete call of this problem; again once it has replayed (no scan from then on)
+        if ((!have || (!c->graph_plan.skip_scan && replay_layout)) && c->last_key_valid && c->last_key == key) {
+            if (!have && snapshot_prediction(c, s) != SPECK_OK) c->pred_valid = false;  // (no room: nothing is placed early)
+            c->graph_plan = plan_replay(c, true, replay_layout);
+            c->graph_key = key;
+            c->graph_valid = have = true;
+            ++c->graph_captures;
         }
         if (have) {
-            // Launching the SAME executable graph again after other launches went onto the same stream in between
-            // (an eager multiply of another problem on this config) ended in GPU memory faults on this runtime --
-            // gone with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, i.e. the runtime's pre-recorded launch packets; found by
-            // the interleaved stress (tests/tools/stress_gpu.py interleave=K).  So: an executable that has seen other
-            // work on the pipeline stream since its last launch is instantiated afresh from the captured graph (a few
-            // hundred us, once per switch between problems); on a CALLER's stream, whose traffic the library cannot
-            // see, the launches of the sequence are enqueued one by one instead (option replay_uncaptured does the same
-            // everywhere: +1..6 % per multiply).
             // A sequence whose analysis only VERIFIES reads the metadata the previous multiply of THIS problem left in the
             // arena.  If something else has used the arena since (another problem on this config, a stage entry point) the
-            // same sequence runs with a writing analysis in front instead -- enqueued, not from the graph -- and leaves
-            // the arena as the next replay needs it.
-            const bool arena_ok = c->arena_key_valid && c->arena_key == key;
-            bool overlapped = c->graph_overlap, skipped = c->graph_plan.skip_scan;
-            const bool self_verified = c->graph_plan.num_verify;
+            // same sequence runs with a writing analysis in front instead and leaves the arena as the next replay needs it.
+            ReplayPlan p = c->graph_plan;
+            if ((p.overlap && !arena_mine) || (p.skip_scan && !replay_layout)) p.overlap = p.skip_scan = p.num_verify = false;
             c->arena_key_valid = false;  // (until this call has completed)
-            if ((c->graph_overlap && !arena_ok) || (c->graph_plan.skip_scan && !replay_layout)) {
-                ReplayPlan p2 = c->graph_plan;
-                p2.overlap = p2.skip_scan = p2.num_verify = false;
-                overlapped = skipped = false;
-                c->exec_dirty = true;
-                rc = enqueue_replay<T>(c, s, A, B, C, sc, p2, nullptr, nullptr);
-                if (rc != SPECK_OK) return rc;
-            } else if (c->replay_uncaptured || c->use_user_stream || c->graph_plan.uncaptured) {
-                rc = enqueue_replay<T>(c, s, A, B, C, sc, c->graph_plan, nullptr, nullptr);
-                if (rc != SPECK_OK) return rc;
-            } else {
-                HIP_TRY(hipGraphLaunch(c->graph_exec, s));
-            }
+            rc = enqueue_replay<T>(c, s, A, B, C, sc, p, nullptr, nullptr);
+            if (rc != SPECK_OK) return rc;
             // (behind the sequence, while it runs: the host would only spin otherwise)
-            if (overlapped) {
+            if (p.overlap) {
                 rc = launch_verifier(c, A, B, sc);
                 if (rc != SPECK_OK) return rc;
             }
-            // the last node of the sequence stores a ticket into pinned memory
+            // the last kernel of the sequence stores a ticket into pinned memory
             rc = wait_ticket(c, s);
             if (rc != SPECK_OK) return rc;
             bool changed = false;
-            if (overlapped) {
+            if (p.overlap) {
                 rc = wait_verifier(c, &changed);
                 if (rc != SPECK_OK) return rc;
             }
+            if (c->h_stats->chain_error) return SPECK_ERR_HIP;
             if (!changed && !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 c->arena_key = key;
                 c->arena_key_valid = true;
                 c->arena_from_replay = true;
-                if (c->snap_pending) c->snap_for_arena = true;  // (the copy of the inputs this call's verifier took: launch_verifier)
+                if (c->snap_pending) c->snap_for_arena = true;  // (the copy of the inputs this call's verifier took)
                 ++c->graph_replays;
-                publish_counts(c);
+                publish_counts(c, s);
                 c->last.replayed = 1;
-                c->last.nf_direct = c->graph_direct ? 1 : 0;
-                c->last.esc_fused = c->graph_fused ? 1 : 0;
-                c->last.pred_stages = (c->graph_pred_scan ? 1 : 0) | (c->graph_pred_sym ? 2 : 0) | (overlapped ? 4 : 0) | (skipped ? 8 : 0) |
-                                      ((skipped && self_verified) ? 16 : 0);
+                c->last.nf_direct = p.direct ? 1 : 0;
+                c->last.esc_fused = p.fused ? 1 : 0;
+                // bits 0-1: rows are placed by / compared with the previous call's offsets (the sequence's own copy); 2: the analysis only
+                // verifies, beside the sequence; 3: no scan kernel; 4: no symbolic pass for the hash / dense rows
+                c->last.pred_stages = (c->pred_valid ? 3 : 0) | (p.overlap ? 4 : 0) | (p.skip_scan ? 8 : 0) | (p.num_verify ? 16 : 0);
                 return finish_complete();
             }
             ++c->graph_misses;  // inputs changed under the same pointers: fall through
@@ -1398,8 +1133,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         }
     }
 
-    // ------------------------------------------------------------------ eager path
-    c->exec_dirty = true;  // (a captured sequence of another problem must not be launched again as it is)
+    // ------------------------------------------------------------------ complete call
     c->arena_key_valid = false;  // (the arena is rewritten: it is this problem's once the call has completed)
     // INIT: C.row_offsets reuse rule (Multiply.cu:156-165)
     u32* c_ro = nullptr;
@@ -1420,39 +1154,27 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     Timing tm;
     u32 sym_now[kMaxClasses];
     const u32* sym_known = nullptr;  // rows per symbolic class, once a read-back of this call has them
-    // what this call leaves behind for a replay of itself (Prediction): its row offsets and tile tables, written by
-    // the scan kernel next to its other outputs.  No room on the device: the replay predicts nothing.
-    c->pred_valid = c->pred_tiles_valid = false;
-    const bool keep_pred = (c->nf_direct || c->pred_scan) && c->use_graph && ensure_pred(c->pred, m);
-    // (the shape of the tile tables: will that replay finish the register-class rows in its symbolic phase?)
-    const bool fold_esc = keep_pred && c->esc_fused && c->nf_direct && c->cp.sym_g8 == c->cp.num_g8 && c->merge_light;
+    // what this call leaves behind for a repeated identical call: its row offsets, written by the scan kernel next to its
+    // other outputs.  No room on the device: that call places nothing early.
+    c->pred_valid = false;
+    const bool keep_pred = c->nf_direct && c->use_graph && ensure_pred(c->pred, m);
     // (the scan mirrors the statistics and stores the ticket itself: await_scan_stats)
     const bool early_stats = c->spin_wait && !c->profile_kernels;
     auto front = [&](u32 parts) {
         // (the offsets go to scratch: C.row_offsets -- possibly the caller's reused buffer -- is written only once
         //  nothing can fail any more)
-        return enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm,
+        return enqueue_front(c, s, A, B, sc, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm,
                              parts == 2u ? sym_known : nullptr, early_stats ? c->h_stats_dev : nullptr, ~0ull, ~0u, parts, ~0ull,
-                             keep_pred ? &c->pred : nullptr, fold_esc);
+                             keep_pred ? c->pred.off : nullptr);
     };
-    // ONE batch, sized from the previous eager call on this config (same shapes): the classes that call had rows in
-    // (a row in any other class raises capacity_miss: publish_bins), grids from its counts, its scratch pool and
-    // numeric-first window (checked by the scatter / numeric-first kernels).  Saves the first of the two read-backs --
-    // a ticket, a spin and the launch latency behind it, ~15 us of a 170 us multiply.
+    // ONE batch, sized from the previous complete call on this config (same shapes): the classes that call had rows in
+    // (a row in any other class raises capacity_miss), grids from its counts, its scratch pool and numeric-first window
+    // (checked by the analysis / numeric-first kernels).  Saves the first of the two read-backs.
     // The input check -- B's rows strictly ascending and in range: one coalesced pass over B.col_ids -- runs BESIDE the
-    // call on the verifier's stream (it rode in the analysis launch until round 4 and cost that launch 13 us); its
-    // verdict is looked at with the statistics of the scan, before anything of C is written.  Until then the kernels
-    // stay inside their tables and windows whatever B holds.  A's column ids are checked -- and clamped -- by the analysis.
-    struct ValidateGuard {  // (no way out of this call leaves the check running: the next call reuses its verdict word)
-        speck_config* c;
-        ~ValidateGuard()
-        {
-            bool ignored;
-            (void)finish_validate(c, &ignored);
-        }
-    } validate_guard{c};
-    // (launched BEHIND the analysis of the call, not in front of it: two launches on another stream cost the host
-    //  5-10 us that the analysis -- the head of the call's critical path -- then starts later; enqueue_front calls it)
+    // call on the verifier's stream; its verdict is looked at with the statistics of the scan, before anything of C is
+    // written.  Until then the kernels stay inside their tables and windows whatever B holds (a requirement for every
+    // kernel body: DESIGN.md 1).  A's column ids are checked -- and clamped -- by the analysis.
+    // (launched BEHIND the analysis of the call, not in front of it: enqueue_front calls it)
     bool validate_started = false;
     auto start_validate = [&]() -> int {
         if (!c->validate_inputs || validate_started) return SPECK_OK;
@@ -1467,20 +1189,19 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     auto b_is_invalid = [&](bool* bad) { return finish_validate(c, bad); };
     bool speculated = false;
     u32 spec_counts[kMaxClasses];
-    if (c->eager_speculate && c->spec_valid && c->spec_rows_a == A->rows && c->spec_rows_b == B->rows &&
-        (c->cp.nf_min_ops || c->cp.gh_per_window)) {
+    if (c->eager_speculate && c->spec_valid && c->spec_rows_a == A->rows && c->spec_rows_b == B->rows) {
         u32 mask = 0;
         for (int k = 0; k < kMaxClasses; ++k) {
-            spec_counts[k] = c->last_sym_counts[k] ? c->last_sym_counts[k] + c->last_sym_counts[k] / 4 + 64 : 0;
+            spec_counts[k] = c->last_sym_counts[k];
             if (spec_counts[k]) mask |= 1u << k;
         }
         // (the light launch is one kernel whatever it holds: every class of it may have rows)
         for (int k = 0; k < kMaxClasses; ++k)
             if ((kSymLightMask >> k & 1u) && !spec_counts[k]) spec_counts[k] = 256;
         mask |= kSymLightMask;
-        rc = enqueue_front(c, s, A, B, sc, sc.offsets, (u32)sizeof(T), ~0ull, mask, kAllNum, true, &tm, spec_counts,
+        rc = enqueue_front(c, s, A, B, sc, (u32)sizeof(T), ~0ull, mask, kAllNum, true, &tm, spec_counts,
                            early_stats ? c->h_stats_dev : nullptr, ~0ull, ~0u, 3u, c->nf_cap_entries,
-                           keep_pred ? &c->pred : nullptr, fold_esc, false);
+                           keep_pred ? c->pred.off : nullptr, true);
         if (rc == SPECK_OK) rc = early_stats ? await_scan_stats(c, s) : read_stats(c, s);
         if (rc != SPECK_OK) return fail(rc);
         if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
@@ -1499,7 +1220,6 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     if (c->cp.nf_min_ops || c->cp.gh_per_window) {
         // numeric-first rows (and the global key sets of SYM_GH rows) need their scratch pool before the
         // symbolic phase: one more read-back
-        // (the replayed sequence has none: the pool of the previous identical call is checked on the device)
         rc = read_stats(c, s);
         if (rc != SPECK_OK) return fail(rc);
         if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
@@ -1519,7 +1239,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         }
         if (rc != SPECK_OK) return fail(rc);
         c->nf_wcols = c->h_stats->nf_max_range ? c->h_stats->nf_max_range : kNumD1Cols;
-        // the read-back also buys right-sized grids, fork decisions and list positions for the symbolic launches
+        // the read-back also buys right-sized grids, fork decisions and exact class counts for the symbolic launches
         std::memcpy(sym_now, c->h_stats->sym.count, sizeof(sym_now));
         sym_known = sym_now;
     }
@@ -1540,7 +1260,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     t->loadBalanceCounting = 0.f;
     t->globalMapsCounting = 0.f;
     t->spGEMMCounting = st.lap();  // analysis + binning + symbolic + scan are one async batch
-    publish_counts(c);
+    publish_counts(c, s);
     if (c->h_stats->nnz_overflow) return fail(SPECK_ERR_NNZ_OVERFLOW);
     const u64 nnz_c = c->h_stats->nnz_c;
 
@@ -1604,7 +1324,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         sp.cell_cap = (u32)cells;
         if (sp.plan != c->spill.plan || sp.pcol[0] != c->spill.pcol[0] || sp.pval[1] != c->spill.pval[1] ||
             sp.bucket_cap != c->spill.bucket_cap)
-            drop_graph(c);  // a captured sequence holds the old layout
+            drop_graph(c);  // a reuse sequence holds the old layout
         c->spill = sp;
     }
     t->globalMapsNumeric = st.lap();
@@ -1639,20 +1359,15 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     C->col_ids = c_col;
     C->row_offsets = c_ro;
     own_ro = false;
-    // the staged offsets -> C.row_offsets: by extra workgroups of the numeric light launch when there is one with the
-    // big kernel (launch_numeric_light), else by a copy of its own
-    constexpr u32 kBigLight = (1u << NUM_D1) | (1u << NUM_B2K) | (1u << NUM_W512) | (1u << NUM_W256);
-    const bool ride = c->merge_light && (num_mask & kBigLight) != 0;
+    // the staged offsets -> C.row_offsets: by extra workgroups of the numeric light launch when there is one, else by a
+    // copy of its own (enqueue_back)
     struct Unstage {
         speck_config* c;
         ~Unstage() { c->stage_off_src = nullptr, c->stage_off_dst = nullptr, c->stage_off_n = 0; }
     } unstage{c};
-    if (ride) {
-        c->stage_off_src = sc.offsets;
-        c->stage_off_dst = c_ro;
-        c->stage_off_n = m + 1;
-    } else
-        HIP_TRY(hipMemcpyAsync(c_ro, sc.offsets, (size_t(m) + 1) * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    c->stage_off_src = sc.offsets;
+    c->stage_off_dst = c_ro;
+    c->stage_off_n = m + 1;
     t->allocC = st.lap();
     t->loadBalanceNumeric = 0.f;
 
@@ -1663,8 +1378,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         tm.ev_num = tm.ev;
         (void)hipEventRecord(kernel_event(c, tm.ev++), s);
     }
-    rc = enqueue_back<T>(c, s, A, B, sc, c_ro, c_col, static_cast<T*>(c_val), num_mask,
-                         c->h_stats->num.count, &tm);
+    rc = enqueue_back<T>(c, s, A, B, sc, c_col, static_cast<T*>(c_val), num_mask, c->h_stats->num.count, &tm);
     if (rc != SPECK_OK) return rc;
     const size_t ev_num_end = tm.ev;
     if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, tm.ev++), s);
@@ -1682,7 +1396,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     t->sorting = 0.f;  // sorting is fused into the numeric kernels
     t->cleanup = 0.f;  // nothing to free: the arena persists
 
-    // remember what this call ran on: an identical next call is captured and replayed
+    // remember what this call ran on: an identical next call may reuse its placement
     c->last_sym_mask = mask_of(c->h_stats->sym.count, SYM_CLASSES);
     c->last_num_mask = num_mask;
     c->last_max_row_nnz = c->h_stats->max_row_nnz_c;
@@ -1696,9 +1410,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     c->spec_valid = true;
     c->spec_rows_a = A->rows;
     c->spec_rows_b = B->rows;
-    // ... and where every row went: the scan kernel wrote the prediction (offsets, tile tables) as it went
-    c->pred_valid = c->pred_tiles_valid = keep_pred;
-    c->pred_fold_esc = fold_esc;
+    // ... and where every row went: the scan kernel wrote the config's copy of the offsets as it went
+    c->pred_valid = keep_pred;
     c->last_eager_stats = *c->h_stats;
 
     rc = finish_complete();
@@ -1715,8 +1428,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         if (t->measureAll) {
             // the reference's eleven stage fields (Timings.h:7-18, filled at Multiply.cu:227-1073) from
             // the kernel events: stages that are fused here report under the field of their role
-            t->countProducts = span(tm.ev_analysis, tm.ev_between);          // readOperations
-            t->loadBalanceCounting = span(tm.ev_between, tm.ev_analysis_end);  // symbolic binning (scatter)
+            t->countProducts = span(tm.ev_analysis, tm.ev_analysis_end);    // readOperations + symbolic binning: ONE kernel
+            t->loadBalanceCounting = 0.f;                                     //   since round 5 (stages.hip)
             t->spGEMMCounting = c->last.sym_phase_ms;                          // symbolic launches
             t->loadBalanceNumeric = c->last.scan_ms;                           // scan + numeric binning
             t->spGEMMNumeric = c->last.num_phase_ms;                           // numeric launches ...
@@ -1812,9 +1525,12 @@ int speck_config_create(int device, speck_config** out)
     HIP_TRY(hipMemset(c->d_vticket, 0, sizeof(u32)));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_verify_dev), c->h_verify, 0));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(DeviceStats)));
-    // (b_bad_epoch is the one word no kernel zeroes: recycled memory of a destroyed config must not hold an epoch
-    //  this config is going to use)
     HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
+    // the look-back chain of the analysis / scan kernels: tags and epoch start from zero, once (chain.hpp)
+    HIP_TRY(hipMalloc(&c->chain_buf, kChainBytes));
+    HIP_TRY(hipMemset(c->chain_buf, 0, kChainBytes));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_bytes), 2 * kMaxClasses * sizeof(u64)));
+    HIP_TRY(hipMemset(c->d_bytes, 0, 2 * kMaxClasses * sizeof(u64)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stats), sizeof(DeviceStats), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_stats_dev), c->h_stats, 0));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_ticket), sizeof(u32)));
@@ -1829,10 +1545,6 @@ int speck_config_create(int device, speck_config** out)
                               // scircuit stand-in 5 %, 1024 leaves the boundary rows of the cant one a launch of their own)
     c->cp.gh_per_window = 8192;  // global key set for rows with fewer products per 1 Mi-column bitmap window (0 = off)
     c->cp.esc16 = 1;       // rows of <= 64 products from <= 16 entries: 16 lanes per row, in registers (esc.hpp)
-    c->cp.esc4 = 0;        // rows of <= 16 products from <= 4 entries: 4 lanes per row, carved out of the 8-lane class.  OFF:
-                           //   measured round 4 -- webbase stand-in -1.5 % time, but mac_econ +2 % (its fused launch 52.4 ->
-                           //   56.0 us although 55 % of its 8-lane rows qualify) and scircuit +1 %: splitting the list of small
-                           //   rows in two costs the B-row locality of neighbouring rows more than the half-size network saves
     c->cp.esc32 = 1;       // rows of <= 128 products from <= 32 entries: 32 lanes per row, in registers (esc_wide.hpp)
     c->cp.esc64 = 1;       // rows of <= 256 products from <= 64 entries: a wave per row, in registers
     c->cp.num_g8 = 1;      // rows of <= 32 products from <= 8 entries: 8 lanes per row, in registers
@@ -1849,7 +1561,6 @@ int speck_config_destroy(speck_config* c)
     if (!c) return SPECK_ERR_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    drop_graph(c);
     for (auto s : c->streams) (void)hipStreamDestroy(s);
     (void)hipEventDestroy(c->completeStart);
     (void)hipEventDestroy(c->completeEnd);
@@ -1866,9 +1577,11 @@ int speck_config_destroy(speck_config* c)
     if (c->snap) (void)hipFree(c->snap);
     if (c->gpool) (void)hipFree(c->gpool);
     if (c->nfpool) (void)hipFree(c->nfpool);
-    if (c->pred.buf) (void)hipFree(c->pred.buf);
-    if (c->gpred.buf) (void)hipFree(c->gpred.buf);
+    if (c->pred.off) (void)hipFree(c->pred.off);
+    if (c->gpred.off) (void)hipFree(c->gpred.off);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->chain_buf) (void)hipFree(c->chain_buf);
+    if (c->d_bytes) (void)hipFree(c->d_bytes);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->h_ticket) (void)hipHostFree(c->h_ticket);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
@@ -1912,156 +1625,49 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
 {
     if (!c || !name) return SPECK_ERR_INVALID;
     const std::string n(name);
+    // every option a test or a script sets; anything that changes how rows are classified or what a reuse sequence
+    // may take for granted also forgets the sequence (and the complete call it was planned from)
+    auto forget = [&](bool also_last_call) {
+        drop_graph(c);
+        if (also_last_call) c->last_key_valid = false;
+    };
     if (n == "sym_bitmap_ratio") c->cp.sym_bitmap_ratio = (u32)value;
     else if (n == "num_dense_ratio") c->cp.num_dense_ratio = (u32)value;
     else if (n == "num_global_passes") c->cp.num_global_passes = (u32)value;
-    else if (n == "gh_per_window") {
-        c->cp.gh_per_window = (u32)value;
-        drop_graph(c);
-        c->last_key_valid = false;
-    } else if (n == "nf_min_ops") {
-        c->cp.nf_min_ops = (u32)value;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
+    else if (n == "gh_per_window") c->cp.gh_per_window = (u32)value, forget(true);
+    else if (n == "nf_min_ops") c->cp.nf_min_ops = (u32)value, forget(true);
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
-    else if (n == "profile_replay") c->profile_replay = value != 0;
-    else if (n == "replay_uncaptured") {
-        c->replay_uncaptured = value != 0;
-        drop_graph(c);
-    }
-    else if (n == "analysis_wide_rows") {
-        set_analysis_wide_rows((u32)value);
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
+    else if (n == "analysis_wide_rows") set_analysis_wide_rows((u32)value), forget(true);
     else if (n == "eager_speculate") c->eager_speculate = value != 0;
-    else if (n == "capture_forked") {
-        c->capture_forked = value != 0;
-        drop_graph(c);
-    }
-    else if (n == "verify_inputs") {
-        c->verify_inputs = value != 0;
-        c->snap_for_arena = false;
-        drop_graph(c);
-    }
-    else if (n == "num_verify") {
-        c->num_verify = (int)value;
-        drop_graph(c);
-    }
-    else if (n == "skip_scan") {
-        c->skip_scan = value != 0;
-        drop_graph(c);
-    }
-    else if (n == "overlap_analysis") {
-        c->overlap_analysis = value != 0;
-        drop_graph(c);
-    }
-    else if (n == "pred_sym") {
-        c->pred_sym = value != 0;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
-    else if (n == "pred_scan") {
-        c->pred_scan = value != 0;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
-    else if (n == "esc_fused") {
-        c->esc_fused = value != 0;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
-    else if (n == "nf_direct") {
-        c->nf_direct = value != 0;
-        drop_graph(c);
-    }
-    else if (n == "sym_w128") {
-        c->cp.sym_w128 = value != 0;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
-    else if (n == "sym_g8") {
-        c->cp.sym_g8 = value != 0;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
-    else if (n == "esc16") {
-        c->cp.esc16 = value != 0;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
-    else if (n == "esc32" || n == "esc64" || n == "esc4") {
-        (n == "esc32" ? c->cp.esc32 : (n == "esc64" ? c->cp.esc64 : c->cp.esc4)) = value != 0;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
-    else if (n == "num_g8") {
-        c->cp.num_g8 = value != 0;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
-    else if (n == "num_w256") {
-        c->cp.num_w256 = value != 0;
-        drop_graph(c);
-        c->last_key_valid = false;
-    }
+    else if (n == "verify_inputs") c->verify_inputs = value != 0, c->snap_for_arena = false, forget(false);
+    else if (n == "num_verify") c->num_verify = (int)value, forget(false);
+    else if (n == "skip_scan") c->skip_scan = value != 0, forget(false);
+    else if (n == "overlap_analysis") c->overlap_analysis = value != 0, forget(false);
+    else if (n == "esc_fused") c->esc_fused = value != 0, forget(true);
+    else if (n == "nf_direct") c->nf_direct = value != 0, forget(false);
+    else if (n == "sym_w128") c->cp.sym_w128 = value != 0, forget(true);
+    else if (n == "sym_g8") c->cp.sym_g8 = value != 0, forget(true);
+    else if (n == "esc16") c->cp.esc16 = value != 0, forget(true);
+    else if (n == "esc32") c->cp.esc32 = value != 0, forget(true);
+    else if (n == "esc64") c->cp.esc64 = value != 0, forget(true);
+    else if (n == "num_g8") c->cp.num_g8 = value != 0, forget(true);
+    else if (n == "num_w256") c->cp.num_w256 = value != 0, forget(true);
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
     else if (n == "validate_inputs") c->validate_inputs = value != 0;
-    else if (n == "spin_wait") {
-        c->spin_wait = value != 0;
-        drop_graph(c);
-    }
-    else if (n == "fork_min_us") {
-        c->fork_min_us = (float)value;
-        drop_graph(c);
-    }
-    else if (n == "split_min_us") {
-        c->split_min_us = (float)value;
-        drop_graph(c);
-    }
-    else if (n == "max_side_streams") {
-        c->max_side_streams = (u32)value;
-        drop_graph(c);
-    }
+    else if (n == "spin_wait") c->spin_wait = value != 0, forget(false);
+    else if (n == "fork_min_us") c->fork_min_us = (float)value, forget(false);
+    else if (n == "max_side_streams") c->max_side_streams = (u32)value, forget(false);
     else if (n == "use_graph") {
-        // (an eager call leaves a prediction behind only for a config that may replay: the call that follows the switch
-        //  is a complete one)
-        if (c->use_graph != (value != 0)) {
-            drop_graph(c);
-            c->last_key_valid = false;
-        }
+        // (a complete call leaves its row offsets behind only for a config that may reuse them: the call that follows
+        //  the switch is a complete one)
+        if (c->use_graph != (value != 0)) forget(true);
         c->use_graph = value != 0;
     }
-    else if (n == "grid_rounds_block") {
-        set_grid_rounds((u32)value, 0);
-        drop_graph(c);
-    }
-    else if (n == "grid_rounds_sub") {
-        set_grid_rounds(0, (u32)value);
-        drop_graph(c);
-    }
-    else if (n == "spill_big_grid") {
-        set_spill_big_grid((u32)value);
-        drop_graph(c);
-    }
-    else if (n == "tiny_threads") {
-        set_tiny_threads((int)value);
-        drop_graph(c);
-    }
-    else if (n == "split_light") {
-        c->split_light = value != 0;
-        drop_graph(c);
-    }
-    else if (n == "xcd_aware") {
-        c->xcd_aware = (u32)value;
-        drop_graph(c);
-    }
-    else if (n == "merge_light") {
-        c->merge_light = value != 0;
-        drop_graph(c);
-    }
+    else if (n == "grid_rounds_block") set_grid_rounds((u32)value, 0), forget(false);
+    else if (n == "grid_rounds_sub") set_grid_rounds(0, (u32)value), forget(false);
+    else if (n == "spill_big_grid") set_spill_big_grid((u32)value), forget(false);
+    else if (n == "xcd_aware") c->xcd_aware = (u32)value, forget(false);
     else return SPECK_ERR_INVALID;
     return SPECK_OK;
 }
@@ -2106,7 +1712,6 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     if (rc != SPECK_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = main_stream(c);
-    c->exec_dirty = true;  // (stage entry point: launches on the pipeline stream)
     c->arena_key_valid = false;  // (... and writes the arena)
     const u32 m = (u32)A->rows;
     if (m == 0 || A->nnz == 0 || B->nnz == 0) {
@@ -2123,15 +1728,15 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     }
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
-    Scratch sc = carve(c, m, A->nnz);  // partials come from the arena, row arrays from the caller
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DeviceStats), s));
-    launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, d_row_ops,
-                    d_row_max_ops, d_row_col_min, d_row_col_max, nullptr, nullptr, sc.partials, sc.recs,
-                    c->d_stats, [&] {
-                        ClassifyParams cp = c->cp;
-                        cp.sym_allowed = cp.num_allowed = 0xFFFFFFFFu;
-                        return cp;
-                    }(), nullptr, nullptr, nullptr, ~0ull, (u32)B->rows);
+    Scratch sc = carve(c, m, A->nnz);  // (the row arrays come from the caller)
+    ClassifyParams cp = c->cp;
+    cp.sym_allowed = cp.num_allowed = 0xFFFFFFFFu;
+    Chain chain;
+    rc = next_chain(c, s, &chain);
+    if (rc != SPECK_OK) return rc;
+    launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, d_row_ops, d_row_max_ops,
+                    d_row_col_min, d_row_col_max, nullptr, nullptr, sc.sym_recs, c->d_stats, cp, nullptr, chain,
+                    nullptr, ~0ull, (u32)B->rows);
     HIP_TRY(hipGetLastError());
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return rc;
@@ -2149,7 +1754,6 @@ int speck_symbolic(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     if (rc != SPECK_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = main_stream(c);
-    c->exec_dirty = true;  // (stage entry point: launches on the pipeline stream)
     c->arena_key_valid = false;  // (... and writes the arena)
     const u32 m = (u32)A->rows;
     if (A->nnz == 0 || B->nnz == 0) {
@@ -2164,10 +1768,11 @@ int speck_symbolic(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     const u32 nf_was = c->cp.nf_min_ops, gh_was = c->cp.gh_per_window;
     c->cp.nf_min_ops = 0;  // structure only: no values here, every row through a symbolic kernel
     c->cp.gh_per_window = 0;  // ... one that needs no scratch pool
-    rc = enqueue_front(c, s, A, B, sc, d_row_offsets, 8, ~0ull, kAllSym, kAllNum, false, nullptr);
+    rc = enqueue_front(c, s, A, B, sc, 8, ~0ull, kAllSym, kAllNum, false, nullptr);
     c->cp.nf_min_ops = nf_was;
     c->cp.gh_per_window = gh_was;
     if (rc != SPECK_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(d_row_offsets, sc.offsets, (size_t(m) + 1) * 4, hipMemcpyDeviceToDevice, s));
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return rc;
     c->last_key_valid = false;

@@ -170,35 +170,52 @@ __device__ __forceinline__ RowSlice row_slice(u32 count, u32 bidx, u32 nblk, u32
     return RowSlice{lo + j * groups + gid, hi, nb_x * groups};
 }
 
-// First step of every class body: where the class' row list starts, which of its rows this group walks, the
-// first record -- and whether the (replayed) launch sequence was declared void by an earlier kernel.  With a
-// host-known position of the list (ClassHint) the first record is requested AT ONCE, next to the device-side
-// table that confirms the position: a workgroup of the sub-wave classes lives for one or two rows, and the
-// chain table -> record -> A entries -> B entries is most of that life.
-struct ListHead {
+// First step of every class body: which rows of the class' list this group walks, and the first record.
+// The list lives at a fixed place (launch.hpp, class_rec_at), so with a host-known count of the class (ClassGrid::cnt) the
+// first record is requested AT ONCE, next to the device-side class table that confirms the count: a workgroup of the
+// sub-wave classes lives for one or two rows, and the chain table -> record -> A entries -> B entries is most of that life.
+struct RowCursor {
     const RowRec* recs;
-    RowSlice rs;
-    RowRec next;
-    u32 miss;
+    u32 m, cls;
+    u32 idx, end, stride;
+    RowRec next;  // record of list entry idx (if idx < end)
+    u32 miss;     // the (replayed) launch sequence was declared void by an earlier kernel: walk nothing
+    __device__ __forceinline__ bool more() const { return idx < end; }
+    __device__ __forceinline__ RowRec at(u32 i) const { return *class_rec_at(recs, m, cls, i); }
+    // the record of the current row; the cursor moves on (the next row's record is requested now)
+    __device__ __forceinline__ RowRec take()
+    {
+        const RowRec r = next;
+        if (idx + stride < end) next = at(idx + stride);
+        idx += stride;
+        return r;
+    }
 };
 template <bool SYM>
-__device__ __forceinline__ ListHead open_list(const RowWork& w, int cls, ClassHint h, u32 bidx, u32 nblk, u32 groups,
-                                              u32 gid, bool xcd_aware)
+__device__ __forceinline__ RowCursor open_list(const RowWork& w, int cls, u32 hint_cnt, u32 bidx, u32 nblk, u32 groups,
+                                               u32 gid, bool xcd_aware)
 {
     const BinTable& bt = SYM ? w.st->sym : w.st->num;
-    ListHead L;
+    RowCursor L;
+    L.recs = w.recs;
+    L.m = w.m;
+    L.cls = (u32)cls;
     L.miss = w.st->capacity_miss;
-    const u32 off = bt.offset[cls], cnt = bt.count[cls];
+    const u32 cnt = min(bt.count[cls], w.m);
     L.next = RowRec{};
-    if (h.cnt != 0xFFFFFFFFu) {
-        L.recs = w.recs + h.off;
-        L.rs = row_slice(h.cnt, bidx, nblk, groups, gid, xcd_aware);
-        if (L.rs.idx < L.rs.end) L.next = L.recs[L.rs.idx];
-        if (off == h.off && cnt == h.cnt) return L;
+    RowSlice rs{0u, 0u, 1u};
+    const bool hinted = hint_cnt != kNoCount && hint_cnt <= w.m;
+    if (hinted) {  // speculative: the record is in flight beside the table
+        rs = row_slice(hint_cnt, bidx, nblk, groups, gid, xcd_aware);
+        if (rs.idx < rs.end) L.next = L.at(rs.idx);
     }
-    L.recs = w.recs + off;
-    L.rs = row_slice(cnt, bidx, nblk, groups, gid, xcd_aware);
-    if (L.rs.idx < L.rs.end) L.next = L.recs[L.rs.idx];
+    if (!hinted || cnt != hint_cnt) {
+        rs = row_slice(cnt, bidx, nblk, groups, gid, xcd_aware);
+        if (rs.idx < rs.end) L.next = L.at(rs.idx);
+    }
+    L.idx = rs.idx;
+    L.end = rs.end;
+    L.stride = rs.stride;
     return L;
 }
 

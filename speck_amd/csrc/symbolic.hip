@@ -38,7 +38,7 @@ constexpr u32 sym_group_lds()
 template <class G, u32 CAP, int THREADS>
 __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const ProductSrc<float>& src,
                                               const RowWork& w, u32* __restrict__ counts, int cls, u32 bidx,
-                                              u32 nblk, ClassHint hint = kNoHint)
+                                              u32 nblk, u32 hint = kNoCount)
 {
     constexpr u32 NG = THREADS / G::SIZE;
     constexpr u32 kGroupBytes = sym_group_lds<G, CAP, THREADS>();
@@ -47,17 +47,11 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
     u32* tab = reinterpret_cast<u32*>(smem + gid * kGroupBytes);
     u32* scratch = tab + CAP + 2 * G::SIZE;
     RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr, scratch + sym_scratch_words<G, THREADS>()};
-    const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
-    // (a replayed sequence that an earlier kernel has declared void: with predicted binning the records of a block
-    //  whose rows changed are NOT written -- nothing may walk them)
-    if (head.miss) return;
-    const RowRec* recs = head.recs;
-    u32 idx = head.rs.idx;
-    const u32 stride = head.rs.stride, count = head.rs.end;
-    RowRec next = head.next;
-    while (idx < count) {
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + stride < count) next = recs[idx + stride];
+    RowCursor cur = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
+    // (a replayed sequence that an earlier kernel has declared void walks nothing)
+    if (cur.miss) return;
+    while (cur.more()) {
+        const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         for (u32 i = g.lane; i < CAP; i += G::SIZE) tab[i] = kEmptyKey;
         g.sync();
         u32 cnt = 0;
@@ -68,7 +62,6 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
         cnt = g.reduce_add(cnt, scratch);
         if (g.lane == 0) store_row_count(w, counts, rec.row, cnt);
         g.sync();
-        idx += stride;
     }
 }
 
@@ -82,25 +75,19 @@ constexpr u32 sym_esc_group_lds() { return L * 4u; }
 template <u32 L, int THREADS>
 __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductSrc<float>& src, const RowWork& w,
                                              u32* __restrict__ counts, int cls, u32 bidx, u32 nblk,
-                                             ClassHint hint = kNoHint)
+                                             u32 hint = kNoCount)
 {
     using G = SubWave<L>;
     constexpr u32 NG = THREADS / L, PER = kEscPerLane;
     const G g;
     const u32 gid = threadIdx.x / L;
     u32* s_off = reinterpret_cast<u32*>(smem + gid * sym_esc_group_lds<L>());
-    const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
-    // (a replayed sequence that an earlier kernel has declared void: with predicted binning the records of a block
-    //  whose rows changed are NOT written -- nothing may walk them)
-    if (head.miss) return;
-    const RowRec* recs = head.recs;
-    u32 idx = head.rs.idx;
-    const u32 stride = head.rs.stride, count = head.rs.end;
-    RowRec next = head.next;
+    RowCursor cur = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
+    // (a replayed sequence that an earlier kernel has declared void walks nothing)
+    if (cur.miss) return;
     const u32 gl = g.lane;
-    while (idx < count) {
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + stride < count) next = recs[idx + stride];
+    while (cur.more()) {
+        const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         uint2 sl = make_uint2(0u, 0u);
         if (rec.a0 + gl < rec.a1) sl = src.b_sl[rec.a0 + gl];
         u32 total;
@@ -136,14 +123,13 @@ __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductS
         heads = g.reduce_add(heads, nullptr);
         if (gl == 0) store_row_count(w, counts, rec.row, heads);
         wave_lds_fence();  // the next row overwrites the offsets
-        idx += stride;
     }
 }
 
 template <u32 WORDS, int THREADS>
 __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const ProductSrc<float>& src,
                                                 const RowWork& w, u32* __restrict__ counts, int cls, u32 bidx,
-                                                u32 nblk, ClassHint hint = kNoHint)
+                                                u32 nblk, u32 hint = kNoCount)
 {
     using G = Block<THREADS>;
     const G g;
@@ -151,16 +137,10 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
     u32* scratch = bm + WORDS + 2 * THREADS;
     RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr, scratch + THREADS / 64 + 2};
     constexpr u64 kWindowCols = u64(WORDS) * 32;
-    const ListHead head = open_list<true>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
-    // (a replayed sequence that an earlier kernel has declared void: with predicted binning the records of a block
-    //  whose rows changed are NOT written -- nothing may walk them)
-    if (head.miss) return;
-    const RowSlice rs = head.rs;
-    const RowRec* recs = head.recs;
-    RowRec next = head.next;
-    for (u32 idx = rs.idx; idx < rs.end; idx += rs.stride) {
-        const RowRec rec = next;  // fetched while the previous row was being processed
-        if (idx + rs.stride < rs.end) next = recs[idx + rs.stride];
+    RowCursor cur = open_list<true>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
+    if (cur.miss) return;
+    while (cur.more()) {
+        const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         u32 total = 0;
         // a row wider than one window: per-entry cursors, every B entry is read once (WindowCursors)
         const bool multi = u64(rec.cmax) - rec.cmin + 1 > kWindowCols;
@@ -264,10 +244,9 @@ __global__ __launch_bounds__(kGhThreads) void sym_global_hash_kernel(ProductSrc<
     u32* lds = reinterpret_cast<u32*>(smem);
     u32* scratch = lds + 2 * kGhThreads;
     RowMeta<float> meta{lds, lds + kGhThreads, nullptr, scratch + kGhThreads / 64 + 2};
-    const u32 count = w.st->sym.count[SYM_GH];
-    const RowRec* recs = w.recs + w.st->sym.offset[SYM_GH];
+    const u32 count = min(w.st->sym.count[SYM_GH], w.m);
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
-        const RowRec rec = recs[idx];
+        const RowRec rec = *class_rec_at(w.recs, w.m, SYM_GH, idx);
         const u32 slots = gh_table_slots(rec.ops);
         const u32 shift = 32u - (u32)__builtin_ctz(slots);
         const u64 slot0 = w.nf_off[rec.row];
@@ -337,32 +316,31 @@ __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
-    // launch order (ClassGrid slots): BM1, B4K, W1K, W256, R64, R32, W128, G16, G8, G4
+    // launch order (ClassGrid slots): BM1, B4K, W1K, W256, R64, R32, W128, G16, G8
     if (b < cg.first[1])
-        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], kNoHint);
+        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], cg.cnt[0]);
     else if (b < cg.first[2])
-        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], kNoHint);
+        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], cg.cnt[1]);
     else if (b < cg.first[3])
-        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], kNoHint);
+        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], cg.cnt[2]);
     else if (b < cg.first[4])
-        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], kNoHint);
+        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.cnt[3]);
     else if (b < cg.first[5])
-        sym_escw_body<64, 256>(smem, src, w, counts, SYM_R64, b - cg.first[4], cg.first[5] - cg.first[4], kNoHint);
+        sym_escw_body<64, 256>(smem, src, w, counts, SYM_R64, b - cg.first[4], cg.first[5] - cg.first[4], cg.cnt[4]);
     else if (b < cg.first[6])
-        sym_escw_body<32, 256>(smem, src, w, counts, SYM_R32, b - cg.first[5], cg.first[6] - cg.first[5], kNoHint);
+        sym_escw_body<32, 256>(smem, src, w, counts, SYM_R32, b - cg.first[5], cg.first[6] - cg.first[5], cg.cnt[5]);
     else if (b < cg.first[7])
-        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], kNoHint);
+        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.cnt[6]);
     else if (b < cg.first[8])
-        sym_esc_body<16, 256>(smem, src, w, counts, SYM_G16, b - cg.first[7], cg.first[8] - cg.first[7], kNoHint);
-    else if (b < cg.first[9])
-        sym_esc_body<8, 256>(smem, src, w, counts, SYM_G8, b - cg.first[8], cg.first[9] - cg.first[8], kNoHint);
+        sym_esc_body<16, 256>(smem, src, w, counts, SYM_G16, b - cg.first[7], cg.first[8] - cg.first[7], cg.cnt[7]);
     else
-        sym_esc_body<4, 256>(smem, src, w, counts, SYM_G4, b - cg.first[9], cg.first[10] - cg.first[9], kNoHint);
+        sym_esc_body<8, 256>(smem, src, w, counts, SYM_G8, b - cg.first[8], cg.first[9] - cg.first[8], cg.cnt[8]);
 }
 
-// The light launch of a REPLAYED sequence: the rows of the two register classes are finished here -- products
-// expanded, sorted, summed and written to the place the previous identical call gave the row in C (num_esc_body,
-// FUSED) -- instead of being counted now and walked again in the numeric phase.  The other classes count as above.
+// The light launch of a sequence that REUSES the placement of the previous identical call: the rows of the
+// register classes are finished here -- products expanded, sorted, summed and written to the place that call gave the row
+// in C (num_esc_body, FUSED) -- instead of being counted now and walked again in the numeric phase.  The other classes
+// count as above.
 template <typename T>
 __global__ __launch_bounds__(256) void sym_light_fused_kernel(ProductSrc<T> nsrc, const u32* a_ro, RowWork w,
                                                               u32* __restrict__ counts, ClassGrid cg)
@@ -372,36 +350,32 @@ __global__ __launch_bounds__(256) void sym_light_fused_kernel(ProductSrc<T> nsrc
     const ProductSrc<float> src{nsrc.b_sl, nullptr, nsrc.b_col, nullptr, nsrc.w_sl};
     const u32 b = blockIdx.x;
     if (b < cg.first[1])
-        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], kNoHint);
+        sym_bitmap_body<kSymBm1Words, 256>(smem, src, w, counts, SYM_BM1, b - cg.first[0], cg.first[1] - cg.first[0], cg.cnt[0]);
     else if (b < cg.first[2])
-        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], kNoHint);
+        sym_hash_body<Block<256>, kSymB4KCap, 256>(smem, src, w, counts, SYM_B4K, b - cg.first[1], cg.first[2] - cg.first[1], cg.cnt[1]);
     else if (b < cg.first[3])
-        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], kNoHint);
+        sym_hash_body<SubWave<64>, kSymW1KCap, 256>(smem, src, w, counts, SYM_W1K, b - cg.first[2], cg.first[3] - cg.first[2], cg.cnt[2]);
     else if (b < cg.first[4])
-        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], kNoHint);
+        sym_hash_body<SubWave<32>, kSymW256Cap, 256>(smem, src, w, counts, SYM_W256, b - cg.first[3], cg.first[4] - cg.first[3], cg.cnt[3]);
     else if (b < cg.first[5])
         num_escw_body<T, 64, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_R64,
-                                        b - cg.first[4], cg.first[5] - cg.first[4], kNoHint, counts);
+                                        b - cg.first[4], cg.first[5] - cg.first[4], cg.cnt[4], counts);
     else if (b < cg.first[6])
         num_escw_body<T, 32, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_R32,
-                                        b - cg.first[5], cg.first[6] - cg.first[5], kNoHint, counts);
+                                        b - cg.first[5], cg.first[6] - cg.first[5], cg.cnt[5], counts);
     else if (b < cg.first[7])
-        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], kNoHint);
+        sym_hash_body<SubWave<16>, kSymW128Cap, 256>(smem, src, w, counts, SYM_W128, b - cg.first[6], cg.first[7] - cg.first[6], cg.cnt[6]);
     else if (b < cg.first[8])
         num_esc_body<T, 16, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G16,
-                                       b - cg.first[7], cg.first[8] - cg.first[7], kNoHint, counts);
-    else if (b < cg.first[9])
-        num_esc_body<T, 8, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G8,
-                                      b - cg.first[8], cg.first[9] - cg.first[8], kNoHint, counts);
+                                       b - cg.first[7], cg.first[8] - cg.first[7], cg.cnt[7], counts);
     else
-        num_esc_body<T, 4, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G4,
-                                      b - cg.first[9], cg.first[10] - cg.first[9], kNoHint, counts);
+        num_esc_body<T, 8, 256, true>(smem, nsrc, w, w.nf_direct_col, static_cast<T*>(w.nf_direct_val), SYM_G8,
+                                      b - cg.first[8], cg.first[9] - cg.first[8], cg.cnt[8], counts);
 }
 
 u32 symbolic_lds_bytes(int cls)
 {
     switch (cls) {
-        case SYM_G4: return 64 * sym_esc_group_lds<4>();
         case SYM_G8: return 32 * sym_esc_group_lds<8>();
         case SYM_G16: return 16 * sym_esc_group_lds<16>();
         case SYM_R32: return 8 * sym_escw_group_lds<32>();
@@ -472,12 +446,11 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
                            u32* counts, int cu_count, bool exact, u32 fused_vsize, const void* a_val,
                            const void* b_val, hipEvent_t e0, hipEvent_t e1)
 {
-    constexpr int NS = 10;
-    static const int slots[NS] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_R64, SYM_R32, SYM_W128, SYM_G16, SYM_G8, SYM_G4};
-    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 16, 16, 32, 64};
+    constexpr int NS = 9;
+    static const int slots[NS] = {SYM_BM1, SYM_B4K, SYM_W1K, SYM_W256, SYM_R64, SYM_R32, SYM_W128, SYM_G16, SYM_G8};
+    static const u32 rows_per_block[NS] = {1, 1, 4, 8, 4, 8, 16, 16, 32};
     const bool fused = fused_vsize != 0 && (mask & kSymEscMask) != 0;
     auto class_lds = [&](int cls) -> u32 {
-        if (fused && cls == SYM_G4) return 64 * (fused_vsize == 8 ? num_esc_group_lds<double, 4>() : num_esc_group_lds<float, 4>());
         if (fused && cls == SYM_G8) return 32 * (fused_vsize == 8 ? num_esc_group_lds<double, 8>() : num_esc_group_lds<float, 8>());
         if (fused && cls == SYM_G16) return 16 * (fused_vsize == 8 ? num_esc_group_lds<double, 16>() : num_esc_group_lds<float, 16>());
         if (fused && cls == SYM_R32) return 8 * (fused_vsize == 8 ? num_escw_group_lds<double, 32>() : num_escw_group_lds<float, 32>());
@@ -491,12 +464,12 @@ void launch_symbolic_light(hipStream_t s, const u32* counts_hint, u32 mask, cons
     for (int k = 0; k < NS; ++k) {
         const bool on = (mask >> slots[k] & 1u) && counts_hint[slots[k]];
         cg.first[k + 1] = cg.first[k] + (on ? grid_for(counts_hint[slots[k]], lds, 256, cu_count, rows_per_block[k]) : 0u);
+        cg.cnt[k] = exact ? counts_hint[slots[k]] : kNoCount;
     }
     if (cg.first[NS] == 0) {
         if (e0) (void)hipEventRecord(e0, s), (void)hipEventRecord(e1, s);  // (nothing to time: an empty interval)
         return;
     }
-    (void)exact;  // (list positions are no longer handed to the merged kernels: launch.hpp, ClassGrid)
     if (fused && fused_vsize == 8) {
         const ProductSrc<double> nsrc{b_sl, static_cast<const double*>(a_val), b_col, static_cast<const double*>(b_val), w.w_sl};
         SPECK_LAUNCH_TIMED((sym_light_fused_kernel<double>), dim3(cg.first[NS]), dim3(256), lds, s, e0, e1, nsrc, a_ro, w, counts, cg);
@@ -520,10 +493,6 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
     const u32* B = a_ro;
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
-        case SYM_G4:
-            hipLaunchKernelGGL(sym_esc_kernel<4>, dim3(grid_for(count, lds, 256, cu_count, 64)), dim3(256), lds, s, A, B, w,
-                               counts, cls);
-            break;
         case SYM_G8:
             hipLaunchKernelGGL(sym_esc_kernel<8>, dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B, w,
                                counts, cls);

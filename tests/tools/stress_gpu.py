@@ -119,9 +119,6 @@ def interleaved(cfg, rng, steps, alive):
             p["R"], p["ab"] = po.spgemm_f64_of(p["A"], p["B"])
         if os.environ.get("STRESS_VERBOSE"):
             print(f"     step {it}: problem {j} call {p['calls'] + 1} {p['name']}", flush=True)
-        if it == int(os.environ.get("STRESS_UNCAPTURED_AT", "-1")):   # this step: the launches of the replay, uncaptured
-            cfg.set_option("profile_replay", 1)
-            cfg.profile_kernels(1)
         ok = True
         # (STRESS_REPEAT=K: the chosen problem K times in a row -- the later calls of a run are replays without a scan and,
         #  option num_verify, without a symbolic pass, and the NEXT in-place change of that problem meets such a sequence)
