@@ -7,7 +7,7 @@ One "step" = one COMPLETE MultiplyspECK call with A and B resident in HBM and th
 steps (the reference's benchmark loop, source/Executor.cpp:43-72): analysis -> binning -> symbolic -> scan ->
 allocation check -> numeric (+ in-kernel sort), every stage inside the timed region, as the reference runs them in
 every iteration (source/GPU/Multiply.cu:488-575, 835-1043).  `value` / `ms_per_step` are THAT call (library option
-use_graph = 0).  The structure-reuse mode of a repeated identical call (the replayed sequence) is
+reuse = 0).  The structure-reuse mode of a repeated identical call (the replayed sequence) is
 reported beside it as `value_reuse` / `ms_reuse` at N = 1 and is never the metric.
 
 stdout carries ONE JSON line (<= 4 KB, no prose).  Everything else -- every launch with bytes / duration / ceilings,
@@ -229,10 +229,10 @@ class Job:
         self.bounds = (0, A.rows) if env.world == 1 else (bounds[env.rank], bounds[env.rank + 1])
 
     def set_reuse(self, on):
-        """on: a repeated identical call may run the structure-reuse sequence (library option use_graph);
+        """on: a repeated identical call may run the structure-reuse sequence (library option reuse);
         off: every call is the complete pipeline."""
         for scfg, _ in self.slots:
-            scfg.set_option("use_graph", int(on))
+            scfg.set_option("reuse", int(on))
 
     def step(self, exchange=True):
         slot = self.n_step % len(self.slots)

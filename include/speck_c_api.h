@@ -71,10 +71,11 @@ typedef struct speck_stats {
     float sym_tiny_ms, num_tiny_ms;              /* ... and of the small classes, launched right behind it */
     int32_t kernel_events_valid;                 /* 1 if *_ms were recorded for the last call */
     int32_t numeric_reruns;                      /* replayed sequences rejected by the device-side checks */
-    int32_t graph_replays;                       /* multiplies served by a replayed hipGraph (cumulative) */
-    int32_t graph_captures;
+    int32_t graph_replays;                       /* multiplies served by a reuse sequence (cumulative; the field names are
+                                                  *    those of rounds 2-4 -- no executable graph is involved any more) */
+    int32_t graph_captures;                      /* reuse sequences planned (cumulative) */
     float sym_phase_ms, num_phase_ms;            /* fork-to-join span of the symbolic / numeric launches (pipeline stream) */
-    int32_t replayed;                            /* 1: the last multiply was served by the replayed hipGraph */
+    int32_t replayed;                            /* 1: the last multiply was served by a reuse sequence */
     int32_t nf_direct;                           /* 1: that sequence wrote the numeric-first rows straight to C at the row
                                                   *    offsets of the previous identical call (verified) */
     int32_t pool_fallbacks;                      /* scratch-pool classes switched off because the pool did not fit */
@@ -167,7 +168,10 @@ int speck_dcsr_upload_padded(speck_dcsr *dst, uint64_t rows, uint64_t cols, uint
                              const uint32_t *h_row_offsets, const uint32_t *h_col_ids, const void *h_data,
                              size_t value_size, uint32_t padding);
 /* convert(dCSR&, const dCSR&, padding) -- source/dCSR.cpp:81-89: device-to-device, no host round trip.  `src` may be
- * a row-range view with absolute offsets: the copy is rebased to start at 0.  dst must not alias src. */
+ * a row-range view with absolute offsets: the copy is rebased to start at 0.  dst must not share any buffer with src
+ * (SPECK_ERR_INVALID: the allocation of dst frees what it held).  Like every speck_dcsr_* call it works on the NULL
+ * stream and returns when the copy is complete; a caller that produced src on its own non-blocking stream synchronises
+ * that stream first. */
 int speck_dcsr_copy(speck_dcsr *dst, const speck_dcsr *src, size_t value_size, uint32_t padding);
 /* overwrite the contents of an existing device matrix in place (same rows / nnz, same device
  * pointers); any of the host arrays may be NULL */

@@ -174,7 +174,8 @@ class dCSR:
         if self._owner:
             _lib.load().speck_dcsr_free(C.byref(self._c))
         else:
-            self._c = DCsr()
+            # in place: a BoundMultiply (or any other holder of byref(self._c)) keeps pointing at THIS struct
+            C.memset(C.byref(self._c), 0, C.sizeof(DCsr))
         self._keep = None
 
     def __del__(self):

@@ -45,14 +45,6 @@ __device__ __forceinline__ u32 esc_group_or(u32 v)
     return v;
 }
 
-// OR over the 4 lanes of a quad
-__device__ __forceinline__ u32 esc_quad_or(u32 v)
-{
-    v |= dpp_fetch<kDppQuadXor1>(v);
-    v |= dpp_fetch<kDppQuadXor2>(v);
-    return v;
-}
-
 // OR over the 16 lanes of a DPP row
 __device__ __forceinline__ u32 esc_row_or(u32 v)
 {
@@ -150,42 +142,6 @@ __device__ __forceinline__ void esc_sort32(u32 (&x)[4], u32 gl)
     esc_cx(x[2], x[3]);
 }
 
-// ... of the 16 elements of a 4-lane group (a quad): the first four stages of the network above
-__device__ __forceinline__ void esc_sort16(u32 (&x)[4], u32 gl)
-{
-    const u32 l0 = esc_dir(gl, 0), l1 = esc_dir(gl, 1);
-    esc_cx(x[0], x[1]);
-    esc_cx(x[2], x[3]);
-    esc_cx(x[0], x[3]);
-    esc_cx(x[1], x[2]);
-    esc_cx(x[0], x[1]);
-    esc_cx(x[2], x[3]);
-    {
-        const u32 y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3];
-        esc_cx_lane<kDppQuadXor1>(x[0], y3, l0);
-        esc_cx_lane<kDppQuadXor1>(x[1], y2, l0);
-        esc_cx_lane<kDppQuadXor1>(x[2], y1, l0);
-        esc_cx_lane<kDppQuadXor1>(x[3], y0, l0);
-    }
-    esc_cx(x[0], x[2]);
-    esc_cx(x[1], x[3]);
-    esc_cx(x[0], x[1]);
-    esc_cx(x[2], x[3]);
-    {
-        const u32 y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3];
-        esc_cx_lane<kDppQuadMirror>(x[0], y3, l1);
-        esc_cx_lane<kDppQuadMirror>(x[1], y2, l1);
-        esc_cx_lane<kDppQuadMirror>(x[2], y1, l1);
-        esc_cx_lane<kDppQuadMirror>(x[3], y0, l1);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) esc_cx_lane<kDppQuadXor1>(x[r], x[r], l0);
-    esc_cx(x[0], x[2]);
-    esc_cx(x[1], x[3]);
-    esc_cx(x[0], x[1]);
-    esc_cx(x[2], x[3]);
-}
-
 // ... and of the 64 elements of a 16-lane group (one DPP row)
 __device__ __forceinline__ void esc_sort64(u32 (&x)[4], u32 gl)
 {
@@ -213,8 +169,7 @@ __device__ __forceinline__ void esc_sort64(u32 (&x)[4], u32 gl)
 template <u32 L>
 __device__ __forceinline__ void esc_sort(u32 (&x)[4], u32 gl)
 {
-    if constexpr (L == 4) esc_sort16(x, gl);
-    else if constexpr (L == 8) esc_sort32(x, gl);
+    if constexpr (L == 8) esc_sort32(x, gl);
     else esc_sort64(x, gl);
 }
 

@@ -38,10 +38,10 @@ __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductS
                                              u32* __restrict__ c_col, T* __restrict__ c_val, int cls, u32 bidx,
                                              u32 nblk, u32 hint = kNoCount, u32* __restrict__ counts = nullptr)
 {
-    static_assert(L == 4 || L == 8 || L == 16, "4, 8 or 16 lanes per row");
+    static_assert(L == 8 || L == 16, "8 or 16 lanes per row");
     using G = SubWave<L>;
     using Mask = typename std::conditional<L <= 8, u32, u64>::type;
-    constexpr u32 NG = THREADS / L, PER = kEscPerLane, NP = PER * L, TAG = L == 4 ? 4u : (L == 8 ? 5u : 6u);
+    constexpr u32 NG = THREADS / L, PER = kEscPerLane, NP = PER * L, TAG = L == 8 ? 5u : 6u;
     const G g;
     const u32 gid = threadIdx.x / L;
     unsigned char* mine = smem + gid * num_esc_group_lds<T, L>();
@@ -77,9 +77,7 @@ __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductS
         }
         // bit k: a (non-empty) entry's products end at k -- the owner of product p is the number of set bits <= p
         Mask ends;
-        if constexpr (L == 4) {
-            ends = esc_quad_or((nonempty && incl < 16u) ? (1u << incl) : 0u);
-        } else if constexpr (L == 8) {
+        if constexpr (L == 8) {
             ends = esc_group_or((nonempty && incl < 32u) ? (1u << incl) : 0u);
         } else {
             const u64 bit = (nonempty && incl < 64u) ? (1ull << incl) : 0ull;

@@ -7,9 +7,9 @@
 //     device-side stats block and its grid depends only on rows(A), so a call needs ONE read-back
 //     (nnz(C), to allocate C) instead of the reference's 5-8;
 //   * a repeated call with the same buffers (the benchmark loop, Executor.cpp:59-72) may REUSE the placement of the
-//     previous identical call (option use_graph -- the name is historical: the sequence is enqueued launch by launch,
-//     no executable graph since round 5) -- verified on the device, never trusted; the complete call is the default
-//     of every measurement (bench.py);
+//     previous identical call (option "reuse"; the sequence is enqueued launch by launch -- no executable graph
+//     since round 5) -- verified on the device, never trusted; the complete call is what every measurement
+//     reports first (bench.py);
 //   * kernel classes run concurrently on separate streams between explicit fork/join events.
 #include <hip/hip_runtime.h>
 
@@ -39,10 +39,10 @@ using namespace speck;
     } while (0)
 
 // Everything a captured launch sequence is specialised to.
-struct GraphKey {
+struct CallKey {
     const void* ptr[10] = {};
     u64 num[8] = {};
-    bool operator==(const GraphKey& o) const
+    bool operator==(const CallKey& o) const
     {
         return std::memcmp(ptr, o.ptr, sizeof(ptr)) == 0 && std::memcmp(num, o.num, sizeof(num)) == 0;
     }
@@ -132,15 +132,15 @@ struct speck_config {
                               //   imbalance)
     u32 last_sym_counts[kMaxClasses] = {}, last_num_counts[kMaxClasses] = {};
 
-    // the reuse sequence of the last repeated call (name of the option: use_graph)
-    bool use_graph = true;
-    bool graph_valid = false;
-    GraphKey graph_key;
+    // the reuse sequence of the last repeated call (option "reuse")
+    bool reuse = true;
+    bool plan_valid = false;
+    CallKey plan_key;
     u32 last_sym_mask = 0, last_num_mask = 0;  // non-empty classes of the last complete call
     u32 last_max_row_nnz = 0;                  // ... and its longest C row
-    GraphKey last_key;                         // ... and what it ran on
+    CallKey last_key;                         // ... and what it ran on
     bool last_key_valid = false;
-    int graph_replays = 0, graph_captures = 0, graph_misses = 0;
+    int replays = 0, plans_made = 0, replay_misses = 0;
     void* gpool = nullptr;    // global-memory buffers of the NUM_G spill path, carved into `spill`
     size_t gpool_bytes = 0;
     void* nfpool = nullptr;   // scratch slots of the numeric-first rows: col_ids | values (grow-only)
@@ -158,7 +158,7 @@ struct speck_config {
     bool capture_fused = false;      // set while a sequence that does so is being enqueued
     u32* capture_c_col = nullptr;
     void* capture_c_val = nullptr;
-    ReplayPlan graph_plan{};
+    ReplayPlan plan{};
     bool skip_scan = true;           // option skip_scan: a reuse sequence that follows a replay of itself has no scan kernel
     bool capture_skip_scan = false;  // set while such a sequence is being enqueued
     int num_verify = 1;              // option num_verify (0: never, 1: when it pays, 2: whenever possible): ... and no symbolic pass for its hash / dense rows (ReplayPlan::num_verify)
@@ -184,7 +184,7 @@ struct speck_config {
     u32 vticket_expected = 0;
     bool verifier_in_flight = false; // a verifier / input check runs on vstream: drained on every way out of the call
     bool validate_in_flight = false; // the input check of a complete call is running on vstream (begin_validate)
-    GraphKey arena_key;              // what the per-row / per-entry metadata in the arena (b_sl, row arrays, records, lists,
+    CallKey arena_key;              // what the per-row / per-entry metadata in the arena (b_sl, row arrays, records, lists,
     bool arena_key_valid = false;    //   class table) was last written for -- by a multiply that COMPLETED
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
@@ -209,12 +209,12 @@ constexpr std::chrono::microseconds kSpinBudget{2000};
 
 hipStream_t main_stream(speck_config* c) { return c->use_user_stream ? c->user_stream : c->streams[0]; }
 
-void drop_graph(speck_config* c) { c->graph_valid = false; }
+void drop_plan(speck_config* c) { c->plan_valid = false; }
 
 int ensure_arena(speck_config* c, size_t bytes)
 {
     if (bytes <= c->arena_bytes) return SPECK_OK;
-    drop_graph(c);
+    drop_plan(c);
     c->last_key_valid = false;
     c->arena_key_valid = false;
     if (c->arena) HIP_TRY(hipFree(c->arena));
@@ -346,7 +346,7 @@ int ensure_nfpool(speck_config* c, u64 entries, size_t vsize)
 {
     const size_t need = Carver::need(entries, 4) + Carver::need(entries, vsize) + 512;
     if (entries <= c->nf_cap_entries && need <= c->nfpool_bytes) return SPECK_OK;
-    drop_graph(c);
+    drop_plan(c);
     c->last_key_valid = false;
     if (c->nfpool) (void)hipFree(c->nfpool);
     c->nfpool = nullptr;
@@ -762,10 +762,10 @@ void publish_counts(speck_config* c, hipStream_t s)
 }
 
 template <typename T>
-GraphKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, const speck_dcsr* C,
+CallKey make_key(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, const speck_dcsr* C,
                   hipStream_t s)
 {
-    GraphKey k;
+    CallKey k;
     k.ptr[0] = A->row_offsets; k.ptr[1] = A->col_ids; k.ptr[2] = A->data;
     k.ptr[3] = B->row_offsets; k.ptr[4] = B->col_ids; k.ptr[5] = B->data;
     k.ptr[6] = C->row_offsets; k.ptr[7] = C->col_ids; k.ptr[8] = C->data;
@@ -942,10 +942,19 @@ int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, c
 {
     __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
     c->verifier_in_flight = true;
+    // The interior of B's rows is no input of the analysis, and nothing the sequence's own checks compare (a row's nnz,
+    // its place in C) tells a row whose ids were reordered in place from a sorted one: the precondition of EVERY call is
+    // checked with the call -- one streaming pass over B.col_ids on this stream; a violation voids the sequence like any
+    // other change and the complete call that re-runs reports it (SPECK_ERR_UNSORTED).
+    auto validate = [&] {
+        if (c->validate_inputs)
+            launch_validate_b(c->vstream, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, B->nnz, c->h_verify_dev);
+    };
     if (c->verify_inputs && c->snap && c->snap_for_arena) {
         // the arena's metadata is a function of inputs that are still what the writing analysis saw: four streams compared
         launch_verify_inputs(c->vstream, A->row_offsets, sc.a_ro_copy, (u32)A->rows, A->col_ids, c->snap, A->nnz, B->row_offsets,
                              B->col_ids, (u32)B->rows, c->snap + c->snap_a_words, c->h_verify_dev);
+        validate();
         launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
         HIP_TRY(hipGetLastError());
         return SPECK_OK;
@@ -964,6 +973,7 @@ int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, c
                                c->snap + c->snap_a_words);
         c->snap_pending = true;
     }
+    validate();
     launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
     HIP_TRY(hipGetLastError());
     return SPECK_OK;
@@ -1070,33 +1080,38 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     if (rc != SPECK_OK) return rc;
     Scratch sc = carve(c, m, A->nnz);
     c->snap_pending = false;
-    if (c->verify_inputs && c->overlap_analysis && c->use_graph) ensure_snap(c, A->nnz, B->rows);
+    if (c->verify_inputs && c->overlap_analysis && c->reuse) ensure_snap(c, A->nnz, B->rows);
     VerifierGuard verifier_guard{c};
 
-    // ------------------------------------------------------------------ reuse path (option use_graph)
+    // ------------------------------------------------------------------ reuse path (option "reuse")
     // Same buffers as the previous call, C already allocated for the expected nnz: the sequence that places rows where
     // that call put them (plan_replay).  The device checks every assumption; on a miss the complete call below re-runs.
     const bool c_ready = C->rows == A->rows && C->row_offsets && C->col_ids && C->data && C->nnz > 0;
-    if (c->use_graph && c_ready && !c->profile_kernels && !t->measureAll) {
-        const GraphKey key = make_key<T>(c, A, B, C, s);
+    if (c->reuse && c_ready && !c->profile_kernels && !t->measureAll) {
+        const CallKey key = make_key<T>(c, A, B, C, s);
         const bool arena_mine = c->arena_key_valid && c->arena_key == key;
         const bool replay_layout = arena_mine && c->arena_from_replay;
-        bool have = c->graph_valid && c->graph_key == key;
+        bool have = c->plan_valid && c->plan_key == key;
         // a new sequence: behind a complete call of this problem; again once it has replayed (no scan from then on)
-        if ((!have || (!c->graph_plan.skip_scan && replay_layout)) && c->last_key_valid && c->last_key == key) {
+        if ((!have || (!c->plan.skip_scan && replay_layout)) && c->last_key_valid && c->last_key == key) {
             if (!have && snapshot_prediction(c, s) != SPECK_OK) c->pred_valid = false;  // (no room: nothing is placed early)
-            c->graph_plan = plan_replay(c, true, replay_layout);
-            c->graph_key = key;
-            c->graph_valid = have = true;
-            ++c->graph_captures;
+            c->plan = plan_replay(c, true, replay_layout);
+            c->plan_key = key;
+            c->plan_valid = have = true;
+            ++c->plans_made;
         }
         if (have) {
             // A sequence whose analysis only VERIFIES reads the metadata the previous multiply of THIS problem left in the
             // arena.  If something else has used the arena since (another problem on this config, a stage entry point) the
             // same sequence runs with a writing analysis in front instead and leaves the arena as the next replay needs it.
-            ReplayPlan p = c->graph_plan;
+            ReplayPlan p = c->plan;
             if ((p.overlap && !arena_mine) || (p.skip_scan && !replay_layout)) p.overlap = p.skip_scan = p.num_verify = false;
             c->arena_key_valid = false;  // (until this call has completed)
+            // (a sequence with its own analysis: the input check of B alone, beside it from its first launch on)
+            if (!p.overlap && c->validate_inputs) {
+                rc = begin_validate(c, B);
+                if (rc != SPECK_OK) return rc;
+            }
             rc = enqueue_replay<T>(c, s, A, B, C, sc, p, nullptr, nullptr);
             if (rc != SPECK_OK) return rc;
             // (behind the sequence, while it runs: the host would only spin otherwise)
@@ -1108,17 +1123,16 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             rc = wait_ticket(c, s);
             if (rc != SPECK_OK) return rc;
             bool changed = false;
-            if (p.overlap) {
-                rc = wait_verifier(c, &changed);
-                if (rc != SPECK_OK) return rc;
-            }
+            if (p.overlap) rc = wait_verifier(c, &changed);
+            else rc = finish_validate(c, &changed);
+            if (rc != SPECK_OK) return rc;
             if (c->h_stats->chain_error) return SPECK_ERR_HIP;
             if (!changed && !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 c->arena_key = key;
                 c->arena_key_valid = true;
                 c->arena_from_replay = true;
                 if (c->snap_pending) c->snap_for_arena = true;  // (the copy of the inputs this call's verifier took)
-                ++c->graph_replays;
+                ++c->replays;
                 publish_counts(c, s);
                 c->last.replayed = 1;
                 c->last.nf_direct = p.direct ? 1 : 0;
@@ -1128,8 +1142,8 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->last.pred_stages = (c->pred_valid ? 3 : 0) | (p.overlap ? 4 : 0) | (p.skip_scan ? 8 : 0) | (p.num_verify ? 16 : 0);
                 return finish_complete();
             }
-            ++c->graph_misses;  // inputs changed under the same pointers: fall through
-            drop_graph(c);
+            ++c->replay_misses;  // inputs changed under the same pointers: fall through
+            drop_plan(c);
         }
     }
 
@@ -1157,7 +1171,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // what this call leaves behind for a repeated identical call: its row offsets, written by the scan kernel next to its
     // other outputs.  No room on the device: that call places nothing early.
     c->pred_valid = false;
-    const bool keep_pred = c->nf_direct && c->use_graph && ensure_pred(c->pred, m);
+    const bool keep_pred = c->nf_direct && c->reuse && ensure_pred(c->pred, m);
     // (the scan mirrors the statistics and stores the ticket itself: await_scan_stats)
     const bool early_stats = c->spin_wait && !c->profile_kernels;
     auto front = [&](u32 parts) {
@@ -1291,7 +1305,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                             Carver::need(cells, 4) + Carver::need(buckets, 8) + 2 * Carver::need(buckets, 4) +
                             2 * Carver::need(pg, 4) + 2 * Carver::need(pg, sizeof(T)) + 4096;
         if (need > c->gpool_bytes) {
-            drop_graph(c);
+            drop_plan(c);
             if (c->gpool) (void)hipFree(c->gpool);
             c->gpool = nullptr;
             c->gpool_bytes = 0;
@@ -1324,7 +1338,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         sp.cell_cap = (u32)cells;
         if (sp.plan != c->spill.plan || sp.pcol[0] != c->spill.pcol[0] || sp.pval[1] != c->spill.pval[1] ||
             sp.bucket_cap != c->spill.bucket_cap)
-            drop_graph(c);  // a reuse sequence holds the old layout
+            drop_plan(c);  // a reuse sequence holds the old layout
         c->spill = sp;
     }
     t->globalMapsNumeric = st.lap();
@@ -1452,23 +1466,6 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         std::printf("--------------------------------------------------------------\n");
     }
     return SPECK_OK;
-}
-
-// speck_dcsr_copy, entirely on the device: the source may be a row-range view whose offsets are absolute -- its first
-// offset is read HERE, not on the host (no device-to-host copy anywhere in the conversion).
-// words: col_ids as u32, values as u32 pairs / singles (vwords = value_size / 4)
-__global__ __launch_bounds__(256) void dcsr_copy_kernel(const u32* __restrict__ s_ro, const u32* __restrict__ s_col,
-                                                        const u32* __restrict__ s_val, u32* __restrict__ d_ro,
-                                                        u32* __restrict__ d_col, u32* __restrict__ d_val, u64 rows, u64 nnz,
-                                                        u32 vwords)
-{
-    const u32 base = rows ? s_ro[0] : 0u;
-    const u64 tid = u64(blockIdx.x) * 256 + threadIdx.x, nth = u64(gridDim.x) * 256;
-    for (u64 i = tid; i <= rows; i += nth) d_ro[i] = rows ? s_ro[i] - base : 0u;
-    for (u64 i = tid; i < nnz; i += nth) d_col[i] = s_col[u64(base) + i];
-    const u64 nv = nnz * vwords;
-    const u32* sv = s_val + u64(base) * vwords;
-    for (u64 i = tid; i < nv; i += nth) d_val[i] = sv[i];
 }
 
 }  // namespace
@@ -1617,7 +1614,7 @@ int speck_config_set_stream(speck_config* c, void* hip_stream)
     if (!c) return SPECK_ERR_INVALID;
     c->user_stream = static_cast<hipStream_t>(hip_stream);
     c->use_user_stream = hip_stream != nullptr;
-    drop_graph(c);  // (a sequence is tied to the stream it was made for, and to HOW it is replayed there)
+    drop_plan(c);  // (a sequence is tied to the stream it was made for, and to HOW it is replayed there)
     return SPECK_OK;
 }
 
@@ -1628,7 +1625,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     // every option a test or a script sets; anything that changes how rows are classified or what a reuse sequence
     // may take for granted also forgets the sequence (and the complete call it was planned from)
     auto forget = [&](bool also_last_call) {
-        drop_graph(c);
+        drop_plan(c);
         if (also_last_call) c->last_key_valid = false;
     };
     if (n == "sym_bitmap_ratio") c->cp.sym_bitmap_ratio = (u32)value;
@@ -1658,11 +1655,11 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "spin_wait") c->spin_wait = value != 0, forget(false);
     else if (n == "fork_min_us") c->fork_min_us = (float)value, forget(false);
     else if (n == "max_side_streams") c->max_side_streams = (u32)value, forget(false);
-    else if (n == "use_graph") {
+    else if (n == "reuse" || n == "use_graph") {  // ("use_graph": the name of rounds 2-4, kept)
         // (a complete call leaves its row offsets behind only for a config that may reuse them: the call that follows
         //  the switch is a complete one)
-        if (c->use_graph != (value != 0)) forget(true);
-        c->use_graph = value != 0;
+        if (c->reuse != (value != 0)) forget(true);
+        c->reuse = value != 0;
     }
     else if (n == "grid_rounds_block") set_grid_rounds((u32)value, 0), forget(false);
     else if (n == "grid_rounds_sub") set_grid_rounds(0, (u32)value), forget(false);
@@ -1683,9 +1680,9 @@ int speck_last_stats(const speck_config* c, speck_stats* out)
 {
     if (!c || !out) return SPECK_ERR_INVALID;
     *out = c->last;
-    out->numeric_reruns = c->graph_misses;
-    out->graph_replays = c->graph_replays;
-    out->graph_captures = c->graph_captures;
+    out->numeric_reruns = c->replay_misses;
+    out->graph_replays = c->replays;
+    out->graph_captures = c->plans_made;
     out->pool_fallbacks = c->pool_fallbacks;
     out->scratch_pool_bytes = c->nfpool_bytes;
     return SPECK_OK;
@@ -1807,112 +1804,6 @@ int speck_partition_rows(speck_config* c, const speck_dcsr* A, const speck_dcsr*
         while (next < parts && run * parts >= total * next) h_bounds[next++] = i + 1;
     }
     while (next <= parts) h_bounds[next++] = m;
-    return SPECK_OK;
-}
-
-int speck_dcsr_alloc(speck_dcsr* m, uint64_t rows, uint64_t cols, uint64_t nnz, int alloc_offsets,
-                     size_t value_size)
-{
-    if (!m) return SPECK_ERR_INVALID;
-    speck_dcsr_free(m);
-    m->rows = rows;
-    m->cols = cols;
-    m->nnz = nnz;
-    HIP_TRY(hipMalloc(&m->data, std::max<size_t>(nnz, 1) * value_size));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->col_ids), std::max<size_t>(nnz, 1) * 4));
-    if (alloc_offsets) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->row_offsets), (rows + 1) * 4));
-    return SPECK_OK;
-}
-
-int speck_dcsr_free(speck_dcsr* m)
-{
-    if (!m) return SPECK_ERR_INVALID;
-    if (m->col_ids) (void)hipFree(m->col_ids);
-    if (m->data) (void)hipFree(m->data);
-    if (m->row_offsets) (void)hipFree(m->row_offsets);
-    m->col_ids = nullptr;
-    m->data = nullptr;
-    m->row_offsets = nullptr;
-    m->nnz = 0;
-    m->rows = 0;
-    return SPECK_OK;
-}
-
-int speck_dcsr_upload(speck_dcsr* dst, uint64_t rows, uint64_t cols, uint64_t nnz,
-                      const uint32_t* h_row_offsets, const uint32_t* h_col_ids, const void* h_data,
-                      size_t value_size)
-{
-    return speck_dcsr_upload_padded(dst, rows, cols, nnz, h_row_offsets, h_col_ids, h_data, value_size, 0u);
-}
-
-int speck_dcsr_upload_padded(speck_dcsr* dst, uint64_t rows, uint64_t cols, uint64_t nnz, const uint32_t* h_row_offsets,
-                             const uint32_t* h_col_ids, const void* h_data, size_t value_size, uint32_t padding)
-{
-    // reference: dst.alloc(rows + padding, cols, nnz + 8 * padding), then rows / nnz of the source (dCSR.cpp:53-54)
-    int rc = speck_dcsr_alloc(dst, rows + padding, cols, nnz + 8ull * padding, 1, value_size);
-    if (rc != SPECK_OK) return rc;
-    dst->rows = rows;
-    dst->nnz = nnz;
-    if (nnz) {
-        HIP_TRY(hipMemcpy(dst->data, h_data, nnz * value_size, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dst->col_ids, h_col_ids, nnz * 4, hipMemcpyHostToDevice));
-    }
-    HIP_TRY(hipMemcpy(dst->row_offsets, h_row_offsets, (rows + 1) * 4, hipMemcpyHostToDevice));
-    if (padding) {  // dCSR.cpp:59-64
-        HIP_TRY(hipMemset(static_cast<char*>(dst->data) + nnz * value_size, 0, 8ull * padding * value_size));
-        HIP_TRY(hipMemset(dst->col_ids + nnz, 0, 8ull * padding * 4));
-        HIP_TRY(hipMemset(dst->row_offsets + rows + 1, 0, size_t(padding) * 4));
-    }
-    return SPECK_OK;
-}
-
-int speck_dcsr_copy(speck_dcsr* dst, const speck_dcsr* src, size_t value_size, uint32_t padding)
-{
-    if (!dst || !src || dst == src) return SPECK_ERR_INVALID;
-    if (src->rows && !src->row_offsets) return SPECK_ERR_INVALID;
-    if (dst->data && dst->data == src->data) return SPECK_ERR_INVALID;  // alloc frees dst first (dCSR.cpp:28)
-    const uint64_t rows = src->rows, nnz = src->nnz;
-    int rc = speck_dcsr_alloc(dst, rows + padding, src->cols, nnz + 8ull * padding, 1, value_size);
-    if (rc != SPECK_OK) return rc;
-    dst->rows = rows;
-    dst->nnz = nnz;
-    const u64 work = std::max<u64>(rows + 1, nnz * (value_size / 4));
-    hipLaunchKernelGGL(dcsr_copy_kernel, dim3((unsigned)std::min<u64>((work + 255) / 256, 8192)), dim3(256), 0, nullptr,
-                       src->row_offsets, src->col_ids, static_cast<const u32*>(src->data), dst->row_offsets, dst->col_ids,
-                       static_cast<u32*>(dst->data), rows, nnz, (u32)(value_size / 4));
-    HIP_TRY(hipGetLastError());
-    if (padding) {
-        HIP_TRY(hipMemsetAsync(static_cast<char*>(dst->data) + nnz * value_size, 0, 8ull * padding * value_size, nullptr));
-        HIP_TRY(hipMemsetAsync(dst->col_ids + nnz, 0, 8ull * padding * 4, nullptr));
-        HIP_TRY(hipMemsetAsync(dst->row_offsets + rows + 1, 0, size_t(padding) * 4, nullptr));
-    }
-    HIP_TRY(hipStreamSynchronize(nullptr));
-    return SPECK_OK;
-}
-
-int speck_dcsr_download(const speck_dcsr* src, uint32_t* h_row_offsets, uint32_t* h_col_ids,
-                        void* h_data, size_t value_size)
-{
-    if (!src) return SPECK_ERR_INVALID;
-    if (src->nnz) {
-        if (h_data) HIP_TRY(hipMemcpy(h_data, src->data, src->nnz * value_size, hipMemcpyDeviceToHost));
-        if (h_col_ids) HIP_TRY(hipMemcpy(h_col_ids, src->col_ids, src->nnz * 4, hipMemcpyDeviceToHost));
-    }
-    if (h_row_offsets && src->row_offsets)
-        HIP_TRY(hipMemcpy(h_row_offsets, src->row_offsets, (src->rows + 1) * 4, hipMemcpyDeviceToHost));
-    return SPECK_OK;
-}
-
-int speck_dcsr_update(speck_dcsr* dst, const uint32_t* h_row_offsets, const uint32_t* h_col_ids,
-                      const void* h_data, size_t value_size)
-{
-    if (!dst) return SPECK_ERR_INVALID;
-    if (dst->nnz) {
-        if (h_data) HIP_TRY(hipMemcpy(dst->data, h_data, dst->nnz * value_size, hipMemcpyHostToDevice));
-        if (h_col_ids) HIP_TRY(hipMemcpy(dst->col_ids, h_col_ids, dst->nnz * 4, hipMemcpyHostToDevice));
-    }
-    if (h_row_offsets && dst->row_offsets)
-        HIP_TRY(hipMemcpy(dst->row_offsets, h_row_offsets, (dst->rows + 1) * 4, hipMemcpyHostToDevice));
     return SPECK_OK;
 }
 

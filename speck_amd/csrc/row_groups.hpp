@@ -43,7 +43,7 @@ static __device__ unsigned long long g_phase_clk[kPhaseSlots * kMaxClasses * 16]
 // ---- group policies -------------------------------------------------------------
 template <int L>
 struct SubWave {
-    static_assert(L == 4 || L == 8 || L == 16 || L == 32 || L == 64, "sub-wave width");
+    static_assert(L == 8 || L == 16 || L == 32 || L == 64, "sub-wave width");
     static constexpr int SIZE = L;
     static constexpr bool kIsBlock = false;
     u32 lane;       // index inside the group
@@ -69,14 +69,6 @@ struct SubWave {
             v = row16_inclusive_scan(v);
             // lane 15 of the own 16-lane row: ds_swizzle bit mode, lane' = (lane & 0x10) | 0x0F
             *total = (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (0x0F << 5));
-        } else if constexpr (L == 4) {
-            // quads of a DPP row: a shifted-in value from the quad before is dropped
-            u32 t = dpp_move<kDppRowShr + 1>(0, v);
-            v += lane >= 1u ? t : 0u;
-            t = dpp_move<kDppRowShr + 2>(0, v);
-            v += lane >= 2u ? t : 0u;
-            // lane 3 of the own quad: lane' = (lane & 0x1C) | 0x03
-            *total = (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x1C | (0x03 << 5));
         } else {
             // halves of a 16-lane DPP row: a shifted-in value from the other half is dropped
             u32 t = dpp_move<kDppRowShr + 1>(0, v);

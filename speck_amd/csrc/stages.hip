@@ -860,8 +860,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
 // Input precondition (undocumented upstream): the column ids of every row of B are
 // strictly ascending (the min/max column range of the analysis, the scaled-copy rows and the bitmap
 // sorts rely on it; the reference's loader guarantees it and silently computes garbage otherwise).
-// One coalesced pass over B.col_ids, eager path only (a replayed sequence runs on unchanged inputs): validate_b_kernel,
-// beside the call on the verifier's stream.
+// One coalesced pass over B.col_ids with EVERY call, complete or reuse sequence (the interior of a row is no input of
+// the analysis: nothing else would notice ids reordered in place): validate_b_kernel, beside the call on the verifier's
+// stream.
 // --------------------------------------------------------------------------------
 // Last node of a replayed launch sequence: a ticket in pinned host memory the host spins on (a blocking
 // stream synchronisation costs ~10-20 us of wake-up latency: a tenth of a 200 us multiply).
@@ -886,33 +887,82 @@ __global__ __launch_bounds__(64) void done_kernel(u32* __restrict__ dev_ticket, 
 // The input check of B (validate_b_slice) as a kernel of its own, for the verifier's stream: an eager call launches it
 // first and looks at the verdict -- bit 2 of the pinned word -- when it reads back the statistics of its scan, long after
 // this kernel is through; nothing of C is written before that (riding in the analysis launch it cost that launch 13 us).
+constexpr u32 kValChunk = 8192;  // entries of B per workgroup and step: eight 16-byte loads per lane, all in flight
 __global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__ b_ro, const u32* __restrict__ b_col, u32 b_rows,
                                                           u32 b_cols, u32* __restrict__ verdict)
 {
-    // four consecutive entries (and the one behind them) per lane and step, all five loads in flight together: the
-    // kernel runs beside the analysis of the call and should be gone before it competes with anything else
-    constexpr u32 E = 4;
+    // O(nnz + rows), streaming: a workgroup owns a contiguous span of entries and walks the row offsets alongside it.  Per
+    // chunk of 8192 entries: the row STARTS inside the chunk as a bitmap in LDS (a pair of neighbours that does not ascend
+    // is fine exactly where a row starts), then the entries as 16-byte loads.  (Round 4 looked every such pair up by binary
+    // search over B.row_offsets -- once per row of B, 23 dependent loads each: 5.9 ms for the nlpkkt stand-in.)
+    __shared__ u32 s_bits[kValChunk / 32];
+    __shared__ u32 s_cursor;
+    const u32 tid = threadIdx.x;
     const u32 e_first = b_ro[0], e_last = b_ro[b_rows];
     bool bad = e_last < e_first;
-    const u64 n = e_last > e_first ? u64(e_last - e_first) : 0;
-    for (u64 i = (u64(blockIdx.x) * 256 + threadIdx.x) * E; i < n; i += u64(gridDim.x) * 256 * E) {
-        const u32 e = e_first + (u32)i;
-        u32 c[E + 1];
-#pragma unroll
-        for (u32 k = 0; k <= E; ++k) c[k] = i + k < n ? b_col[e + k] : 0xFFFFFFFFu;
-#pragma unroll
-        for (u32 k = 0; k < E; ++k) {
-            if (i + k >= n) continue;
-            if (c[k] >= b_cols) bad = true;
-            if (i + k + 1 < n && c[k + 1] <= c[k]) {  // not ascending: fine only where a row starts (almost never looked up)
-                const u32 at = e + k + 1;
-                u32 lo = 0, hi = b_rows;  // first row whose offset is >= at
-                while (lo < hi) {
-                    const u32 mid = lo + ((hi - lo) >> 1);
-                    if (b_ro[mid] < at) lo = mid + 1; else hi = mid;
-                }
-                if (b_ro[lo] != at) bad = true;
+    // the offsets themselves: ascending (so every one of them lies in [e_first, e_last])
+    for (u64 r = u64(blockIdx.x) * 256 + tid; r < b_rows; r += u64(gridDim.x) * 256) bad |= b_ro[r + 1] < b_ro[r];
+    const u64 base = e_first & ~3u;  // (groups of four aligned in the array, so that the 16-byte loads are)
+    const u64 nchunks = e_last > base ? (u64(e_last) - base + kValChunk - 1) / kValChunk : 0;
+    const u64 per = (nchunks + gridDim.x - 1) / gridDim.x;
+    const u64 c0 = u64(blockIdx.x) * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+    if (c0 < c1 && e_last >= e_first) {
+        if (tid == 0) {  // first row that starts behind the first entry of the span
+            const u64 cs0 = base + c0 * kValChunk;
+            u32 lo = 0, hi = b_rows + 1;
+            while (lo < hi) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                if (u64(b_ro[mid]) <= cs0) lo = mid + 1; else hi = mid;
             }
+            s_cursor = lo;
+        }
+        __syncthreads();
+        u32 rc = s_cursor;
+        for (u64 c = c0; c < c1; ++c) {
+            const u64 cs = base + c * kValChunk;
+            s_bits[tid] = 0;
+            __syncthreads();
+            // bit i: a row starts at entry cs + 1 + i
+            while (true) {
+                const u64 r = u64(rc) + tid;
+                bool in = false;
+                if (r <= b_rows) {
+                    const u64 v = b_ro[r];
+                    in = v <= cs + kValChunk;
+                    if (in && v > cs) atomicOr(&s_bits[(u32)(v - cs - 1) >> 5], 1u << ((u32)(v - cs - 1) & 31u));
+                }
+                const u32 n = (u32)__syncthreads_count(in);  // (offsets that do not ascend are `bad` already)
+                rc += n;
+                if (n < 256u) break;
+            }
+            uint4 q[8];
+            u32 nx[8];
+#pragma unroll
+            for (u32 k = 0; k < 8; ++k) {
+                const u64 e = cs + 4ull * (tid + 256u * k);
+                q[k] = make_uint4(0u, 0u, 0u, 0u);
+                nx[k] = 0xFFFFFFFFu;
+                if (e + 4 <= e_last) q[k] = *reinterpret_cast<const uint4*>(b_col + e);
+                else if (e < e_last)  // (the last, partial group: nothing beyond the array is touched)
+                    q[k] = make_uint4(b_col[e], e + 1 < e_last ? b_col[e + 1] : 0u, e + 2 < e_last ? b_col[e + 2] : 0u, 0u);
+                if (e + 4 < e_last) nx[k] = b_col[e + 4];
+            }
+#pragma unroll
+            for (u32 k = 0; k < 8; ++k) {
+                const u64 e = cs + 4ull * (tid + 256u * k);
+                const u32 col[5] = {q[k].x, q[k].y, q[k].z, q[k].w, nx[k]};
+#pragma unroll
+                for (u32 j = 0; j < 4; ++j) {
+                    const u64 at = e + j;
+                    if (at < e_first || at >= e_last) continue;
+                    if (col[j] >= b_cols) bad = true;
+                    if (at + 1 < e_last && col[j + 1] <= col[j]) {
+                        const u32 bit = (u32)(at - cs);  // (entry at + 1)
+                        if (!((s_bits[bit >> 5] >> (bit & 31u)) & 1u)) bad = true;
+                    }
+                }
+            }
+            __syncthreads();  // the next chunk clears the bitmap
         }
     }
     if (__ballot(bad) != 0 && lane_id() == 0) __hip_atomic_fetch_or(verdict, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -920,8 +970,9 @@ __global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__
 void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_rows, u32 b_cols, u64 b_nnz, u32* verdict)
 {
     if (b_rows == 0) return;
-    const u32 want = cdiv(b_nnz ? b_nnz : 1, 256 * 4);
-    hipLaunchKernelGGL(validate_b_kernel, dim3(want > 2048u ? 2048u : want), dim3(256), 0, s, b_ro, b_col, b_rows, b_cols, verdict);
+    const u64 want = std::max<u64>(cdiv(b_nnz + 4, kValChunk), cdiv(u64(b_rows), 256 * 16));
+    hipLaunchKernelGGL(validate_b_kernel, dim3((u32)std::min<u64>(std::max<u64>(want, 1), 2048)), dim3(256), 0, s, b_ro, b_col,
+                       b_rows, b_cols, verdict);
 }
 
 // ... and the ticket of the verifier's stream (launch_verifier): the kernel boundary in front of it orders the verifier's

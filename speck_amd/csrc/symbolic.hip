@@ -96,9 +96,7 @@ __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductS
         const u32 before = (u32)__popcll(g.ballot(nonempty) & ((1ull << gl) - 1ull));
         if (nonempty) s_off[before] = sl.x - (incl - sl.y);
         u64 ends;
-        if constexpr (L == 4) {
-            ends = esc_quad_or((nonempty && incl < 16u) ? (1u << incl) : 0u);
-        } else if constexpr (L == 8) {
+        if constexpr (L == 8) {
             ends = esc_group_or((nonempty && incl < 32u) ? (1u << incl) : 0u);
         } else {
             const u64 bit = (nonempty && incl < 64u) ? (1ull << incl) : 0ull;

@@ -67,7 +67,7 @@ import contextlib
 @contextlib.contextmanager
 def options(cfg, **kv):
     """Library options for the duration of a block (restored to the given defaults afterwards)."""
-    defaults = {"esc32": 1, "esc64": 1, "esc4": 0, "skip_scan": 1}
+    defaults = {"esc32": 1, "esc64": 1, "skip_scan": 1}
     for k, v in kv.items():
         cfg.set_option(k, v)
     try:
@@ -1218,6 +1218,206 @@ def test_unsorted_or_out_of_range_b_is_rejected(cfg):
     check(cfg, A, B)          # the untouched B is fine
 
 
+def test_input_check_of_b_at_chunk_and_row_boundaries(cfg):
+    """validate_b_kernel walks B in chunks of 8192 entries with the row starts of a chunk as a bitmap: a pair that does
+    not ascend is legal exactly across a row boundary.  Violations placed at the first / last pair of a chunk, across
+    chunk boundaries inside a row, at the last entry, in a row of two entries between empty rows; legal descents at row
+    boundaries that coincide with chunk boundaries; a view of B whose first entry is not 16-byte aligned."""
+    rng = np.random.default_rng(3)
+    rows, cols = 1500, 1 << 20
+    ln = rng.integers(0, 60, size=rows)
+    ln[rng.random(rows) < 0.3] = 0
+    ln[100] = 9000                      # one row across two chunk boundaries
+    ro = np.zeros(rows + 1, dtype=np.int64)
+    ro[1:] = np.cumsum(ln)
+    col = np.concatenate([np.sort(rng.choice(cols, size=k, replace=False)) for k in ln]).astype(np.uint32)
+    B = po.HostCSR(rows, cols, ro.astype(np.uint32), col, np.ones(col.size))
+    A = po.HostCSR(3, rows, np.array([0, 1, 2, 3], np.uint32), np.array([5, 100, 900], np.uint32), np.ones(3))
+    dA = sa.dCSR.from_host(to_sa(A))
+    check(cfg, A, B)
+    starts = set(ro.tolist())
+    inside = [p for p in (0, 1, 8190, 8191, 8192, 8193, 16383, 16384, int(ro[100]) + 1, int(ro[101]) - 2, col.size - 2)
+              if p + 1 not in starts and p + 1 < col.size]
+    assert len(inside) >= 8
+    for p in inside:
+        for kind in ("equal", "descending", "beyond"):
+            bad = col.copy()
+            if kind == "equal":
+                bad[p + 1] = bad[p]
+            elif kind == "descending":
+                bad[p], bad[p + 1] = bad[p + 1], bad[p]
+            else:
+                bad[p] = cols
+            Bx = po.HostCSR(rows, cols, B.row_offsets, bad, B.data)
+            with pytest.raises(sa.SpeckError) as e:
+                sa.MultiplyspECK(dA, sa.dCSR.from_host(to_sa(Bx)), sa.dCSR(), cfg)
+            assert e.value.status == 8, (p, kind)
+    # row boundaries ON chunk boundaries: rows of exactly 4096 entries, every one starting at column 0
+    k = 4096
+    ro2 = (np.arange(7, dtype=np.int64) * k).astype(np.uint32)
+    col2 = np.tile(np.arange(k, dtype=np.uint32) * 3, 6)
+    B2 = po.HostCSR(6, 3 * k, ro2, col2, np.ones(col2.size))
+    A2 = po.HostCSR(2, 6, np.array([0, 2, 3], np.uint32), np.array([1, 4, 5], np.uint32), np.ones(3))
+    check(cfg, A2, B2)
+    # a view of rows 1 .. of B (absolute offsets, first entry at an odd position)
+    dB = sa.dCSR.from_host(to_sa(B))
+    first = int(np.flatnonzero(ro % 4 != 0)[0])
+    view = dB.row_view(first, rows)
+    Av = po.HostCSR(2, rows - first, np.array([0, 1, 2], np.uint32), np.array([0, 100 - first], np.uint32), np.ones(2))
+    dC = sa.dCSR()
+    sa.MultiplyspECK(sa.dCSR.from_host(to_sa(Av)), view, dC, cfg)
+    Bv = po.HostCSR(rows - first, cols, (ro[first:] - ro[first]).astype(np.uint32), col[ro[first]:], np.ones(col.size - ro[first]))
+    _assert_matches_oracle(dC, Av, Bv)
+
+
+def _hostile_cases():
+    """(name, A, B, options, classes the valid input must reach): one input per family of kernels that walk B."""
+    def wide_sparse():
+        rng = np.random.default_rng(11)
+        kb, n = 300, 40 << 20
+        pool = np.unique(rng.integers(0, n, size=30000, dtype=np.int64))
+        pick = np.sort(rng.integers(0, pool.size, size=(kb, 220)), axis=1)
+        keep = np.ones(pick.shape, dtype=bool)
+        keep[:, 1:] = pick[:, 1:] != pick[:, :-1]
+        bro = np.zeros(kb + 1, dtype=np.uint32)
+        bro[1:] = np.cumsum(keep.sum(axis=1))
+        bcol = pool[pick[keep]].astype(np.uint32)
+        B = po.HostCSR(kb, n, bro, bcol, 0.5 + rng.random(bcol.size))
+        lens = np.array([140, 300, 300, 200, 125, 300])
+        aro = np.zeros(lens.size + 1, dtype=np.uint32)
+        aro[1:] = np.cumsum(lens)
+        acol = np.concatenate([np.sort(rng.choice(kb, size=k, replace=False)) for k in lens]).astype(np.uint32)
+        return po.HostCSR(lens.size, kb, aro, acol, 0.5 + rng.random(acol.size)), B
+
+    cant = lambda: (lambda M: (M, M))(to_po(sa.gen_matrix("cant", 0.05, 3, signed=True)))
+    return {
+        "register_8": (lambda: (fast_random_csr(3000, 2000, 4, 1), fast_random_csr(2000, 50000, 5, 2)), {},
+                       [("sym", "g8"), ("num", "g8")]),
+        "register_16": (lambda: (fast_random_csr(3000, 2000, 9, 1, jitter=False),
+                                 fast_random_csr(2000, 50000, 5, 2, jitter=False)), {},
+                        [("sym", "g16"), ("num", "g16")]),
+        "register_32_64": (lambda: (fast_random_csr(4000, 900, 24, 11), fast_random_csr(900, 300, 9, 12)), {},
+                           [("sym", "r32"), ("sym", "r64"), ("num", "r64")]),
+        "wave_hash": (lambda: (fast_random_csr(800, 4000, 12, 5), fast_random_csr(4000, 3000000, 14, 6)),
+                      {"esc32": 0, "esc64": 0}, [("sym", "wave256"), ("num", "wave256")]),
+        "block_hash_small": (lambda: (fast_random_csr(600, 4000, 20, 1), fast_random_csr(4000, 30000, 30, 2)), {},
+                             [("sym", "wave1k"), ("num", "block2k")]),
+        "block_hash_8k": (lambda: (fast_random_csr(200, 6000, 64, 3), fast_random_csr(6000, 300000, 64, 4)), {},
+                          [("sym", "block4k"), ("num", "block8k")]),
+        "block16k_spill": (lambda: (fast_random_csr(100, 5000, 100, 71, jitter=False),
+                                    fast_random_csr(5000, 300000, 100, 72, jitter=False)),
+                           {"sym_bitmap_ratio": 0}, [("sym", "block16k"), ("num", "global")]),
+        "block32k_dense_windows": (lambda: (fast_random_csr(48, 5000, 150, 5, jitter=False),
+                                            fast_random_csr(5000, 2000000, 150, 6, jitter=False)),
+                                   {"sym_bitmap_ratio": 0, "num_global_passes": 1 << 30},
+                                   [("sym", "block32k"), ("num", "dense16k")]),
+        "bitmap_windows": (lambda: (fast_random_csr(24, 4000, 300, 7, jitter=False),
+                                    fast_random_csr(4000, 2500000, 110, 8, jitter=False)), {},
+                           [("sym", "bitmap1m"), ("num", "global")]),
+        "global_key_set": (wide_sparse, {}, [("sym", "global_hash"), ("num", "global")]),
+        "numeric_first": (cant, {}, [("sym", "numeric_first"), ("num", "nfcopy")]),
+        "bitmap_dense": (cant, {"nf_min_ops": 0}, [("sym", "bitmap256k"), ("num", "dense4k")]),
+    }
+
+
+def _hostile_b(B, how, rng):
+    """The same row lengths (the analysis classes the same rows), column ids no sorted row could hold."""
+    col = B.col_ids.copy()
+    ro = B.row_offsets.astype(np.int64)
+    ln = np.diff(ro)
+    rows = np.flatnonzero(ln >= 2)
+    if how == "ends_swapped":           # first > last: the range the analysis derives from the ends is negative
+        col[ro[rows]], col[ro[rows + 1] - 1] = B.col_ids[ro[rows + 1] - 1], B.col_ids[ro[rows]]
+    elif how == "reversed":
+        for r in rows[: 4000]:
+            col[ro[r]:ro[r + 1]] = col[ro[r]:ro[r + 1]][::-1]
+    elif how == "duplicates":           # every entry of a row its first column
+        col[:] = np.repeat(B.col_ids[ro[:-1][ln > 0]], ln[ln > 0])
+    elif how == "beyond_cols":          # ids far outside [0, cols) in the middle of rows, the ends intact
+        inner = np.ones(col.size, dtype=bool)
+        inner[ro[:-1][ln > 0]] = False
+        inner[ro[1:][ln > 0] - 1] = False
+        pick = inner & (rng.random(col.size) < 0.2)
+        col[pick] = rng.integers(0xF0000000, 0xFFFFFFFF, size=int(pick.sum()), dtype=np.int64).astype(np.uint32)
+    elif how == "shuffled":             # a random permutation of all ids: rows unsorted, ends arbitrary
+        col = rng.permutation(col)
+    return po.HostCSR(B.rows, B.cols, B.row_offsets, col, B.data)
+
+
+@pytest.mark.parametrize("how", ["ends_swapped", "reversed", "duplicates", "beyond_cols", "shuffled"])
+@pytest.mark.parametrize("case", sorted(_hostile_cases()))
+def test_every_kernel_family_survives_a_b_that_is_not_sorted(case, how):
+    """Every kernel that walks B does so BEFORE the verdict of validate_b is read (the validation runs on its own
+    stream beside analysis .. scan; the eager call reads it with the scan's counts, a speculated call and a reuse
+    sequence likewise): a B whose rows are not strictly ascending -- or hold ids far beyond cols -- must leave every one
+    of them inside its buffers and its loops finite.  Per family of kernels: the complete call sized from the previous
+    one, and a reuse sequence whose B is overwritten under the same pointers; status SPECK_ERR_UNSORTED, C untouched,
+    and the config serves the valid input again."""
+    import ctypes as C_
+    make, opts, classes = _hostile_cases()[case]
+    A, B = make()
+    Bx = _hostile_b(B, how, np.random.default_rng(5))
+    assert not (Bx.col_ids == B.col_ids).all()
+    cfg = sa.spECKConfig.initialize(0)
+    try:
+        for k, v in opts.items():
+            cfg.set_option(k, v)
+        dA, dB, dBx = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B)), sa.dCSR.from_host(to_sa(Bx))
+        dC = sa.dCSR()
+        # ---- complete calls: the second one is sized from the first, the hostile one from the second
+        cfg.set_option("reuse", 0)
+        _, st, _ = check(cfg, A, B, classes, C_reuse=dC)
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["eager_speculated"] == 1
+        before = dC.to_host()
+        with pytest.raises(sa.SpeckError) as e:
+            sa.MultiplyspECK(dA, dBx, dC, cfg)
+        assert e.value.status == 8
+        after = dC.to_host()
+        assert after.nnz == before.nnz and (after.col_ids == before.col_ids).all() and (after.data == before.data).all()
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+        _assert_matches_oracle(dC, A, B)
+        # ---- a reuse sequence, then B overwritten in place
+        cfg.set_option("reuse", 1)
+        for _ in range(4):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["replayed"] == 1
+        bad = np.ascontiguousarray(Bx.col_ids)
+        assert _lib.load().speck_dcsr_update(C_.byref(dB._c), None, bad.ctypes.data, None, 8) == 0
+        with pytest.raises(sa.SpeckError) as e:
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert e.value.status == 8
+        good = np.ascontiguousarray(B.col_ids)
+        assert _lib.load().speck_dcsr_update(C_.byref(dB._c), None, good.ctypes.data, None, 8) == 0
+        for _ in range(3):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        _assert_matches_oracle(dC, A, B)
+    finally:
+        cfg.cleanup()
+
+
+def test_bound_multiply_follows_a_reset_output(cfg):
+    """BoundMultiply holds byref(matOut._c): a reset() of a borrowed (from_device) output clears THAT struct in place
+    instead of replacing it, so the bound call keeps writing the matrix the caller reads."""
+    A = fast_random_csr(500, 400, 5, 1)
+    B = fast_random_csr(400, 600, 6, 2)
+    dA, dB = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B))
+    dC = sa.dCSR()
+    call = sa.BoundMultiply(dA, dB, dC, cfg)
+    call()
+    _assert_matches_oracle(dC, A, B)
+    held = sa.dCSR()
+    sa.MultiplyspECK(dA, dB, held, cfg)
+    view = sa.dCSR.from_device(held.rows, held.cols, held.nnz, held._c.row_offsets, held._c.col_ids, held._c.data)
+    bound = sa.BoundMultiply(dA, dB, view, cfg)
+    addr = ctypes.addressof(view._c)
+    view.reset()
+    assert ctypes.addressof(view._c) == addr and view.nnz == 0 and not view._c.data
+    bound()                                     # (the library allocates: the view's struct is empty)
+    _assert_matches_oracle(view, A, B)
+    _lib.load().speck_dcsr_free(ctypes.byref(view._c))
+
+
 def test_products_beyond_2_32_use_the_u64_path(cfg):
     """P = 4096 * 1100 * 1100 = 4.96e9 > 2^32 (the reference's u32 sumProducts wraps, Multiply.cu:237)."""
     rng = np.random.default_rng(5)
@@ -1330,7 +1530,7 @@ def test_eager_call_sized_from_the_previous_one_needs_one_read_back():
     (-1).  Same results either way; an invalid B is still rejected with C untouched."""
     cfg = sa.spECKConfig.initialize(0)
     try:
-        cfg.set_option("use_graph", 0)
+        cfg.set_option("reuse", 0)
         rows, inner, cols = 3000, 2500, 400000      # (wide: a 600-entry row is a SYM_B16K row, not a bitmap one)
         dC = sa.dCSR()
 
