@@ -3,7 +3,7 @@ import ctypes as C, numpy as np, torch, sys
 import speck_amd as sa
 from speck_amd import _lib
 lib = _lib.load(); fn = lib.speck_debug_analysis_clocks; fn.restype = C.c_int; fn.argtypes = [C.c_void_p]
-cfg = sa.spECKConfig.initialize(0); cfg.set_option("use_graph", 0)
+cfg = sa.spECKConfig.initialize(0); cfg.set_option("reuse", 0)
 for o in sys.argv[2:]:
     n, v = o.split("="); cfg.set_option(n, int(v)); print(n, v)
 A = sa.gen_matrix(sys.argv[1] if len(sys.argv) > 1 else "scircuit", 1.0, 1); dA = sa.dCSR.from_host(A); dC = sa.dCSR(np.float64)

@@ -33,7 +33,7 @@ def best_ms(cfg, dA, dB, n=6):
 
 
 cfg = sa.spECKConfig.initialize(0)
-cfg.set_option("use_graph", 0)
+cfg.set_option("reuse", 0)
 A, B = rand_csr(48, 5000, 150, 5), rand_csr(5000, 2000000, 150, 6)
 dA, dB = sa.dCSR.from_host(A), sa.dCSR.from_host(B)
 cfg.set_option("sym_bitmap_ratio", 0)

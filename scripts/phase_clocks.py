@@ -24,7 +24,7 @@ def main():
         if "=" in a and not a.startswith("--"):
             k, v = a.split("=")
             cfg.set_option(k, int(v))
-    cfg.set_option("use_graph", 0)
+    cfg.set_option("reuse", 0)
     A = sa.gen_matrix(wl, 1.0, 1)
     dA = sa.dCSR.from_host(A)
     dC = sa.dCSR(np.float64)

@@ -8,7 +8,7 @@ run() { tag=$1; shift; timeout 1500 python tests/tools/stress_gpu.py "$@" > gpur
 run single_a 400 4001
 run single_b 300 4002 esc32=0
 run single_c 300 4003 overlap_analysis=0 eager_speculate=0
-run single_d 300 4004 use_graph=0
+run single_d 300 4004 reuse=0
 run turns_a 1500 4101 interleave=4
 run turns_b 1500 4102 interleave=3 esc64=0
 run turns_c 1000 4103 interleave=5 nf_min_ops=1

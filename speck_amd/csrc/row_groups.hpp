@@ -422,6 +422,7 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
                 ownv[1] = before + (t01 & 0xFFFFu) + (inc01 >> 16);
                 ownv[2] = before + (t01 & 0xFFFFu) + (t01 >> 16) + (inc23 & 0xFFFFu);
                 ownv[3] = before + (t01 & 0xFFFFu) + (t01 >> 16) + (t23 & 0xFFFFu) + (inc23 >> 16);
+                PHASE_MARK(14);
                 u32 c[kBatch];
                 T bv[kBatch], a[kBatch], prod[kBatch];
                 u32 nvalid = 0;
@@ -444,8 +445,11 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
                 }
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) prod[u] = a[u] * bv[u];
+                PHASE_WAIT_VMEM();
+                PHASE_MARK(15);
                 f(c, prod, nvalid);
                 wave_lds_fence();
+                PHASE_MARK(12);
             }
         }
         PHASE_MARK(12);
@@ -590,56 +594,13 @@ __device__ __forceinline__ u32 set_insert_batch(u32* tab, const u32 (&key)[kBatc
 // dropped: a trip counter with a break, per lane or per wave on the ballot of pending lanes -- the loop doubled in
 // instructions and the launch took 20-30 % longer.)
 // Returns true if any key of this lane gave up.
-template <typename T, bool BOUNDED = false, bool READ_PROBE = false>
+template <typename T, bool BOUNDED = false>
 __device__ __forceinline__ bool table_accumulate_batch(u32* keys, T* vals, u32 bits, const u32 (&key)[kBatch],
                                                        const T (&prod)[kBatch], u32 nvalid)
 {
     const u32 mask = (1u << bits) - 1u;
     u32 slot[kBatch], old[kBatch];
     bool gave_up = false;
-    if constexpr (READ_PROBE) {
-        // Probing with plain LDS READS, compare-and-swap only to CLAIM an empty slot.  An LDS atomic costs its pipe ~20
-        // cycles per wave-instruction however few lanes are active, and every retry iteration of the loop below is one:
-        // on rows that mostly HIT keys they already hold (nlpkkt stand-in: 5.8 products per entry) the numeric launch ran
-        // at 0.998 of the LDS-atomic ceiling with 5.4 atomics per 64 products -- 1 first probe + 3.4 retries + 1 add.
-        // A slot that holds a key never changes, so a read is as good as a compare-and-swap until an EMPTY slot shows up.
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            slot[u] = (key[u] * 0x9E3779B1u) >> (32u - bits);
-            old[u] = key[u];
-            if ((u32)u < nvalid) old[u] = __hip_atomic_load(&keys[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            if ((u32)u >= nvalid) continue;
-            bool placed = true;
-            if (old[u] != key[u]) {
-                const u32 step = probe_step(key[u], 32u - bits);
-                u32 inc = kFirstProbeInc ? kFirstProbeInc : step;
-                u32 home = 0xFFFFFFFFu;
-                while (true) {
-                    if (old[u] == kEmptyKey) {
-                        old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, key[u]);
-                        if (old[u] == kEmptyKey || old[u] == key[u]) break;  // (else: another key took it first)
-                    }
-                    slot[u] = (slot[u] + inc) & mask;
-                    if constexpr (BOUNDED) {
-                        if (slot[u] == home) {
-                            placed = false;
-                            break;
-                        }
-                        if (home == 0xFFFFFFFFu) home = slot[u];
-                    }
-                    inc = step;
-                    old[u] = __hip_atomic_load(&keys[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (old[u] == key[u]) break;
-                }
-            }
-            if (placed) atomicAdd(&vals[slot[u]], prod[u]);
-            else gave_up = true;
-        }
-        return gave_up;
-    }
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
         slot[u] = (key[u] * 0x9E3779B1u) >> (32u - bits);

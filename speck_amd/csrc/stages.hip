@@ -907,14 +907,20 @@ __global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__
     const u64 per = (nchunks + gridDim.x - 1) / gridDim.x;
     const u64 c0 = u64(blockIdx.x) * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
     if (c0 < c1 && e_last >= e_first) {
-        if (tid == 0) {  // first row that starts behind the first entry of the span
+        if (tid < 64) {  // first row that starts behind the first entry of the span: a 64-ary search by one wave
             const u64 cs0 = base + c0 * kValChunk;
-            u32 lo = 0, hi = b_rows + 1;
+            u32 lo = 0, hi = b_rows + 1;  // rows below lo start at or before cs0, rows from hi on behind it
             while (lo < hi) {
-                const u32 mid = lo + ((hi - lo) >> 1);
-                if (u64(b_ro[mid]) <= cs0) lo = mid + 1; else hi = mid;
+                const u32 step = (hi - lo + 63u) >> 6;
+                const u64 p = u64(lo) + u64(tid) * step;
+                const bool behind = p >= hi || u64(b_ro[p]) > cs0;
+                const u64 mask = __ballot(behind);
+                const u32 f = mask ? (u32)__builtin_ctzll(mask) : 64u;
+                const u32 lo0 = lo;
+                if (f < 64u) hi = min(hi, lo0 + f * step);
+                if (f > 0u) lo = lo0 + (f - 1u) * step + 1u;
             }
-            s_cursor = lo;
+            if (tid == 0) s_cursor = lo;
         }
         __syncthreads();
         u32 rc = s_cursor;
