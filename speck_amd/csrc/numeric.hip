@@ -528,10 +528,11 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
         bits = min(max(bits, (u32)__builtin_ctz(G::SIZE)), (u32)__builtin_ctz(CAP));
         if constexpr (G::SIZE >= 64) bits = (u32)__builtin_amdgcn_readfirstlane((int)bits);
         const u32 cap_row = 1u << bits;
-        for (u32 i = g.lane; i < cap_row; i += G::SIZE) {
-            keys[i] = kEmptyKey;
-            vals[i] = 0;
-        }
+        // (16 bytes per lane and step; cap_row >= the group's lanes, a power of two)
+        static_assert(sizeof(Acc<T>) == 8, "two accumulator cells per 16 bytes");
+        for (u32 q = g.lane; q < cap_row / 4; q += G::SIZE)
+            reinterpret_cast<uint4*>(keys)[q] = make_uint4(kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey);
+        for (u32 q = g.lane; q < cap_row / 2; q += G::SIZE) reinterpret_cast<uint4*>(vals)[q] = make_uint4(0u, 0u, 0u, 0u);
         g.sync();
         PHASE_MARK(0);
         // (KEEP: the row's previous column ids, requested now -- emit_by_previous)

@@ -359,7 +359,14 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
             const u32 wend = (u32)__builtin_amdgcn_readfirstlane((int)end);
             u32* win = m.win + (G::kIsBlock ? (threadIdx.x >> 6) * kWinWords : 0u);
             u32 s0 = 0;
-            if (base < wend) s0 = uniform_owner(m.incl, cnt, base);
+            if constexpr (!G::kIsBlock) {
+                // (a wave per row: lane e holds incl[e] of the chunk -- the owner of `base` is a ballot, not a binary
+                //  search of five dependent LDS reads)
+                const u64 behind = g.ballot(g.lane < cnt && incl > base);
+                s0 = behind ? (u32)__builtin_ctzll(behind) : cnt - 1u;
+            } else if (base < wend) {
+                s0 = uniform_owner(m.incl, cnt, base);
+            }
             PHASE_MARK(11);
             while (base < wend) {
                 u32 own[kBatch];
@@ -367,6 +374,34 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
                 PHASE_MARK(14);
                 u32 c[kBatch];
                 T bv[kBatch], a[kBatch], prod[kBatch];
+                if (base + kWinProducts <= wend) {
+                    // a FULL window (wave-uniform): no predicate on any lane -- the LDS reads of the four owners'
+                    // offsets go out together, the gathers behind them, and `f` is compiled for a constant count
+                    // (these loops are bound by VALU issue: the predicated form below spends an eighth of its
+                    // instructions on the tail it only has in a row's last window)
+                    u32 off[kBatch];
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) off[u] = m.off[own[u]];
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        const u32 ib = off[u] + base + u * 64 + l;
+                        c[u] = src.b_col[ib];
+                        bv[u] = T(0);
+                        a[u] = T(0);
+                        if (WITH_VALUES) {
+                            bv[u] = src.b_val[ib];
+                            a[u] = m.av[own[u]];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) prod[u] = a[u] * bv[u];
+                    PHASE_WAIT_VMEM();
+                    PHASE_MARK(15);
+                    f(c, prod, (u32)kBatch);
+                    PHASE_MARK(12);
+                    base += kWinProducts;
+                    continue;
+                }
                 u32 nvalid = 0;
                 // all kBatch gathers are issued before the first product is formed
 #pragma unroll
@@ -425,6 +460,31 @@ __device__ __forceinline__ void for_each_product(const G& g, const ProductSrc<T>
                 PHASE_MARK(14);
                 u32 c[kBatch];
                 T bv[kBatch], a[kBatch], prod[kBatch];
+                // (a full window for EVERY group of the wave that is still walking: the unpredicated form, as above)
+                if (__ballot(base + kBatch * L <= total) == __ballot(true)) {
+                    u32 off[kBatch];
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) off[u] = m.off[ownv[u]];
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        const u32 ib = off[u] + base + u * L + g.lane;
+                        c[u] = src.b_col[ib];
+                        bv[u] = T(0);
+                        a[u] = T(0);
+                        if (WITH_VALUES) {
+                            bv[u] = src.b_val[ib];
+                            a[u] = m.av[ownv[u]];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) prod[u] = a[u] * bv[u];
+                    PHASE_WAIT_VMEM();
+                    PHASE_MARK(15);
+                    f(c, prod, (u32)kBatch);
+                    wave_lds_fence();
+                    PHASE_MARK(12);
+                    continue;
+                }
                 u32 nvalid = 0;
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {

@@ -52,7 +52,9 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
     if (cur.miss) return;
     while (cur.more()) {
         const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
-        for (u32 i = g.lane; i < CAP; i += G::SIZE) tab[i] = kEmptyKey;
+        static_assert(CAP % (4 * G::SIZE) == 0, "the key set is cleared 16 bytes per lane and step");
+        for (u32 q = g.lane; q < CAP / 4; q += G::SIZE)
+            reinterpret_cast<uint4*>(tab)[q] = make_uint4(kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey);
         g.sync();
         u32 cnt = 0;
         for_each_product<false>(g, src, rec.a0, rec.a1, meta, scratch,
