@@ -110,6 +110,8 @@ struct speck_config {
     std::vector<hipStream_t> aux;  // one stream per kernel class: classes run concurrently
     std::vector<hipEvent_t> aux_done;
     hipEvent_t fork = nullptr;
+    hipEvent_t vgate = nullptr;  // behind the analysis launch: the input check of a LARGE B starts there (begin_validate)
+    u64 validate_after_nnz = 1ull << 25;  // nnz(B) from which on the check waits for the analysis (option)
     bool eager_speculate = true;  // option eager_speculate: a complete call that follows another one on this config sizes
                                   //   its symbolic phase (grids, launched classes, scratch pool, numeric-first window) from
                                   //   THAT call and runs analysis .. scan as one batch -- one read-back instead of two; the
@@ -1010,7 +1012,7 @@ struct VerifierGuard {
 };
 
 // The input check of a complete call, beside it on the verifier's stream (stages.hip: validate_b_kernel).
-int begin_validate(speck_config* c, const speck_dcsr* B)
+int begin_validate(speck_config* c, const speck_dcsr* B, hipStream_t gate = nullptr)
 {
     __atomic_store_n(c->h_verify, 0u, __ATOMIC_RELEASE);
     if (c->use_user_stream) {
@@ -1019,6 +1021,13 @@ int begin_validate(speck_config* c, const speck_dcsr* B)
         HIP_TRY(hipStreamWaitEvent(c->vstream, c->fork, 0));
     }
     c->verifier_in_flight = true;
+    // A large B: the check is a stream of nnz(B) column ids, the analysis it would run beside is bound by the same
+    // bandwidth and heads the call's critical path -- the check starts BEHIND it, beside the symbolic launches (bound by
+    // instruction issue).  (`gate`: the stream the analysis was just enqueued on)
+    if (gate && B->nnz >= c->validate_after_nnz) {
+        HIP_TRY(hipEventRecord(c->vgate, gate));
+        HIP_TRY(hipStreamWaitEvent(c->vstream, c->vgate, 0));
+    }
     launch_validate_b(c->vstream, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, B->nnz, c->h_verify_dev);
     launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
     HIP_TRY(hipGetLastError());
@@ -1193,7 +1202,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     auto start_validate = [&]() -> int {
         if (!c->validate_inputs || validate_started) return SPECK_OK;
         validate_started = true;
-        return begin_validate(c, B);
+        return begin_validate(c, B, s);
     };
     struct HookGuard {
         speck_config* c;
@@ -1509,6 +1518,7 @@ int speck_config_create(int device, speck_config** out)
         c->aux_done.push_back(e);
     }
     HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->vgate, hipEventDisableTiming));
     {
         // the verifier yields to the sequence it runs beside: lowest stream priority (the sequence's light launches
         // lost 5-8 % to it at equal priority)
@@ -1567,6 +1577,7 @@ int speck_config_destroy(speck_config* c)
     for (auto s : c->aux) (void)hipStreamDestroy(s);
     for (auto e : c->aux_done) (void)hipEventDestroy(e);
     if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->vgate) (void)hipEventDestroy(c->vgate);
     if (c->vstream) (void)hipStreamDestroy(c->vstream);
     if (c->h_verify) (void)hipHostFree(c->h_verify);
     if (c->d_vticket) (void)hipFree(c->d_vticket);
@@ -1652,6 +1663,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "collect_bytes") c->cp.want_bytes = value != 0;        // per-class byte model
     else if (n == "concurrent_classes") c->concurrent_classes = value != 0;
     else if (n == "validate_inputs") c->validate_inputs = value != 0;
+    else if (n == "validate_after_nnz") c->validate_after_nnz = (u64)value;
     else if (n == "spin_wait") c->spin_wait = value != 0, forget(false);
     else if (n == "fork_min_us") c->fork_min_us = (float)value, forget(false);
     else if (n == "max_side_streams") c->max_side_streams = (u32)value, forget(false);
