@@ -66,6 +66,11 @@ struct ReplayPlan {
     bool direct, fused;
     bool skip_scan;  // every kernel that produces a row's nnz compares it with the previous call's (RowWork::verify_counts):
                      //   no scan kernel -- the numeric launches read the records, lists and class table that call's scan left
+    bool safe_numeric;  // the numeric launches run in their VERIFYING forms (bounded probing, stores clamped to the row's
+                        //   room, counts compared: numeric.hip) -- a reuse sequence walks B before the verdict of the input
+                        //   check is read, and the plain forms trust what only a validated B guarantees (every id inside
+                        //   the record's column range, the symbolic count = what the table will hold).  Possible when the
+                        //   light launch carries no register-class rows of its own; else the check runs FIRST.
     bool num_verify;  // ... and no symbolic pass for the rows of the hash / dense classes: the numeric light launch verifies
                       //   their nnz itself (RowWork::verify_numeric) -- the symbolic phase is the register-class rows alone
     bool overlap;  // the analysis only VERIFIES what the previous identical call left in the arena, on a stream of its
@@ -853,6 +858,7 @@ ReplayPlan plan_replay(const speck_config* c, bool arena_mine, bool arena_replay
     p.skip_scan = c->skip_scan && arena_replay_ok && p.overlap && early_ok &&
                   (p.launch_mask & kBigLight) != 0 && (eff_sym & ~kSymLightMask) == 0;
     p.num_verify = want_verify && p.skip_scan;
+    p.safe_numeric = (p.launch_mask & kEscNum) == 0;
     return p;
 }
 
@@ -865,7 +871,7 @@ int enqueue_replay(speck_config* c, hipStream_t s, const speck_dcsr* A, const sp
     c->capture_direct = p.direct;
     c->capture_overlap = p.overlap;
     c->capture_skip_scan = p.skip_scan;
-    c->capture_num_verify = p.num_verify;
+    c->capture_num_verify = p.num_verify || p.safe_numeric;
     // C.row_offsets <- the staged offsets of this call's scan, or (no scan) the sequence's own copy of the offsets
     c->stage_off_src = p.skip_scan ? c->gpred.off : sc.offsets;
     c->stage_off_dst = C->row_offsets;
@@ -1116,11 +1122,18 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             ReplayPlan p = c->plan;
             if ((p.overlap && !arena_mine) || (p.skip_scan && !replay_layout)) p.overlap = p.skip_scan = p.num_verify = false;
             c->arena_key_valid = false;  // (until this call has completed)
-            // (a sequence with its own analysis: the input check of B alone, beside it from its first launch on)
-            if (!p.overlap && c->validate_inputs) {
+            // (a sequence with its own analysis: the input check of B alone, beside it from its first launch on; one whose
+            //  numeric launches are the plain forms: the check FIRST -- they must not see a B that fails it)
+            bool b_first_bad = false;
+            if (!p.safe_numeric && !p.num_verify && c->validate_inputs) {
+                rc = begin_validate(c, B);
+                if (rc == SPECK_OK) rc = finish_validate(c, &b_first_bad);
+                if (rc != SPECK_OK) return rc;
+            } else if (!p.overlap && c->validate_inputs) {
                 rc = begin_validate(c, B);
                 if (rc != SPECK_OK) return rc;
             }
+            if (!b_first_bad) {
             rc = enqueue_replay<T>(c, s, A, B, C, sc, p, nullptr, nullptr);
             if (rc != SPECK_OK) return rc;
             // (behind the sequence, while it runs: the host would only spin otherwise)
@@ -1151,6 +1164,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                 c->last.pred_stages = (c->pred_valid ? 3 : 0) | (p.overlap ? 4 : 0) | (p.skip_scan ? 8 : 0) | (p.num_verify ? 16 : 0);
                 return finish_complete();
             }
+            }  // !b_first_bad
             ++c->replay_misses;  // inputs changed under the same pointers: fall through
             drop_plan(c);
         }

@@ -1978,14 +1978,19 @@ def test_a_captured_sequence_owns_its_prediction(cfg):
     replays = st["graph_replays"]
     sa.MultiplyspECK(dB, dB, dD, cfg)                          # eager, other buffers: rewrites the config's prediction
     _assert_matches_oracle(dD, Bg, Bg)
-    junk = np.full(dC.nnz, 0xFFFFFFF0, dtype=np.uint32)
-    assert _lib.load().speck_dcsr_update(ctypes.byref(dC._c), None, junk.ctypes.data,
-                                         np.full(dC.nnz, np.nan).ctypes.data, 8) == 0
-    sa.MultiplyspECK(dA, dA, dC, cfg)                          # the captured sequence of the first problem, again
+    # (every VALUE of C is rewritten by the sequence; the column ids of its hash rows are KEPT when they are still the
+    #  row's columns -- round 5: every reuse sequence runs the verifying numeric kernels)
+    assert _lib.load().speck_dcsr_update(ctypes.byref(dC._c), None, None, np.full(dC.nnz, np.nan).ctypes.data, 8) == 0
+    sa.MultiplyspECK(dA, dA, dC, cfg)                          # the sequence of the first problem, again
     st = cfg.last_stats()
     assert st["graph_replays"] == replays + 1 and st["replayed"]
     _assert_matches_oracle(dC, A, A)
     _assert_matches_oracle(dD, Bg, Bg)                         # ... which wrote nothing into the other problem's C
+    # junk in C.col_ids: whatever the sequence kept of it is found out, the complete call re-runs inside the same call
+    junk = np.full(dC.nnz, 0xFFFFFFF0, dtype=np.uint32)
+    assert _lib.load().speck_dcsr_update(ctypes.byref(dC._c), None, junk.ctypes.data, None, 8) == 0
+    sa.MultiplyspECK(dA, dA, dC, cfg)
+    _assert_matches_oracle(dC, A, A)
 
 
 @pytest.mark.parametrize("kind,scale", [("scircuit", 0.3), ("mac_econ", 0.3), ("cant", 0.1), ("webbase", 0.1),
