@@ -744,7 +744,7 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
             slot = w.nf_off[rec.row];
         const u32 wbase = rec.cmin, ncols = rec.cmax - rec.cmin + 1u, nwords = (ncols + 31) >> 5;
         // a replayed sequence met a wider row than its window was sized for, or a slot past the pool it was
-        // captured with: eager re-run
+        // planned with: the complete call re-runs
         if (ncols > WCOLS || (!direct && slot + nf_slot_entries(rec.cmin, rec.cmax, rec.ops) > w.nf_cap)) {
             if (threadIdx.x == 0) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
             continue;

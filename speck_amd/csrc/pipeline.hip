@@ -38,7 +38,7 @@ using namespace speck;
         }                                                                                   \
     } while (0)
 
-// Everything a captured launch sequence is specialised to.
+// Everything a reuse sequence is specialised to.
 struct CallKey {
     const void* ptr[10] = {};
     u64 num[8] = {};
