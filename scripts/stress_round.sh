@@ -14,3 +14,7 @@ run turns_b 1500 4102 interleave=3 esc64=0
 run turns_c 1000 4103 interleave=5 nf_min_ops=1
 STRESS_REPEAT=4 run repeat_a 500 7101 interleave=3 num_verify=2
 STRESS_REPEAT=4 run repeat_b 400 7103 interleave=3
+STRESS_HOSTILE=1 STRESS_REPEAT=3 run hostile_a 600 8101 interleave=3
+STRESS_HOSTILE=1 run hostile_b 1000 8102 interleave=4 num_verify=2
+STRESS_HOSTILE=1 STRESS_REPEAT=2 run hostile_c 500 8103 interleave=3 esc_fused=0
+STRESS_HOSTILE=1 STRESS_REPEAT=4 run hostile_d 800 8104 interleave=5

@@ -70,6 +70,7 @@ def materialise(p):
 def interleaved(cfg, rng, steps, alive):
     probs = [random_problem(rng) for _ in range(alive)]
     bad = 0
+    hostile = 0
     for it in range(steps):
         j = int(rng.integers(0, alive))
         if rng.random() < 0.08:          # now and then a problem is replaced by a new one (buffers freed, reused)
@@ -117,6 +118,41 @@ def interleaved(cfg, rng, steps, alive):
             assert _lib.load().speck_dcsr_update(ctypes.byref(p["dB"]._c), None, np.ascontiguousarray(col).ctypes.data,
                                                  None, B.data.dtype.itemsize) == 0
             p["R"], p["ab"] = po.spgemm_f64_of(p["A"], p["B"])
+        if os.environ.get("STRESS_HOSTILE") and rng.random() < 0.08 and p["B"].nnz > 4 and p["calls"] > 0:
+            # a B that violates the precondition, under the same pointers, whatever sequence the problem is in: rejected
+            # (SPECK_ERR_UNSORTED), nothing out of bounds on the way, and the valid B is served again afterwards
+            import ctypes
+            from speck_amd import _lib
+            B = p["B"]
+            kind = int(rng.integers(0, 4))
+            col = B.col_ids.copy()
+            ro = B.row_offsets.astype(np.int64)
+            if kind == 0:
+                col = rng.permutation(col)
+            elif kind == 1:
+                pick = rng.random(col.size) < 0.2
+                col[pick] = rng.integers(0xF0000000, 0xFFFFFFFF, size=int(pick.sum()), dtype=np.int64).astype(np.uint32)
+            elif kind == 2:
+                ln = np.diff(ro)
+                col[:] = np.repeat(B.col_ids[ro[:-1][ln > 0]], ln[ln > 0])
+            else:
+                for r in np.flatnonzero(np.diff(ro) >= 2)[:2000]:
+                    col[ro[r]:ro[r + 1]] = col[ro[r]:ro[r + 1]][::-1]
+            if not (col == B.col_ids).all() and (np.diff(ro) >= 2).any():
+                assert _lib.load().speck_dcsr_update(ctypes.byref(p["dB"]._c), None, np.ascontiguousarray(col).ctypes.data,
+                                                     None, B.data.dtype.itemsize) == 0
+                try:
+                    sa.MultiplyspECK(p["dA"], p["dB"], p["dC"], cfg)
+                    hostile_ok = False
+                except sa.SpeckError as e:
+                    hostile_ok = e.status == 8
+                assert _lib.load().speck_dcsr_update(ctypes.byref(p["dB"]._c), None,
+                                                     np.ascontiguousarray(B.col_ids).ctypes.data, None,
+                                                     B.data.dtype.itemsize) == 0
+                hostile += 1
+                if not hostile_ok:
+                    bad += 1
+                    print(f"{it:4d} BAD hostile B kind {kind} was not rejected: problem {j} {p['name']}", flush=True)
         if os.environ.get("STRESS_VERBOSE"):
             print(f"     step {it}: problem {j} call {p['calls'] + 1} {p['name']}", flush=True)
         ok = True
@@ -137,6 +173,8 @@ def interleaved(cfg, rng, steps, alive):
         if os.environ.get("STRESS_VERBOSE"):
             print("       sym", {k: v for k, v in st["sym_bin_rows"].items() if v}, "num",
                   {k: v for k, v in st["num_bin_rows"].items() if v}, "pool", st["scratch_pool_bytes"], flush=True)
+    if hostile:
+        print("hostile B rejected:", hostile)
     print("failures:", bad)
     sys.exit(1 if bad else 0)
 
