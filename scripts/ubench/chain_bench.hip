@@ -14,7 +14,7 @@ template <bool CHAIN>
 __global__ __launch_bounds__(256) void k(Chain ch, u32 nb, u64* out, u32 spin, u64* times)
 {
     __shared__ u32 s_mine[kChainWords];
-    __shared__ u64 s_pref[kChainWords], s_tmp[2 * kChainWords];
+    __shared__ u64 s_pref[kChainWords], s_tmp[2 * kChainWords + 2];
     // some work first, as long for every workgroup (the analysis walks ~17 us)
     const u64 t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < spin) __builtin_amdgcn_s_sleep(4);

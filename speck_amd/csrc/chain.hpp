@@ -15,7 +15,9 @@
 //     and publishes them; a workgroup then needs the aggregates of its own super-block before it (<= 63) and the sums
 //     of the super-blocks before (<= 64): one or two dependent round trips, whatever the grid;
 //   * a workgroup only ever waits for workgroups with a LOWER index (in-order dispatch makes that deadlock-free; a
-//     wait that does not end in ~1 s raises Chain::error, and the host returns SPECK_ERR_HIP);
+//     wait that does not end in ~1 s raises Chain::error -- agent-scope, BEFORE the workgroup publishes anything made
+//     from the truncated prefix -- the workgroup places nothing, the last workgroup reports it together with
+//     capacity_miss (so that the kernels queued behind walk nothing), the host returns SPECK_ERR_HIP and clears the flag);
 //   * the tag comes from the host with every launch (1 .. 65535 in turn; the host clears the buffers, one memset on the
 //     stream, before a tag comes round again: no stale word can carry the tag of a later launch).
 #pragma once
@@ -62,26 +64,30 @@ struct Chain {
     u32 tag;     // 1 .. 65535, from the HOST: one per launch; the host clears the buffers before a tag comes round again
 };
 constexpr size_t kChainAggWords = size_t(kChainMaxBlocks) * kDescWords, kChainSupWords = size_t(kChainSuper) * kDescWords;
-constexpr size_t kChainBytes = (kChainAggWords + kChainSupWords) * 8 + 256;
+constexpr size_t kChainBytes = (kChainAggWords + kChainSupWords) * 8 + 256;  // one buffer; the config holds two (launches alternate)
 constexpr u32 kChainTags = 65535;
 
 #ifdef __HIPCC__
-// word d of the descriptor made from a workgroup's aggregate (`m`: kChainWords values; u64 so that sums can pass through;
-// the 64-bit quantities complete in Lo + (Hi << 32))
-__device__ __forceinline__ u64 chain_pack(const u64* m, u32 d, u32 tag)
+// word d of the descriptor made from a workgroup's aggregate: `m(k)` = value k of its kChainWords values (as u64, so that
+// sums can pass through; the 64-bit quantities complete in Lo + (Hi << 32)).  The values are READ WHERE THEY LIVE (LDS) by
+// the lane that packs word d -- a lane-indexed local array of them went through scratch memory (round 5: a 208-byte private
+// segment in both integer kernels, on the critical hop of the chain).
+template <class M>
+__device__ __forceinline__ u64 chain_pack(M&& m, u32 d, u32 tag)
 {
-    const u64 pfx = m[kCwPfxLo] + (m[kCwPfxHi] << 32), tot = m[kCwTotLo] + (m[kCwTotHi] << 32);
     u64 v = 0;
-    if (d < 7) v = (m[kCwClass + 2 * d] & 0xFFFFFFu) | ((m[kCwClass + 2 * d + 1] & 0xFFFFFFu) << 24);
-    else if (d == 7) v = pfx & kPayMask;
-    else if (d == 8) v = (pfx >> 48) | ((m[kCwFlags] & 0xFFFFFFu) << 24);
-    else if (d == 9) v = tot & kPayMask;
-    else if (d == 10) v = tot >> 48;
-    else if (d == 11) v = m[kCwMax];
-    else if (d == 12) v = m[kCwAuxMax];
+    if (d < 7) v = (m(kCwClass + 2 * d) & 0xFFFFFFu) | ((m(kCwClass + 2 * d + 1) & 0xFFFFFFu) << 24);
+    else if (d <= 10) {
+        const bool is_pfx = d <= 8;
+        const u64 q = is_pfx ? m(kCwPfxLo) + (m(kCwPfxHi) << 32) : m(kCwTotLo) + (m(kCwTotHi) << 32);
+        if (d == 7 || d == 9) v = q & kPayMask;
+        else v = (q >> 48) | (d == 8 ? (m(kCwFlags) & 0xFFFFFFu) << 24 : 0ull);
+    } else if (d == 11) v = m(kCwMax);
+    else if (d == 12) v = m(kCwAuxMax);
     return (u64(tag) << 48) | (v & kPayMask);
 }
-__device__ __forceinline__ void chain_publish(u64* desc, const u64* m, u32 tag)  // lanes 0 .. 15 of a wave
+template <class M>
+__device__ __forceinline__ void chain_publish(u64* desc, M&& m, u32 tag)  // lanes 0 .. 15 of a wave
 {
     const u32 t = lane_id();
     if (t < kDescWords) __hip_atomic_store(desc + t, chain_pack(m, t, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -157,8 +163,10 @@ __device__ __forceinline__ void chain_combine(const u64* set, u32 n, u32 tag, u6
         } else if (lane == 5) {
             out[kCwTotHi] = u64(s0) << 16;
             out[kCwMax] = m1;
-        } else if (lane == 6)
+        } else if (lane == 6) {
             out[kCwAuxMax] = m0;
+            out[19] = out[22] = out[23] = 0;  // (unused words of the callers' layout: summed / maxed like the others)
+        }
     }
 }
 
@@ -166,12 +174,19 @@ __device__ __forceinline__ void chain_combine(const u64* set, u32 n, u32 tag, u6
 // workgroup still has to do that needs no prefix hides the trip.
 __device__ __forceinline__ void chain_publish_own(const Chain& ch, u32 b, const u32* s_mine)
 {
-    if (threadIdx.x < 64) {
-        u64 m[kChainWords];
-#pragma unroll
-        for (u32 k = 0; k < kChainWords; ++k) m[k] = s_mine[k];
-        chain_publish(ch.agg + size_t(b) * kDescWords, m, ch.tag);
-    }
+    if (threadIdx.x < 64) chain_publish(ch.agg + size_t(b) * kDescWords, [&](u32 k) { return u64(s_mine[k]); }, ch.tag);
+}
+
+// a wait of the chain did not end: the flag goes out with a RETURNING agent-scope atomic -- it is performed at the
+// coherence point when the value comes back, i.e. before anything this workgroup publishes afterwards
+__device__ __forceinline__ void chain_raise_error(const Chain& ch)
+{
+    const u32 was = __hip_atomic_fetch_or(ch.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(was));
+}
+__device__ __forceinline__ u32 chain_error(const Chain& ch)
+{
+    return __hip_atomic_load(ch.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Exclusive combination over the workgroups before `b` (chain_publish_own called), for a workgroup of >= 128 threads
@@ -179,39 +194,55 @@ __device__ __forceinline__ void chain_publish_own(const Chain& ch, u32 b, const 
 //   s_mine [kChainWords] (LDS, u32): this workgroup's aggregate -- written by the caller, a barrier behind it
 //   s_pref [kChainWords] (LDS, u64): on return the sum / max over the workgroups [0, b); a 64-bit quantity is
 //                                    chain_u64(s_pref, Lo, Hi) = Lo + (Hi << 32)
-//   s_tmp  [2 * kChainWords] (LDS, u64): scratch
-__device__ __forceinline__ void chain_exclusive(const Chain& ch, u32 b, u32 nb, const u32* s_mine, u64* s_pref, u64* s_tmp)
+//   s_tmp  [2 * kChainWords + 2] (LDS, u64): scratch
+// Returns false (to every thread) if a wait timed out: s_pref is then a truncated prefix and the caller must place NOTHING
+// by it.  Chain::error is raised before this workgroup publishes a super-block sum made from such a prefix, so whoever
+// builds on that sum -- in particular the LAST workgroup, which reports to the host -- finds the flag set.
+__device__ __forceinline__ bool chain_exclusive(const Chain& ch, u32 b, u32 nb, const u32* s_mine, u64* s_pref, u64* s_tmp)
 {
     const u32 t = threadIdx.x, wid = t >> 6;
     const u32 tag = ch.tag;
     const u32 sb = b / kChainSuper, first = sb * kChainSuper;
     bool timed_out = false;
+    if (t == 0) s_tmp[2 * kChainWords] = s_tmp[2 * kChainWords + 1] = 0;  // timeout flags of wave 0 / wave 1
+    __syncthreads();
     // the last workgroup of a FULL super-block publishes the super-block's sum (nobody needs the last, partial one)
     const bool closes = (b % kChainSuper) == kChainSuper - 1u && b + 1u < nb;
     // the aggregates of my super-block before me (wave 0) + the sums of the super-blocks before (wave 1)
     if (wid == 0) {
         chain_combine(ch.agg + size_t(first) * kDescWords, b - first, tag, s_tmp, &timed_out);
+        if (__ballot(timed_out) != 0) {
+            if (lane_id() == 0) {
+                chain_raise_error(ch);
+                s_tmp[2 * kChainWords] = 1;
+            }
+        }
         if (closes) {
             // ... published by the SAME wave, at once: the sum of a super-block must not wait for the sums of the
             // super-blocks before it (a workgroup barrier here would chain the closers one behind the other)
             wave_lds_fence();
-            u64 m[kChainWords];
-#pragma unroll
-            for (u32 k = 0; k < kChainWords; ++k) {
-                const u64 own = s_mine[k];
-                m[k] = k < kChainSumWords ? s_tmp[k] + own : (s_tmp[k] > own ? s_tmp[k] : own);
-            }
             // (every 64-bit quantity is Lo + (Hi << 32), in s_tmp as in s_mine: chain_pack puts them together)
-            chain_publish(ch.sup + size_t(sb) * kDescWords, m, tag);
+            chain_publish(ch.sup + size_t(sb) * kDescWords,
+                          [&](u32 k) {
+                              const u64 own = s_mine[k], pre = s_tmp[k];
+                              return k < kChainSumWords ? pre + own : (pre > own ? pre : own);
+                          },
+                          tag);
         }
-    } else if (wid == 1)
+    } else if (wid == 1) {
         chain_combine(ch.sup, sb, tag, s_tmp + kChainWords, &timed_out);
-    if (__ballot(timed_out) != 0 && lane_id() == 0) *ch.error = 1u;
+        if (__ballot(timed_out) != 0 && lane_id() == 0) {
+            chain_raise_error(ch);
+            s_tmp[2 * kChainWords + 1] = 1;  // (its own word: wave 0 may be writing the other one)
+        }
+    }
     __syncthreads();
     if (t < kChainWords)
         s_pref[t] = t < kChainSumWords ? s_tmp[t] + s_tmp[kChainWords + t]
                                        : (s_tmp[t] > s_tmp[kChainWords + t] ? s_tmp[t] : s_tmp[kChainWords + t]);
+    const bool ok = s_tmp[2 * kChainWords] == 0 && s_tmp[2 * kChainWords + 1] == 0;
     __syncthreads();
+    return ok;
 }
 __device__ __forceinline__ u64 chain_u64(const u64* s, u32 lo, u32 hi) { return s[lo] + (s[hi] << 32); }
 #endif

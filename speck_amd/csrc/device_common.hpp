@@ -282,7 +282,7 @@ struct DeviceStats {
     u64 g_products;          // products of the NUM_G rows (the host sizes the spill pool from it)
     u64 nf_entries;          // scratch entries of the SYM_NF rows (sum of min(column range, products)) and of the
                              //   SYM_GH rows (slots of their key sets)
-    u32 b_invalid;           // a row of B is not strictly ascending / holds a column >= cols (eager path)
+    u32 walk_rows;           // rows finished by the one-walk kernel of the call (walk.hip; 0: a two-phase call)
     u32 nf_max_range;        // widest column range among the SYM_NF rows (sizes the LDS window of their kernel)
     u32 a_invalid;           // a column id of A is >= rows(B) (the analysis clamps it, so nothing reads out of bounds)
     u32 chain_error;         // a workgroup of the analysis / scan waited in vain for the workgroups before it (chain.hpp)

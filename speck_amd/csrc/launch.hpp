@@ -19,7 +19,9 @@ u32 scan_tiles(u32 m);
 // (First form of round 5: row ids in the lists, records in row order -- 4 bytes per list entry instead of 32, but every
 //  row of every class kernel paid a dependent load: numeric light launch 52 -> 57 us on the scircuit stand-in, the
 //  669 k single-entry rows of the webbase stand-in +5 % on the whole multiply.)
-constexpr u32 kListRegions = (kMaxClasses + 1) / 2;
+// Arena cost: kListRegions x rows(A) x 32 B per phase (two phases) = 448 B per row of A with the 14 classes of either
+// phase (seven regions; round 5 sized them for kMaxClasses = 16: an eighth region nobody addressed).
+constexpr u32 kListRegions = ((SYM_CLASSES > NUM_CLASSES ? SYM_CLASSES : NUM_CLASSES) + 1) / 2;
 __host__ __device__ inline size_t class_list_records(u32 m) { return size_t(kListRegions) * (m ? m : 1u); }
 __host__ __device__ __forceinline__ RowRec* class_rec_at(RowRec* lists, u32 m, u32 cls, u32 i)
 {
@@ -39,7 +41,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
                      RowRec* sym_recs, DeviceStats* st, const ClassifyParams& cp, uint2* b_sl, const Chain& chain,
                      u64* nf_off = nullptr, u64 expect_nf = ~0ull, u32 b_rows = ~0u,
                      u32* a_ro_copy = nullptr /* A's row offsets as this call saw them (a later VERIFY compares) */,
-                     u32* verdict = nullptr, u64* bytes_acc = nullptr /* [2][kMaxClasses], with cp.want_bytes */);
+                     u32* verdict = nullptr, u64* bytes_acc = nullptr /* [2][kMaxClasses], with cp.want_bytes */,
+                     u64 b_nnz = ~0ull /* entries of B: every B-row bound is clamped to them */);
 
 // completion ticket of a launch sequence (pinned host word the host spins on)
 // (the kernel also copies the statistics block into its pinned mirror, before the ticket)

@@ -314,20 +314,30 @@ Scratch carve(speck_config* c, u32 m, u64 nnz_a)
     return s;
 }
 
-// The chain of the next analysis / scan launch on `s`: a tag of its own (chain.hpp); the buffers are cleared -- on the
-// stream, in front of the launch -- before a tag comes round again.
+// The chain of the next analysis / scan / walk launch on `s`: a tag of its own (chain.hpp).  Two buffers, used in turn: two
+// chained launches that follow each other never share descriptors, whatever overlaps them.  A buffer
+// is cleared -- on the stream, in front of the launch -- before a tag comes round again.
 int next_chain(speck_config* c, hipStream_t s, Chain* out)
 {
     Chain ch;
-    ch.agg = static_cast<u64*>(c->chain_buf);
+    const u64 turn = c->chain_launches >> 1;
+    ch.agg = reinterpret_cast<u64*>(static_cast<unsigned char*>(c->chain_buf) + (c->chain_launches & 1u) * kChainBytes);
     ch.sup = ch.agg + kChainAggWords;
     ch.error = reinterpret_cast<u32*>(ch.sup + kChainSupWords);
-    if (c->chain_launches % kChainTags == 0 && c->chain_launches != 0)
-        HIP_TRY(hipMemsetAsync(c->chain_buf, 0, (kChainAggWords + kChainSupWords) * 8, s));
-    ch.tag = (u32)(c->chain_launches % kChainTags) + 1u;
+    if (turn % kChainTags == 0 && turn != 0) HIP_TRY(hipMemsetAsync(ch.agg, 0, (kChainAggWords + kChainSupWords) * 8, s));
+    ch.tag = (u32)(turn % kChainTags) + 1u;
     ++c->chain_launches;
     *out = ch;
     return SPECK_OK;
+}
+// a wait of a chain timed out (DeviceStats::chain_error): the call returns SPECK_ERR_HIP; the flags are cleared so that
+// the NEXT call on the config starts clean
+int chain_failed(speck_config* c, hipStream_t s)
+{
+    for (int k = 0; k < 2; ++k)
+        (void)hipMemsetAsync(static_cast<unsigned char*>(c->chain_buf) + k * kChainBytes + (kChainAggWords + kChainSupWords) * 8, 0, 4, s);
+    (void)hipStreamSynchronize(s);
+    return SPECK_ERR_HIP;
 }
 
 // (re)allocate a Prediction for `m` rows; false if the device has no room (the reuse sequence then places nothing)
@@ -608,7 +618,8 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
             if (crc != SPECK_OK) return crc;
             launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, sc.row_ops,
                             sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, c_ro, sc.sym_recs,
-                            c->d_stats, cp, sc.b_sl, chain, sc.nf_off, expect_nf, (u32)B->rows, sc.a_ro_copy, nullptr, bytes);
+                            c->d_stats, cp, sc.b_sl, chain, sc.nf_off, expect_nf, (u32)B->rows, sc.a_ro_copy, nullptr, bytes,
+                            B->nnz);
             c->snap_for_arena = false;  // (a writing analysis: the copy of the inputs is not its)
         }
         // (complete call: the input check of B goes onto its stream HERE -- behind the launch of the analysis, the head of
@@ -738,7 +749,7 @@ int read_stats(speck_config* c, hipStream_t s)
         HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DeviceStats), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
-    return c->h_stats->chain_error ? SPECK_ERR_HIP : SPECK_OK;
+    return c->h_stats->chain_error ? chain_failed(c, s) : SPECK_OK;
 }
 
 // ... when the scan of the batch mirrors the block and stores the ticket itself (enqueue_front with a host mirror):
@@ -748,7 +759,7 @@ int await_scan_stats(speck_config* c, hipStream_t s)
     if (!c->spin_wait) return read_stats(c, s);
     const int rc = wait_ticket(c, s);
     if (rc != SPECK_OK) return rc;
-    return c->h_stats->chain_error ? SPECK_ERR_HIP : SPECK_OK;
+    return c->h_stats->chain_error ? chain_failed(c, s) : SPECK_OK;
 }
 
 void publish_counts(speck_config* c, hipStream_t s)
@@ -973,7 +984,7 @@ int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, c
     cp.esc_fused = 0;
     launch_analysis(c->vstream, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, (u32)A->rows, A->nnz, sc.row_ops,
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, sc.counts, sc.sym_recs, c->d_stats, cp,
-                    sc.b_sl, Chain{}, sc.nf_off, ~0ull, (u32)B->rows, sc.a_ro_copy, c->h_verify_dev);
+                    sc.b_sl, Chain{}, sc.nf_off, ~0ull, (u32)B->rows, sc.a_ro_copy, c->h_verify_dev, nullptr, B->nnz);
     // ... and behind it the copy of the inputs it has just verified the arena against (they do not change while the call
     // is in flight): the verifiers of the next replays compare with that.
     if (c->verify_inputs && c->snap) {
@@ -1148,7 +1159,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             if (p.overlap) rc = wait_verifier(c, &changed);
             else rc = finish_validate(c, &changed);
             if (rc != SPECK_OK) return rc;
-            if (c->h_stats->chain_error) return SPECK_ERR_HIP;
+            if (c->h_stats->chain_error) return chain_failed(c, s);
             if (!changed && !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz) {
                 c->arena_key = key;
                 c->arena_key_valid = true;
@@ -1548,8 +1559,8 @@ int speck_config_create(int device, speck_config** out)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(DeviceStats)));
     HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
     // the look-back chain of the analysis / scan kernels: tags and epoch start from zero, once (chain.hpp)
-    HIP_TRY(hipMalloc(&c->chain_buf, kChainBytes));
-    HIP_TRY(hipMemset(c->chain_buf, 0, kChainBytes));
+    HIP_TRY(hipMalloc(&c->chain_buf, 2 * kChainBytes));
+    HIP_TRY(hipMemset(c->chain_buf, 0, 2 * kChainBytes));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_bytes), 2 * kMaxClasses * sizeof(u64)));
     HIP_TRY(hipMemset(c->d_bytes, 0, 2 * kMaxClasses * sizeof(u64)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stats), sizeof(DeviceStats), hipHostMallocMapped));
@@ -1759,7 +1770,7 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     if (rc != SPECK_OK) return rc;
     launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, d_row_ops, d_row_max_ops,
                     d_row_col_min, d_row_col_max, nullptr, nullptr, sc.sym_recs, c->d_stats, cp, nullptr, chain,
-                    nullptr, ~0ull, (u32)B->rows);
+                    nullptr, ~0ull, (u32)B->rows, nullptr, nullptr, nullptr, B->nnz);
     HIP_TRY(hipGetLastError());
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return rc;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     u32* row_max_ops, u32* row_col_min, u32* row_col_max,
     u8* sym_cls, u32* __restrict__ counts, ClassifyParams cp, uint2* b_sl, DeviceStats* __restrict__ st, u32 b_rows,
     RowRec* __restrict__ sym_recs, u64* __restrict__ nf_off, u64 expect_nf, Chain chain,
-    u32* a_ro_copy, u32* __restrict__ verdict, u64* __restrict__ bytes_acc)
+    u32* a_ro_copy, u32* __restrict__ verdict, u64* __restrict__ bytes_acc, u64 b_nnz)
 {
     constexpr int kAnThreads = NW * 64;
     constexpr int U = 4;   // entries per lane and tile: 256 entries cover most 32-row sub-chunks in ONE
@@ -94,6 +94,11 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
                            //   lasts as long as its slowest wave, so the waves are kept short and many
     static_assert(NW * R == kChunk, "one pass of a block covers one kChunk of rows");
     const u32 e_base = a_ro[0];  // A may be a row-range view with absolute offsets
+    // Every (start, end) pair read from B.row_offsets is clamped to the entries B holds: the input check that says whether
+    // those offsets ascend runs BESIDE this kernel, and every later kernel takes its B rows from the pairs written here --
+    // so no kernel of the call indexes B.col_ids / B.data out of bounds whatever B.row_offsets holds.
+    const u32 b_lo = b_ro[0];
+    const u32 b_hi = (u32)std::min<u64>(u64(b_lo) + b_nnz, 0xFFFFFFFFull);
     __shared__ u32 s_ro_all[NW][R + 1];
     __shared__ u64 s_ops_all[NW][R];
     __shared__ u32 s_mx_all[NW][R], s_cmin_all[NW][R], s_cmax_all[NW][R];
@@ -140,8 +145,8 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
                 // B.rowptr[k], B.rowptr[k+1] as ONE 8-byte gather (4-byte aligned): the random
                 // gathers of this kernel are bound by addresses per cycle, not by bytes
                 const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
-                bs[u] = ok[u] ? pr.x : 0u;
-                be[u] = ok[u] ? pr.y : 0u;
+                bs[u] = ok[u] ? min(max(pr.x, b_lo), b_hi) : 0u;
+                be[u] = ok[u] ? min(max(pr.y, bs[u]), b_hi) : 0u;
                 // hand the B-row bounds to the symbolic / numeric kernels
                 if constexpr (VERIFY) {
                     if (ok[u]) {
@@ -321,8 +326,8 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
                         k = 0;
                     }
                     const RowPtrPair pr = *reinterpret_cast<const RowPtrPair*>(b_ro + k);
-                    bs[u] = ok[u] ? pr.x : 0u;
-                    be[u] = ok[u] ? pr.y : 0u;
+                    bs[u] = ok[u] ? min(max(pr.x, b_lo), b_hi) : 0u;
+                    be[u] = ok[u] ? min(max(pr.y, bs[u]), b_hi) : 0u;
                     if constexpr (VERIFY) {
                         if (ok[u]) {
                             const uint2 was = b_sl[e - e_base];
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     __syncthreads();
     // ---- my aggregate -> the chain -> what the workgroups before me found (chain.hpp)
     __shared__ u32 s_mine[kChainWords];
-    __shared__ u64 s_pref[kChainWords], s_tmp[2 * kChainWords];
+    __shared__ u64 s_pref[kChainWords], s_tmp[2 * kChainWords + 2];
     if (t < kChainWords) {
         u32 v = 0;
         if (t < SYM_CLASSES)
@@ -443,12 +448,13 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
         p_max = row_col_max[row];
         p_ops = row_ops[row];
     }
-    chain_exclusive(chain, blockIdx.x, nb, s_mine, s_pref, s_tmp);
+    // (false: a wait of the chain timed out -- this workgroup places nothing; the last one reports, chain.hpp)
+    const bool chain_ok = chain_exclusive(chain, blockIdx.x, nb, s_mine, s_pref, s_tmp);
     AN_MARK(7);
 
     // ---- binning: my rows' records (row order) and their row ids in the class lists, behind the rows of the
     // workgroups before me; scratch slots of the numeric-first rows / key sets of the SYM_GH rows in row order
-    if (sym_cls) {
+    if (sym_cls && chain_ok) {
         __shared__ u32 s_wcnt[SYM_CLASSES][kChunk / 64];
         __shared__ u32 s_run[SYM_CLASSES];
         __shared__ u32 s_nfscan[kChunk / 64 + 2];
@@ -549,7 +555,10 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
         }
         // the scratch pool of a launch sequence sized from an earlier call holds `expect_nf` entries
         if (expect_nf != ~0ull && nf > expect_nf) st->capacity_miss = 1;
-        if (*chain.error) st->chain_error = 1;
+        if (!chain_ok || chain_error(chain)) {  // some workgroup placed nothing: the kernels queued behind walk nothing either
+            st->chain_error = 1;
+            st->capacity_miss = 1;
+        }
     }
 }
 
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
     constexpr int NW = kScanThreads / 64;
     constexpr u32 kSubRows = kScanThreads * ITEMS;
     __shared__ u32 s_mine[kChainWords];
-    __shared__ u64 s_pref[kChainWords], s_tmp[2 * kChainWords];
+    __shared__ u64 s_pref[kChainWords], s_tmp[2 * kChainWords + 2];
     __shared__ u32 s_scan[NW + 1];
     __shared__ u64 s_wave[NW][4];
     __shared__ u64 s_sum[NW], s_gops[NW];
@@ -709,7 +718,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
     __syncthreads();
     const u32 nb = gridDim.x;
     chain_publish_own(chain, blockIdx.x, s_mine);
-    chain_exclusive(chain, blockIdx.x, nb, s_mine, s_pref, s_tmp);
+    const bool chain_ok = chain_exclusive(chain, blockIdx.x, nb, s_mine, s_pref, s_tmp);
     const u64 nnz_before = chain_u64(s_pref, kCwPfxLo, kCwPfxHi);
     const bool last = blockIdx.x == nb - 1;
     // ---- the LAST tile has the totals: statistics, the checks of a sequence sized from an earlier call, and -- eager
@@ -733,7 +742,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
             // ... and so was the spill pool of the NUM_G rows
             st->g_products = g_total;
             if (expect_g != ~0ull && g_total != expect_g) st->capacity_miss = 1;
-            if (*chain.error) st->chain_error = 1;
+            if (!chain_ok || chain_error(chain)) {
+                st->chain_error = 1;
+                st->capacity_miss = 1;
+            }
         }
         __syncthreads();
         if (host_mirror && wid == 0) {
@@ -755,7 +767,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
             if (pred_off && pred_off[m] != (u32)nnz_c) st->capacity_miss = 1;
         }
     }
-    // ---- pass 2: offsets, records, class lists
+    // ---- pass 2: offsets, records, class lists (nothing from a truncated prefix: chain.hpp)
+    if (!chain_ok) return;
     if (t < kMaxClasses) s_run[t] = (u32)s_pref[kCwClass + t];
     if (t == 0) s_off_run = nnz_before;
     __syncthreads();
@@ -889,7 +902,7 @@ __global__ __launch_bounds__(64) void done_kernel(u32* __restrict__ dev_ticket, 
 // this kernel is through; nothing of C is written before that (riding in the analysis launch it cost that launch 13 us).
 constexpr u32 kValChunk = 8192;  // entries of B per workgroup and step: eight 16-byte loads per lane, all in flight
 __global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__ b_ro, const u32* __restrict__ b_col, u32 b_rows,
-                                                          u32 b_cols, u32* __restrict__ verdict)
+                                                          u32 b_cols, u64 b_nnz, u32* __restrict__ verdict)
 {
     // O(nnz + rows), streaming: a workgroup owns a contiguous span of entries and walks the row offsets alongside it.  Per
     // chunk of 8192 entries: the row STARTS inside the chunk as a bitmap in LDS (a pair of neighbours that does not ascend
@@ -898,8 +911,12 @@ __global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__
     __shared__ u32 s_bits[kValChunk / 32];
     __shared__ u32 s_cursor;
     const u32 tid = threadIdx.x;
-    const u32 e_first = b_ro[0], e_last = b_ro[b_rows];
-    bool bad = e_last < e_first;
+    // (the offsets span exactly the nnz entries the container holds: an array whose last offset lies beyond them would
+    //  send this very kernel out of bounds -- ADVICE round 5)
+    const u32 e_first = b_ro[0];
+    u32 e_last = b_ro[b_rows];
+    bool bad = e_last < e_first || u64(e_last) - e_first != b_nnz;
+    if (u64(e_last) > u64(e_first) + b_nnz) e_last = (u32)(u64(e_first) + b_nnz);
     // the offsets themselves: ascending (so every one of them lies in [e_first, e_last])
     for (u64 r = u64(blockIdx.x) * 256 + tid; r < b_rows; r += u64(gridDim.x) * 256) bad |= b_ro[r + 1] < b_ro[r];
     const u64 base = e_first & ~3u;  // (groups of four aligned in the array, so that the 16-byte loads are)
@@ -978,7 +995,7 @@ void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_r
     if (b_rows == 0) return;
     const u64 want = std::max<u64>(cdiv(b_nnz + 4, kValChunk), cdiv(u64(b_rows), 256 * 16));
     hipLaunchKernelGGL(validate_b_kernel, dim3((u32)std::min<u64>(std::max<u64>(want, 1), 2048)), dim3(256), 0, s, b_ro, b_col,
-                       b_rows, b_cols, verdict);
+                       b_rows, b_cols, b_nnz, verdict);
 }
 
 // ... and the ticket of the verifier's stream (launch_verifier): the kernel boundary in front of it orders the verifier's
@@ -1115,7 +1132,7 @@ u32 scan_tiles(u32 m) { return cdiv(m ? m : 1, u64(kScanThreads) * scan_items(m)
 void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32* b_ro, const u32* b_col, u32 m, u64 nnz_a,
                      u32* row_ops, u32* row_max_ops, u32* row_col_min, u32* row_col_max, u8* sym_cls, u32* counts,
                      RowRec* sym_recs, DeviceStats* st, const ClassifyParams& cp, uint2* b_sl, const Chain& chain,
-                     u64* nf_off, u64 expect_nf, u32 b_rows, u32* a_ro_copy, u32* verdict, u64* bytes_acc)
+                     u64* nf_off, u64 expect_nf, u32 b_rows, u32* a_ro_copy, u32* verdict, u64* bytes_acc, u64 b_nnz)
 {
     u32 rows_per_block, blocks;
     row_chunking(m, &rows_per_block, &blocks);
@@ -1124,7 +1141,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
     auto go = [&](auto kernel, int threads) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, s, a_ro, a_col, b_ro, b_col, m, rows_per_block, row_ops,
                            row_max_ops, row_col_min, row_col_max, sym_cls, counts, cp, b_sl, st, b_rows, sym_recs, nf_off,
-                           expect_nf, chain, a_ro_copy, verdict, bytes_acc);
+                           expect_nf, chain, a_ro_copy, verdict, bytes_acc, b_nnz);
     };
     if (verdict) {  // replayed sequence with the analysis beside it: compare, write nothing (analysis_kernel, VERIFY)
         if (wide) go(analysis_kernel<4, 64, true>, 256);
