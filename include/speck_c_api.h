@@ -94,6 +94,11 @@ typedef struct speck_stats {
                                                   * eager call on the config (one read-back instead of two; option
                                                   * eager_speculate): 1 = its device-side checks held, -1 = they did not and
                                                   * the two-read-back sequence re-ran, 0 = not attempted */
+    int32_t one_walk;                            /* 1: the last multiply was a ONE-WALK complete call (walk.hip): the
+                                                  * rows of the register classes were finished inside the kernel that places the
+                                                  * rows -- no symbolic pass for them, no scan kernel; scan_ms is that kernel */
+    int32_t walk_misses;                         /* one-walk calls the device-side checks declared void (cumulative; the
+                                                  * two-phase call re-ran) */
 } speck_stats;
 
 typedef struct speck_config speck_config; /* opaque; reference: spECKConfig, include/spECKConfig.h:8-53 */
@@ -129,7 +134,10 @@ int speck_last_stats(const speck_config *cfg, speck_stats *out);
  * straight into C->col_ids / C->data (options nf_direct / esc_fused, both on by default) before the device-side
  * checks of that sequence can reject it; if the eager re-run that follows then fails as well (inputs changed in
  * place into something invalid, out of memory for a grown C), the call returns the error with the contents of
- * col_ids / data unspecified.  row_offsets is rewritten only by a call that completes. */
+ * col_ids / data unspecified.  The same holds for a ONE-WALK complete call (option one_walk, on by default: a complete
+ * call on a matOut that is already allocated finishes short rows straight into C->col_ids / C->data before the input
+ * check of B and its own device-side checks have spoken; a miss re-runs the two-phase call, an invalid input returns its
+ * error with the contents unspecified).  row_offsets is rewritten only by a call that completes. */
 int speck_multiply_f64(speck_config *cfg, const speck_dcsr *A, const speck_dcsr *B, speck_dcsr *C,
                        speck_timings *timings);
 /* the <float,...> instantiation, source/GPU/Multiply.cu:1130 */

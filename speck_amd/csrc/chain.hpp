@@ -62,6 +62,7 @@ struct Chain {
     u64* sup;    // [kChainSuper][kDescWords]
     u32* error;  // != 0: a wait timed out (never cleared by the device)
     u32 tag;     // 1 .. 65535, from the HOST: one per launch; the host clears the buffers before a tag comes round again
+    u32 fault;   // test hook (option chain_fault): this workgroup never publishes -- the timeout path; ~0: none
 };
 constexpr size_t kChainAggWords = size_t(kChainMaxBlocks) * kDescWords, kChainSupWords = size_t(kChainSuper) * kDescWords;
 constexpr size_t kChainBytes = (kChainAggWords + kChainSupWords) * 8 + 256;  // one buffer; the config holds two (launches alternate)
@@ -174,6 +175,7 @@ __device__ __forceinline__ void chain_combine(const u64* set, u32 n, u32 tag, u6
 // workgroup still has to do that needs no prefix hides the trip.
 __device__ __forceinline__ void chain_publish_own(const Chain& ch, u32 b, const u32* s_mine)
 {
+    if (b == ch.fault) return;
     if (threadIdx.x < 64) chain_publish(ch.agg + size_t(b) * kDescWords, [&](u32 k) { return u64(s_mine[k]); }, ch.tag);
 }
 

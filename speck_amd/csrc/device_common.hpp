@@ -156,6 +156,7 @@ struct ClassifyParams {
     u32 gh_per_window;      // SYM_GH instead of a multi-window SYM_BM2 when the row holds fewer products than this
                             //   per bitmap window; 0 = off
     u32 want_bytes;         // accumulate the per-class algorithmic byte counts (profiling)
+    u32 one_walk;           // one-walk call (walk.hip): the rows of the register classes take a slot of the scratch pool
     u32 sym_allowed;        // classes whose kernels are part of this launch sequence; a row
     u32 num_allowed;        //   outside them raises DeviceStats::capacity_miss (graph replay)
 };

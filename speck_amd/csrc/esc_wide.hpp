@@ -175,158 +175,168 @@ constexpr u32 sym_escw_group_lds()
 }
 
 // ------------------------------------------------------------------ NUM_R32 / NUM_R64 (and their FUSED form, esc_rows.hpp)
+// One row by its lane group (see num_esc_row): `cmin` = the first column the row can reach (the sort key holds the
+// column relative to it).  Returns the row's nnz; the row is stored if nnz <= room.
+template <typename T, u32 L>
+__device__ __forceinline__ u32 num_escw_row(const SubWave<L>& g, unsigned char* mine, const ProductSrc<T>& src, u32 a0, u32 a1,
+                                            u32 cmin, u32* __restrict__ out_col, T* __restrict__ out_val, u32 room)
+{
+    static_assert(L == 32 || L == 64, "32 or 64 lanes per row");
+    constexpr u32 PER = kEscPerLane, NP = PER * L, TAG = L == 32 ? 7u : 8u;
+    static_assert((1u << TAG) == NP, "the product number fills the tag");
+    static_assert(TAG + (L == 32 ? kNumEsc32RangeBits : kNumEsc64RangeBits) == 32, "key = column offset << TAG | product");
+    Acc<T>* s_vals = reinterpret_cast<Acc<T>*>(mine);     // [4 L] products by number
+    Acc<T>* s_av = s_vals + NP;                           // [L]   a_ik of the j-th non-empty entry
+    u32* s_off = reinterpret_cast<u32*>(s_av + L);        // [L]   its B-row start minus its first product number
+    const EscEnds<L> ends{reinterpret_cast<uint2*>(s_off + L)};
+    const u32 gl = g.lane;
+    // ---- expand: my entry of A, where its products end
+    const bool have = a0 + gl < a1;
+    uint2 sl = make_uint2(0u, 0u);
+    Acc<T> av = 0;
+    if (have) {
+        sl = src.b_sl[a0 + gl];
+        av = (Acc<T>)src.a_val[a0 + gl];
+    }
+    u32 total;
+    const u32 incl = g.inclusive_scan(sl.y, &total, nullptr);
+    const bool nonempty = sl.y != 0;
+    const u32 before = (u32)__popcll(g.ballot(nonempty) & ((1ull << gl) - 1ull));  // non-empty entries before mine
+    if (nonempty) {
+        s_off[before] = sl.x - (incl - sl.y);
+        s_av[before] = av;
+    }
+    ends.build(g, nonempty, incl);  // (fences inside: the staging above is visible as well)
+    u32 key[PER];
+#pragma unroll
+    for (u32 u = 0; u < PER; ++u) {
+        const u32 p = u * L + gl;
+        key[u] = kEscInvalid;
+        if (p < total) {
+            const u32 j = ends.owner(p);
+            const u32 ib = s_off[j] + p;
+            const u32 c = src.b_col[ib];
+            const T bv = src.b_val[ib];
+            const T prod = (T)s_av[j] * bv;  // rounded product, added later (no FMA across the add)
+            s_vals[p] = (Acc<T>)prod;
+            key[u] = ((c - cmin) << TAG) | p;
+        }
+    }
+    wave_lds_fence();
+    // ---- sort by (column, product number)
+    esc_sort_wide<L>(key, gl);
+    // ---- compress: sums of the runs of equal columns, in sorted order (validity by position: esc_rows.hpp)
+    u32 col[PER];
+    Acc<T> sum[PER];
+#pragma unroll
+    for (u32 r = 0; r < PER; ++r) {
+        const bool valid = gl * PER + r < total;
+        col[r] = valid ? key[r] >> TAG : kEscInvalid;
+        sum[r] = valid ? s_vals[key[r] & (NP - 1u)] : Acc<T>(0);
+    }
+    bool lead[PER];  // element r continues the run of element 0 of this lane
+    lead[0] = true;
+#pragma unroll
+    for (u32 r = 1; r < PER; ++r) {
+        const bool same = col[r] == col[r - 1] && col[r] != kEscInvalid;
+        lead[r] = lead[r - 1] && same;
+        sum[r] += same ? sum[r - 1] : Acc<T>(0);
+    }
+    // across the lanes: what the lanes before me contribute to the run my element 0 continues
+    const u32 prev_col = dpp_move<kDppWaveShr1>(kEscInvalid, col[PER - 1]);
+    const bool cont = gl != 0 && col[0] != kEscInvalid && prev_col == col[0];
+    Acc<T> chain = sum[PER - 1];             // running sum of the run that ends this lane
+    bool stop = !(lead[PER - 1] && cont);    // ... which does not reach back into the lane before
+    // segmented scan of (chain, stop) inside every 16-lane row (Kogge-Stone; a lane whose source would lie in the
+    // row before keeps what it has: it already covers its row from the start) ...
+    const u32 rl = gl & 15u;
+#define SPECK_SEG_ROW(D_)                                                        \
+    {                                                                            \
+        const Acc<T> t = dpp_move_f64<kDppRowShr + D_>(0.0, chain);              \
+        const bool ts = dpp_move<kDppRowShr + D_>(1u, (u32)stop) != 0;           \
+        const bool take = !stop && rl >= D_;                                     \
+        chain += take ? t : Acc<T>(0);                                           \
+        stop = take ? ts : stop;                                                 \
+    }
+    SPECK_SEG_ROW(1)
+    SPECK_SEG_ROW(2)
+    SPECK_SEG_ROW(4)
+    SPECK_SEG_ROW(8)
+#undef SPECK_SEG_ROW
+    // ... then across the rows of the group: lane 15 of the row before (rows 1 and 3), lane 31 (rows 2 and 3)
+    {
+        const Acc<T> t = __longlong_as_double(
+            (u64(dpp_move<kDppRowBcast15, 0xA>(0u, (u32)(__double_as_longlong(chain) >> 32))) << 32) |
+            dpp_move<kDppRowBcast15, 0xA>(0u, (u32)__double_as_longlong(chain)));
+        const bool ts = dpp_move<kDppRowBcast15, 0xA>(1u, (u32)stop) != 0;
+        const bool take = !stop && (gl & 16u) != 0;
+        chain += take ? t : Acc<T>(0);
+        stop = take ? ts : stop;
+    }
+    if constexpr (L == 64) {
+        const Acc<T> t = __longlong_as_double(
+            (u64(dpp_move<kDppRowBcast31, 0xC>(0u, (u32)(__double_as_longlong(chain) >> 32))) << 32) |
+            dpp_move<kDppRowBcast31, 0xC>(0u, (u32)__double_as_longlong(chain)));
+        const bool ts = dpp_move<kDppRowBcast31, 0xC>(1u, (u32)stop) != 0;
+        const bool take = !stop && (gl & 32u) != 0;
+        chain += take ? t : Acc<T>(0);
+        stop = take ? ts : stop;
+    }
+    const Acc<T> from_prev = wave_move_f64<kDppWaveShr1>(0.0, chain);
+    const Acc<T> carry = cont ? from_prev : Acc<T>(0);
+#pragma unroll
+    for (u32 r = 0; r < PER; ++r) sum[r] += lead[r] ? carry : Acc<T>(0);
+    // the last element of a run carries the entry; its rank = runs that end before it
+    const u32 next_col = dpp_move<kDppWaveShl1>(kEscInvalid, col[0]);
+    bool tail[PER];
+    u32 ntail = 0;
+#pragma unroll
+    for (u32 r = 0; r < PER; ++r) {
+        const u32 after = r + 1 < PER ? col[r + 1] : (gl == L - 1 ? kEscInvalid : next_col);
+        tail[r] = col[r] != kEscInvalid && after != col[r];
+        ntail += tail[r] ? 1u : 0u;
+    }
+    u32 all;
+    u32 pos = g.inclusive_scan(ntail, &all, nullptr) - ntail;
+    const bool write = all <= room;
+#pragma unroll
+    for (u32 r = 0; r < PER; ++r)
+        if (tail[r] && write) {
+            out_col[pos] = col[r] + cmin;
+            out_val[pos] = (T)sum[r];
+            ++pos;
+        }
+    wave_lds_fence();  // the next row overwrites the staging and the products
+    return all;
+}
+
 template <typename T, u32 L, int THREADS, bool FUSED = false>
 __device__ __forceinline__ void num_escw_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
                                               u32* __restrict__ c_col, T* __restrict__ c_val, int cls, u32 bidx,
                                               u32 nblk, u32 hint = kNoCount, u32* __restrict__ counts = nullptr)
 {
-    static_assert(L == 32 || L == 64, "32 or 64 lanes per row");
     using G = SubWave<L>;
-    constexpr u32 NG = THREADS / L, PER = kEscPerLane, NP = PER * L, TAG = L == 32 ? 7u : 8u;
-    static_assert((1u << TAG) == NP, "the product number fills the tag");
-    static_assert(TAG + (L == 32 ? kNumEsc32RangeBits : kNumEsc64RangeBits) == 32, "key = column offset << TAG | product");
+    constexpr u32 NG = THREADS / L;
     const G g;
     const u32 gid = threadIdx.x / L;
     unsigned char* mine = smem + gid * num_escw_group_lds<T, L>();
-    Acc<T>* s_vals = reinterpret_cast<Acc<T>*>(mine);     // [4 L] products by number
-    Acc<T>* s_av = s_vals + NP;                           // [L]   a_ik of the j-th non-empty entry
-    u32* s_off = reinterpret_cast<u32*>(s_av + L);        // [L]   its B-row start minus its first product number
-    const EscEnds<L> ends{reinterpret_cast<uint2*>(s_off + L)};
     RowCursor cur = open_list<FUSED>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
     // (a replayed sequence that an earlier kernel has declared void walks nothing)
     if (cur.miss) return;
-    const u32 gl = g.lane;
     while (cur.more()) {
         const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
-        u32 place = rec.base, place_len = 0;
+        u32 place = rec.base, room = 0xFFFFFFFFu;
         if constexpr (FUSED) {
             place = w.nf_pred_off[rec.row];
-            place_len = w.nf_pred_off[rec.row + 1] - place;
+            room = w.nf_pred_off[rec.row + 1] - place;
         }
-        // ---- expand: my entry of A, where its products end
-        const bool have = rec.a0 + gl < rec.a1;
-        uint2 sl = make_uint2(0u, 0u);
-        Acc<T> av = 0;
-        if (have) {
-            sl = src.b_sl[rec.a0 + gl];
-            av = (Acc<T>)src.a_val[rec.a0 + gl];
-        }
-        u32 total;
-        const u32 incl = g.inclusive_scan(sl.y, &total, nullptr);
-        const bool nonempty = sl.y != 0;
-        const u32 before = (u32)__popcll(g.ballot(nonempty) & ((1ull << gl) - 1ull));  // non-empty entries before mine
-        if (nonempty) {
-            s_off[before] = sl.x - (incl - sl.y);
-            s_av[before] = av;
-        }
-        ends.build(g, nonempty, incl);  // (fences inside: the staging above is visible as well)
-        u32 key[PER];
-#pragma unroll
-        for (u32 u = 0; u < PER; ++u) {
-            const u32 p = u * L + gl;
-            key[u] = kEscInvalid;
-            if (p < total) {
-                const u32 j = ends.owner(p);
-                const u32 ib = s_off[j] + p;
-                const u32 c = src.b_col[ib];
-                const T bv = src.b_val[ib];
-                const T prod = (T)s_av[j] * bv;  // rounded product, added later (no FMA across the add)
-                s_vals[p] = (Acc<T>)prod;
-                key[u] = ((c - rec.cmin) << TAG) | p;
-            }
-        }
-        wave_lds_fence();
-        // ---- sort by (column, product number)
-        esc_sort_wide<L>(key, gl);
-        // ---- compress: sums of the runs of equal columns, in sorted order (validity by position: esc_rows.hpp)
-        u32 col[PER];
-        Acc<T> sum[PER];
-#pragma unroll
-        for (u32 r = 0; r < PER; ++r) {
-            const bool valid = gl * PER + r < total;
-            col[r] = valid ? key[r] >> TAG : kEscInvalid;
-            sum[r] = valid ? s_vals[key[r] & (NP - 1u)] : Acc<T>(0);
-        }
-        bool lead[PER];  // element r continues the run of element 0 of this lane
-        lead[0] = true;
-#pragma unroll
-        for (u32 r = 1; r < PER; ++r) {
-            const bool same = col[r] == col[r - 1] && col[r] != kEscInvalid;
-            lead[r] = lead[r - 1] && same;
-            sum[r] += same ? sum[r - 1] : Acc<T>(0);
-        }
-        // across the lanes: what the lanes before me contribute to the run my element 0 continues
-        const u32 prev_col = dpp_move<kDppWaveShr1>(kEscInvalid, col[PER - 1]);
-        const bool cont = gl != 0 && col[0] != kEscInvalid && prev_col == col[0];
-        Acc<T> chain = sum[PER - 1];             // running sum of the run that ends this lane
-        bool stop = !(lead[PER - 1] && cont);    // ... which does not reach back into the lane before
-        // segmented scan of (chain, stop) inside every 16-lane row (Kogge-Stone; a lane whose source would lie in the
-        // row before keeps what it has: it already covers its row from the start) ...
-        const u32 rl = gl & 15u;
-#define SPECK_SEG_ROW(D_)                                                        \
-        {                                                                        \
-            const Acc<T> t = dpp_move_f64<kDppRowShr + D_>(0.0, chain);          \
-            const bool ts = dpp_move<kDppRowShr + D_>(1u, (u32)stop) != 0;       \
-            const bool take = !stop && rl >= D_;                                 \
-            chain += take ? t : Acc<T>(0);                                       \
-            stop = take ? ts : stop;                                             \
-        }
-        SPECK_SEG_ROW(1)
-        SPECK_SEG_ROW(2)
-        SPECK_SEG_ROW(4)
-        SPECK_SEG_ROW(8)
-#undef SPECK_SEG_ROW
-        // ... then across the rows of the group: lane 15 of the row before (rows 1 and 3), lane 31 (rows 2 and 3)
-        {
-            const Acc<T> t = __longlong_as_double(
-                (u64(dpp_move<kDppRowBcast15, 0xA>(0u, (u32)(__double_as_longlong(chain) >> 32))) << 32) |
-                dpp_move<kDppRowBcast15, 0xA>(0u, (u32)__double_as_longlong(chain)));
-            const bool ts = dpp_move<kDppRowBcast15, 0xA>(1u, (u32)stop) != 0;
-            const bool take = !stop && (gl & 16u) != 0;
-            chain += take ? t : Acc<T>(0);
-            stop = take ? ts : stop;
-        }
-        if constexpr (L == 64) {
-            const Acc<T> t = __longlong_as_double(
-                (u64(dpp_move<kDppRowBcast31, 0xC>(0u, (u32)(__double_as_longlong(chain) >> 32))) << 32) |
-                dpp_move<kDppRowBcast31, 0xC>(0u, (u32)__double_as_longlong(chain)));
-            const bool ts = dpp_move<kDppRowBcast31, 0xC>(1u, (u32)stop) != 0;
-            const bool take = !stop && (gl & 32u) != 0;
-            chain += take ? t : Acc<T>(0);
-            stop = take ? ts : stop;
-        }
-        const Acc<T> from_prev = wave_move_f64<kDppWaveShr1>(0.0, chain);
-        const Acc<T> carry = cont ? from_prev : Acc<T>(0);
-#pragma unroll
-        for (u32 r = 0; r < PER; ++r) sum[r] += lead[r] ? carry : Acc<T>(0);
-        // the last element of a run carries the entry; its rank = runs that end before it
-        const u32 next_col = dpp_move<kDppWaveShl1>(kEscInvalid, col[0]);
-        bool tail[PER];
-        u32 ntail = 0;
-#pragma unroll
-        for (u32 r = 0; r < PER; ++r) {
-            const u32 after = r + 1 < PER ? col[r + 1] : (gl == L - 1 ? kEscInvalid : next_col);
-            tail[r] = col[r] != kEscInvalid && after != col[r];
-            ntail += tail[r] ? 1u : 0u;
-        }
-        u32 all;
-        u32 pos = place + g.inclusive_scan(ntail, &all, nullptr) - ntail;
-        bool write = true;
+        const u32 all = num_escw_row<T, L>(g, mine, src, rec.a0, rec.a1, rec.cmin, c_col + place, c_val + place, room);
         if constexpr (FUSED) {
-            write = all == place_len;
-            if (gl == 0) {
+            if (g.lane == 0) {
                 counts[rec.row] = all;
-                if (!write) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
+                if (all != room) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
             }
         }
-#pragma unroll
-        for (u32 r = 0; r < PER; ++r)
-            if (tail[r] && write) {
-                c_col[pos] = col[r] + rec.cmin;
-                c_val[pos] = (T)sum[r];
-                ++pos;
-            }
-        wave_lds_fence();  // the next row overwrites the staging and the products
     }
 }
 

@@ -21,7 +21,7 @@ u32 scan_tiles(u32 m);
 //  669 k single-entry rows of the webbase stand-in +5 % on the whole multiply.)
 // Arena cost: kListRegions x rows(A) x 32 B per phase (two phases) = 448 B per row of A with the 14 classes of either
 // phase (seven regions; round 5 sized them for kMaxClasses = 16: an eighth region nobody addressed).
-constexpr u32 kListRegions = ((SYM_CLASSES > NUM_CLASSES ? SYM_CLASSES : NUM_CLASSES) + 1) / 2;
+constexpr u32 kListRegions = (((u32)SYM_CLASSES > (u32)NUM_CLASSES ? (u32)SYM_CLASSES : (u32)NUM_CLASSES) + 1u) / 2u;
 __host__ __device__ inline size_t class_list_records(u32 m) { return size_t(kListRegions) * (m ? m : 1u); }
 __host__ __device__ __forceinline__ RowRec* class_rec_at(RowRec* lists, u32 m, u32 cls, u32 i)
 {
@@ -68,6 +68,33 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
                  const ClassifyParams& cp, u32 vsize, u64 exact_nnz, const Chain& chain, DeviceStats* host_mirror = nullptr,
                  u64 expect_g = ~0ull, u32 expect_g_rows = ~0u, const u32* pred_off = nullptr, u32* pred_off_out = nullptr,
                  u32* dev_ticket = nullptr, u32* host_ticket = nullptr, u64* bytes_acc = nullptr);
+
+// ---- the one-walk kernel (walk.hip): scan + numeric binning + the numeric walk of the register-class rows, one launch
+struct WalkArgs {
+    const u32* a_ro;                                   // A.row_offsets (may be a row-range view: absolute offsets)
+    const u32 *row_ops, *row_col_min, *row_col_max;    // per row, from the analysis
+    const u8* cls_sym;                                 // symbolic class of every row (analysis)
+    const u32* counts;                                 // nnz of the rows OTHER kernels counted before this launch
+    const u64* nf_off;                                 // slot of every staged row in the scratch pool (analysis, one_walk)
+    u32 *offsets_out, *pred_off_out;                   // row offsets of C (staged in scratch) / the config's own copy
+    RowRec* recs;                                      // numeric class lists (as the scan kernel leaves them)
+    DeviceStats* st;
+    u32* c_col;                                        // the caller's C buffers and the entries they hold
+    void* c_val;
+    u64 c_cap;
+    u32* pool_col;                                     // scratch pool: column ids | values, pool_cap entries each
+    void* pool_val;
+    u64 pool_cap;
+    u32 m, tile_rows, vsize;
+    ClassifyParams cp;
+    u64 expect_g;
+    u32 expect_g_rows;
+    u64* bytes_acc;
+    u32 debug;                                         // development switches (set_walk_debug)
+};
+void set_walk_debug(u32 tile_rows, u32 flags);
+u32 walk_tile_rows(u32 m);
+u32 walk_max_rows();  // rows(A) up to which the one-walk call exists (the chain holds kChainMaxBlocks tiles)
 
 // Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
 // and two product pools (expanded by column bucket; reduced and sorted).
@@ -195,6 +222,12 @@ void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& A, const C
 template <typename T>
 void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& A, const CsrView<T>& B,
                     const RowWork& w, u32* c_col, T* c_val, int cu_count);
+
+template <typename T>
+struct ProductSrc;  // row_groups.hpp
+template <typename T>
+void launch_walk(hipStream_t s, const WalkArgs& args, const ProductSrc<T>& src, const Chain& chain, hipEvent_t e0 = nullptr,
+                 hipEvent_t e1 = nullptr);
 
 u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block);
 // resident-set multiples a class grid may reach before its workgroups start striding over rows

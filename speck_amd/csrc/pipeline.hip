@@ -25,6 +25,7 @@
 #include "../../include/speck_c_api.h"
 #include "device_common.hpp"
 #include "launch.hpp"
+#include "row_groups.hpp"
 
 using namespace speck;
 
@@ -107,6 +108,7 @@ struct speck_config {
     bool spin_wait = true;
     void* chain_buf = nullptr;           // look-back chain of the analysis / scan kernels (chain.hpp)
     u64 chain_launches = 0;              // ... launches that used it: the tag of the next one (next_chain)
+    u32 chain_fault = ~0u;               // test hook (option chain_fault): that workgroup of the NEXT chained launch stays silent
     u64* d_bytes = nullptr;              // [2][kMaxClasses] algorithmic bytes per class (option collect_bytes only)
     ClassifyParams cp{};
     int profile_kernels = 0;  // 1: HIP events around every launch; 2: around the phases only (no event between
@@ -197,6 +199,16 @@ struct speck_config {
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the reuse sequence were sized for
     speck_stats last{};
+    // the ONE-WALK complete call (walk.hip; option one_walk): analysis -> symbolic launches of the rows no register class
+    // takes -> walk kernel (scan + the register-class rows finished in place) -> the other numeric launches.  Needs C
+    // allocated (the caller's matOut of the previous call) and the class counts of the previous complete call for grids.
+    int one_walk = 0;                // option: 0 never (default: measured and lost on every stand-in but cant),
+                                     //   1 when the previous call says the walk kernel takes a good share of the rows, 2 whenever possible
+    bool capture_one_walk = false;   // set while such a call is being enqueued
+    u64 ow_c_cap = 0;                // ... entries the caller's C buffers hold
+    bool last_was_walk = false;      // the last complete call was one (its nf_entries count the register-class slots too)
+    u64 last_nf_entries = 0;         // scratch-pool entries the last complete call's analysis counted
+    int walks = 0, walk_misses = 0;
 };
 
 namespace {
@@ -326,6 +338,8 @@ int next_chain(speck_config* c, hipStream_t s, Chain* out)
     ch.error = reinterpret_cast<u32*>(ch.sup + kChainSupWords);
     if (turn % kChainTags == 0 && turn != 0) HIP_TRY(hipMemsetAsync(ch.agg, 0, (kChainAggWords + kChainSupWords) * 8, s));
     ch.tag = (u32)(turn % kChainTags) + 1u;
+    ch.fault = c->chain_fault;  // (one launch only)
+    c->chain_fault = ~0u;
     ++c->chain_launches;
     *out = ch;
     return SPECK_OK;
@@ -603,6 +617,11 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
     cp.num_allowed = num_mask;
     cp.esc16 = (c->cp.esc16 && B->cols <= (1ull << 26)) ? 1u : 0u;  // (column << 6 | product number) fits 32 bits
     cp.esc_fused = c->capture_fused ? 1u : 0u;
+    cp.one_walk = c->capture_one_walk ? 1u : 0u;
+    if (c->capture_one_walk) {  // (the walk kernel takes the register-class rows and moves the numeric-first ones itself)
+        cp.sym_allowed |= kSymEscMask;
+        cp.num_allowed |= kNumEscMask | (1u << NUM_NFCOPY);
+    }
     u64* const bytes = c->cp.want_bytes ? c->d_bytes : nullptr;
     const bool timed = c->profile_kernels && tm;
     if (parts & 1u) {
@@ -664,6 +683,50 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
                                                  B->col_ids, w, c_ro, c->sm);
                          });
     if (rc != SPECK_OK) return rc;
+    if (c->capture_one_walk) {
+        // the walk kernel: scan + numeric binning + the numeric walk of the register-class rows (walk.hip); its events
+        // carry the kernel's own begin and end
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) {
+            tm->ev_scan = tm->ev;
+            e0 = kernel_event(c, tm->ev++);
+            e1 = kernel_event(c, tm->ev++);
+        }
+        Chain chain;
+        const int crc = next_chain(c, s, &chain);
+        if (crc != SPECK_OK) return crc;
+        WalkArgs wa{};
+        wa.a_ro = A->row_offsets;
+        wa.row_ops = sc.row_ops, wa.row_col_min = sc.row_col_min, wa.row_col_max = sc.row_col_max;
+        wa.cls_sym = sc.cls_sym;
+        wa.counts = c_ro;
+        wa.nf_off = sc.nf_off;
+        wa.offsets_out = sc.offsets;
+        wa.pred_off_out = pred_off_out;
+        wa.recs = sc.num_recs;
+        wa.st = c->d_stats;
+        wa.c_col = c->capture_c_col;
+        wa.c_val = c->capture_c_val;
+        wa.c_cap = c->ow_c_cap;
+        wa.pool_col = w.nf_col;
+        wa.pool_val = w.nf_val;
+        wa.pool_cap = w.nf_cap;
+        wa.m = m;
+        wa.vsize = vsize;
+        wa.cp = cp;
+        wa.expect_g = expect_g;
+        wa.expect_g_rows = expect_g_rows;
+        wa.bytes_acc = bytes;
+        if (vsize == 8) {
+            const ProductSrc<double> src{sc.b_sl, static_cast<const double*>(A->data), B->col_ids, static_cast<const double*>(B->data), sc.w_sl};
+            launch_walk<double>(s, wa, src, chain, e0, e1);
+        } else {
+            const ProductSrc<float> src{sc.b_sl, static_cast<const float*>(A->data), B->col_ids, static_cast<const float*>(B->data), sc.w_sl};
+            launch_walk<float>(s, wa, src, chain, e0, e1);
+        }
+        HIP_TRY(hipGetLastError());
+        return SPECK_OK;
+    }
     if (timed) {
         tm->ev_scan = tm->ev;
         (void)hipEventRecord(kernel_event(c, tm->ev++), s);
@@ -984,7 +1047,7 @@ int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, c
     cp.esc_fused = 0;
     launch_analysis(c->vstream, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, (u32)A->rows, A->nnz, sc.row_ops,
                     sc.row_max_ops, sc.row_col_min, sc.row_col_max, sc.cls_sym, sc.counts, sc.sym_recs, c->d_stats, cp,
-                    sc.b_sl, Chain{}, sc.nf_off, ~0ull, (u32)B->rows, sc.a_ro_copy, c->h_verify_dev, nullptr, B->nnz);
+                    sc.b_sl, Chain{nullptr, nullptr, nullptr, 0u, ~0u}, sc.nf_off, ~0ull, (u32)B->rows, sc.a_ro_copy, c->h_verify_dev, nullptr, B->nnz);
     // ... and behind it the copy of the inputs it has just verified the arena against (they do not change while the call
     // is in flight): the verifiers of the next replays compare with that.
     if (c->verify_inputs && c->snap) {
@@ -1235,6 +1298,81 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     } hook_guard{c};
     c->after_analysis = start_validate;
     auto b_is_invalid = [&](bool* bad) { return finish_validate(c, bad); };
+    // ---- ONE-WALK call (walk.hip): when matOut is allocated and a complete call of the same shapes has run on the config,
+    // the rows of the register classes are finished in ONE walk inside the kernel that places the rows -- no symbolic
+    // pass for them, no scan kernel, no read-back before the numeric launches.  Everything the sequence assumes (classes
+    // with rows, pool and buffer sizes, nnz(C) = what the caller's buffers hold) is checked on the device; on a miss the
+    // two-phase call below re-runs (and re-allocates C as the reference does when nnz changes, Multiply.cu:589-592).
+    u32 num_mask = 0;
+    size_t ev_num_end = 0;
+    bool walked = false;
+    if (c->one_walk && c_ready && C->nnz <= 0xFFFFFFFFull && c->spec_valid && c->spec_rows_a == A->rows &&
+        c->spec_rows_b == B->rows && m <= walk_max_rows() && !c->use_user_stream) {
+        const u32* sc_last = c->last_sym_counts;
+        const u64 esc_rows = u64(sc_last[SYM_G8]) + sc_last[SYM_G16] + sc_last[SYM_R32] + sc_last[SYM_R64];
+        const u64 esc_bound = 32ull * sc_last[SYM_G8] + 64ull * sc_last[SYM_G16] + 128ull * sc_last[SYM_R32] + 256ull * sc_last[SYM_R64];
+        // it pays when the rows the walk kernel finishes (or moves) are a good share of all rows
+        const bool pays = c->one_walk >= 2 || 8 * (esc_rows + sc_last[SYM_NF]) >= m;
+        const u64 want = c->last_was_walk ? c->last_nf_entries + c->last_nf_entries / 32 + 4096 : c->last_nf_entries + esc_bound + 4096;
+        if (pays && want < (1ull << 40) && ensure_nfpool(c, want, sizeof(T)) == SPECK_OK) {
+            u32 sym_mask = kSymLightMask, hints[kMaxClasses];
+            for (int k = 0; k < kMaxClasses; ++k) {
+                hints[k] = c->last_sym_counts[k];
+                if (hints[k]) sym_mask |= 1u << k;
+                if ((kSymLightMask >> k & 1u) && !hints[k]) hints[k] = 256;
+            }
+            sym_mask &= ~kSymEscMask;
+            const u32 launch_mask = c->last_num_mask & ~(kNumEscMask | (1u << NUM_NFCOPY));
+            struct WalkFlags {
+                speck_config* c;
+                ~WalkFlags()
+                {
+                    c->capture_one_walk = false;
+                    c->capture_c_col = nullptr, c->capture_c_val = nullptr;
+                    c->stage_off_src = nullptr, c->stage_off_dst = nullptr, c->stage_off_n = 0;
+                }
+            } walk_flags{c};
+            c->capture_one_walk = true;
+            c->capture_c_col = C->col_ids;
+            c->capture_c_val = C->data;
+            c->ow_c_cap = C->nnz;
+            c->stage_off_src = sc.offsets;
+            c->stage_off_dst = C->row_offsets;
+            c->stage_off_n = m + 1;
+            rc = enqueue_front(c, s, A, B, sc, (u32)sizeof(T), ~0ull, sym_mask, launch_mask, true, &tm, hints, nullptr,
+                               c->last_g_products, c->last_num_counts[NUM_G], 3u, c->nf_cap_entries,
+                               keep_pred ? c->pred.off : nullptr, false);
+            if (rc != SPECK_OK) return rc;
+            if (c->profile_kernels) {
+                tm.ev_num = tm.ev;
+                (void)hipEventRecord(kernel_event(c, tm.ev++), s);
+            }
+            rc = enqueue_back<T>(c, s, A, B, sc, C->col_ids, static_cast<T*>(C->data), launch_mask, c->last_num_counts, &tm);
+            if (rc != SPECK_OK) return rc;
+            ev_num_end = tm.ev;
+            if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, tm.ev++), s);
+            rc = read_stats(c, s);  // (done_kernel + ticket; the one wait of the call)
+            if (rc != SPECK_OK) return rc;
+            if (c->h_stats->a_invalid) return SPECK_ERR_INVALID;
+            bool b_bad = false;
+            rc = b_is_invalid(&b_bad);
+            if (rc != SPECK_OK) return rc;
+            if (b_bad) return SPECK_ERR_UNSORTED;
+            walked = !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz &&
+                     c->h_stats->sum_products != 0;
+            ++(walked ? c->walks : c->walk_misses);
+            if (walked) {
+                publish_counts(c, s);
+                num_mask = mask_of(c->h_stats->num.count, NUM_CLASSES);
+                c->last.one_walk = 1;
+                t->spGEMMCounting = 0.f;
+                t->spGEMMNumeric = st.lap();
+            } else {
+                validate_started = false;  // (the two-phase call checks B again: its verdict word was consumed)
+            }
+        }
+    }
+    if (!walked) {
     bool speculated = false;
     u32 spec_counts[kMaxClasses];
     if (c->eager_speculate && c->spec_valid && c->spec_rows_a == A->rows && c->spec_rows_b == B->rows) {
@@ -1324,7 +1462,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     }
 
     // Spill pool of the NUM_G rows FIRST: every failure up to here leaves C untouched (header contract).
-    const u32 num_mask = mask_of(c->h_stats->num.count, NUM_CLASSES);
+    num_mask = mask_of(c->h_stats->num.count, NUM_CLASSES);
     if (num_mask >> NUM_G & 1u) {
         // global-memory spill buffers of the heavy rows (role of the reference's global maps,
         // Multiply.cu:357-427), grow-only: per-row plan, per-bucket counters, and two product
@@ -1428,7 +1566,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     }
     rc = enqueue_back<T>(c, s, A, B, sc, c_col, static_cast<T*>(c_val), num_mask, c->h_stats->num.count, &tm);
     if (rc != SPECK_OK) return rc;
-    const size_t ev_num_end = tm.ev;
+    ev_num_end = tm.ev;
     if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, tm.ev++), s);
     // The reference may return before its kernels finish when measureCompleteTime is off
     // (Multiply.cu:1082-1085) and relies on blocking streams to order later copies.  The
@@ -1441,10 +1579,13 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         HIP_TRY(hipStreamSynchronize(s));
     }
     t->spGEMMNumeric = st.lap();
+    }  // !walked
     t->sorting = 0.f;  // sorting is fused into the numeric kernels
     t->cleanup = 0.f;  // nothing to free: the arena persists
 
     // remember what this call ran on: an identical next call may reuse its placement
+    c->last_was_walk = walked;
+    c->last_nf_entries = c->h_stats->nf_entries;
     c->last_sym_mask = mask_of(c->h_stats->sym.count, SYM_CLASSES);
     c->last_num_mask = num_mask;
     c->last_max_row_nnz = c->h_stats->max_row_nnz_c;
@@ -1672,6 +1813,9 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
     else if (n == "analysis_wide_rows") set_analysis_wide_rows((u32)value), forget(true);
     else if (n == "eager_speculate") c->eager_speculate = value != 0;
+    else if (n == "one_walk") c->one_walk = (int)value;
+    else if (n == "chain_fault") c->chain_fault = (u32)value;
+    else if (n == "walk_debug") set_walk_debug((u32)value & 0xFFFFu, (u32)(value >> 16));  // (tile rows | flags << 16)
     else if (n == "verify_inputs") c->verify_inputs = value != 0, c->snap_for_arena = false, forget(false);
     else if (n == "num_verify") c->num_verify = (int)value, forget(false);
     else if (n == "skip_scan") c->skip_scan = value != 0, forget(false);
@@ -1722,6 +1866,7 @@ int speck_last_stats(const speck_config* c, speck_stats* out)
     out->graph_captures = c->plans_made;
     out->pool_fallbacks = c->pool_fallbacks;
     out->scratch_pool_bytes = c->nfpool_bytes;
+    out->walk_misses = c->walk_misses;
     return SPECK_OK;
 }
 

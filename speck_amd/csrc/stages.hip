@@ -250,6 +250,8 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
                     my_nfr = max(my_nfr, cmax - cmin + 1);
                 }
                 if (cls == SYM_GH) my_nf += gh_table_slots(ops32);  // ... = the row's key set in global memory
+                // one-walk call (walk.hip): a register-class row is finished into a slot as well
+                if (cp.one_walk && cls < SYM_CLASSES && ((kSymEscMask >> cls) & 1u)) my_nf += nf_slot_entries(cmin, cmax, ops32);
                 if (cls == SYM_NONE) {
                     // empty row, or a single A entry: the C row is a scaled copy of one B row
                     counts[row] = ops32;
@@ -499,8 +501,12 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
             }
             u32 any_slot = 0;
             for (int w = 0; w < kChunk / 64; ++w) any_slot += s_wcnt[SYM_NF][w] + s_wcnt[SYM_GH][w];
+            if (cp.one_walk)
+                for (int w = 0; w < kChunk / 64; ++w)
+                    any_slot += s_wcnt[SYM_G8][w] + s_wcnt[SYM_G16][w] + s_wcnt[SYM_R32][w] + s_wcnt[SYM_R64][w];
+            const bool esc_slot = cp.one_walk && c < SYM_CLASSES && ((kSymEscMask >> c) & 1u);
             if (any_slot) {  // (uniform)
-                const u32 ub = c == SYM_NF ? nf_slot_entries(r_min, r_max, r_ops) : (c == SYM_GH ? gh_table_slots(r_ops) : 0u);
+                const u32 ub = (c == SYM_NF || esc_slot) ? nf_slot_entries(r_min, r_max, r_ops) : (c == SYM_GH ? gh_table_slots(r_ops) : 0u);
                 // (the scan runs over the first kChunk threads' values: the others hold 0)
                 u32 chunk_total = 0;
                 u32 excl = 0;
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
                 if (t < kChunk) {
                     for (u32 w = 0; w < wid; ++w) excl += s_nfscan[w];
                     for (int w = 0; w < kChunk / 64; ++w) chunk_total += s_nfscan[w];
-                    if (c == SYM_NF || c == SYM_GH) nf_off[row] = s_nfrun + excl;
+                    if (c == SYM_NF || c == SYM_GH || esc_slot) nf_off[row] = s_nfrun + excl;
                 }
                 __syncthreads();
                 if (t == 0) s_nfrun += chunk_total;
