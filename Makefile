@@ -9,19 +9,42 @@ HIPFLAGS += -DSPECK_PHASE_CLOCKS
 endif
 HIP_SRCS := $(wildcard $(CSRC)/*.hip)
 CPP_SRCS := $(wildcard $(CSRC)/*.cpp)
-OBJS := $(HIP_SRCS:.hip=.o) $(CPP_SRCS:.cpp=.o)
+# make ASAN=1: the HOST side of every object under AddressSanitizer + UndefinedBehaviorSanitizer (the device code is
+# untouched), into a library of its own -- speck_amd/libspeck_amd_asan.so, loaded with SPECK_LIB=... and the sanitizer
+# runtime preloaded (scripts/asan_suite.sh).  SURVEY.md 5: the reference has no sanitizer pass either.
+# make UBSAN=1: UndefinedBehaviorSanitizer alone (libspeck_amd_ubsan.so) -- what a process that talks to a GPU can run
+# under: ROCm's ASan runtime intercepts hsa_amd_memory_pool_allocate and aborts without an xnack+ device build.
+ifdef ASAN
+OSUF := .asan.o
+LIB := speck_amd/libspeck_amd_asan.so
+SANFLAGS := -Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -Xarch_host -g -shared-libsan
+HIPFLAGS += $(SANFLAGS)
+LDSAN := -fsanitize=address,undefined -shared-libsan
+else ifdef UBSAN
+OSUF := .ubsan.o
+LIB := speck_amd/libspeck_amd_ubsan.so
+# (-fno-sanitize=function: with the function-type check a kernel launched through a function-pointer variable --
+#  `auto k = kernel<...>; hipLaunchKernelGGL(k, ...)` -- pushes its launch configuration and never reaches its stub)
+SANFLAGS := -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize=function -Xarch_host -fno-omit-frame-pointer -Xarch_host -g -shared-libsan
+HIPFLAGS += $(SANFLAGS)
+LDSAN := -fsanitize=undefined -shared-libsan
+else
+OSUF := .o
 LIB := speck_amd/libspeck_amd.so
+LDSAN :=
+endif
+OBJS := $(HIP_SRCS:.hip=$(OSUF)) $(CPP_SRCS:.cpp=$(OSUF))
 
 all: $(LIB) oracle apps
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/speck_c_api.h
+$(CSRC)/%$(OSUF): $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/speck_c_api.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.hpp) include/speck_c_api.h
+$(CSRC)/%$(OSUF): $(CSRC)/%.cpp $(wildcard $(CSRC)/*.hpp) include/speck_c_api.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(LDSAN) -o $@ $(OBJS)
 
 oracle:
 	$(MAKE) -s -C oracle
@@ -32,6 +55,6 @@ apps: $(LIB)
 	      -L/opt/rocm/lib -lrocsparse -Wl,-rpath,'$$ORIGIN/../speck_amd' -Wl,-rpath,/opt/rocm/lib; fi
 
 clean:
-	rm -f $(OBJS) $(LIB) apps/runspECK
+	rm -f $(OBJS) $(LIB) $(CSRC)/*.asan.o $(CSRC)/*.ubsan.o speck_amd/libspeck_amd_asan.so speck_amd/libspeck_amd_ubsan.so apps/runspECK
 	$(MAKE) -s -C oracle clean
 .PHONY: all oracle apps clean

@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspeck_amd.so")
+# (SPECK_LIB: another build of the same library, e.g. the sanitizer build of `make ASAN=1`)
+LIB_PATH = os.environ.get("SPECK_LIB") or os.path.join(_HERE, "libspeck_amd.so")
 
 NUM_SYM_BINS = 16
 NUM_NUM_BINS = 16

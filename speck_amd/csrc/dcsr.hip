@@ -10,6 +10,7 @@
 
 #include "../../include/speck_c_api.h"
 #include "device_common.hpp"
+#include "guards.hpp"
 
 using namespace speck;
 
@@ -54,18 +55,18 @@ int speck_dcsr_alloc(speck_dcsr* m, uint64_t rows, uint64_t cols, uint64_t nnz, 
     m->rows = rows;
     m->cols = cols;
     m->nnz = nnz;
-    HIP_TRY(hipMalloc(&m->data, std::max<size_t>(nnz, 1) * value_size));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->col_ids), std::max<size_t>(nnz, 1) * 4));
-    if (alloc_offsets) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->row_offsets), (rows + 1) * 4));
+    HIP_TRY(guarded_malloc(&m->data, std::max<size_t>(nnz, 1) * value_size));
+    HIP_TRY(guarded_malloc(reinterpret_cast<void**>(&m->col_ids), std::max<size_t>(nnz, 1) * 4));
+    if (alloc_offsets) HIP_TRY(guarded_malloc(reinterpret_cast<void**>(&m->row_offsets), (rows + 1) * 4));
     return SPECK_OK;
 }
 
 int speck_dcsr_free(speck_dcsr* m)
 {
     if (!m) return SPECK_ERR_INVALID;
-    if (m->col_ids) (void)hipFree(m->col_ids);
-    if (m->data) (void)hipFree(m->data);
-    if (m->row_offsets) (void)hipFree(m->row_offsets);
+    if (m->col_ids) (void)guarded_free(m->col_ids);
+    if (m->data) (void)guarded_free(m->data);
+    if (m->row_offsets) (void)guarded_free(m->row_offsets);
     m->col_ids = nullptr;
     m->data = nullptr;
     m->row_offsets = nullptr;

@@ -212,10 +212,23 @@ void launch_numeric_first(hipStream_t s, u32 count, const CsrView<T>& A, const C
 // the caller profiles: with a pair of events the launch goes through hipExtLaunchKernelGGL, which stamps them with the
 // kernel's own begin and end -- what rocprofv3 reports -- instead of bracketing the launch with two event records
 // (which adds the dispatch latency, ~4 us, to every duration).
+// A launch that FAILS (a kernel whose LDS opt-in was refused, an invalid configuration) must not go unnoticed: the
+// runtime keeps only the status of the LAST call, so a failed launch followed by a successful event record is gone by
+// the time a stage asks hipGetLastError() -- round 6 found a sanitizer build whose >64 KiB-LDS kernels never ran and whose
+// multiply returned "ok" with nnz(C) = 0.  Every launch of the library goes through SPECK_LAUNCH: the status is read at
+// once and latched per thread; the pipeline collects it behind every batch (take_launch_error) -> SPECK_ERR_HIP.
+void note_launch_status(hipError_t e, const char* what);
+int take_launch_error();  // the first failure since the last call (0: none); clears the latch
+#define SPECK_LAUNCH(kernel_, ...)                                          \
+    do {                                                                    \
+        hipLaunchKernelGGL(kernel_, __VA_ARGS__);                           \
+        ::speck::note_launch_status(hipGetLastError(), #kernel_);           \
+    } while (0)
 #define SPECK_LAUNCH_TIMED(kernel_, grid_, block_, lds_, stream_, e0_, e1_, ...)                            \
     do {                                                                                                   \
         if (e0_) hipExtLaunchKernelGGL(kernel_, grid_, block_, lds_, stream_, e0_, e1_, 0, __VA_ARGS__);   \
         else hipLaunchKernelGGL(kernel_, grid_, block_, lds_, stream_, __VA_ARGS__);                       \
+        ::speck::note_launch_status(hipGetLastError(), #kernel_);                                          \
     } while (0)
 
 // Launch the numeric kernel of class `cls` (same convention for `count`).

@@ -1416,8 +1416,9 @@ template <typename K>
 static void set_dyn_lds(K kernel, u32 bytes)
 {
     if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        note_launch_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                           "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
 }
 
 template <class G, typename T, u32 CAP, u32 W1, u32 NMAX, int MODE, int THREADS, u32 NLO = 0, bool VERIFY = false>
@@ -1427,7 +1428,7 @@ static void launch_num_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
     auto k = num_hash_kernel<G, T, CAP, W1, NMAX, MODE, THREADS, NLO, VERIFY>;
     const u32 lds = (THREADS / G::SIZE) * num_group_lds<G, T, CAP, THREADS>();
     set_dyn_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3(grid_for(count, lds, THREADS, cu_count, THREADS / G::SIZE)),
+    SPECK_LAUNCH(k, dim3(grid_for(count, lds, THREADS, cu_count, THREADS / G::SIZE)),
                        dim3(THREADS), lds, s, A, B, w, c_col, c_val, cls);
 }
 
@@ -1516,24 +1517,24 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
     switch (cls) {
         case NUM_DIRECT: {
             constexpr int TH = 256;
-            hipLaunchKernelGGL((num_direct_kernel<T, TH>), dim3(grid_for(count, lds, TH, cu_count, TH)),
+            SPECK_LAUNCH((num_direct_kernel<T, TH>), dim3(grid_for(count, lds, TH, cu_count, TH)),
                                dim3(TH), lds, s, A, B, w, c_col, c_val);
             break;
         }
         case NUM_G8:
-            hipLaunchKernelGGL((num_esc_kernel<T, 8>), dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B,
+            SPECK_LAUNCH((num_esc_kernel<T, 8>), dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B,
                                w, c_col, c_val, cls);
             break;
         case NUM_G16:
-            hipLaunchKernelGGL((num_esc_kernel<T, 16>), dim3(grid_for(count, lds, 256, cu_count, 16)), dim3(256), lds, s, A, B,
+            SPECK_LAUNCH((num_esc_kernel<T, 16>), dim3(grid_for(count, lds, 256, cu_count, 16)), dim3(256), lds, s, A, B,
                                w, c_col, c_val, cls);
             break;
         case NUM_R32:
-            hipLaunchKernelGGL((num_escw_kernel<T, 32>), dim3(grid_for(count, lds, 256, cu_count, 8)), dim3(256), lds, s, A, B,
+            SPECK_LAUNCH((num_escw_kernel<T, 32>), dim3(grid_for(count, lds, 256, cu_count, 8)), dim3(256), lds, s, A, B,
                                w, c_col, c_val, cls);
             break;
         case NUM_R64:
-            hipLaunchKernelGGL((num_escw_kernel<T, 64>), dim3(grid_for(count, lds, 256, cu_count, 4)), dim3(256), lds, s, A, B,
+            SPECK_LAUNCH((num_escw_kernel<T, 64>), dim3(grid_for(count, lds, 256, cu_count, 4)), dim3(256), lds, s, A, B,
                                w, c_col, c_val, cls);
             break;
         case NUM_W128:
@@ -1581,7 +1582,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
         case NUM_D1: {
             auto k = num_dense_kernel<T, kNumD1Win, 256>;
             set_dyn_lds(k, lds);
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, A, B, w,
+            SPECK_LAUNCH(k, dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, A, B, w,
                                c_col, c_val, cls);
             break;
         }
@@ -1589,13 +1590,13 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             if (w.verify_numeric) {
                 auto kv = num_dense_kernel<T, kNumD2Cols, 1024, true>;
                 set_dyn_lds(kv, lds);
-                hipLaunchKernelGGL(kv, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,
+                SPECK_LAUNCH(kv, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,
                                    w, c_col, c_val, cls);
                 break;
             }
             auto k = num_dense_kernel<T, kNumD2Cols, 1024>;
             set_dyn_lds(k, lds);
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,
+            SPECK_LAUNCH(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A, B,
                                w, c_col, c_val, cls);
             break;
         }
@@ -1603,7 +1604,7 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             u32 blocks = (count + 3) / 4;  // four waves per workgroup, a row per wave
             const u32 cap = (u32)cu_count * 8u * 4u;
             if (blocks > cap) blocks = cap;
-            hipLaunchKernelGGL((nf_copy_kernel<T>), dim3(blocks ? blocks : 1), dim3(256), 0, s, w, c_col, c_val);
+            SPECK_LAUNCH((nf_copy_kernel<T>), dim3(blocks ? blocks : 1), dim3(256), 0, s, w, c_col, c_val);
             break;
         }
         case NUM_G: {
@@ -1611,16 +1612,16 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             const u32 rows = count < 8192u ? (count ? count : 1u) : 8192u;
             (void)hipMemsetAsync(w.spill.fcount, 0,
                                  (size_t(w.spill.cell_cap) + 3 * size_t(w.spill.bucket_cap) + 4) * sizeof(u32), s);
-            hipLaunchKernelGGL(num_spill_plan_kernel, dim3(1), dim3(1024), 0, s, w, cls);
+            SPECK_LAUNCH(num_spill_plan_kernel, dim3(1), dim3(1024), 0, s, w, cls);
             auto kc = num_spill_count_kernel<T>;
-            hipLaunchKernelGGL(kc, dim3(rows, kGParts), dim3(kGWalkThreads), (num_spill_walk_lds<T, false>()), s,
+            SPECK_LAUNCH(kc, dim3(rows, kGParts), dim3(kGWalkThreads), (num_spill_walk_lds<T, false>()), s,
                                A, B, w, cls);
-            hipLaunchKernelGGL(num_spill_offsets_kernel, dim3(rows), dim3(256), 0, s, w, cls);
+            SPECK_LAUNCH(num_spill_offsets_kernel, dim3(rows), dim3(256), 0, s, w, cls);
             auto ks = num_spill_scatter_kernel<T>;
-            hipLaunchKernelGGL(ks, dim3(rows, kGParts), dim3(kGWalkThreads), (num_spill_walk_lds<T, true>()), s,
+            SPECK_LAUNCH(ks, dim3(rows, kGParts), dim3(kGWalkThreads), (num_spill_walk_lds<T, true>()), s,
                                A, B, w, cls);
             auto kr_small = num_spill_reduce_kernel<T, kNumB2KCap, kB2KW1, 256, 0, kNumB2KMaxNnz, false>;
-            hipLaunchKernelGGL(kr_small, dim3(rows, 32), dim3(256), (num_spill_reduce_lds<T, kNumB2KCap, 256>()), s, w,
+            SPECK_LAUNCH(kr_small, dim3(rows, 32), dim3(256), (num_spill_reduce_lds<T, kNumB2KCap, 256>()), s, w,
                                cls);
             // (the big table takes a bucket up to a load of 0.85: beyond it only the dense windows are left, and a bucket
             //  that misses the 2/3 mark by a few entries would pay dozens of them over its column span)
@@ -1629,8 +1630,8 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             // (its workgroups stride over the list of oversized buckets, which only the device knows -- usually a handful.
             //  Each needs 106 KiB of LDS just to find that out: a grid of 2048 queued behind the NUM_B8K launches of the
             //  same phase for 0.3-0.5 ms on the webbase stand-in; option spill_big_grid)
-            hipLaunchKernelGGL(kr_big, dim3(g_spill_big_grid), dim3(512), lds, s, w, cls);
-            hipLaunchKernelGGL((num_spill_copy_kernel<T>), dim3(rows, 32), dim3(256), 0, s, w, c_col, c_val, cls);
+            SPECK_LAUNCH(kr_big, dim3(g_spill_big_grid), dim3(512), lds, s, w, cls);
+            SPECK_LAUNCH((num_spill_copy_kernel<T>), dim3(rows, 32), dim3(256), 0, s, w, c_col, c_val, cls);
             break;
         }
     }

@@ -24,6 +24,7 @@
 
 #include "../../include/speck_c_api.h"
 #include "device_common.hpp"
+#include "guards.hpp"
 #include "launch.hpp"
 #include "row_groups.hpp"
 
@@ -38,6 +39,30 @@ using namespace speck;
             return (_e == hipErrorOutOfMemory) ? SPECK_ERR_OOM : SPECK_ERR_HIP;             \
         }                                                                                   \
     } while (0)
+
+// the launches enqueued since the last check went out (launch.hpp, SPECK_LAUNCH: a failed launch is latched where it
+// happens -- the runtime's own "last error" is overwritten by the next successful call)
+#define LAUNCHES_OK()                                                                                       \
+    do {                                                                                                    \
+        if (speck::take_launch_error()) return SPECK_ERR_HIP;                                               \
+        HIP_TRY(hipGetLastError());                                                                         \
+    } while (0)
+
+namespace speck {
+static thread_local int t_launch_error = 0;
+void note_launch_status(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return;
+    std::fprintf(stderr, "speck_amd: launch of %s failed: %s\n", what, hipGetErrorString(e));
+    if (!t_launch_error) t_launch_error = (int)e;
+}
+int take_launch_error()
+{
+    const int e = t_launch_error;
+    t_launch_error = 0;
+    return e;
+}
+}  // namespace speck
 
 // Everything a reuse sequence is specialised to.
 struct CallKey {
@@ -198,6 +223,12 @@ struct speck_config {
     u32 nf_wcols = kNumD1Cols;  // LDS window of the numeric-first kernel: the widest such row of the last analysis
     SpillBuffers spill{};
     u64 last_g_products = 0;  // what the spill pools of the reuse sequence were sized for
+    // debug option guard_bytes (guards.hpp): the zones between the regions carved from the arena / the spill pool, and what
+    // layout the arena's were last filled for
+    std::vector<GuardZone> arena_zones, gpool_zones, nfpool_zones;
+    const void* zones_arena = nullptr;
+    u64 zones_m = 0, zones_nnz = 0, zones_gap = 0;
+    bool gpool_zones_filled = false;
     speck_stats last{};
     // the ONE-WALK complete call (walk.hip; option one_walk): analysis -> symbolic launches of the rows no register class
     // takes -> walk kernel (scan + the register-class rows finished in place) -> the other numeric launches.  Needs C
@@ -236,11 +267,11 @@ int ensure_arena(speck_config* c, size_t bytes)
     drop_plan(c);
     c->last_key_valid = false;
     c->arena_key_valid = false;
-    if (c->arena) HIP_TRY(hipFree(c->arena));
+    if (c->arena) HIP_TRY(guarded_free(c->arena));
     c->arena = nullptr;
     c->arena_bytes = 0;
     size_t want = bytes + bytes / 4 + (1 << 20);
-    HIP_TRY(hipMalloc(&c->arena, want));
+    HIP_TRY(guarded_malloc(&c->arena, want));
     c->arena_bytes = want;
     return SPECK_OK;
 }
@@ -250,12 +281,12 @@ void ensure_snap(speck_config* c, u64 nnz_a, u64 b_rows)
 {
     const size_t a_words = (size_t(nnz_a) + 63) & ~size_t(63), need = a_words + 3 * size_t(b_rows) + 1;
     if (need > c->snap_words) {
-        if (c->snap) (void)hipFree(c->snap);
+        if (c->snap) (void)guarded_free(c->snap);
         c->snap = nullptr;
         c->snap_words = 0;
         c->snap_for_arena = false;
         const size_t want = need + need / 8;
-        if (hipMalloc(reinterpret_cast<void**>(&c->snap), want * sizeof(u32)) != hipSuccess) {
+        if (guarded_malloc(reinterpret_cast<void**>(&c->snap), want * sizeof(u32)) != hipSuccess) {
             (void)hipGetLastError();
             c->snap = nullptr;
             return;
@@ -269,16 +300,21 @@ void ensure_snap(speck_config* c, u64 nnz_a, u64 b_rows)
 struct Carver {
     unsigned char* p;
     size_t used = 0;
-    explicit Carver(void* base) : p(static_cast<unsigned char*>(base)) {}
+    size_t gap;                        // debug option guard_bytes: a canary zone behind every region (guards.hpp)
+    std::vector<GuardZone>* zones;     // ... listed here
+    explicit Carver(void* base, size_t gap_ = 0, std::vector<GuardZone>* zones_ = nullptr)
+        : p(static_cast<unsigned char*>(base)), gap(gap_), zones(zones_) {}
     template <typename U>
     U* take(size_t n)
     {
         size_t bytes = (n * sizeof(U) + 255) & ~size_t(255);
         U* r = reinterpret_cast<U*>(p + used);
-        used += bytes;
+        // (the zone starts right behind the last entry of the region, inside its alignment padding)
+        if (gap && zones && p) zones->push_back(GuardZone{p + used + n * sizeof(U), bytes - n * sizeof(U) + gap});
+        used += bytes + gap;
         return r;
     }
-    static size_t need(size_t n, size_t elem) { return (n * elem + 255) & ~size_t(255); }
+    static size_t need(size_t n, size_t elem) { return ((n * elem + 255) & ~size_t(255)) + guard_bytes(); }
 };
 
 struct Scratch {
@@ -306,9 +342,9 @@ size_t scratch_bytes(u32 m, u64 nnz_a)
     return b + 4096;
 }
 
-Scratch carve(speck_config* c, u32 m, u64 nnz_a)
+Scratch carve(speck_config* c, u32 m, u64 nnz_a, std::vector<GuardZone>* zones = nullptr)
 {
-    Carver cv(c->arena);
+    Carver cv(c->arena, guard_bytes(), zones);
     Scratch s;
     s.b_sl = cv.take<uint2>(nnz_a);
     s.w_sl = cv.take<uint2>(nnz_a);
@@ -359,9 +395,9 @@ bool ensure_pred(Prediction& p, u32 m)
 {
     const size_t need = size_t(m) + 1;
     if (need > p.words) {
-        if (p.off) (void)hipFree(p.off);
+        if (p.off) (void)guarded_free(p.off);
         p = Prediction{};
-        if (hipMalloc(reinterpret_cast<void**>(&p.off), need * 4) != hipSuccess) {
+        if (guarded_malloc(reinterpret_cast<void**>(&p.off), need * 4) != hipSuccess) {
             (void)hipGetLastError();
             p.off = nullptr;
             return false;
@@ -379,7 +415,7 @@ int ensure_nfpool(speck_config* c, u64 entries, size_t vsize)
     if (entries <= c->nf_cap_entries && need <= c->nfpool_bytes) return SPECK_OK;
     drop_plan(c);
     c->last_key_valid = false;
-    if (c->nfpool) (void)hipFree(c->nfpool);
+    if (c->nfpool) (void)guarded_free(c->nfpool);
     c->nfpool = nullptr;
     c->nfpool_bytes = 0;
     c->nf_cap_entries = 0;
@@ -391,12 +427,19 @@ int ensure_nfpool(speck_config* c, u64 entries, size_t vsize)
     size_t budget = c->nf_pool_max_bytes;
     if (!budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = free_b / 2;
     if (budget && bytes > budget) return SPECK_ERR_OOM;
-    if (hipMalloc(&c->nfpool, bytes) != hipSuccess) {
+    if (guarded_malloc(&c->nfpool, bytes) != hipSuccess) {
         (void)hipGetLastError();
         return SPECK_ERR_OOM;
     }
     c->nfpool_bytes = bytes;
     c->nf_cap_entries = cap;
+    c->nfpool_zones.clear();
+    if (guard_bytes()) {  // between the column ids and the values, behind the values
+        unsigned char* b = static_cast<unsigned char*>(c->nfpool);
+        c->nfpool_zones.push_back(GuardZone{b + cap * 4, Carver::need(cap, 4) - cap * 4});
+        c->nfpool_zones.push_back(GuardZone{b + Carver::need(cap, 4) + cap * 8, bytes - Carver::need(cap, 4) - cap * 8});  // (behind 8-byte values: a float call uses half)
+        if (guard_fill(c->nfpool_zones, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return SPECK_ERR_HIP;
+    }
     return SPECK_OK;
 }
 
@@ -569,7 +612,7 @@ int run_classes(speck_config* c, hipStream_t s, const int* order, int n_order, u
         HIP_TRY(hipEventRecord(c->aux_done[k], c->aux[k]));
         HIP_TRY(hipStreamWaitEvent(s, c->aux_done[k], 0));
     }
-    HIP_TRY(hipGetLastError());
+    LAUNCHES_OK();
     return SPECK_OK;
 }
 
@@ -651,7 +694,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
             tm->ev_analysis_end = tm->ev;
             (void)hipEventRecord(kernel_event(c, tm->ev++), s);
         }
-        HIP_TRY(hipGetLastError());
+        LAUNCHES_OK();
     }
     if (!(parts & 2u)) return SPECK_OK;
     const RowWork w = make_work(c, sc, SpillBuffers{}, m, true);
@@ -724,7 +767,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
             const ProductSrc<float> src{sc.b_sl, static_cast<const float*>(A->data), B->col_ids, static_cast<const float*>(B->data), sc.w_sl};
             launch_walk<float>(s, wa, src, chain, e0, e1);
         }
-        HIP_TRY(hipGetLastError());
+        LAUNCHES_OK();
         return SPECK_OK;
     }
     if (timed) {
@@ -744,7 +787,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
                     host_mirror ? c->d_ticket : nullptr, host_mirror ? c->h_ticket_dev : nullptr, bytes);
     }
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
-    HIP_TRY(hipGetLastError());
+    LAUNCHES_OK();
     return SPECK_OK;
 }
 
@@ -1038,7 +1081,7 @@ int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, c
                              B->col_ids, (u32)B->rows, c->snap + c->snap_a_words, c->h_verify_dev);
         validate();
         launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
-        HIP_TRY(hipGetLastError());
+        LAUNCHES_OK();
         return SPECK_OK;
     }
     ClassifyParams cp = c->cp;
@@ -1057,7 +1100,7 @@ int launch_verifier(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, c
     }
     validate();
     launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
-    HIP_TRY(hipGetLastError());
+    LAUNCHES_OK();
     return SPECK_OK;
 }
 int wait_verifier(speck_config* c, bool* changed)
@@ -1110,7 +1153,7 @@ int begin_validate(speck_config* c, const speck_dcsr* B, hipStream_t gate = null
     }
     launch_validate_b(c->vstream, B->row_offsets, B->col_ids, (u32)B->rows, (u32)B->cols, B->nnz, c->h_verify_dev);
     launch_ticket(c->vstream, c->d_vticket, c->h_verify_dev + 16);
-    HIP_TRY(hipGetLastError());
+    LAUNCHES_OK();
     c->validate_in_flight = true;
     return SPECK_OK;
 }
@@ -1167,7 +1210,14 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     rc = ensure_arena(c, scratch_bytes(m, A->nnz));
     if (rc != SPECK_OK) return rc;
-    Scratch sc = carve(c, m, A->nnz);
+    std::vector<GuardZone> carved;
+    Scratch sc = carve(c, m, A->nnz, guard_bytes() ? &carved : nullptr);
+    if (guard_bytes() && (c->zones_arena != c->arena || c->zones_m != m || c->zones_nnz != A->nnz || c->zones_gap != guard_bytes())) {
+        // (another layout of the arena than the one whose zones were filled last: canaries between ITS regions)
+        HIP_TRY(guard_fill(carved, s));
+        c->arena_zones = carved;
+        c->zones_arena = c->arena, c->zones_m = m, c->zones_nnz = A->nnz, c->zones_gap = guard_bytes();
+    }
     c->snap_pending = false;
     if (c->verify_inputs && c->overlap_analysis && c->reuse) ensure_snap(c, A->nnz, B->rows);
     VerifierGuard verifier_guard{c};
@@ -1252,11 +1302,11 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     if (C->rows == A->rows && C->row_offsets != nullptr) {
         c_ro = C->row_offsets;
     } else {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c_ro), (size_t(m) + 1) * sizeof(u32)));
+        HIP_TRY(guarded_malloc(reinterpret_cast<void**>(&c_ro), (size_t(m) + 1) * sizeof(u32)));
         own_ro = true;
     }
     auto fail = [&](int code) {
-        if (own_ro) (void)hipFree(c_ro);
+        if (own_ro) (void)guarded_free(c_ro);
         return code;
     };
     t->init = st.lap();
@@ -1452,7 +1502,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
 
     if (c->h_stats->sum_products == 0) {
         // reference: Multiply.cu:256-261 -> matOut.alloc(rows, cols, 0, false)
-        if (own_ro) (void)hipFree(c_ro);
+        if (own_ro) (void)guarded_free(c_ro);
         speck_dcsr_free(C);
         C->rows = A->rows;
         C->cols = B->cols;
@@ -1478,16 +1528,17 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
                             2 * Carver::need(pg, 4) + 2 * Carver::need(pg, sizeof(T)) + 4096;
         if (need > c->gpool_bytes) {
             drop_plan(c);
-            if (c->gpool) (void)hipFree(c->gpool);
+            if (c->gpool) (void)guarded_free(c->gpool);
             c->gpool = nullptr;
             c->gpool_bytes = 0;
-            if (hipMalloc(&c->gpool, need + need / 8) != hipSuccess) {
+            if (guarded_malloc(&c->gpool, need + need / 8) != hipSuccess) {
                 (void)hipGetLastError();
                 return fail(SPECK_ERR_OOM);
             }
             c->gpool_bytes = need + need / 8;
         }
-        Carver cv(c->gpool);
+        c->gpool_zones.clear();
+        Carver cv(c->gpool, guard_bytes(), &c->gpool_zones);
         SpillBuffers sp{};
         sp.plan = cv.take<GRowPlan>(rows_g);
         // fcount | bcount | bcursor | dcount are cleared by ONE memset: keep them back to back
@@ -1512,6 +1563,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             sp.bucket_cap != c->spill.bucket_cap)
             drop_plan(c);  // a reuse sequence holds the old layout
         c->spill = sp;
+        if (guard_bytes()) HIP_TRY(guard_fill(c->gpool_zones, s));  // (nothing of an earlier call is in flight on the pool)
     }
     t->globalMapsNumeric = st.lap();
     // ALLOC C: only when nnz changed (Multiply.cu:589-602)
@@ -1520,22 +1572,22 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     if (C->nnz != nnz_c || !c_val || !c_col) {
         void* nv = nullptr;
         u32* nc = nullptr;
-        hipError_t e1 = hipMalloc(&nv, std::max<size_t>(nnz_c, 1) * sizeof(T));
+        hipError_t e1 = guarded_malloc(&nv, std::max<size_t>(nnz_c, 1) * sizeof(T));
         hipError_t e2 = e1 == hipSuccess
-                            ? hipMalloc(reinterpret_cast<void**>(&nc), std::max<size_t>(nnz_c, 1) * 4)
+                            ? guarded_malloc(reinterpret_cast<void**>(&nc), std::max<size_t>(nnz_c, 1) * 4)
                             : e1;
         if (e1 != hipSuccess || e2 != hipSuccess) {
-            if (nv) (void)hipFree(nv);
+            if (nv) (void)guarded_free(nv);
             (void)hipGetLastError();
             return fail(SPECK_ERR_OOM);
         }
-        if (C->data) (void)hipFree(C->data);
-        if (C->col_ids) (void)hipFree(C->col_ids);
-        if (C->row_offsets && C->row_offsets != c_ro) (void)hipFree(C->row_offsets);
+        if (C->data) (void)guarded_free(C->data);
+        if (C->col_ids) (void)guarded_free(C->col_ids);
+        if (C->row_offsets && C->row_offsets != c_ro) (void)guarded_free(C->row_offsets);
         c_val = nv;
         c_col = nc;
     } else if (C->row_offsets && C->row_offsets != c_ro) {
-        (void)hipFree(C->row_offsets);
+        (void)guarded_free(C->row_offsets);
     }
     // publish (Multiply.cu:1116-1121); from here C owns c_ro
     C->rows = A->rows;
@@ -1747,12 +1799,12 @@ int speck_config_destroy(speck_config* c)
     if (c->vstream) (void)hipStreamDestroy(c->vstream);
     if (c->h_verify) (void)hipHostFree(c->h_verify);
     if (c->d_vticket) (void)hipFree(c->d_vticket);
-    if (c->arena) (void)hipFree(c->arena);
-    if (c->snap) (void)hipFree(c->snap);
-    if (c->gpool) (void)hipFree(c->gpool);
-    if (c->nfpool) (void)hipFree(c->nfpool);
-    if (c->pred.off) (void)hipFree(c->pred.off);
-    if (c->gpred.off) (void)hipFree(c->gpred.off);
+    if (c->arena) (void)guarded_free(c->arena);
+    if (c->snap) (void)guarded_free(c->snap);
+    if (c->gpool) (void)guarded_free(c->gpool);
+    if (c->nfpool) (void)guarded_free(c->nfpool);
+    if (c->pred.off) (void)guarded_free(c->pred.off);
+    if (c->gpred.off) (void)guarded_free(c->gpred.off);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->chain_buf) (void)hipFree(c->chain_buf);
     if (c->d_bytes) (void)hipFree(c->d_bytes);
@@ -1815,6 +1867,19 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "eager_speculate") c->eager_speculate = value != 0;
     else if (n == "one_walk") c->one_walk = (int)value;
     else if (n == "chain_fault") c->chain_fault = (u32)value;
+    else if (n == "guard_bytes") {
+        // debug (guards.hpp): canary zones of `value` bytes around / inside everything allocated FROM NOW ON -- the
+        // config's own buffers are dropped so that they come back with zones
+        (void)hipDeviceSynchronize();
+        set_guard_bytes((size_t)value);
+        forget(true);
+        c->arena_bytes = 0, c->arena_key_valid = false, c->zones_arena = nullptr, c->arena_zones.clear();
+        if (c->nfpool) (void)guarded_free(c->nfpool);
+        c->nfpool = nullptr, c->nfpool_bytes = 0, c->nf_cap_entries = 0, c->nfpool_zones.clear();
+        if (c->gpool) (void)guarded_free(c->gpool);
+        c->gpool = nullptr, c->gpool_bytes = 0, c->gpool_zones.clear(), c->spill = SpillBuffers{};
+        c->spec_valid = false;
+    }
     else if (n == "walk_debug") set_walk_debug((u32)value & 0xFFFFu, (u32)(value >> 16));  // (tile rows | flags << 16)
     else if (n == "verify_inputs") c->verify_inputs = value != 0, c->snap_for_arena = false, forget(false);
     else if (n == "num_verify") c->num_verify = (int)value, forget(false);
@@ -1870,16 +1935,45 @@ int speck_last_stats(const speck_config* c, speck_stats* out)
     return SPECK_OK;
 }
 
+// debug option guard_bytes: every canary zone of the config's buffers and of C after the call (guards.hpp)
+static int check_guards(speck_config* c, const speck_dcsr* C, int rc)
+{
+    if (!guard_bytes() || !c) return rc;
+    std::vector<GuardZone> z = c->arena_zones;
+    z.insert(z.end(), c->gpool_zones.begin(), c->gpool_zones.end());
+    z.insert(z.end(), c->nfpool_zones.begin(), c->nfpool_zones.end());
+    const size_t inner = z.size();
+    const void* whole[] = {c->arena, c->snap, c->pred.off, c->gpred.off, c->nfpool, c->gpool,
+                           C ? C->data : nullptr, C ? C->col_ids : nullptr, C ? C->row_offsets : nullptr};
+    static const char* names[] = {"arena", "input snapshot", "row-offset copy", "row-offset copy (sequence)", "scratch pool",
+                                  "spill pool", "C.data", "C.col_ids", "C.row_offsets"};
+    std::vector<int> owner;
+    for (int i = 0; i < 9; ++i) {
+        const size_t before = z.size();
+        if (whole[i]) guard_zones_of(whole[i], &z);
+        for (size_t k = before; k < z.size(); ++k) owner.push_back(i);
+    }
+    int bad = -1;
+    size_t at = 0;
+    const int n = guard_check(z, main_stream(c), &bad, &at);
+    if (n == 0) return rc;
+    if (n < 0) return rc == SPECK_OK ? SPECK_ERR_HIP : rc;
+    const char* what = (size_t)bad < inner ? "between two regions of the arena / a pool" : names[owner[bad - inner]];
+    std::fprintf(stderr, "speck_amd: guard_bytes: %d canary zone(s) touched; first: zone %d (%s, %s the buffer), byte %zu\n", n, bad,
+                 what, (size_t)bad >= inner && ((bad - inner) & 1u) == 0 ? "in front of" : "behind", at);
+    return rc == SPECK_OK ? SPECK_ERR_HIP : rc;
+}
+
 int speck_multiply_f64(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, speck_dcsr* C,
                        speck_timings* t)
 {
-    return multiply_impl<double>(c, A, B, C, t);
+    return check_guards(c, C, multiply_impl<double>(c, A, B, C, t));
 }
 
 int speck_multiply_f32(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, speck_dcsr* C,
                        speck_timings* t)
 {
-    return multiply_impl<float>(c, A, B, C, t);
+    return check_guards(c, C, multiply_impl<float>(c, A, B, C, t));
 }
 
 int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, uint32_t* d_row_ops,
@@ -1916,7 +2010,7 @@ int speck_analysis(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, ui
     launch_analysis(s, A->row_offsets, A->col_ids, B->row_offsets, B->col_ids, m, A->nnz, d_row_ops, d_row_max_ops,
                     d_row_col_min, d_row_col_max, nullptr, nullptr, sc.sym_recs, c->d_stats, cp, nullptr, chain,
                     nullptr, ~0ull, (u32)B->rows, nullptr, nullptr, nullptr, B->nnz);
-    HIP_TRY(hipGetLastError());
+    LAUNCHES_OK();
     rc = read_stats(c, s);
     if (rc != SPECK_OK) return rc;
     if (c->h_stats->a_invalid) return SPECK_ERR_INVALID;

@@ -1000,7 +1000,7 @@ void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_r
 {
     if (b_rows == 0) return;
     const u64 want = std::max<u64>(cdiv(b_nnz + 4, kValChunk), cdiv(u64(b_rows), 256 * 16));
-    hipLaunchKernelGGL(validate_b_kernel, dim3((u32)std::min<u64>(std::max<u64>(want, 1), 2048)), dim3(256), 0, s, b_ro, b_col,
+    SPECK_LAUNCH(validate_b_kernel, dim3((u32)std::min<u64>(std::max<u64>(want, 1), 2048)), dim3(256), 0, s, b_ro, b_col,
                        b_rows, b_cols, b_nnz, verdict);
 }
 
@@ -1089,24 +1089,24 @@ static u32 input_blocks(u64 nnz_a, u32 b_rows)
 void launch_snapshot_inputs(hipStream_t s, const u32* a_ro, const u32* a_col, u32* a_col_copy, u64 nnz_a, const u32* b_ro,
                             const u32* b_col, u32 b_rows, u32* b_snap)
 {
-    hipLaunchKernelGGL(snapshot_inputs_kernel, dim3(input_blocks(nnz_a, b_rows)), dim3(256), 0, s, a_ro, a_col, a_col_copy,
+    SPECK_LAUNCH(snapshot_inputs_kernel, dim3(input_blocks(nnz_a, b_rows)), dim3(256), 0, s, a_ro, a_col, a_col_copy,
                        nnz_a, b_ro, b_col, b_rows, b_snap);
 }
 void launch_verify_inputs(hipStream_t s, const u32* a_ro, const u32* a_ro_copy, u32 m, const u32* a_col,
                           const u32* a_col_copy, u64 nnz_a, const u32* b_ro, const u32* b_col, u32 b_rows, const u32* b_snap,
                           u32* verdict)
 {
-    hipLaunchKernelGGL(verify_inputs_kernel, dim3(input_blocks(nnz_a, b_rows)), dim3(256), 0, s, a_ro, a_ro_copy, m, a_col,
+    SPECK_LAUNCH(verify_inputs_kernel, dim3(input_blocks(nnz_a, b_rows)), dim3(256), 0, s, a_ro, a_ro_copy, m, a_col,
                        a_col_copy, nnz_a, b_ro, b_col, b_rows, b_snap, verdict);
 }
 
 void launch_ticket(hipStream_t s, u32* dev_ticket, u32* host_ticket)
 {
-    hipLaunchKernelGGL(ticket_kernel, dim3(1), dim3(64), 0, s, dev_ticket, host_ticket);
+    SPECK_LAUNCH(ticket_kernel, dim3(1), dim3(64), 0, s, dev_ticket, host_ticket);
 }
 void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceStats* st, DeviceStats* host_mirror)
 {
-    hipLaunchKernelGGL(done_kernel, dim3(1), dim3(64), 0, s, dev_ticket, host_ticket, st, host_mirror);
+    SPECK_LAUNCH(done_kernel, dim3(1), dim3(64), 0, s, dev_ticket, host_ticket, st, host_mirror);
 }
 // the staged row offsets of a call -> C.row_offsets, for a numeric phase without the light launch that carries them
 // (RowWork::off_src); a sequence an earlier kernel has declared void leaves the caller's buffer alone
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256) void copy_offsets_kernel(const u32* __restrict
 }
 void launch_copy_offsets(hipStream_t s, const u32* src, u32* dst, u32 n, const DeviceStats* st)
 {
-    hipLaunchKernelGGL(copy_offsets_kernel, dim3(std::min<u32>(cdiv(n ? n : 1, 2048), 512u)), dim3(256), 0, s, src, dst, n, st);
+    SPECK_LAUNCH(copy_offsets_kernel, dim3(std::min<u32>(cdiv(n ? n : 1, 2048), 512u)), dim3(256), 0, s, src, dst, n, st);
 }
 
 // --------------------------------------------------------------------------------
@@ -1145,7 +1145,7 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
     // 64 rows per wave for short rows (g_an_wide_rows: average entries per row up to which; 0 = never)
     const bool wide = g_an_wide_rows && m && nnz_a / m <= g_an_wide_rows;
     auto go = [&](auto kernel, int threads) {
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, s, a_ro, a_col, b_ro, b_col, m, rows_per_block, row_ops,
+        SPECK_LAUNCH(kernel, dim3(blocks), dim3(threads), 0, s, a_ro, a_col, b_ro, b_col, m, rows_per_block, row_ops,
                            row_max_ops, row_col_min, row_col_max, sym_cls, counts, cp, b_sl, st, b_rows, sym_recs, nf_off,
                            expect_nf, chain, a_ro_copy, verdict, bytes_acc, b_nnz);
     };
@@ -1167,11 +1167,11 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
     auto go = [&](auto items) {
         constexpr int I = decltype(items)::value;
         if (sub > 1)
-            hipLaunchKernelGGL((scan_kernel<32, true>), dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, sub, st, chain, a_ro,
+            SPECK_LAUNCH((scan_kernel<32, true>), dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, sub, st, chain, a_ro,
                                row_ops, row_col_min, row_col_max, num_recs, cp, vsize, exact_nnz, expect_g, expect_g_rows,
                                host_mirror, pred_off, pred_off_out, dev_ticket, host_ticket, bytes_acc);
         else
-        hipLaunchKernelGGL((scan_kernel<I, false>), dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, sub, st, chain, a_ro,
+        SPECK_LAUNCH((scan_kernel<I, false>), dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, sub, st, chain, a_ro,
                            row_ops, row_col_min, row_col_max, num_recs, cp, vsize, exact_nnz, expect_g, expect_g_rows,
                            host_mirror, pred_off, pred_off_out, dev_ticket, host_ticket, bytes_acc);
     };

@@ -398,8 +398,9 @@ static void set_dyn_lds(K kernel, u32 bytes)
 {
     // kernels above 64 KiB of LDS need the opt-in (a workgroup may own all 160 KiB on gfx950)
     if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        note_launch_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                           "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
 }
 
 static u32 g_grid_rounds_block = 1, g_grid_rounds_sub = 4;
@@ -435,7 +436,7 @@ static void launch_sym_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
     auto k = sym_hash_kernel<G, CAP, THREADS>;
     const u32 lds = symbolic_lds_bytes(cls);
     set_dyn_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3(grid_for(count, lds, THREADS, cu_count, THREADS / G::SIZE)),
+    SPECK_LAUNCH(k, dim3(grid_for(count, lds, THREADS, cu_count, THREADS / G::SIZE)),
                        dim3(THREADS), lds, s, A, B, w, counts, cls);
 }
 
@@ -494,19 +495,19 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
     const u32 lds = symbolic_lds_bytes(cls);
     switch (cls) {
         case SYM_G8:
-            hipLaunchKernelGGL(sym_esc_kernel<8>, dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B, w,
+            SPECK_LAUNCH(sym_esc_kernel<8>, dim3(grid_for(count, lds, 256, cu_count, 32)), dim3(256), lds, s, A, B, w,
                                counts, cls);
             break;
         case SYM_G16:
-            hipLaunchKernelGGL(sym_esc_kernel<16>, dim3(grid_for(count, lds, 256, cu_count, 16)), dim3(256), lds, s, A, B, w,
+            SPECK_LAUNCH(sym_esc_kernel<16>, dim3(grid_for(count, lds, 256, cu_count, 16)), dim3(256), lds, s, A, B, w,
                                counts, cls);
             break;
         case SYM_R32:
-            hipLaunchKernelGGL(sym_escw_kernel<32>, dim3(grid_for(count, lds, 256, cu_count, 8)), dim3(256), lds, s, A, B, w,
+            SPECK_LAUNCH(sym_escw_kernel<32>, dim3(grid_for(count, lds, 256, cu_count, 8)), dim3(256), lds, s, A, B, w,
                                counts, cls);
             break;
         case SYM_R64:
-            hipLaunchKernelGGL(sym_escw_kernel<64>, dim3(grid_for(count, lds, 256, cu_count, 4)), dim3(256), lds, s, A, B, w,
+            SPECK_LAUNCH(sym_escw_kernel<64>, dim3(grid_for(count, lds, 256, cu_count, 4)), dim3(256), lds, s, A, B, w,
                                counts, cls);
             break;
         case SYM_W128: launch_sym_hash<SubWave<16>, kSymW128Cap, 256>(s, cls, count, A, B, w, counts, cu_count); break;
@@ -517,19 +518,19 @@ void launch_symbolic(hipStream_t s, int cls, u32 count, const u32* a_ro, const u
         case SYM_B32K: launch_sym_hash<Block<1024>, kSymB32KCap, 1024>(s, cls, count, A, B, w, counts, cu_count); break;
         case SYM_BM1: {
             auto k = sym_bitmap_kernel<kSymBm1Words, 256>;
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, A, B,
+            SPECK_LAUNCH(k, dim3(grid_for(count, lds, 256, cu_count, 1)), dim3(256), lds, s, A, B,
                                w, counts, cls);
             break;
         }
         case SYM_BM2: {
             auto k = sym_bitmap_kernel<kSymBm2Words, 1024>;
             set_dyn_lds(k, lds);
-            hipLaunchKernelGGL(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A,
+            SPECK_LAUNCH(k, dim3(grid_for(count, lds, 1024, cu_count, 1)), dim3(1024), lds, s, A,
                                B, w, counts, cls);
             break;
         }
         case SYM_GH:
-            hipLaunchKernelGGL(sym_global_hash_kernel, dim3(grid_for(count, lds, kGhThreads, cu_count, 1)),
+            SPECK_LAUNCH(sym_global_hash_kernel, dim3(grid_for(count, lds, kGhThreads, cu_count, 1)),
                                dim3(kGhThreads), lds, s, A, B, w, counts);
             break;
     }
