@@ -1,7 +1,7 @@
 // runspECK -- the reference's benchmark driver (source/runspECK.cpp:13-32, source/Executor.cpp:13-81,
 // source/RunConfig.cpp:8-23, source/DataLoader.cpp:24-75) on top of the MI355X backend.
 //
-//   runspECK <matrix.mtx | gen:<kind>[:scale[:seed]]> [config.ini] [--gpus N] [--shared-gpu]
+//   runspECK <matrix.mtx | gen:<kind>[:scale[:seed]]> [config.ini] [--gpus N] [--shared-gpu] [--time-library]
 //
 // --gpus N (new: the reference is single-GPU, source/Executor.cpp:25): the driver re-launches itself as N rank
 // processes, one per GPU.  Every rank loads the matrix, multiplies its row range of A (speck_partition_rows: equal
@@ -167,6 +167,87 @@ bool rocsparse_reference(const dCSR<double>& A, const dCSR<double>& B, dCSR<doub
     return true;
 }
 
+// The same-box LIBRARY baseline (role of the reference's cuSPARSE product beside its own, source/Executor.cpp:29-40, here
+// TIMED): rocSPARSE generic SpGEMM on the same device buffers, the reference's protocol -- `warm` untimed and `iters`
+// timed products, work buffer and C allocated once and reused (the way the loop above reuses matOut) -- each product =
+// the nnz stage + the compute stage (rocSPARSE's symbolic + numeric), HIP events around the pair.  Its rows come out
+// UNSORTED (a csrsort would be extra); reported as it is.  Returns mean ms, < 0 on failure.
+double rocsparse_timed(const dCSR<double>& A, const dCSR<double>& B, int warm, int iters, size_t* nnz_out)
+{
+#define RT(expr)                                                                   \
+    do {                                                                           \
+        rocsparse_status _s = (expr);                                              \
+        if (_s != rocsparse_status_success) {                                      \
+            std::printf("rocSPARSE error %d at %s:%d\n", (int)_s, __FILE__, __LINE__); \
+            return -1.0;                                                           \
+        }                                                                          \
+    } while (0)
+    rocsparse_handle h;
+    RT(rocsparse_create_handle(&h));
+    const double alpha = 1.0, beta = 0.0;
+    rocsparse_spmat_descr dA, dB, dC, dD;
+    RT(rocsparse_create_csr_descr(&dA, A.rows, A.cols, A.nnz, A.row_offsets, A.col_ids, A.data, rocsparse_indextype_i32,
+                                  rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    RT(rocsparse_create_csr_descr(&dB, B.rows, B.cols, B.nnz, B.row_offsets, B.col_ids, B.data, rocsparse_indextype_i32,
+                                  rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    unsigned int *c_ro = nullptr, *d_ro = nullptr, *c_col = nullptr;
+    double* c_val = nullptr;
+    if (hipMalloc((void**)&c_ro, (A.rows + 1) * 4) != hipSuccess || hipMalloc((void**)&d_ro, (A.rows + 1) * 4) != hipSuccess ||
+        hipMalloc((void**)&c_col, 16) != hipSuccess || hipMalloc((void**)&c_val, 16) != hipSuccess)
+        return -1.0;
+    (void)hipMemset(c_ro, 0, (A.rows + 1) * 4);
+    (void)hipMemset(d_ro, 0, (A.rows + 1) * 4);
+    RT(rocsparse_create_csr_descr(&dC, A.rows, B.cols, 0, c_ro, c_col, c_val, rocsparse_indextype_i32, rocsparse_indextype_i32,
+                                  rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    RT(rocsparse_create_csr_descr(&dD, A.rows, B.cols, 0, d_ro, c_col, c_val, rocsparse_indextype_i32, rocsparse_indextype_i32,
+                                  rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    size_t bytes = 0;
+    RT(rocsparse_spgemm(h, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, &beta, dD, dC,
+                        rocsparse_datatype_f64_r, rocsparse_spgemm_alg_default, rocsparse_spgemm_stage_buffer_size, &bytes, nullptr));
+    void* buf = nullptr;
+    if (hipMalloc(&buf, bytes ? bytes : 16) != hipSuccess) return -1.0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    int64_t r = 0, c = 0, nnz = 0, cap = 0;
+    double total_ms = 0.0;
+    for (int it = 0; it < warm + iters; ++it) {
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0, nullptr);
+        RT(rocsparse_spgemm(h, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, &beta, dD, dC,
+                            rocsparse_datatype_f64_r, rocsparse_spgemm_alg_default, rocsparse_spgemm_stage_nnz, &bytes, buf));
+        RT(rocsparse_spmat_get_size(dC, &r, &c, &nnz));
+        if (nnz > cap) {  // (first product only: C is reused from then on, like matOut)
+            (void)hipFree(c_col);
+            (void)hipFree(c_val);
+            if (hipMalloc((void**)&c_col, (size_t)nnz * 4) != hipSuccess || hipMalloc((void**)&c_val, (size_t)nnz * 8) != hipSuccess)
+                return -1.0;
+            cap = nnz;
+        }
+        RT(rocsparse_csr_set_pointers(dC, c_ro, c_col, c_val));
+        RT(rocsparse_spgemm(h, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, &beta, dD, dC,
+                            rocsparse_datatype_f64_r, rocsparse_spgemm_alg_default, rocsparse_spgemm_stage_compute, &bytes, buf));
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (it >= warm) total_ms += ms;
+    }
+    if (nnz_out) *nnz_out = (size_t)nnz;
+    (void)hipFree(buf);
+    (void)hipFree(c_ro);
+    (void)hipFree(d_ro);
+    (void)hipFree(c_col);
+    (void)hipFree(c_val);
+    rocsparse_destroy_spmat_descr(dA);
+    rocsparse_destroy_spmat_descr(dB);
+    rocsparse_destroy_spmat_descr(dC);
+    rocsparse_destroy_spmat_descr(dD);
+    rocsparse_destroy_handle(h);
+    return iters > 0 ? total_ms / iters : -1.0;
+#undef RT
+}
+
 CSR<double> load_input(const std::string& path)
 {
     if (path.rfind("gen:", 0) == 0) {
@@ -264,12 +345,13 @@ int main(int argc, char* argv[])
 {
     // ---- options behind the two positional arguments of the reference
     int gpus = 1;
-    bool shared_gpu = false;
+    bool shared_gpu = false, time_library = false;
     std::vector<char*> pos;
     for (int i = 0; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--gpus" && i + 1 < argc) gpus = std::atoi(argv[++i]);
         else if (a == "--shared-gpu") shared_gpu = true;
+        else if (a == "--time-library") time_library = true;
         else pos.push_back(argv[i]);
     }
     const char* env_rank = std::getenv("SPECK_RANK");
@@ -410,6 +492,19 @@ int main(int argc, char* argv[])
                 convert(cpuRef, dCsrReference, 0);
                 storeCSR(cpuRef, dump);
             }
+        }
+        if (time_library) {
+            // --time-library: the rocSPARSE product of the same inputs, same protocol, INSTEAD of the library's own
+            size_t nnz_lib = 0;
+            const double ms = rocsparse_timed(gpuA, gpuB, iterationsWarmup, iterationsExecution, &nnz_lib);
+            if (ms < 0) {
+                std::printf("Error: rocSPARSE SpGEMM failed\n");
+                return 2;
+            }
+            std::cout << std::setw(20) << "rocSPARSE -> NNZ: " << nnz_lib << std::endl;
+            std::cout << std::setw(20) << "rocSPARSE SpGEMM: " << ms << " ms" << std::endl;
+            config.cleanup();
+            return 0;
         }
         Timings timings, warmupTimings, benchTimings;
         int errors = 0;

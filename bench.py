@@ -53,6 +53,18 @@ L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XC
 # LDS atomic issue ceiling, wave-instructions per second for the whole chip: ds_add_f64 takes 20.6 cycles per
 # wave-instruction and CU (scripts/ubench/lds_atomics.hip); 256 CUs at 2.4 GHz
 LDS_ATOMIC_PEAK_GWPS = 256 * 2.4 / 20.6
+# ... and for the MIX a hash kernel issues (round 6, profiles/r06_lds_atomics_ubench.txt): cycles per wave-instruction and CU
+# at a given share of ds_add_f64 among returning ds_cmpst_b32 (random slots): pure compare-and-swap 11.2, 7:1 11.9,
+# 3:1 13.0, 1:1 15.4, pure add 20.7 -- a launch is priced against the rate of ITS mix (piecewise linear in the share)
+LDS_MIX_CYCLES = ((0.0, 11.2), (0.125, 11.9), (0.25, 13.0), (0.5, 15.4), (1.0, 20.7))
+
+
+def lds_atomic_peak_gwps(add_share):
+    a = min(max(add_share, 0.0), 1.0)
+    for (x0, y0), (x1, y1) in zip(LDS_MIX_CYCLES, LDS_MIX_CYCLES[1:]):
+        if a <= x1:
+            return 256 * 2.4 / (y0 + (y1 - y0) * (a - x0) / (x1 - x0))
+    return LDS_ATOMIC_PEAK_GWPS
 # VALU issue ceiling: a wave64 instruction occupies its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
 VALU_PEAK_GWPS = 256 * 4 * 2.4 / 4
 SUITESPARSE_FILES = {"scircuit": "scircuit", "webbase": "webbase-1M", "mac_econ": "mac_econ_fwd500",
@@ -338,11 +350,12 @@ def profile_prepass(job, prof_steps=5):
     return st, kernel_ms, stage_ms, sym_ms, num_ms
 
 
-def ceilings_for(counters, workload, launch_name, ms):
+def ceilings_for(counters, workload, launch_name, ms, products=0):
     """Secondary ceilings of one launch from the committed rocprofv3 --pmc passes of the same command
     (profiles/counters.json; NOT measured in this run -- only the duration is): HBM-side bytes, L1 -> L2 requests,
-    LDS atomic wave-instructions, VALU wave-instructions -- each as a fraction of its peak over `ms`.  A fraction
-    above 1 means counters and duration do not belong together: dropped (None), never printed."""
+    LDS atomic wave-instructions, VALU wave-instructions -- each as a fraction of its peak over `ms`.  The LDS-atomic
+    peak is the one of the launch's own MIX: one ds_add_f64 per product (`products` / 64 wave-instructions), the rest
+    returning compare-and-swaps (lds_atomic_peak_gwps).  Nothing is dropped: a fraction above 1 is printed as it is."""
     c = counters.get(f"{workload}:{COUNTER_KEYS.get(launch_name, 'num_' + launch_name)}")
     if not c or ms <= 0:
         return None
@@ -354,11 +367,13 @@ def ceilings_for(counters, workload, launch_name, ms):
     if "TCP_TCC_READ_REQ_sum" in c:
         l2 = (c.get("TCP_TCC_READ_REQ_sum", 0) + c.get("TCP_TCC_WRITE_REQ_sum", 0)) * 64
         out["l2_frac"] = l2 / sec / 1e9 / L2_PEAK_GBS
-    if "SQ_INSTS_LDS_ATOMIC" in c:
-        out["lds_atomic_frac"] = c["SQ_INSTS_LDS_ATOMIC"] / sec / 1e9 / LDS_ATOMIC_PEAK_GWPS
+    if c.get("SQ_INSTS_LDS_ATOMIC"):
+        share = min(1.0, products / 64.0 / c["SQ_INSTS_LDS_ATOMIC"]) if products else 1.0
+        out["lds_atomic_frac"] = c["SQ_INSTS_LDS_ATOMIC"] / sec / 1e9 / lds_atomic_peak_gwps(share)
+        out["lds_add_share"] = share
     if "SQ_INSTS_VALU" in c:
         out["valu_frac"] = c["SQ_INSTS_VALU"] / sec / 1e9 / VALU_PEAK_GWPS
-    out = {k: (round(v, 4) if v <= 1.0 else None) for k, v in out.items()}
+    out = {k: round(v, 4) for k, v in out.items()}
     if c.get("SQ_LDS_IDX_ACTIVE"):
         out["lds_bank_conflict_ratio"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 3)
     return out or None
@@ -391,15 +406,19 @@ def roofline_blocks(workload, st, kernel_ms, num_ms, b_num):
     if not launches:
         return None, None
     traffic_tab, counters = _load_json("traffic.json"), _load_json("counters.json")
+    all_bytes = sum(x["bytes"] for x in launches) or 1
     for x in launches:
-        x["ceilings"] = ceilings_for(counters, workload, x["name"], x["ms"])
+        # (products of a launch ~ its share of the numeric bytes: 12 of the ~13-26 bytes per product are the product's)
+        x["ceilings"] = ceilings_for(counters, workload, x["name"], x["ms"], st["sum_products"] * x["bytes"] / all_bytes)
         x["traffic"] = traffic_tab.get(f"{workload}:{COUNTER_KEYS.get(x['name'], 'num_' + x['name'])}")
     dom = launches[0]
     ceil = dom["ceilings"] or {}
     named = {"hbm": ceil.get("hbm_measured_frac"), "l2": ceil.get("l2_frac"), "lds_atomic": ceil.get("lds_atomic_frac"),
              "valu": ceil.get("valu_frac")}
     named = {k: v for k, v in named.items() if v is not None}
-    bound = max(named, key=named.get) if named else "hbm"
+    # the ceiling with the highest measured fraction; when none reaches a quarter of its peak the launch is bound by
+    # LATENCY x occupancy (chains of dependent trips), not by any pipe -- said so instead of naming the largest small number
+    bound = (max(named, key=named.get) if max(named.values()) >= 0.25 else "latency") if named else "hbm"
     phase_frac = round(b_num / max(num_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)
     compact = {
         "bound": bound, "kernel": f"numeric:{dom['name']}", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -549,6 +568,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mtx", default=None, help="real MatrixMarket file instead of the stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lib-baseline", action="store_true", help="skip the rocSPARSE SpGEMM timing (apps/runspECK --time-library)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gatherv exchange")
     ap.add_argument("--exchange", choices=("native", "torch"), default="native",
                     help="N>1: speck_gather_* of the C ABI (RCCL inside the library) or torch.distributed")
@@ -612,6 +632,12 @@ def main():
                 detail["exchange_note"] = out["config"]["exchange_note"] = env.exchange_note[:160]
             out["multiply_only"] = res["multiply_only"]
         verdicts.append(short["verified"])
+        if n_gpus == 1 and not args.no_lib_baseline:
+            lb = lib_baseline(args.workload, args.scale, args.seed, args.mtx)
+            out["lib_baseline"] = {k: lb[k] for k in ("kind", "ms")} if lb else None
+            if lb:
+                out["lib_baseline"]["value"] = round(2.0 * res["P"] / (lb["ms"] * 1e-3) / 1e9, 2)
+            detail["lib_baseline"] = lb
     del res
 
     # ---- N = 1: every other single-GPU configuration of BASELINE.json (configs[1..3]), one short object each
@@ -623,6 +649,10 @@ def main():
             Aw, label_w, name_w = load_workload(w, 1.0, args.seed)
             rw = measure(env, Aw, args.configs_steps, 3, gather=False, profile=True, verify=verify_mode(w, Aw), reuse=reuse)
             s, f, _ = config_objects(w, name_w, label_w, Aw, rw, args.configs_steps)
+            if not args.no_lib_baseline:
+                lb = lib_baseline(w, 1.0, args.seed)
+                s["lib_ms"] = lb["ms"] if lb else None      # rocSPARSE SpGEMM, same input and protocol (lib_baseline)
+                f["lib_baseline"] = lb
             entries.append(s)
             full_entries.append(f)
             verdicts.append(s["verified"])
@@ -645,8 +675,11 @@ def main():
     # ---- BASELINE.json configs[4]: the nlpkkt160 stand-in, STRONG scaling, at this N
     if not args.no_config5 and not (args.workload == "nlpkkt" and args.scaling == "strong"):
         A5, label5, name5 = load_workload("nlpkkt", args.config5_scale, args.seed)
-        r5 = measure(env, A5, args.config5_steps, 2, gather=not args.no_gather, profile=False,
+        r5 = measure(env, A5, args.config5_steps, 2, gather=not args.no_gather, profile=n_gpus == 1,
                      verify=verify_mode("nlpkkt", A5), reuse=reuse)
+        roof5 = full5 = None
+        if rank == 0 and n_gpus == 1:
+            _, full5, roof5 = config_objects("nlpkkt", name5, label5, A5, r5, args.config5_steps)
         if rank == 0:
             out["config5"] = {
                 "name": "nlpkkt", "scaling": "strong", "n_gpus": n_gpus, "rows": A5.rows, "products": r5["P"],
@@ -655,6 +688,14 @@ def main():
                 "ms_reuse": round(r5["ms_reuse"], 4) if r5["ms_reuse"] else None,
                 "multiply_only": r5["multiply_only"], "exchange_floor_ms": r5["exchange_floor_ms"], "verified": leg_ok(r5),
             }
+            if roof5:  # (N = 1: the one leg that is HBM-scale carries its fractions too)
+                out["config5"].update(roofline_frac=roof5["frac"], numeric_phase_frac=roof5["numeric_phase_frac"], bound=roof5["bound"],
+                                      kernel=roof5["kernel"])
+                detail["config5_full"] = full5
+            if n_gpus == 1 and not args.no_lib_baseline and args.config5_scale <= 1.0:
+                lb = lib_baseline("nlpkkt", args.config5_scale, args.seed, timeout=420)
+                out["config5"]["lib_ms"] = lb["ms"] if lb else None
+                detail["config5_lib_baseline"] = lb
             detail["config5"] = dict(out["config5"], workload=name5, data=label5, nnzA=A5.nnz, nnzC=r5["nnzC"],
                                      verify=r5["verify"], verify_reuse=r5["verify_reuse"])
             verdicts.append(out["config5"]["verified"])
@@ -714,6 +755,36 @@ def spawn_ranks(n):
             if pr.poll() is None:
                 pr.terminate()
     return worst
+
+
+def lib_baseline(workload, scale, seed, mtx=None, timeout=240):
+    """The same-box LIBRARY baseline: rocSPARSE generic SpGEMM on the same input with the reference's protocol (10 + 10
+    products, buffers reused), timed by apps/runspECK --time-library in a process of its own (this one carries torch's HIP
+    runtime; the driver links /opt/rocm's rocSPARSE).  Role of the cuSPARSE product the reference's driver computes beside
+    its own (source/Executor.cpp:29-40).  None if the driver is missing or fails."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "apps", "runspECK")
+    if not os.path.exists(exe):
+        return None
+    spec = mtx or find_suitesparse(workload) or f"gen:{workload}:{scale}:{seed}"
+    try:
+        with tempfile.NamedTemporaryFile("w", suffix=".ini", delete=False) as f:
+            f.write("IterationsWarmUp=10\nIterationsExecution=10\nTrackCompleteTimes=true\nCompareResult=false\n")
+            ini = f.name
+        r = subprocess.run([exe, spec, ini, "--time-library"], capture_output=True, text=True, timeout=timeout)
+        os.unlink(ini)
+        ms = nnz = None
+        for ln in r.stdout.splitlines():
+            if "rocSPARSE SpGEMM:" in ln:
+                ms = float(ln.split(":")[1].split()[0])
+            if "rocSPARSE -> NNZ:" in ln:
+                nnz = int(ln.split(":")[1])
+        if ms is None:
+            return None
+        return {"kind": "rocsparse_spgemm", "ms": round(ms, 4), "nnzC": nnz, "protocol": "10+10, nnz+compute stages, buffers reused, rows unsorted"}
+    except Exception:
+        return None
 
 
 def cpu_baseline(A, P):

@@ -5,7 +5,10 @@
 #include <cstdint>
 #include <vector>
 
-enum Op { OR_B32, ADD_U32_RTN, CAS_B32, ADD_F32, ADD_F64, ADD_F64_RTN, MAX_U32, ADD_U64 };
+enum Op { OR_B32, ADD_U32_RTN, CAS_B32, ADD_F32, ADD_F64, ADD_F64_RTN, MAX_U32, ADD_U64,
+          // the numeric hash kernels' own mix: K returning compare-and-swaps (u32 keys) per fp64 add (round 6: the ceiling
+          // bench.py prices SQ_INSTS_LDS_ATOMIC against is the mix's, not the slower op's)
+          MIX_1CAS_1ADD, MIX_3CAS_1ADD, MIX_7CAS_1ADD };
 enum Pat { LINEAR, RANDOM, SAME, RANDOM_SMALL };
 
 template <int OP, int PAT>
@@ -37,6 +40,12 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned* sink)
             if (OP == ADD_F64_RTN) acc += (unsigned)atomicAdd(&lds_d[idx], 1.0);
             if (OP == MAX_U32) atomicMax(&lds_u[idx], x);
             if (OP == ADD_U64) atomicAdd(&lds_ull[idx], 1ull);
+            if (OP == MIX_1CAS_1ADD || OP == MIX_3CAS_1ADD || OP == MIX_7CAS_1ADD) {
+                const int period = OP == MIX_1CAS_1ADD ? 2 : (OP == MIX_3CAS_1ADD ? 4 : 8);
+                // (keys in the upper half of the array, values in the lower: as the tables of numeric.hip)
+                if (u % period == period - 1) atomicAdd(&lds_d[idx & 2047], 1.0);
+                else acc += atomicCAS(&lds_u[4096 + idx], 0u, x | 1u);
+            }
         }
     }
     __syncthreads();
@@ -77,5 +86,6 @@ int main()
     R(ADD_F64, LINEAR); R(ADD_F64, RANDOM); R(ADD_F64, RANDOM_SMALL); R(ADD_F64, SAME);
     R(ADD_F64_RTN, RANDOM);
     R(ADD_U64, LINEAR); R(ADD_U64, RANDOM);
+    R(MIX_1CAS_1ADD, RANDOM); R(MIX_3CAS_1ADD, RANDOM); R(MIX_7CAS_1ADD, RANDOM);
     return 0;
 }
