@@ -24,7 +24,7 @@ PASSES=(
 )
 for w in $WORKLOADS; do
   base=${w%_f32}
-  BENCH="python bench.py --no-cpu-baseline --no-config5 --no-configs --no-verify --workload $base --detail gpurun_out/_p_$w/detail.json"
+  BENCH="python bench.py --no-cpu-baseline --no-lib-baseline --no-config5 --no-configs --no-verify --workload $base --detail gpurun_out/_p_$w/detail.json"
   if [ "$base" != "$w" ]; then BENCH="$BENCH --dtype f32"; fi
   rm -rf gpurun_out/_p_$w
   mkdir -p gpurun_out/_p_$w

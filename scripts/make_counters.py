@@ -17,6 +17,7 @@ import sys
 KEYS = [
     # canonical keys = the kernels of the COMPLETE call (what bench.py's line quotes); the kernels only the structure-reuse
     # mode runs carry names of their own and *_reuse keys
+    (r"walk_kernel", "num_walk"),
     (r"nf_dense_kernel<\w+, \d+, true>", "num_numeric_first_reuse"), (r"nf_dense_kernel", "num_numeric_first"), (r"nf_copy_kernel", "num_nfcopy"),
     (r"num_light_kernel<\w+, true", "num_light"), (r"num_light_kernel<\w+, false, true>", "num_light_reuse_verify"),
     (r"num_light_kernel", "num_light_reuse"),

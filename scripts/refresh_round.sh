@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every measured artefact of a round on the GPU box (results under gpurun_out/profiles/, copy them
 # into profiles/):  bash scripts/refresh_round.sh r05
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 WORKLOADS=${2:-"scircuit mac_econ cant webbase nlpkkt mac_econ_f32 cant_f32"}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export PYTHONPATH=$PWD
@@ -10,7 +10,7 @@ mkdir -p $OUT
 bash scripts/collect_counters.sh $ROUND "$WORKLOADS" > $OUT/collect.log 2>&1
 cp $OUT/counters.json $OUT/traffic.json profiles/   # the bench lines read the ceilings of THIS round's passes
 for w in scircuit mac_econ cant webbase uniform nlpkkt; do
-  timeout 600 python bench.py --workload $w --no-cpu-baseline --no-config5 --no-configs --detail $OUT/${ROUND}_bench_${w}_detail.json 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_$w.json
+  timeout 600 python bench.py --workload $w --no-cpu-baseline --no-lib-baseline --no-config5 --no-configs --detail $OUT/${ROUND}_bench_${w}_detail.json 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_$w.json
 done
 # the launch durations of the plain lines against the traces of the same commands under rocprofv3 (<= 5 %)
 for w in scircuit mac_econ cant webbase nlpkkt; do
@@ -19,6 +19,16 @@ for w in scircuit mac_econ cant webbase nlpkkt; do
 done
 timeout 900 python bench.py --detail $OUT/${ROUND}_bench_default_detail.json 2> /dev/null | tail -n 1 > $OUT/${ROUND}_bench_default.json
 wc -c $OUT/${ROUND}_bench_default.json
+# the ONE-WALK complete call (option one_walk, off by default: measured and lost): line + kernel trace per input
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+for w in scircuit mac_econ cant; do
+  rm -rf gpurun_out/_ow
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/_ow -o r -- python bench.py --workload $w --opt one_walk=2 --no-cpu-baseline --no-lib-baseline --no-config5 --no-configs --no-reuse --detail gpurun_out/_ow/detail.json 2> /dev/null | tail -n 1 > $OUT/${ROUND}_onewalk_${w}.json
+  python scripts/rocpd_summary.py $(find gpurun_out/_ow -name "*.db" | head -1) $OUT/${ROUND}_onewalk_${w}_kernel_stats.csv > /dev/null
+done
+rm -rf gpurun_out/_ow
+bash scripts/timeline.sh ${ROUND}_onewalk_scircuit scircuit 12 --no-reuse --no-lib-baseline --opt one_walk=2 > /dev/null 2>&1; cp gpurun_out/timeline/${ROUND}_onewalk_scircuit.txt $OUT/
+bash scripts/timeline.sh ${ROUND}_complete_scircuit scircuit 10 --no-reuse --no-lib-baseline > /dev/null 2>&1; cp gpurun_out/timeline/${ROUND}_complete_scircuit.txt $OUT/
 timeout 300 python scripts/multiwindow_time.py 2>&1 | grep windows > $OUT/${ROUND}_multiwindow_now.txt
 python - <<'PY'
 import json, glob
