@@ -304,10 +304,12 @@ class Job:
             scfg.cleanup()
 
 
-def profile_prepass(job, prof_steps=5):
+def profile_prepass(job, prof_steps=9):
     """Untimed COMPLETE calls with HIP events, each recorded on the stream the launch runs on (the light launches and
     the numeric-first one carry kernel-exact begin / end stamps).  One call collects the algorithmic bytes per class;
-    prof_steps calls with events around every launch; prof_steps calls with one event pair per phase only."""
+    prof_steps calls with events around every launch -- the MEDIAN per launch (round 6: the first profiled calls start
+    on a chip the event records have drained and measured up to 6 % above the kernel-trace average of the same command);
+    prof_steps calls with one event pair per phase only."""
     cfg = job.cfg
     job.step()                           # (allocates C; the next calls are sized from this one like the timed ones)
     cfg.profile_kernels(1)
@@ -316,30 +318,32 @@ def profile_prepass(job, prof_steps=5):
     torch.cuda.synchronize()
     st = cfg.last_stats()
     cfg.set_option("collect_bytes", 0)
-    kernel_ms = {k: 0.0 for k in list(NUM_CLASS_NAMES) + ["light", "numeric_first"]}
-    stage_ms = {"analysis_binning": 0.0, "scan": 0.0, "sym_light": 0.0}
+    kernel_s = {k: [] for k in list(NUM_CLASS_NAMES) + ["light", "numeric_first"]}
+    stage_s = {"analysis_binning": [], "scan": [], "sym_light": []}
     for _ in range(prof_steps):
         job.step()
         s = cfg.last_stats()
         for k in NUM_CLASS_NAMES:
-            kernel_ms[k] += s["num_bin_ms"][k] / prof_steps
-        kernel_ms["light"] += (s["num_light_ms"] + s["num_tiny_ms"]) / prof_steps
+            kernel_s[k].append(s["num_bin_ms"][k])
+        kernel_s["light"].append(s["num_light_ms"] + s["num_tiny_ms"])
         # numeric-first rows: their NUMERIC kernel runs inside the symbolic phase -- a numeric launch
-        if s["sym_bin_rows"]["numeric_first"]:
-            kernel_ms["numeric_first"] += s["sym_bin_ms"]["numeric_first"] / prof_steps
-        stage_ms["analysis_binning"] += s["analysis_ms"] / prof_steps
-        stage_ms["scan"] += s["scan_ms"] / prof_steps
-        stage_ms["sym_light"] += (s["sym_light_ms"] + s["sym_tiny_ms"]) / prof_steps
+        kernel_s["numeric_first"].append(s["sym_bin_ms"]["numeric_first"] if s["sym_bin_rows"]["numeric_first"] else 0.0)
+        stage_s["analysis_binning"].append(s["analysis_ms"])
+        stage_s["scan"].append(s["scan_ms"])
+        stage_s["sym_light"].append(s["sym_light_ms"] + s["sym_tiny_ms"])
+    kernel_ms = {k: float(np.median(v)) for k, v in kernel_s.items()}
+    stage_ms = {k: float(np.median(v)) for k, v in stage_s.items()}
     # the phases, WITHOUT an event between their class launches (mode 2: one event pair per phase)
     cfg.profile_kernels(2)
-    sym_ms = num_ms = 0.0
+    sym_l, num_l = [], []
     for _ in range(prof_steps):
         job.step()
         s = cfg.last_stats()
         # symbolic = analysis + binning + symbolic launches + scan (the reference's countProducts + loadBalanceCounting
         # + globalMapsCounting + spGEMMCounting); the numeric-first kernel is numeric work inside it
-        sym_ms += (s["analysis_ms"] + s["sym_phase_ms"] + s["scan_ms"] - kernel_ms["numeric_first"]) / prof_steps
-        num_ms += (s["num_phase_ms"] + kernel_ms["numeric_first"]) / prof_steps
+        sym_l.append(s["analysis_ms"] + s["sym_phase_ms"] + s["scan_ms"] - kernel_ms["numeric_first"])
+        num_l.append(s["num_phase_ms"] + kernel_ms["numeric_first"])
+    sym_ms, num_ms = float(np.median(sym_l)), float(np.median(num_l))
     cfg.profile_kernels(0)
     kernel_bytes = dict(st["num_bin_bytes"])
     # the algorithmic bytes of the numeric-first rows belong to the launch that computes them; the copy of the
