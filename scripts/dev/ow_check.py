@@ -38,8 +38,8 @@ def run(kind, scale, reuse, calls=4, opts=()):
 
 if __name__ == "__main__":
     allok = True
-    for kind, scale in [("scircuit", 0.05), ("mac_econ", 0.05), ("scircuit", 1.0), ("mac_econ", 1.0), ("uniform", 1.0), ("webbase", 0.1), ("cant", 0.2)]:
+    for kind, scale in [("nlpkkt", 0.01), ("nlpkkt", 0.1), ("scircuit", 0.05), ("mac_econ", 0.05), ("uniform", 1.0), ("webbase", 0.1), ("cant", 0.2)]:
         for reuse in (0, 1):
-            allok &= run(kind, scale, reuse)
+            allok &= run(kind, scale, reuse, opts=(('one_walk', 2),))
     print("ALL OK" if allok else "FAILURES")
     sys.exit(0 if allok else 1)

@@ -69,6 +69,9 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
                  u64 expect_g = ~0ull, u32 expect_g_rows = ~0u, const u32* pred_off = nullptr, u32* pred_off_out = nullptr,
                  u32* dev_ticket = nullptr, u32* host_ticket = nullptr, u64* bytes_acc = nullptr);
 
+template <typename T>
+struct ProductSrc;  // row_groups.hpp
+
 // ---- the one-walk kernel (walk.hip): scan + numeric binning + the numeric walk of the register-class rows, one launch
 struct WalkArgs {
     const u32* a_ro;                                   // A.row_offsets (may be a row-range view: absolute offsets)
@@ -95,6 +98,27 @@ struct WalkArgs {
 void set_walk_debug(u32 tile_rows, u32 flags);
 u32 walk_tile_rows(u32 m);
 u32 walk_max_rows();  // rows(A) up to which the one-walk call exists (the chain holds kChainMaxBlocks tiles)
+
+// ---- the one-walk kernel of the HASH classes (numeric.hip, walk_hash_kernel; chain3.hpp): eight rows per workgroup,
+// accumulated in sub-wave LDS tables sized from the product bound, placed through a three-level chain, sorted and stored
+struct WalkHashArgs {
+    const u32* a_ro;
+    const u32 *row_ops, *row_col_min, *row_col_max;
+    u32 *offsets_out, *pred_off_out;
+    DeviceStats* st;
+    u32* c_col;
+    void* c_val;
+    u64 c_cap;
+    u32 m, max_ops, want_bytes, vsize;
+    u64* bytes_acc;
+    u32 debug;
+    u32 turns;   // consecutive 8-row groups per workgroup (0: the default)
+};
+struct Chain3;
+template <typename T>
+void launch_walk_hash(hipStream_t s, const WalkHashArgs& args, const ProductSrc<T>& src, const Chain3& chain, hipEvent_t e0 = nullptr,
+                      hipEvent_t e1 = nullptr);
+constexpr u32 kWalkHashRows = 8;  // rows per workgroup (two per wave)
 
 // Global-memory buffers of the NUM_G spill path (numeric.hip): per-row plan, per-bucket counters,
 // and two product pools (expanded by column bucket; reduced and sorted).
@@ -236,8 +260,6 @@ template <typename T>
 void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& A, const CsrView<T>& B,
                     const RowWork& w, u32* c_col, T* c_val, int cu_count);
 
-template <typename T>
-struct ProductSrc;  // row_groups.hpp
 template <typename T>
 void launch_walk(hipStream_t s, const WalkArgs& args, const ProductSrc<T>& src, const Chain& chain, hipEvent_t e0 = nullptr,
                  hipEvent_t e1 = nullptr);

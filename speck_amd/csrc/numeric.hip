@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "chain3.hpp"
 #include "device_common.hpp"
 #include "launch.hpp"
 #include "row_groups.hpp"
@@ -397,6 +398,86 @@ __device__ __forceinline__ u32 emit_bitmap_sorted(const G& g, u32* keys, Acc<T>*
         PHASE_MARK(9);
     }
     return emitted;
+}
+
+// The same sort in two halves, for a caller that learns WHERE the row goes only after its ranks are known (walk_hash_kernel:
+// the look-back for the row's offset runs beside the sort): bitmap_rank_slots leaves every slot's key / value / rank in
+// registers (rank 0xFFFFFFFF: empty slot, or a column outside [cmin, cmax]), store_ranked_slots writes them.  One sort
+// window only (range <= W1 * 1024 columns); returns the number of ranked entries.
+template <class G, typename T, u32 CAP, u32 W1>
+__device__ __forceinline__ u32 bitmap_rank_slots(const G& g, const u32* keys, const Acc<T>* vals, u32* S, u32* scan_scratch,
+                                                 u32 cap_row, u32 cmin, u32 cmax, u32 (&k)[CAP / G::SIZE],
+                                                 Acc<T> (&v)[CAP / G::SIZE], u32 (&r)[CAP / G::SIZE])
+{
+    constexpr u32 OWN = CAP / G::SIZE;
+    u32 brank[OWN];
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j) {
+        k[j] = kEmptyKey;
+        v[j] = 0;
+        brank[j] = 0;
+        r[j] = 0xFFFFFFFFu;
+        if (j * G::SIZE < cap_row) {
+            k[j] = keys[j * G::SIZE + g.lane];
+            v[j] = vals[j * G::SIZE + g.lane];
+        }
+    }
+    g.sync();
+    uint2* l1x = reinterpret_cast<uint2*>(S);
+    uint2* mx = reinterpret_cast<uint2*>(S);
+    const u32 ncols = cmax - cmin + 1u;
+    const u32 nw1 = (((ncols + 31) >> 5) + 31) >> 5;
+    for (u32 i = g.lane; i < nw1; i += G::SIZE) l1x[i].x = 0;
+    g.sync();
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j) {
+        if (j * G::SIZE >= cap_row) continue;
+        const u32 d = k[j] - cmin;
+        if (k[j] != kEmptyKey && d < ncols) atomicOr(&l1x[d >> 10].x, 1u << ((d >> 5) & 31));
+    }
+    g.sync();
+    const u32 nocc = bitmap_prefix<G, 2>(g, &l1x[0].x, &l1x[0].y, nw1, scan_scratch);
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j) {
+        if (j * G::SIZE >= cap_row) continue;
+        const u32 d = k[j] - cmin;
+        if (k[j] != kEmptyKey && d < ncols) {
+            const uint2 e = l1x[d >> 10];
+            brank[j] = e.y + __popc(e.x & ((1u << ((d >> 5) & 31)) - 1u));
+        }
+    }
+    g.sync();  // level-1 arrays are dead from here: the masks alias them
+    for (u32 i = g.lane; i < nocc; i += G::SIZE) mx[i].x = 0;
+    g.sync();
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j) {
+        if (j * G::SIZE >= cap_row) continue;
+        const u32 d = k[j] - cmin;
+        if (k[j] != kEmptyKey && d < ncols) atomicOr(&mx[brank[j]].x, 1u << (d & 31));
+    }
+    g.sync();
+    const u32 total = bitmap_prefix<G, 2>(g, &mx[0].x, &mx[0].y, nocc, scan_scratch);
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j) {
+        if (j * G::SIZE >= cap_row) continue;
+        const u32 d = k[j] - cmin;
+        if (k[j] != kEmptyKey && d < ncols) {
+            const uint2 e = mx[brank[j]];
+            r[j] = e.y + __popc(e.x & ((1u << (d & 31)) - 1u));
+        }
+    }
+    return total;
+}
+template <typename T, u32 OWN>
+__device__ __forceinline__ void store_ranked_slots(const u32 (&k)[OWN], const Acc<T> (&v)[OWN], const u32 (&r)[OWN], u32 base,
+                                                   u32 room, u32* __restrict__ c_col, T* __restrict__ c_val)
+{
+#pragma unroll
+    for (u32 j = 0; j < OWN; ++j)
+        if (r[j] < room) {
+            c_col[base + r[j]] = k[j];
+            c_val[base + r[j]] = (T)v[j];
+        }
 }
 
 // A sequence without a symbolic pass (VERIFY) follows a completed replay of ITSELF: the sorted column ids of every row are
@@ -923,6 +1004,175 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
         for (u32 i = (b - cg.first[10]) * 256u + threadIdx.x; i < w.off_n; i += (cg.first[11] - cg.first[10]) * 256u)
             w.off_dst[i] = w.off_src[i];
 }
+
+// ------------------------------------------------------------------ one walk for the hash rows (round 6)
+// Inputs whose rows ALL fit the 256-entry sub-wave table (stencils, meshes: the nlpkkt stand-in -- 8.4 M rows of 729
+// products and 125 entries) are walked ONCE: no symbolic pass, no scan kernel, no read-back.  A workgroup owns EIGHT
+// CONTIGUOUS rows (two per wave, as NUM_W256): every 32-lane group accumulates its row into a table sized from the row's
+// PRODUCT bound (at most 256 slots; bounded probing, so a row with more distinct columns than slots is noticed, not
+// overrun), counts the slots it filled, the workgroup publishes the eight counts' sum, takes the entries of C before it
+// from the three-level chain (chain3.hpp) -- while its waves would otherwise idle through one trip to memory -- and then
+// sorts and stores each row at its place (emit_bitmap_sorted; the row offsets go to scratch like the scan's).  What the
+// table cannot hold (nnz > its slots), a row beyond `max_ops` products, buffers of C that do not hold the product:
+// capacity_miss, the two-phase call re-runs.  Nothing of a previous call is read; the host only CHOOSES this path from the
+// previous call's figures (longest row of C <= 170, as the two-phase NUM_W256 class guarantees; pipeline.hip).
+// Role: the reference's symbolic + scan + numeric passes for these rows (source/GPU/Multiply.cu:488-602, 848-1014).
+// MEASURED AND LOST (option one_walk_hash, off): a fifth of the nlpkkt stand-in 4.29 ms against 4.71 for the two-phase call
+// (the kernel 3.78 ms against 2.78 for the numeric light launch of the same rows), the FULL size 33.1 ms against 24.2 (the
+// kernel 30.7 against 14.9): a group cannot store before every group before it has published its count, so the resident
+// workgroups -- which hold their LDS while they wait -- finish in lock step with their slowest predecessor, and the longer
+// and more variable the gathers (B no longer cache-resident at full size) the more of the chip waits.  DESIGN.md 4.8.
+template <typename T>
+__global__ __launch_bounds__(256) void walk_hash_kernel(ProductSrc<T> src, WalkHashArgs a, Chain3 chain)
+{
+    using G = SubWave<32>;
+    constexpr u32 CAP = kNumW256Cap, NG = 256 / G::SIZE;
+    static_assert(NG == kWalkHashRows, "eight rows per workgroup");
+    constexpr u32 kGroupBytes = num_group_lds<G, T, CAP, 256>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ u32 s_cnt[NG];
+    __shared__ u32 s_bad;
+    __shared__ u64 s_tmp[12];
+    src.rebase(a.a_ro);
+    const G g;
+    const u32 t = threadIdx.x, gid = t / G::SIZE;
+    unsigned char* mine = smem + gid * kGroupBytes;
+    Acc<T>* vals = reinterpret_cast<Acc<T>*>(mine);
+    u32* keys = reinterpret_cast<u32*>(vals + CAP);
+    T* m_av = reinterpret_cast<T*>(keys + CAP);
+    u32* m_incl = reinterpret_cast<u32*>(m_av + G::SIZE);
+    u32* scan_scratch = m_incl + 2 * G::SIZE;
+    RowMeta<T> meta{m_incl, m_incl + G::SIZE, m_av, scan_scratch + scan_scratch_words<G, 256>()};
+    u32* S = reinterpret_cast<u32*>(mine);
+    const u32 ngroups = (a.m + NG - 1u) / NG;
+    // (a call an earlier kernel has declared void computes nothing; the chain still runs so that the last group reports)
+    const bool void_call = a.st->capacity_miss != 0;
+    // ONE 8-row group per workgroup: a group waits only for groups with a lower number, i.e. workgroups DISPATCHED BEFORE
+    // this one (chain.hpp's argument).  Measured and dropped: a persistent grid of exactly the chip's capacity with the
+    // groups taken in turn (6.5 ms instead of 3.7 at a fifth of the nlpkkt stand-in: the input check beside it held wave
+    // slots, part of the grid could not start, and the resident part polled the fabric until it did); several CONSECUTIVE
+    // groups per workgroup (seconds: a workgroup's second group needs the LAST group of the workgroup before it, which is
+    // computed three turns later -- the workgroups run one behind the other).
+    {
+        const u32 grp = blockIdx.x;
+        const u32 row = grp * NG + gid;
+        const bool valid = row < a.m;
+        u32 a0 = 0, a1 = 0, ops = 0, cmin = 0, cmax = 0;
+        if (valid) {
+            a0 = a.a_ro[row];
+            a1 = a.a_ro[row + 1];
+            ops = a.row_ops[row];
+            cmin = a.row_col_min[row];
+            cmax = a.row_col_max[row];
+        }
+        if (t == 0) {
+            s_bad = 0;
+            s_tmp[8] = 0;  // (chain3_finish: the timeout flag; the barrier behind the counts orders it)
+        }
+        bool bad = valid && ops > a.max_ops;
+        const bool walk = valid && !bad && !void_call && ops != 0;
+        // the row's table: the smallest power of two that keeps min(products, class limit) entries at the class load, at
+        // least one slot per lane
+        u32 bits = table_bits(min(ops, kNumW256MaxNnz), SPECK_LOAD_TINY_PCT);
+        bits = min(max(bits, (u32)__builtin_ctz(G::SIZE)), (u32)__builtin_ctz(CAP));
+        const u32 cap_row = 1u << bits;
+        for (u32 q = g.lane; q < cap_row / 4; q += G::SIZE)
+            reinterpret_cast<uint4*>(keys)[q] = make_uint4(kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey);
+        for (u32 q = g.lane; q < cap_row / 2; q += G::SIZE) reinterpret_cast<uint4*>(vals)[q] = make_uint4(0u, 0u, 0u, 0u);
+        g.sync();
+        bool gave_up = false;
+        // (an idle group walks an empty entry range: every lane of the wave takes part in the wave-wide steps)
+        for_each_product<true>(g, src, walk ? a0 : 0u, walk ? a1 : 0u, meta, scan_scratch,
+                               [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
+                                   Acc<T> pa[kBatch];
+#pragma unroll
+                                   for (int u = 0; u < kBatch; ++u) pa[u] = p[u];
+                                   gave_up |= table_accumulate_batch<Acc<T>, true>(keys, vals, bits, c, pa, n);
+                               }, NUM_W256);
+        g.sync();
+        u32 cnt = 0;
+        for (u32 q = g.lane; q < cap_row; q += G::SIZE) cnt += keys[q] != kEmptyKey ? 1u : 0u;
+        cnt = g.reduce_add(cnt, nullptr);
+        bad |= g.ballot(gave_up) != 0;
+        if (!walk) cnt = 0;
+        if (g.lane == 0) {
+            s_cnt[gid] = cnt;
+            if (bad) s_bad = 1;
+        }
+        if (a.want_bytes && a.bytes_acc && g.lane == 0 && cnt)
+            atomicAdd((unsigned long long*)&a.bytes_acc[kMaxClasses + NUM_W256], (unsigned long long)numeric_row_bytes(a1 - a0, ops, cnt, a.vsize));
+        __syncthreads();
+        u32 tile = 0, before_me = 0, tile_max = 0;
+#pragma unroll
+        for (u32 k = 0; k < NG; ++k) {
+            before_me += k < gid ? s_cnt[k] : 0u;
+            tile += s_cnt[k];
+            tile_max = max(tile_max, s_cnt[k]);
+        }
+        const bool tile_bad = s_bad != 0;
+        // my group's count goes out NOW; the rows are ranked (the two-level bitmap sort, a third of a row's time) before
+        // anybody asks for the prefix: by then the groups before this one have published theirs
+        // ... and the words of the groups before mine are REQUESTED now: their trip runs beside the sort as well
+        const Chain3Words<1> pend = chain3_begin(chain, grp, tile);
+        constexpr u32 OWN = CAP / G::SIZE;
+        u32 sk[OWN], sr[OWN];
+        Acc<T> sv[OWN];
+        // (one sort window covers the row: wave-uniform, so that no wave runs both forms)
+        const bool one_window = __ballot(valid && u64(cmax) - cmin + 1u > u64(kW256W1) * 1024u) == 0;
+        if (one_window && !void_call && !tile_bad)
+            bitmap_rank_slots<G, T, CAP, kW256W1>(g, keys, vals, S, scan_scratch, cap_row, cmin, cmax < cmin ? cmin : cmax, sk, sv, sr);
+        bool chain_ok = true;
+        u64 pre = 0;
+        if (!(a.debug & 1u)) pre = chain3_finish(chain, grp, ngroups, tile, pend, s_tmp, &chain_ok);
+        else pre = u64(grp) * 1000u;  // (development: wrong places, no look-back)
+        const bool fits = pre + tile <= a.c_cap && pre + tile <= 0xFFFFFFFFull;
+        if (t == 0) {
+            if (tile_max) atomicMax(&a.st->max_row_nnz_c, tile_max);   // (device-scope atomics: any group may hold the maximum)
+            if (tile_bad || !fits || !chain_ok) atomicOr(&a.st->capacity_miss, 1u);
+            if (grp == ngroups - 1u) {
+                const u64 nnz_c = pre + tile;
+                a.st->nnz_c = nnz_c;
+                if (nnz_c > 0xFFFFFFFFull) a.st->nnz_overflow = 1;
+                if (nnz_c > a.c_cap) atomicOr(&a.st->capacity_miss, 1u);
+                a.st->walk_rows = a.m;
+                if (!chain_ok || __hip_atomic_load(chain.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    a.st->chain_error = 1;
+                    atomicOr(&a.st->capacity_miss, 1u);
+                }
+                a.offsets_out[a.m] = (u32)nnz_c;
+                if (a.pred_off_out) a.pred_off_out[a.m] = (u32)nnz_c;
+            }
+        }
+        // (a truncated prefix: this workgroup places nothing more -- the groups behind it time out likewise and report)
+        if (!chain_ok) return;
+        if (fits && !tile_bad && !void_call) {
+            const u32 base = (u32)pre + before_me;
+            if (valid && g.lane == 0) {
+                a.offsets_out[row] = base;
+                if (a.pred_off_out) a.pred_off_out[row] = base;
+            }
+            // store: at most `cnt` entries leave, whatever B holds (a column outside the row's range got no rank)
+            if (one_window)
+                store_ranked_slots<T, OWN>(sk, sv, sr, base, cnt, a.c_col, static_cast<T*>(a.c_val));
+            else
+                emit_bitmap_sorted<G, T, CAP, kW256W1, CAP, false, true>(g, keys, vals, S, scan_scratch, cap_row, cmin, cmax, base,
+                                                                         a.c_col, static_cast<T*>(a.c_val), NUM_W256, cnt);
+        }
+    }
+}
+
+template <typename T>
+void launch_walk_hash(hipStream_t s, const WalkHashArgs& args, const ProductSrc<T>& src, const Chain3& chain, hipEvent_t e0,
+                      hipEvent_t e1)
+{
+    const u32 groups = (args.m + kWalkHashRows - 1) / kWalkHashRows;
+    const u32 lds = kWalkHashRows * num_group_lds<SubWave<32>, T, kNumW256Cap, 256>();
+    const WalkHashArgs& a = args;
+    const u32 grid = groups;
+    SPECK_LAUNCH_TIMED((walk_hash_kernel<T>), dim3(grid), dim3(256), lds, s, e0, e1, src, a, chain);
+}
+template void launch_walk_hash<double>(hipStream_t, const WalkHashArgs&, const ProductSrc<double>&, const Chain3&, hipEvent_t, hipEvent_t);
+template void launch_walk_hash<float>(hipStream_t, const WalkHashArgs&, const ProductSrc<float>&, const Chain3&, hipEvent_t, hipEvent_t);
 
 // The small classes alone: the merged kernel above takes the register count of its
 // hungriest body (5 waves per SIMD); these bodies need 70 VGPRs, and a launch of their own

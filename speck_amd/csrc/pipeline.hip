@@ -24,6 +24,7 @@
 
 #include "../../include/speck_c_api.h"
 #include "device_common.hpp"
+#include "chain3.hpp"
 #include "guards.hpp"
 #include "launch.hpp"
 #include "row_groups.hpp"
@@ -240,6 +241,14 @@ struct speck_config {
     bool last_was_walk = false;      // the last complete call was one (its nf_entries count the register-class slots too)
     u64 last_nf_entries = 0;         // scratch-pool entries the last complete call's analysis counted
     int walks = 0, walk_misses = 0;
+    // ... and of the HASH classes (numeric.hip, walk_hash_kernel; option one_walk_hash): inputs whose rows all fit the 256-entry
+    // sub-wave table (the previous complete call says so) -- analysis -> walk_hash_kernel -> done
+    int one_walk_hash = 0;           // (0: off -- measured and lost at full size; 1: when the figures fit; 2: + whatever the row mix)
+    u32 walk_hash_debug = 0;
+    void* chain3_buf = nullptr;      // three-level chain of that kernel (chain3.hpp): grow-only
+    size_t chain3_cap_words = 0;
+    u64 chain3_launches = 0;
+    u32 last_max_row_ops = 0;        // longest row (products) of the last complete call
 };
 
 namespace {
@@ -380,12 +389,47 @@ int next_chain(speck_config* c, hipStream_t s, Chain* out)
     *out = ch;
     return SPECK_OK;
 }
+// ... and the three-level chain of the hash one-walk kernel (chain3.hpp) for `groups` workgroups
+int next_chain3(speck_config* c, hipStream_t s, u64 groups, Chain3* out)
+{
+    const size_t words = chain3_words(groups);
+    if (words > c->chain3_cap_words) {
+        if (c->chain3_buf) (void)guarded_free(c->chain3_buf);
+        c->chain3_buf = nullptr;
+        c->chain3_cap_words = 0;
+        const size_t want = words + words / 8;
+        if (guarded_malloc(&c->chain3_buf, want * 8 + 256) != hipSuccess) {
+            (void)hipGetLastError();
+            return SPECK_ERR_OOM;
+        }
+        HIP_TRY(hipMemsetAsync(c->chain3_buf, 0, want * 8 + 256, s));
+        c->chain3_cap_words = want;
+        c->chain3_launches = 0;
+    }
+    Chain3 ch;
+    u64* at = static_cast<u64*>(c->chain3_buf);
+    for (u32 k = 0; k < kChain3Levels; ++k) {
+        ch.l[k] = at;
+        at += chain3_level_words(groups, k);
+    }
+    ch.error = reinterpret_cast<u32*>(static_cast<u64*>(c->chain3_buf) + c->chain3_cap_words);
+    // (the layout depends on `groups`: a word of another launch can only carry ANOTHER tag -- tags are used once per wrap)
+    if (c->chain3_launches % kChainTags == 0 && c->chain3_launches != 0)
+        HIP_TRY(hipMemsetAsync(c->chain3_buf, 0, c->chain3_cap_words * 8, s));
+    ch.tag = (u32)(c->chain3_launches % kChainTags) + 1u;
+    ch.fault = c->chain_fault;
+    c->chain_fault = ~0u;
+    ++c->chain3_launches;
+    *out = ch;
+    return SPECK_OK;
+}
 // a wait of a chain timed out (DeviceStats::chain_error): the call returns SPECK_ERR_HIP; the flags are cleared so that
 // the NEXT call on the config starts clean
 int chain_failed(speck_config* c, hipStream_t s)
 {
     for (int k = 0; k < 2; ++k)
         (void)hipMemsetAsync(static_cast<unsigned char*>(c->chain_buf) + k * kChainBytes + (kChainAggWords + kChainSupWords) * 8, 0, 4, s);
+    if (c->chain3_buf) (void)hipMemsetAsync(static_cast<u64*>(c->chain3_buf) + c->chain3_cap_words, 0, 4, s);
     (void)hipStreamSynchronize(s);
     return SPECK_ERR_HIP;
 }
@@ -1356,6 +1400,91 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     u32 num_mask = 0;
     size_t ev_num_end = 0;
     bool walked = false;
+    // ... first its form for inputs whose rows all fit the sub-wave hash table (walk_hash_kernel, numeric.hip): chosen from
+    // the previous complete call's figures -- longest row of C within the 256-entry class, most rows hash rows -- and
+    // checked row by row on the device
+    {
+        const u32* sl = c->last_sym_counts;
+        const u64 hash_rows = u64(sl[SYM_W128]) + sl[SYM_W256] + sl[SYM_W1K];
+        const u64 groups = (u64(m) + kWalkHashRows - 1) / kWalkHashRows;
+        const bool pays = c->one_walk_hash >= 2 || 2 * hash_rows >= m;
+        if (c->one_walk_hash && pays && c_ready && C->nnz <= 0xFFFFFFFFull && c->spec_valid && c->spec_rows_a == A->rows &&
+            c->spec_rows_b == B->rows && !c->use_user_stream && c->last_max_row_nnz != 0 &&
+            c->last_max_row_nnz <= kNumW256MaxNnz && c->last_max_row_ops <= 4096 && groups <= kChain3MaxGroups) {
+            Chain3 ch3;
+            rc = next_chain3(c, s, groups, &ch3);
+            if (rc != SPECK_OK) return rc;
+            rc = enqueue_front(c, s, A, B, sc, (u32)sizeof(T), ~0ull, kAllSym, kAllNum, true, &tm, nullptr, nullptr, ~0ull, ~0u, 1u, ~0ull,
+                               nullptr);
+            if (rc != SPECK_OK) return rc;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->profile_kernels) {
+                tm.ev_scan = tm.ev;
+                e0 = kernel_event(c, tm.ev++);
+                e1 = kernel_event(c, tm.ev++);
+            }
+            WalkHashArgs wa{};
+            wa.a_ro = A->row_offsets;
+            wa.row_ops = sc.row_ops, wa.row_col_min = sc.row_col_min, wa.row_col_max = sc.row_col_max;
+            wa.offsets_out = sc.offsets;
+            wa.pred_off_out = nullptr;
+            wa.st = c->d_stats;
+            wa.c_col = C->col_ids;
+            wa.c_val = C->data;
+            wa.c_cap = C->nnz;
+            wa.m = m;
+            wa.max_ops = 4096;
+            wa.want_bytes = c->cp.want_bytes;
+            wa.vsize = (u32)sizeof(T);
+            wa.bytes_acc = c->cp.want_bytes ? c->d_bytes : nullptr;
+            wa.debug = c->walk_hash_debug & 0xFFu;
+            wa.turns = c->walk_hash_debug >> 8;
+            const ProductSrc<T> src{sc.b_sl, static_cast<const T*>(A->data), B->col_ids, static_cast<const T*>(B->data), sc.w_sl};
+            launch_walk_hash<T>(s, wa, src, ch3, e0, e1);
+            if (c->profile_kernels) {
+                tm.ev_num = tm.ev;
+                (void)hipEventRecord(kernel_event(c, tm.ev++), s);
+            }
+            launch_copy_offsets(s, sc.offsets, C->row_offsets, m + 1, c->d_stats);
+            ev_num_end = tm.ev;
+            if (c->profile_kernels) (void)hipEventRecord(kernel_event(c, tm.ev++), s);
+            LAUNCHES_OK();
+            rc = read_stats(c, s);
+            if (rc != SPECK_OK) return rc;
+            if (c->h_stats->a_invalid) return SPECK_ERR_INVALID;
+            bool b_bad = false;
+            rc = b_is_invalid(&b_bad);
+            if (rc != SPECK_OK) return rc;
+            if (b_bad) return SPECK_ERR_UNSORTED;
+            const bool ok = !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz &&
+                            c->h_stats->sum_products != 0;
+            ++(ok ? c->walks : c->walk_misses);
+            if (ok) {
+                publish_counts(c, s);
+                c->last.one_walk = 2;
+                c->last.num_bin_rows[NUM_W256] = m;  // (every row went through the 256-entry sub-wave body)
+                t->spGEMMCounting = 0.f;
+                t->spGEMMNumeric = st.lap();
+                // the arena holds no numeric records / lists of this call: a reuse sequence is planned from a two-phase
+                // call only; the figures this path was chosen by are refreshed
+                c->last_max_row_nnz = c->h_stats->max_row_nnz_c;
+                c->last_max_row_ops = c->h_stats->max_row_ops;
+                c->last_key_valid = false;
+                c->arena_key_valid = false;
+                c->pred_valid = false;
+                drop_plan(c);
+                rc = finish_complete();
+                if (rc != SPECK_OK) return rc;
+                if (c->profile_kernels) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    publish_kernel_times(c, tm, ev_num_end);
+                }
+                return SPECK_OK;
+            }
+            validate_started = false;  // (the two-phase call checks B again)
+            tm = Timing{};
+        }
+    }
     if (c->one_walk && c_ready && C->nnz <= 0xFFFFFFFFull && c->spec_valid && c->spec_rows_a == A->rows &&
         c->spec_rows_b == B->rows && m <= walk_max_rows() && !c->use_user_stream) {
         const u32* sc_last = c->last_sym_counts;
@@ -1641,6 +1770,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     c->last_sym_mask = mask_of(c->h_stats->sym.count, SYM_CLASSES);
     c->last_num_mask = num_mask;
     c->last_max_row_nnz = c->h_stats->max_row_nnz_c;
+    c->last_max_row_ops = c->h_stats->max_row_ops;
     std::memcpy(c->last_sym_counts, c->h_stats->sym.count, sizeof(c->last_sym_counts));
     std::memcpy(c->last_num_counts, c->h_stats->num.count, sizeof(c->last_num_counts));
     c->last_key = make_key<T>(c, A, B, C, s);
@@ -1807,6 +1937,7 @@ int speck_config_destroy(speck_config* c)
     if (c->gpred.off) (void)guarded_free(c->gpred.off);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->chain_buf) (void)hipFree(c->chain_buf);
+    if (c->chain3_buf) (void)guarded_free(c->chain3_buf);
     if (c->d_bytes) (void)hipFree(c->d_bytes);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->h_ticket) (void)hipHostFree(c->h_ticket);
@@ -1866,6 +1997,8 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "analysis_wide_rows") set_analysis_wide_rows((u32)value), forget(true);
     else if (n == "eager_speculate") c->eager_speculate = value != 0;
     else if (n == "one_walk") c->one_walk = (int)value;
+    else if (n == "one_walk_hash") c->one_walk_hash = (int)value;
+    else if (n == "walk_hash_debug") c->walk_hash_debug = (u32)value;
     else if (n == "chain_fault") c->chain_fault = (u32)value;
     else if (n == "guard_bytes") {
         // debug (guards.hpp): canary zones of `value` bytes around / inside everything allocated FROM NOW ON -- the

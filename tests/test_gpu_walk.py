@@ -285,3 +285,91 @@ def test_the_chain_makes_progress_beside_a_stream_that_fills_the_chip():
             torch.cuda.synchronize()
     finally:
         cfg.cleanup()
+
+
+# ---------------------------------------------------------------- the one-walk kernel of the hash classes (option one_walk_hash)
+@pytest.fixture
+def hcfg():
+    c = sa.spECKConfig.initialize(0)
+    c.set_option("reuse", 0)
+    c.set_option("one_walk_hash", 2)
+    yield c
+    c.cleanup()
+
+
+def test_hash_walk_call_matches_the_oracle(hcfg):
+    """numeric.hip: walk_hash_kernel -- eight rows per workgroup accumulated in sub-wave tables sized from the product
+    bound, placed through the three-level chain (chain3.hpp), sorted and stored: no symbolic pass, no scan."""
+    A = to_po(sa.gen_matrix("nlpkkt", 0.01, 3, signed=True))
+    R, ab = po.spgemm(A, A)
+    dA = sa.dCSR.from_host(to_sa(A))
+    dC = sa.dCSR()
+    sa.MultiplyspECK(dA, dA, dC, hcfg)
+    assert hcfg.last_stats()["one_walk"] == 0
+    for _ in range(3):
+        _scribble(dC)
+        sa.MultiplyspECK(dA, dA, dC, hcfg)
+        assert hcfg.last_stats()["one_walk"] == 2, hcfg.last_stats()
+        _matches(dC, R, ab)
+    # fp32, a rectangular B, rows of every small size incl. empty ones and single entries
+    rng = np.random.default_rng(2)
+    A2 = fast_random_csr(70001, 3000, 9, 91)
+    B2 = fast_random_csr(3000, 40000, 12, 92)
+    A32 = po.HostCSR(A2.rows, A2.cols, A2.row_offsets, A2.col_ids, A2.data.astype(np.float32))
+    B32 = po.HostCSR(B2.rows, B2.cols, B2.row_offsets, B2.col_ids, B2.data.astype(np.float32))
+    R32, ab32 = po.spgemm_f64_of(A32, B32)
+    dA2, dB2 = sa.dCSR.from_host(to_sa(A32)), sa.dCSR.from_host(to_sa(B32))
+    dC2 = sa.dCSR(np.float32)
+    for i in range(3):
+        sa.MultiplyspECK(dA2, dB2, dC2, hcfg)
+        assert hcfg.last_stats()["one_walk"] == (2 if i else 0)
+        _matches(dC2, R32, ab32, TOL32)
+
+
+def test_hash_walk_rows_that_outgrow_the_table_fall_back(hcfg):
+    """The path is CHOSEN from the previous call's longest row of C (<= 170: the 256-entry class); a row that has more
+    distinct columns than its table has slots now is noticed by the bounded probing, the call is declared void and the
+    two-phase call re-runs: exact either way."""
+    A = fast_random_csr(20000, 4000, 8, 101)
+    B1 = fast_random_csr(4000, 60000, 10, 102)               # rows of C up to ~100 entries
+    dA = sa.dCSR.from_host(to_sa(A))
+    dC = sa.dCSR()
+    for i in range(3):
+        dB = sa.dCSR.from_host(to_sa(B1))
+        sa.MultiplyspECK(dA, dB, dC, hcfg)
+        assert hcfg.last_stats()["one_walk"] == (2 if i else 0)
+        _assert_matches_oracle(dC, A, B1)
+    B2 = fast_random_csr(4000, 60000, 60, 103)               # same shapes, rows of C of several hundred entries
+    dB = sa.dCSR.from_host(to_sa(B2))
+    sa.MultiplyspECK(dA, dB, dC, hcfg)
+    st = hcfg.last_stats()
+    assert st["one_walk"] == 0 and st["walk_misses"] == 1
+    _assert_matches_oracle(dC, A, B2)
+    sa.MultiplyspECK(dA, dB, dC, hcfg)                        # ... and the figures now rule the path out
+    assert hcfg.last_stats()["one_walk"] == 0 and hcfg.last_stats()["walk_misses"] == 1
+    _assert_matches_oracle(dC, A, B2)
+
+
+@pytest.mark.parametrize("how", ["ends_swapped", "duplicates", "beyond_cols", "shuffled"])
+def test_hash_walk_call_survives_a_b_that_is_not_sorted(how):
+    A = to_po(sa.gen_matrix("nlpkkt", 0.005, 5, signed=True))
+    Bx = _hostile_b(A, how, np.random.default_rng(5))
+    cfg = sa.spECKConfig.initialize(0)
+    try:
+        cfg.set_option("reuse", 0)
+        cfg.set_option("one_walk_hash", 2)
+        dA, dB = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(A))
+        dC = sa.dCSR()
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+        sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert cfg.last_stats()["one_walk"] == 2
+        assert _lib.load().speck_dcsr_update(C_.byref(dB._c), None, np.ascontiguousarray(Bx.col_ids).ctypes.data, None, 8) == 0
+        with pytest.raises(sa.SpeckError) as e:
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        assert e.value.status == 8
+        assert _lib.load().speck_dcsr_update(C_.byref(dB._c), None, np.ascontiguousarray(A.col_ids).ctypes.data, None, 8) == 0
+        for _ in range(2):
+            sa.MultiplyspECK(dA, dB, dC, cfg)
+        _assert_matches_oracle(dC, A, A)
+    finally:
+        cfg.cleanup()
