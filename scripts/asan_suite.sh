@@ -24,7 +24,8 @@ export UBSAN_OPTIONS=print_stacktrace=1:log_path=$PWD/gpurun_out/asan/ubsan_$MOD
 rm -f gpurun_out/asan/asan_$MODE.* gpurun_out/asan/ubsan_$MODE.*
 LOG=gpurun_out/asan/$MODE.log
 if [ "$MODE" = cpu ]; then
-  LD_PRELOAD=$RT timeout 1500 python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider > $LOG 2>&1
+  # (no device for this process even on a GPU box: ROCm's ASan runtime aborts as soon as the HIP runtime allocates)
+  HIP_VISIBLE_DEVICES=-1 ROCR_VISIBLE_DEVICES=-1 LD_PRELOAD=$RT timeout 1500 python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider > $LOG 2>&1
   rc=$?
   /opt/rocm/bin/hipcc -std=c++17 -O1 -g -fsanitize=address,undefined -Ispeck_amd/csrc tests/cpp/test_gather_layout.cpp -o gpurun_out/asan/test_gather_layout >> $LOG 2>&1 \
     && gpurun_out/asan/test_gather_layout >> $LOG 2>&1
