@@ -188,9 +188,10 @@ def test_walk_call_survives_a_b_that_is_not_sorted(how):
         cfg.cleanup()
 
 
-@pytest.mark.parametrize("rows", [64 * 4096, 64 * 4096 + 1])
+@pytest.mark.parametrize("rows", [64 * 4096, 64 * 4096 + 1, 256 * 4096 + 1])
 def test_walk_tiles_at_the_capacity_of_the_chain(wcfg, rows):
-    """4096 tiles of 64 rows (kChainMaxBlocks, chain.hpp) and one row more (the tiles double)."""
+    """4096 tiles of 64 rows (kChainMaxBlocks, chain.hpp), one row more (the tiles double), and the first row count
+    whose tiles are 512 rows (two rows per thread in the tile kernel)."""
     A = fast_random_csr(rows, 3000, 3, 61)
     B = fast_random_csr(3000, 4000, 4, 62)
     dA, dB = sa.dCSR.from_host(to_sa(A)), sa.dCSR.from_host(to_sa(B))
