@@ -112,7 +112,6 @@ struct WalkHashArgs {
     u32 m, max_ops, want_bytes, vsize;
     u64* bytes_acc;
     u32 debug;
-    u32 turns;   // consecutive 8-row groups per workgroup (0: the default)
 };
 struct Chain3;
 template <typename T>

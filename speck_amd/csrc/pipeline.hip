@@ -1437,8 +1437,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             wa.want_bytes = c->cp.want_bytes;
             wa.vsize = (u32)sizeof(T);
             wa.bytes_acc = c->cp.want_bytes ? c->d_bytes : nullptr;
-            wa.debug = c->walk_hash_debug & 0xFFu;
-            wa.turns = c->walk_hash_debug >> 8;
+            wa.debug = c->walk_hash_debug;
             const ProductSrc<T> src{sc.b_sl, static_cast<const T*>(A->data), B->col_ids, static_cast<const T*>(B->data), sc.w_sl};
             launch_walk_hash<T>(s, wa, src, ch3, e0, e1);
             if (c->profile_kernels) {
