@@ -137,6 +137,15 @@ constexpr u32 kNumD1Cols = 4096;   // rows up to this column range are NUM_D1 / 
 constexpr u32 kNumD1Win = 2560;    // NUM_D1's LDS window (wider rows take two windows): no more LDS than NUM_W512 /
                                    //   NUM_B2K, which share the merged light launch with it (5 instead of 4 workgroups per CU)
 constexpr u32 kNumD2Cols = 16384;
+// NUM_B8K rows in COLUMN SLICES (numeric.hip, num_sliced_body; ClassifyParams::slice_ops): the row's products are counted
+// per bin of a column histogram that lives where the 2 Ki table's accumulators will, the bins are cut into slices that
+// cannot hold more distinct columns than that table takes, and the slices are accumulated / sorted / stored one after
+// the other -- a heavy row holds 30 KiB of LDS and four waves instead of 61-106 KiB and eight.
+constexpr u32 kSliceBins = 4096;      // bins of the histogram (= 2 x kNumB2KCap words)
+constexpr u32 kSliceMaxWidth = 512;   // columns per bin at most
+constexpr u32 kSliceMaxCols = kSliceBins * kSliceMaxWidth;  // cols(B) up to 2 Mi
+constexpr u32 kSliceMax = 48;         // slices of a row at most
+constexpr u32 kSliceMaxOps = 49152;   // ... which a row of this many products cannot exceed (a slice takes >= 1229 of them)
 
 // Tunables that travel to the classifying kernels.
 struct ClassifyParams {
@@ -157,6 +166,8 @@ struct ClassifyParams {
                             //   per bitmap window; 0 = off
     u32 want_bytes;         // accumulate the per-class algorithmic byte counts (profiling)
     u32 one_walk;           // one-walk call (walk.hip): the rows of the register classes take a slot of the scratch pool
+    u32 slice_ops;          // NUM_B8K rows are produced in column slices (num_sliced_body): rows of up to this many
+                            //   products are NUM_B8K (kSliceMaxOps; 0 = off: the two workgroup(512) launches)
     u32 sym_allowed;        // classes whose kernels are part of this launch sequence; a row
     u32 num_allowed;        //   outside them raises DeviceStats::capacity_miss (graph replay)
 };
@@ -243,7 +254,7 @@ __host__ __device__ inline u8 classify_numeric(u32 len_a, u32 ops, u32 nnz, u32 
     if (p.num_w256 && nnz <= kNumW256MaxNnz) return NUM_W256;
     if (nnz <= kNumW512MaxNnz) return NUM_W512;
     if (nnz <= kNumB2KMaxNnz) return NUM_B2K;
-    if (nnz <= kNumB8KMaxNnz) return NUM_B8K;
+    if (nnz <= kNumB8KMaxNnz && (p.slice_ops == 0 || ops <= p.slice_ops)) return NUM_B8K;
     const u64 passes = (range + kNumD2Cols - 1) / kNumD2Cols;
     if (passes > p.num_global_passes) return NUM_G;
     return NUM_D2;

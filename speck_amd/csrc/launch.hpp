@@ -178,6 +178,7 @@ struct RowWork {
     // ... and WITHOUT a symbolic pass for the rows of the hash / dense classes of the numeric light launch
     // (ReplayPlan::num_verify): their numeric bodies check the nnz themselves (numeric.hip, VERIFY) -- one walk per row.
     u32 verify_numeric;
+    u32 sliced;             // the NUM_B8K rows go through num_sliced_kernel (ClassifyParams::slice_ops != 0)
 };
 
 #ifdef __HIPCC__

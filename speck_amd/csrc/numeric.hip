@@ -667,6 +667,166 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
 
 // (NUM_G8 / NUM_G16, expand / sort / compress in registers: num_esc_body in esc_rows.hpp)
 
+constexpr u32 kW256W1 = 256;   // 256 Ki columns per sort window
+constexpr u32 kW512W1 = 768;   // 768 Ki columns per sort window (its level-1 pairs fill the 6 KiB table exactly)
+constexpr u32 kB2KW1 = 1024;   // 1 Mi columns per sort window
+constexpr u32 kB8KW1 = 2048;  // 2 Mi columns per sort window
+
+// ------------------------------------------------------------------ NUM_B8K in column slices (round 6)
+// A row of 1 741 .. 6 963 entries used to own a 4 Ki / 8 Ki table -- 61 / 106 KiB of LDS and eight waves for ~40 us, one
+// or two such rows per CU: on the webbase stand-in the 6 k rows of this class held more LDS-time than the 36 k NUM_B2K
+// rows with twice their products, and the numeric phase is bound by exactly that.  Here the row keeps the
+// 30 KiB / four waves of a NUM_B2K row and is produced in COLUMN SLICES, one after the other:
+//   1. the row's products are counted per bin of a column histogram (kSliceBins bins of 2^shift columns over
+//      [cmin, cmax]; the bins live where the table's accumulators will);
+//   2. a bin holds at most min(products, width) distinct columns; with P the running sum of these bounds, bin i belongs to
+//      slice (P_i - 1) / C, C = capacity + 1 - (largest bound) -- a slice then sums to <= capacity (its first bin starts
+//      above k C - bound, its last ends at or below (k + 1) C), every bin decides alone, no sequential cutting;
+//   3. per slice: clear the table, walk the row's products again and accumulate those whose column falls into the slice
+//      (the walk re-reads B from L1 / L2: the row was read a moment ago), sort (emit_bitmap_sorted over the slice's columns
+//      only) and store behind the previous slice -- slices are column-ordered, the row comes out sorted.
+// The table cannot overflow whatever B holds (a product outside [cmin, cmax] lands in no slice), so plain probing is safe;
+// VERIFY (replayed sequence without a symbolic pass): nothing is stored beyond the row's room, the total is compared.
+// Host: ClassifyParams::slice_ops / RowWork::sliced, for cols(B) <= kSliceMaxCols; rows with more products than
+// kSliceMaxOps (more slices than the cut arrays hold) take the dense-window / spill classes.
+// Role: the reference gives such rows its largest shared-memory maps or the global ones
+// (include/GPU/spECK_HashSpGEMM.cuh:1300-1436, source/GPU/Multiply.cu:700-760).
+// MEASURED AND LOST (option slice_rows, off; profiles/r06_sliced_webbase.txt): the webbase stand-in 1.164 -> 1.234 ms
+// complete, 0.79 -> 0.94 replayed.  The 6 018 rows of the class take 782 us in this kernel (beside the light launch, which
+// they slow from 536 to 700 us) against 592 + 166 us in the two workgroup(512) launches: a row is walked 1 + S times
+// (S = 2 .. 5), every walk is a few barrier-separated windows of four waves, and what these rows cost is not the LDS they
+// hold but the LATENCY of each such step -- a row takes ~100 us this way against ~40.
+constexpr u32 num_sliced_lds(u32 group_bytes) { return group_bytes + (2u * (kSliceMax + 1u) + 3u) / 4u * 16u; }
+
+template <typename T, bool VERIFY = false>
+__device__ __forceinline__ void num_sliced_body(unsigned char* smem, const ProductSrc<T>& src, const RowWork& w,
+                                                u32* __restrict__ c_col, T* __restrict__ c_val, int cls, u32 bidx, u32 nblk,
+                                                u32 hint = kNoCount)
+{
+    using G = Block<256>;
+    constexpr u32 CAP = kNumB2KCap, CAPMAX = kNumB2KMaxNnz;
+    static_assert(kSliceBins * 4u == CAP * sizeof(Acc<T>), "the histogram takes the place of the accumulators");
+    static_assert(kSliceMaxWidth <= (CAPMAX + 1u) / 2u, "a bin's bound never exceeds a slice's quota (slice ids rise by one)");
+    static_assert(kSliceMaxOps / (CAPMAX + 1u - kSliceMaxWidth) + 2u <= kSliceMax, "a row's slices fit the cut arrays");
+    const G g;
+    Acc<T>* vals = reinterpret_cast<Acc<T>*>(smem);
+    u32* keys = reinterpret_cast<u32*>(vals + CAP);
+    T* m_av = reinterpret_cast<T*>(keys + CAP);
+    u32* m_incl = reinterpret_cast<u32*>(m_av + G::SIZE);
+    u32* scan_scratch = m_incl + 2 * G::SIZE;
+    RowMeta<T> meta{m_incl, m_incl + G::SIZE, m_av, scan_scratch + scan_scratch_words<G, 256>()};
+    u32* s_cut = reinterpret_cast<u32*>(smem + num_group_lds<G, T, CAP, 256>());  // first bin of slice k
+    u32* s_pref = s_cut + kSliceMax + 1;                                           // bound of the slices before k
+    u32* hist = reinterpret_cast<u32*>(smem);
+    u32* S = reinterpret_cast<u32*>(smem);
+    const u32 t = threadIdx.x;
+    RowCursor cur = open_list<false>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 4u) != 0);
+    if (cur.miss) return;
+    while (cur.more()) {
+        const RowRec rec = cur.take();
+        const u32 span_row = rec.cmax - rec.cmin;  // (columns - 1: no overflow for a row that reaches every column)
+        u32 shift = 0;
+        while ((span_row >> shift) >= kSliceBins) ++shift;
+        if ((1u << shift) > kSliceMaxWidth) {  // (column ids beyond cols(B): the input check rejects the call)
+            if (t == 0) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
+            continue;
+        }
+        // (a column outside [cmin, cmax] -- a B the input check is about to reject -- counts in the LAST bin of the row:
+        //  every slice starts at or below cmax, and no slice ever takes such a product)
+        const u32 last_bin = span_row >> shift;
+        for (u32 q = t; q < kSliceBins / 4; q += G::SIZE) reinterpret_cast<uint4*>(hist)[q] = make_uint4(0u, 0u, 0u, 0u);
+        g.sync();
+        for_each_product<false>(g, src, rec.a0, rec.a1, meta, scan_scratch,
+                                [&](const u32(&c)[kBatch], const T(&)[kBatch], u32 n) {
+#pragma unroll
+                                    for (int u = 0; u < kBatch; ++u)
+                                        if ((u32)u < n) atomicAdd(&hist[min((c[u] - rec.cmin) >> shift, last_bin)], 1u);
+                                }, cls);
+        // (for_each_product ends behind a barrier)
+        constexpr u32 PER = kSliceBins / G::SIZE;
+        static_assert(PER % 4 == 0, "bins are read 16 bytes at a time");
+        const u32 width = 1u << shift;
+        u32 b[PER], sum = 0, mx = 0;
+#pragma unroll
+        for (u32 q = 0; q < PER / 4; ++q) {
+            const uint4 h = reinterpret_cast<const uint4*>(hist)[t * (PER / 4) + q];
+            b[4 * q] = min(h.x, width), b[4 * q + 1] = min(h.y, width), b[4 * q + 2] = min(h.z, width), b[4 * q + 3] = min(h.w, width);
+        }
+#pragma unroll
+        for (u32 i = 0; i < PER; ++i) sum += b[i], mx = max(mx, b[i]);
+        mx = wave_reduce_max(mx);
+        if (lane_id() == 0) s_cut[t >> 6] = mx;
+        u32 total;
+        u32 run = block_exclusive_scan<256>(sum, scan_scratch, &total);  // (its barriers publish s_cut[0..3] as well)
+        mx = max(max(s_cut[0], s_cut[1]), max(s_cut[2], s_cut[3]));
+        g.sync();
+        const u32 quota = CAPMAX + 1u - max(mx, 1u);
+        const u32 nslices = total ? (total - 1u) / quota + 1u : 0u;
+        if (nslices > kSliceMax) {  // (cannot happen to a row the classifier let in; a replayed sequence on other inputs)
+            if (t == 0) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
+            continue;
+        }
+        u32 sid_prev = run ? (run - 1u) / quota : 0u;
+        if (t == 0) s_cut[0] = 0u, s_pref[0] = 0u;
+        if (t == G::SIZE - 1u) s_pref[nslices] = total;
+#pragma unroll
+        for (u32 i = 0; i < PER; ++i) {
+            run += b[i];
+            const u32 sid = run ? (run - 1u) / quota : 0u;
+            if (sid != sid_prev) s_cut[sid] = t * PER + i, s_pref[sid] = run - b[i];
+            sid_prev = sid;
+        }
+        g.sync();
+        u32 emitted = 0;
+        for (u32 k = 0; k < nslices; ++k) {
+            const u32 lo = rec.cmin + (s_cut[k] << shift);
+            const u32 last = k + 1u < nslices ? rec.cmin + (s_cut[k + 1u] << shift) - 1u : rec.cmax;  // (inclusive)
+            const u32 cols_m1 = last - lo;
+            u32 bits = table_bits(s_pref[k + 1u] - s_pref[k], SPECK_LOAD_PCT);
+            bits = min(max(bits, (u32)__builtin_ctz(G::SIZE)), (u32)__builtin_ctz(CAP));
+            bits = (u32)__builtin_amdgcn_readfirstlane((int)bits);
+            const u32 cap_row = 1u << bits, mask = cap_row - 1u;
+            for (u32 q = t; q < cap_row / 4; q += G::SIZE)
+                reinterpret_cast<uint4*>(keys)[q] = make_uint4(kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey);
+            for (u32 q = t; q < cap_row / 2; q += G::SIZE) reinterpret_cast<uint4*>(vals)[q] = make_uint4(0u, 0u, 0u, 0u);
+            g.sync();
+            for_each_product<true>(g, src, rec.a0, rec.a1, meta, scan_scratch,
+                                   [&](const u32(&c)[kBatch], const T(&p)[kBatch], u32 n) {
+                                       u32 slot[kBatch], old[kBatch];
+                                       bool in[kBatch];
+#pragma unroll
+                                       for (int u = 0; u < kBatch; ++u) {
+                                           in[u] = (u32)u < n && c[u] - lo <= cols_m1;
+                                           slot[u] = (c[u] * 0x9E3779B1u) >> (32u - bits);
+                                           old[u] = kEmptyKey;
+                                           if (in[u]) old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, c[u]);
+                                       }
+#pragma unroll
+                                       for (int u = 0; u < kBatch; ++u) {
+                                           if (!in[u]) continue;
+                                           if (old[u] != kEmptyKey && old[u] != c[u]) {
+                                               const u32 step = probe_step(c[u], 32u - bits);
+                                               u32 inc = kFirstProbeInc ? kFirstProbeInc : step;
+                                               do {
+                                                   slot[u] = (slot[u] + inc) & mask;
+                                                   inc = step;
+                                                   old[u] = atomicCAS(&keys[slot[u]], kEmptyKey, c[u]);
+                                               } while (old[u] != kEmptyKey && old[u] != c[u]);
+                                           }
+                                           atomicAdd(&vals[slot[u]], (Acc<T>)p[u]);
+                                       }
+                                   }, cls);
+            const u32 room = rec.nnz - min(rec.nnz, emitted);
+            emitted += emit_bitmap_sorted<G, T, CAP, kB2KW1, CAPMAX, true, VERIFY>(g, keys, vals, S, scan_scratch, cap_row, lo, last,
+                                                                                  rec.base + emitted, c_col, c_val, cls, room);
+            g.sync();
+        }
+        if constexpr (VERIFY) {
+            if (emitted != rec.nnz) const_cast<DeviceStats*>(w.st)->capacity_miss = 1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ NUM_D1/D2
 template <typename T, u32 WCOLS, int THREADS>
 constexpr u32 num_dense_lds()
@@ -923,6 +1083,15 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, co
                                                                    gridDim.x);
 }
 
+template <typename T, bool VERIFY = false>
+__global__ __launch_bounds__(256) void num_sliced_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w, u32* __restrict__ c_col,
+                                                         T* __restrict__ c_val, int cls)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    src.rebase(a_ro);
+    num_sliced_body<T, VERIFY>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
+}
+
 template <typename T, u32 WCOLS, int THREADS, bool VERIFY = false>
 __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                             u32* __restrict__ c_col,
@@ -951,10 +1120,6 @@ __global__ __launch_bounds__(256) void num_escw_kernel(ProductSrc<T> src, const 
     num_escw_body<T, L, 256>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
 }
 
-constexpr u32 kW256W1 = 256;   // 256 Ki columns per sort window
-constexpr u32 kW512W1 = 768;   // 768 Ki columns per sort window (its level-1 pairs fill the 6 KiB table exactly)
-constexpr u32 kB2KW1 = 1024;   // 1 Mi columns per sort window
-constexpr u32 kB8KW1 = 2048;  // 2 Mi columns per sort window
 
 // WITH_ESC = false: the launch of a sequence whose register-class rows are finished in its symbolic phase (fused
 // replay) -- those bodies are not even compiled in, and the kernel carries another NAME than the launch of an eager
@@ -1807,6 +1972,16 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
             // two launches over the class: the rows of the lower half fit a half-size table, whose
             // workgroups run two per CU (the full table owns 106 of a CU's 160 KiB)
             // (a handful of rows cannot fill the CUs anyway: one launch, one row's latency less)
+            if (w.sliced) {  // in column slices of the 2 Ki table (num_sliced_body)
+                const u32 sl = num_sliced_lds(num_group_lds<Block<256>, T, kNumB2KCap, 256>());
+                if (w.verify_numeric)
+                    SPECK_LAUNCH((num_sliced_kernel<T, true>), dim3(grid_for(count, sl, 256, cu_count, 1)), dim3(256), sl, s, A, B, w,
+                                 c_col, c_val, cls);
+                else
+                    SPECK_LAUNCH((num_sliced_kernel<T, false>), dim3(grid_for(count, sl, 256, cu_count, 1)), dim3(256), sl, s, A, B, w,
+                                 c_col, c_val, cls);
+                break;
+            }
             if (w.verify_numeric) {  // (a sequence without a symbolic pass: the verifying forms of the same launches)
                 if (count * 2 < (u32)cu_count) {
                     launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, 0, true>(

@@ -705,6 +705,7 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
     cp.esc16 = (c->cp.esc16 && B->cols <= (1ull << 26)) ? 1u : 0u;  // (column << 6 | product number) fits 32 bits
     cp.esc_fused = c->capture_fused ? 1u : 0u;
     cp.one_walk = c->capture_one_walk ? 1u : 0u;
+    cp.slice_ops = (c->cp.slice_ops && u64(B->cols) <= kSliceMaxCols) ? c->cp.slice_ops : 0u;  // (as enqueue_back launches)
     if (c->capture_one_walk) {  // (the walk kernel takes the register-class rows and moves the numeric-first ones itself)
         cp.sym_allowed |= kSymEscMask;
         cp.num_allowed |= kNumEscMask | (1u << NUM_NFCOPY);
@@ -845,6 +846,7 @@ int enqueue_back(speck_config* c, hipStream_t s, const speck_dcsr* A, const spec
     CsrView<T> Bv{B->row_offsets, B->col_ids, static_cast<const T*>(B->data), (u32)B->rows,
                   (u32)B->cols};
     RowWork w = make_work(c, sc, c->spill, m);
+    w.sliced = (c->cp.slice_ops && u64(B->cols) <= kSliceMaxCols) ? 1u : 0u;  // (as enqueue_front classifies)
     // the staged offsets -> C.row_offsets: by extra workgroups of the numeric light launch when there is one, else by a
     // (guarded) copy of its own
     if (w.off_n && !(num_mask & kNumLightMask)) {
@@ -1906,6 +1908,8 @@ int speck_config_create(int device, speck_config** out)
     c->cp.sym_w128 = 1;    // rows of 52..102 products: 16 lanes per row
     c->cp.num_w256 = 1;    // rows of 86..170 entries: 32 lanes per row
     c->cp.want_bytes = 0;
+    c->cp.slice_ops = 0;   // option slice_rows: NUM_B8K rows in column slices of the 2 Ki table (num_sliced_body) -- measured
+                           //   and lost on the webbase stand-in (1.16 -> 1.23 ms), off
     *out = c;
     return SPECK_OK;
 }
@@ -2022,6 +2026,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "sym_w128") c->cp.sym_w128 = value != 0, forget(true);
     else if (n == "sym_g8") c->cp.sym_g8 = value != 0, forget(true);
     else if (n == "esc16") c->cp.esc16 = value != 0, forget(true);
+    else if (n == "slice_rows") c->cp.slice_ops = value ? kSliceMaxOps : 0u, forget(true);
     else if (n == "esc32") c->cp.esc32 = value != 0, forget(true);
     else if (n == "esc64") c->cp.esc64 = value != 0, forget(true);
     else if (n == "num_g8") c->cp.num_g8 = value != 0, forget(true);

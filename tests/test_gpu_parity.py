@@ -1304,6 +1304,8 @@ def _hostile_cases():
                              [("sym", "wave1k"), ("num", "block2k")]),
         "block_hash_8k": (lambda: (fast_random_csr(200, 6000, 64, 3), fast_random_csr(6000, 300000, 64, 4)), {},
                           [("sym", "block4k"), ("num", "block8k")]),
+        "block_hash_8k_sliced": (lambda: (fast_random_csr(200, 6000, 64, 3), fast_random_csr(6000, 300000, 64, 4)),
+                                 {"slice_rows": 1}, [("sym", "block4k"), ("num", "block8k")]),
         "block16k_spill": (lambda: (fast_random_csr(100, 5000, 100, 71, jitter=False),
                                     fast_random_csr(5000, 300000, 100, 72, jitter=False)),
                            {"sym_bitmap_ratio": 0}, [("sym", "block16k"), ("num", "global")]),
