@@ -180,7 +180,7 @@ __device__ __forceinline__ void num_esc_body(unsigned char* smem, const ProductS
     unsigned char* mine = smem + gid * num_esc_group_lds<T, L>();
     RowCursor cur = open_list<FUSED>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
     // (a replayed sequence that an earlier kernel has declared void walks nothing)
-    if (cur.miss) return;
+    if (wave_void(cur.miss)) return;
     while (cur.more()) {
         const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         u32 place = rec.base, room = 0xFFFFFFFFu;

@@ -322,7 +322,7 @@ __device__ __forceinline__ void num_escw_body(unsigned char* smem, const Product
     unsigned char* mine = smem + gid * num_escw_group_lds<T, L>();
     RowCursor cur = open_list<FUSED>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
     // (a replayed sequence that an earlier kernel has declared void walks nothing)
-    if (cur.miss) return;
+    if (wave_void(cur.miss)) return;
     while (cur.more()) {
         const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         u32 place = rec.base, room = 0xFFFFFFFFu;
@@ -356,7 +356,7 @@ __device__ __forceinline__ void sym_escw_body(unsigned char* smem, const Product
     const EscEnds<L> ends{reinterpret_cast<uint2*>(s_off + L)};
     RowCursor cur = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
     // (a replayed sequence that an earlier kernel has declared void walks nothing)
-    if (cur.miss) return;
+    if (wave_void(cur.miss)) return;
     const u32 gl = g.lane;
     while (cur.more()) {
         const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)

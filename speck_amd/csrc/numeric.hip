@@ -74,7 +74,7 @@ __device__ __forceinline__ void num_direct_body(unsigned char* smem, const Produ
         rs = row_slice(hint, bidx, nblk, THREADS, 0u, (w.xcd_aware & 1u) != 0);
         if (rs.idx + threadIdx.x < rs.end) first_rec = *class_rec_at(w.recs, w.m, NUM_DIRECT, rs.idx + threadIdx.x);
     }
-    if (miss) return;
+    if (block_void(miss)) return;
     const bool spec_ok = hinted && count == hint;
     if (!spec_ok) rs = row_slice(count, bidx, nblk, THREADS, 0u, (w.xcd_aware & 1u) != 0);
     for (u32 first = rs.idx; first < rs.end; first += rs.stride) {
@@ -596,7 +596,7 @@ __device__ __forceinline__ void num_hash_body(unsigned char* smem, const Product
     u32* S = reinterpret_cast<u32*>(mine);
     RowCursor cur = open_list<false>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
     // (a replayed sequence that an earlier kernel has declared void walks nothing)
-    if (cur.miss) return;
+    if (group_void(g, cur.miss)) return;
     while (cur.more()) {
         PHASE_BEGIN(cls);
         const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
@@ -721,7 +721,7 @@ __device__ __forceinline__ void num_sliced_body(unsigned char* smem, const Produ
     u32* S = reinterpret_cast<u32*>(smem);
     const u32 t = threadIdx.x;
     RowCursor cur = open_list<false>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 4u) != 0);
-    if (cur.miss) return;
+    if (block_void(cur.miss)) return;
     while (cur.more()) {
         const RowRec rec = cur.take();
         const u32 span_row = rec.cmax - rec.cmin;  // (columns - 1: no overflow for a row that reaches every column)
@@ -851,7 +851,7 @@ __device__ __forceinline__ void num_dense_body(unsigned char* smem, const Produc
     u32* scratch = pref + WORDS + 2 * THREADS;
     RowMeta<T> meta{pref + WORDS, pref + WORDS + THREADS, m_av, scratch + THREADS / 64 + 2};
     RowCursor cur = open_list<false>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
-    if (cur.miss) return;
+    if (block_void(cur.miss)) return;
     for (u32 i = threadIdx.x; i < WCOLS; i += THREADS) vals[i] = 0;
     for (u32 i = threadIdx.x; i < WORDS; i += THREADS) bm[i] = 0;
     __syncthreads();
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
     // and this kernel's time is ~ floor + latency / (waves per SIMD) -- cant stand-in, range 2187: 6 instead of
     // 4 workgroups per CU.
     const u32 WCOLS = wcols, WORDS = WCOLS / 32;
-    if (w.st->capacity_miss) return;  // the scratch pool of this (replayed) sequence is too small
+    if (block_void(w.st->capacity_miss)) return;  // the scratch pool of this (replayed) sequence is too small
     if (w.st->sym.count[SYM_NF] == 0) return;  // eager path: launched for every class, rows or not
     src.rebase(a_ro);
     using G = Block<THREADS>;
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
 template <typename T>
 __global__ __launch_bounds__(256) void nf_copy_kernel(RowWork w, u32* __restrict__ c_col, T* __restrict__ c_val)
 {
-    if (w.st->capacity_miss) return;
+    if (block_void(w.st->capacity_miss)) return;
     const u32 count = min(w.st->num.count[NUM_NFCOPY], w.m);
     const u32* __restrict__ s_col = w.nf_col;
     const T* __restrict__ s_val = static_cast<const T*>(w.nf_val);
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(256) void walk_hash_kernel(ProductSrc<T> src, WalkH
     u32* S = reinterpret_cast<u32*>(mine);
     const u32 ngroups = (a.m + NG - 1u) / NG;
     // (a call an earlier kernel has declared void computes nothing; the chain still runs so that the last group reports)
-    const bool void_call = a.st->capacity_miss != 0;
+    const bool void_call = block_void(a.st->capacity_miss);  // (one decision per workgroup: row_groups.hpp)
     // ONE 8-row group per workgroup: a group waits only for groups with a lower number, i.e. workgroups DISPATCHED BEFORE
     // this one (chain.hpp's argument).  Measured and dropped: a persistent grid of exactly the chip's capacity with the
     // groups taken in turn (6.5 ms instead of 3.7 at a fifth of the nlpkkt stand-in: the input check beside it held wave
@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(1024) void num_spill_plan_kernel(RowWork w, int cls
     __shared__ u32 s_scan[1024 / 64 + 2];
     __shared__ u64 s_run_p;
     __shared__ u32 s_run_b, s_run_f;
-    if (w.st->capacity_miss) return;
+    if (block_void(w.st->capacity_miss)) return;
     const u32 count = min(w.st->num.count[cls], w.m);
     if (threadIdx.x == 0) {
         s_run_p = 0;
@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_count_kernel(ProductS
     u32* win = scratch + kGWalkThreads / 64 + 2;
     u32* hist = win + win_words<G>();
     RowMeta<T> meta{m_incl, m_incl + kGWalkThreads, nullptr, win};
-    if (w.st->capacity_miss) return;
+    if (block_void(w.st->capacity_miss)) return;
     src.rebase(a_ro);
     const u32 count = min(w.st->num.count[cls], w.m);
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(256) void num_spill_offsets_kernel(RowWork w, int c
     __shared__ u32 s_map[256];
     __shared__ u32 s_bc[kGMaxBuckets];  // products per bucket of the row (this workgroup owns them all)
     __shared__ u32 s_lo[kGMaxBuckets], s_hi[kGMaxBuckets];  // column span of every bucket
-    if (w.st->capacity_miss) return;
+    if (block_void(w.st->capacity_miss)) return;
     const u32 count = min(w.st->num.count[cls], w.m);
     for (u32 idx = blockIdx.x; idx < count; idx += gridDim.x) {
         const GRowPlan pl = w.spill.plan[idx];
@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(Produc
     u32* lbase = hist + kGMaxBuckets;
     unsigned short* cell2b = reinterpret_cast<unsigned short*>(lbase + kGMaxBuckets);
     RowMeta<T> meta{m_incl, m_incl + kGWalkThreads, m_av, win};
-    if (w.st->capacity_miss) return;
+    if (block_void(w.st->capacity_miss)) return;
     src.rebase(a_ro);
     u32* pcol = w.spill.pcol[0];
     T* pval = static_cast<T*>(w.spill.pval[0]);
@@ -1665,7 +1665,7 @@ __global__ __launch_bounds__(THREADS) void num_spill_reduce_kernel(RowWork w, in
     static_assert(kGDenseCols * sizeof(Acc<T>) + 2 * (kGDenseCols / 32) * 4 <= CAP * (sizeof(Acc<T>) + 4),
                   "the dense fallback window aliases the table");
     static_assert(u64(N_HI) * 100 <= u64(CAP) * 85, "load factor <= 0.85");
-    if (w.st->capacity_miss) return;
+    if (block_void(w.st->capacity_miss)) return;
     const u32* pcol = w.spill.pcol[0];
     const T* pval = static_cast<const T*>(w.spill.pval[0]);
     u32* ocol = w.spill.pcol[1];
@@ -1766,7 +1766,7 @@ __global__ __launch_bounds__(256) void num_spill_copy_kernel(RowWork w, u32* __r
     __shared__ u32 s_red[256 / 64 + 2];
     using G = Block<256>;
     const G g;
-    if (w.st->capacity_miss) return;
+    if (block_void(w.st->capacity_miss)) return;
     const u32* ocol = w.spill.pcol[1];
     const T* oval = static_cast<const T*>(w.spill.pval[1]);
     const u32 count = min(w.st->num.count[cls], w.m);

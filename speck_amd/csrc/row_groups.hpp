@@ -162,6 +162,27 @@ __device__ __forceinline__ RowSlice row_slice(u32 count, u32 bidx, u32 nblk, u32
     return RowSlice{lo + j * groups + gid, hi, nb_x * groups};
 }
 
+// DeviceStats::capacity_miss ("this launch sequence is void") can be raised by ANOTHER workgroup or kernel while this workgroup
+// starts -- a verifying body that meets a row it was not planned for, a scan that finds another nnz(C).  The lanes that
+// synchronise with each other must take ONE decision on it: a wave that leaves while the others of its workgroup stay takes
+// its share of every cooperative LDS write with it -- staging entries of the A row that hold whatever the previous kernel
+// left in LDS, a gather at a wild index (found by the hostile-B suite under canary zones: nf_dense_kernel of a replayed
+// sequence, a memory fault once in ~10 runs).  Workgroup groups: thread 0 decides for all (one barrier); sub-wave groups: per wave.
+__device__ __forceinline__ bool block_void(u32 miss)
+{
+    __shared__ u32 s_void;  // thread 0's reading of the flag is the workgroup's: one LDS word, one barrier
+    if (threadIdx.x == 0) s_void = miss;
+    __syncthreads();
+    return s_void != 0u;
+}
+__device__ __forceinline__ bool wave_void(u32 miss) { return __ballot(miss != 0u) != 0ull; }
+template <class G>
+__device__ __forceinline__ bool group_void(const G&, u32 miss)
+{
+    if constexpr (G::kIsBlock) return block_void(miss);
+    else return wave_void(miss);
+}
+
 // First step of every class body: which rows of the class' list this group walks, and the first record.
 // The list lives at a fixed place (launch.hpp, class_rec_at), so with a host-known count of the class (ClassGrid::cnt) the
 // first record is requested AT ONCE, next to the device-side class table that confirms the count: a workgroup of the

@@ -49,7 +49,7 @@ __device__ __forceinline__ void sym_hash_body(unsigned char* smem, const Product
     RowMeta<float> meta{tab + CAP, tab + CAP + G::SIZE, nullptr, scratch + sym_scratch_words<G, THREADS>()};
     RowCursor cur = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & (G::kIsBlock ? 4u : 1u)) != 0);
     // (a replayed sequence that an earlier kernel has declared void walks nothing)
-    if (cur.miss) return;
+    if (group_void(g, cur.miss)) return;
     while (cur.more()) {
         const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         static_assert(CAP % (4 * G::SIZE) == 0, "the key set is cleared 16 bytes per lane and step");
@@ -86,7 +86,7 @@ __device__ __forceinline__ void sym_esc_body(unsigned char* smem, const ProductS
     u32* s_off = reinterpret_cast<u32*>(smem + gid * sym_esc_group_lds<L>());
     RowCursor cur = open_list<true>(w, cls, hint, bidx, nblk, NG, gid, (w.xcd_aware & 8u) != 0);
     // (a replayed sequence that an earlier kernel has declared void walks nothing)
-    if (cur.miss) return;
+    if (wave_void(cur.miss)) return;
     const u32 gl = g.lane;
     while (cur.more()) {
         const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
@@ -138,7 +138,7 @@ __device__ __forceinline__ void sym_bitmap_body(unsigned char* smem, const Produ
     RowMeta<float> meta{bm + WORDS, bm + WORDS + THREADS, nullptr, scratch + THREADS / 64 + 2};
     constexpr u64 kWindowCols = u64(WORDS) * 32;
     RowCursor cur = open_list<true>(w, cls, hint, bidx, nblk, 1u, 0u, (w.xcd_aware & 2u) != 0);
-    if (cur.miss) return;
+    if (block_void(cur.miss)) return;
     while (cur.more()) {
         const RowRec rec = cur.take();  // (its successor's record is requested now: RowCursor)
         u32 total = 0;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kGhThreads) void sym_global_hash_kernel(ProductSrc<
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // a replayed sequence whose scratch pool no longer holds the key sets (sym_scatter_kernel raised the flag)
     // must not clear or probe them: the eager path re-runs with a pool of the right size
-    if (w.st->capacity_miss) return;
+    if (block_void(w.st->capacity_miss)) return;
     src.rebase(a_ro);
     using G = Block<kGhThreads>;
     const G g;

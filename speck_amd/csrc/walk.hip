@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kWalkThreads, 7) void walk_kernel(ProductSrc<T> src
     const u32 r0 = blockIdx.x * TR, nrows = min(TR, a.m - r0);
     // (a call an earlier kernel has declared void -- the pool does not hold the slots, a class nobody launched has rows --
     //  computes and moves nothing; its offsets still go through the chain so that the last tile can report)
-    const bool void_call = a.st->capacity_miss != 0;
+    const bool void_call = block_void(a.st->capacity_miss);  // (one decision per workgroup: row_groups.hpp)
     T* const pool_val = static_cast<T*>(a.pool_val);
     T* const c_val = static_cast<T*>(a.c_val);
 

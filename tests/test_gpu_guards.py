@@ -115,3 +115,19 @@ def test_hostile_and_randomised_inputs_under_canary_zones(select):
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "guard_bytes" not in r.stderr, tail
+
+
+def test_a_sequence_declared_void_while_its_workgroups_start():
+    """A workgroup of a replayed sequence reads DeviceStats::capacity_miss when it starts; another workgroup of the same
+    launch may raise it at that moment (nf_dense_kernel with direct placement on a B overwritten in place: a row whose nnz
+    is no longer what its place in C was made for).  Round 6 found waves of ONE workgroup taking different decisions: the
+    ones that stayed gathered B through staging entries the ones that left never wrote -- whatever the previous kernel had
+    left in LDS, e.g. the 40 Mi-column ids of the global-key-set input -- and the process died of a memory fault once in
+    ~10 runs of exactly this sequence of tests (row_groups.hpp, block_void: one decision per workgroup).  Repeated here,
+    under canary zones, each time in a fresh process."""
+    env = dict(os.environ, SPECK_GUARD_BYTES="4096", PYTHONPATH=ROOT)
+    for attempt in range(6):
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k",
+                            "test_every_kernel_family_survives_a_b_that_is_not_sorted and (global_key_set or numeric_first)",
+                            os.path.join(ROOT, "tests", "test_gpu_parity.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "10 passed" in r.stdout, (attempt, (r.stdout + r.stderr)[-2000:])
