@@ -28,6 +28,12 @@ LIB := speck_amd/libspeck_amd_ubsan.so
 SANFLAGS := -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize=function -Xarch_host -fno-omit-frame-pointer -Xarch_host -g -shared-libsan
 HIPFLAGS += $(SANFLAGS)
 LDSAN := -fsanitize=undefined -shared-libsan
+else ifdef POISON
+# make POISON=1: every kernel poisons its LDS first (device_common.hpp, poison_lds) -- libspeck_amd_poison.so
+OSUF := .poison.o
+LIB := speck_amd/libspeck_amd_poison.so
+HIPFLAGS += -DSPECK_POISON_LDS
+LDSAN :=
 else
 OSUF := .o
 LIB := speck_amd/libspeck_amd.so
@@ -35,7 +41,12 @@ LDSAN :=
 endif
 OBJS := $(HIP_SRCS:.hip=$(OSUF)) $(CPP_SRCS:.cpp=$(OSUF))
 
+# (the variant libraries -- ASAN / UBSAN / POISON -- are built alone: the driver and the oracle belong to the plain build)
+ifeq ($(OSUF),.o)
 all: $(LIB) oracle apps
+else
+all: $(LIB)
+endif
 
 $(CSRC)/%$(OSUF): $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/speck_c_api.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -55,6 +66,6 @@ apps: $(LIB)
 	      -L/opt/rocm/lib -lrocsparse -Wl,-rpath,'$$ORIGIN/../speck_amd' -Wl,-rpath,/opt/rocm/lib; fi
 
 clean:
-	rm -f $(OBJS) $(LIB) $(CSRC)/*.asan.o $(CSRC)/*.ubsan.o speck_amd/libspeck_amd_asan.so speck_amd/libspeck_amd_ubsan.so apps/runspECK
+	rm -f $(OBJS) $(LIB) $(CSRC)/*.asan.o $(CSRC)/*.ubsan.o $(CSRC)/*.poison.o speck_amd/libspeck_amd_asan.so speck_amd/libspeck_amd_ubsan.so speck_amd/libspeck_amd_poison.so apps/runspECK
 	$(MAKE) -s -C oracle clean
 .PHONY: all oracle apps clean

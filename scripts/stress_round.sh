@@ -12,6 +12,7 @@ run single_b 300 4002 esc32=0
 run single_c 300 4003 overlap_analysis=0 eager_speculate=0
 run single_d 300 4004 reuse=0
 run single_w 300 4005 reuse=0 one_walk=2
+run single_s 300 4006 slice_rows=1
 run turns_a 1500 4101 interleave=4
 run turns_b 1500 4102 interleave=3 esc64=0
 run turns_c 1000 4103 interleave=5 nf_min_ops=1
@@ -23,6 +24,7 @@ STRESS_HOSTILE=1 run hostile_b 1000 8102 interleave=4 num_verify=2
 STRESS_HOSTILE=1 STRESS_REPEAT=2 run hostile_c 500 8103 interleave=3 esc_fused=0
 STRESS_HOSTILE=1 STRESS_REPEAT=4 run hostile_d 800 8104 interleave=5
 STRESS_HOSTILE=1 STRESS_REPEAT=2 run hostile_w 600 8105 interleave=3 reuse=0 one_walk=2
+STRESS_HOSTILE=1 STRESS_REPEAT=2 run hostile_s 600 8106 interleave=3 slice_rows=1
 # ... and under canary zones: a touched zone turns a call into SPECK_ERR_HIP, which the tool counts as a failure
 export SPECK_GUARD_BYTES=4096
 run guard_single 300 9001
@@ -30,6 +32,7 @@ run guard_turns 800 9002 interleave=4
 STRESS_HOSTILE=1 STRESS_REPEAT=3 run guard_hostile_a 600 9003 interleave=3
 STRESS_HOSTILE=1 run guard_hostile_b 600 9004 interleave=4 num_verify=2
 STRESS_HOSTILE=1 STRESS_REPEAT=2 run guard_hostile_w 500 9005 interleave=3 reuse=0 one_walk=2
+STRESS_HOSTILE=1 STRESS_REPEAT=2 run guard_hostile_s 500 9006 interleave=3 slice_rows=1
 (time python -m pytest tests -m gpu -x -q -p no:cacheprovider --deselect tests/test_gpu_guards.py) > gpurun_out/stress/${R}_guard_full_suite.log 2>&1
 echo "guard_full_suite rc=$? $(tail -n 4 gpurun_out/stress/${R}_guard_full_suite.log | head -n 1)"
 unset SPECK_GUARD_BYTES

@@ -415,6 +415,25 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* warp_sums, u32* 
     __syncthreads();
     return base + incl - v;
 }
+// make POISON=1 (libspeck_amd_poison.so, SPECK_LIB=...): every kernel starts by filling the workgroup's WHOLE LDS allocation
+// (static + dynamic: the dispatch packet's group_segment_size) with a word no count, offset or index can be mistaken for.
+// LDS keeps what the previous kernel on that CU left in it; a body that reads a word it never wrote works by accident
+// until the previous kernel was another one (round 6: the staging entries of waves that had left their workgroup early,
+// row_groups.hpp block_void).  With the poison such a read gathers at a wild address or fails its parity test at once.
+#ifdef SPECK_POISON_LDS
+__device__ __forceinline__ void poison_lds()
+{
+    const u32 bytes = ((const __attribute__((address_space(4))) u32*)__builtin_amdgcn_dispatch_ptr())[7];  // group_segment_size
+    const u32 nt = blockDim.x * blockDim.y * blockDim.z;
+    const u32 t = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    for (u32 b = t * 4u; b + 4u <= bytes; b += nt * 4u) asm volatile("ds_write_b32 %0, %1" ::"v"(b), "v"(0xFFFFFFF1u) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+#define SPECK_POISON() ::speck::poison_lds()
+#else
+#define SPECK_POISON()
+#endif
 #endif  // __HIPCC__
 
 }  // namespace speck

@@ -43,6 +43,7 @@ __global__ void compare_kernel(const u32* __restrict__ ro_a, const u32* __restri
                                u32 rows, int compare_data, double rel_tol,
                                unsigned long long* __restrict__ mismatches /*[2]: structure, values*/)
 {
+    SPECK_POISON();
     const u32 lane = lane_id();
     const u64 wave = (u64(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const u64 nwaves = (u64(gridDim.x) * blockDim.x) >> 6;
@@ -71,6 +72,7 @@ __global__ void compare_kernel(const u32* __restrict__ ro_a, const u32* __restri
 __global__ void expand_rows_kernel(const u32* __restrict__ ro, u32 rows, u32 base,
                                    u32* __restrict__ row_of)
 {
+    SPECK_POISON();
     const u32 lane = lane_id();
     const u64 wave = (u64(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const u64 nwaves = (u64(gridDim.x) * blockDim.x) >> 6;
@@ -82,6 +84,7 @@ __global__ void expand_rows_kernel(const u32* __restrict__ ro, u32 rows, u32 bas
 
 __global__ void iota_kernel(u32* p, u32 n)
 {
+    SPECK_POISON();
     for (u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += u64(gridDim.x) * blockDim.x)
         p[i] = (u32)i;
 }
@@ -91,6 +94,7 @@ __global__ void transpose_gather_kernel(const u32* __restrict__ perm, const u32*
                                         const T* __restrict__ val, u32 nnz,
                                         u32* __restrict__ t_col, T* __restrict__ t_val)
 {
+    SPECK_POISON();
     for (u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; i < nnz; i += u64(gridDim.x) * blockDim.x) {
         const u32 src = perm[i];
         t_col[i] = row_of[src];
@@ -102,6 +106,7 @@ __global__ void transpose_gather_kernel(const u32* __restrict__ perm, const u32*
 __global__ void offsets_from_sorted_kernel(const u32* __restrict__ keys, u32 nnz, u32 cols,
                                            u32* __restrict__ t_ro)
 {
+    SPECK_POISON();
     for (u64 c = u64(blockIdx.x) * blockDim.x + threadIdx.x; c <= cols; c += u64(gridDim.x) * blockDim.x) {
         u32 lo = 0, hi = nnz;
         while (lo < hi) {
@@ -137,6 +142,7 @@ __device__ __forceinline__ u32 slice_begin(u32 n, u32 b)
 __global__ __launch_bounds__(kRadixThreads) void radix_hist_kernel(const u32* __restrict__ keys, u32 n, u32 shift,
                                                                   u32* __restrict__ hist)
 {
+    SPECK_POISON();
     __shared__ u32 s_cnt[256];
     s_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(kRadixThreads) void radix_hist_kernel(const u32* __
 
 __global__ __launch_bounds__(1024) void radix_scan_kernel(u32* __restrict__ hist)
 {
+    SPECK_POISON();
     __shared__ u32 s_scan[1024 / 64 + 1];
     constexpr u32 per = 256 * kRadixBlocks / 1024;
     u32* mine = hist + threadIdx.x * per;
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(kRadixThreads) void radix_scatter_kernel(const u32*
                                                                      u32* __restrict__ keys_out,
                                                                      u32* __restrict__ vals_out)
 {
+    SPECK_POISON();
     constexpr int NW = kRadixThreads / 64;
     __shared__ u32 s_base[256];        // where the next key of each digit goes (this workgroup's share of the output)
     __shared__ u32 s_wave[NW][256];    // keys of each digit seen by each wave in the current tile

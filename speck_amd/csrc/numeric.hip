@@ -942,6 +942,7 @@ template <typename T, int THREADS, bool DIRECT = false>
 __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                            u32* __restrict__ counts, u32 wcols)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // The window is as wide as the widest numeric-first row of the previous identical call / of the analysis
     // read-back (a multiple of 256 columns), not kNumD1Cols: the launch holds 160 KiB / LDS workgroups per CU,
@@ -1040,6 +1041,7 @@ __global__ __launch_bounds__(THREADS) void nf_dense_kernel(ProductSrc<T> src, co
 template <typename T>
 __global__ __launch_bounds__(256) void nf_copy_kernel(RowWork w, u32* __restrict__ c_col, T* __restrict__ c_val)
 {
+    SPECK_POISON();
     if (block_void(w.st->capacity_miss)) return;
     const u32 count = min(w.st->num.count[NUM_NFCOPY], w.m);
     const u32* __restrict__ s_col = w.nf_col;
@@ -1067,6 +1069,7 @@ __global__ __launch_bounds__(THREADS) void num_direct_kernel(ProductSrc<T> src, 
                                                              u32* __restrict__ c_col,
                                                              T* __restrict__ c_val)
 {
+    SPECK_POISON();
     src.rebase(a_ro);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     num_direct_body<T, THREADS>(smem, src, w, c_col, c_val, blockIdx.x, gridDim.x);
@@ -1077,6 +1080,7 @@ __global__ __launch_bounds__(THREADS) void num_hash_kernel(ProductSrc<T> src, co
                                                            u32* __restrict__ c_col,
                                                            T* __restrict__ c_val, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     num_hash_body<G, T, CAP, W1, NMAX, MODE, THREADS, NLO, VERIFY>(smem, src, w, c_col, c_val, cls, blockIdx.x,
@@ -1087,6 +1091,7 @@ template <typename T, bool VERIFY = false>
 __global__ __launch_bounds__(256) void num_sliced_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w, u32* __restrict__ c_col,
                                                          T* __restrict__ c_val, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     num_sliced_body<T, VERIFY>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
@@ -1097,6 +1102,7 @@ __global__ __launch_bounds__(THREADS) void num_dense_kernel(ProductSrc<T> src, c
                                                             u32* __restrict__ c_col,
                                                             T* __restrict__ c_val, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     num_dense_body<T, WCOLS, THREADS, VERIFY>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
@@ -1106,6 +1112,7 @@ template <typename T, u32 L>
 __global__ __launch_bounds__(256) void num_esc_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                       u32* __restrict__ c_col, T* __restrict__ c_val, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     num_esc_body<T, L, 256>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
@@ -1115,6 +1122,7 @@ template <typename T, u32 L>
 __global__ __launch_bounds__(256) void num_escw_kernel(ProductSrc<T> src, const u32* a_ro, RowWork w,
                                                        u32* __restrict__ c_col, T* __restrict__ c_val, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     num_escw_body<T, L, 256>(smem, src, w, c_col, c_val, cls, blockIdx.x, gridDim.x);
@@ -1131,6 +1139,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
                                                         u32* __restrict__ c_col, T* __restrict__ c_val,
                                                         ClassGrid cg)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
@@ -1190,6 +1199,7 @@ __global__ __launch_bounds__(256) void num_light_kernel(ProductSrc<T> src, const
 template <typename T>
 __global__ __launch_bounds__(256) void walk_hash_kernel(ProductSrc<T> src, WalkHashArgs a, Chain3 chain)
 {
+    SPECK_POISON();
     using G = SubWave<32>;
     constexpr u32 CAP = kNumW256Cap, NG = 256 / G::SIZE;
     static_assert(NG == kWalkHashRows, "eight rows per workgroup");
@@ -1347,6 +1357,7 @@ __global__ __launch_bounds__(256) void num_tiny_kernel(ProductSrc<T> src, const 
                                                        u32* __restrict__ c_col, T* __restrict__ c_val,
                                                        ClassGrid cg)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
@@ -1394,6 +1405,7 @@ constexpr int kGWalkThreads = 256;
 
 __global__ __launch_bounds__(1024) void num_spill_plan_kernel(RowWork w, int cls)
 {
+    SPECK_POISON();
     __shared__ u32 s_scan[1024 / 64 + 2];
     __shared__ u64 s_run_p;
     __shared__ u32 s_run_b, s_run_f;
@@ -1472,6 +1484,7 @@ template <typename T>
 __global__ __launch_bounds__(kGWalkThreads) void num_spill_count_kernel(ProductSrc<T> src, const u32* a_ro,
                                                                         RowWork w, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = Block<kGWalkThreads>;
     const G g;
@@ -1510,6 +1523,7 @@ __device__ __forceinline__ u32 spill_bucket_need(u32 products, u32 c_lo, u32 c_h
 
 __global__ __launch_bounds__(256) void num_spill_offsets_kernel(RowWork w, int cls)
 {
+    SPECK_POISON();
     __shared__ u32 s_scan[256 / 64 + 2];
     __shared__ u32 s_map[256];
     __shared__ u32 s_bc[kGMaxBuckets];  // products per bucket of the row (this workgroup owns them all)
@@ -1577,6 +1591,7 @@ template <typename T>
 __global__ __launch_bounds__(kGWalkThreads) void num_spill_scatter_kernel(ProductSrc<T> src, const u32* a_ro,
                                                                           RowWork w, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = Block<kGWalkThreads>;
     const G g;
@@ -1653,6 +1668,7 @@ constexpr u32 num_spill_reduce_lds()
 template <typename T, u32 CAP, u32 W1, int THREADS, u32 N_LO, u32 N_HI, bool DENSE>
 __global__ __launch_bounds__(THREADS) void num_spill_reduce_kernel(RowWork w, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kGReduceThreads = THREADS;
     constexpr u32 kGDenseCols = CAP;
@@ -1763,6 +1779,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void num_spill_copy_kernel(RowWork w, u32* __restrict__ c_col,
                                                              T* __restrict__ c_val, int cls)
 {
+    SPECK_POISON();
     __shared__ u32 s_red[256 / 64 + 2];
     using G = Block<256>;
     const G g;

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
     RowRec* __restrict__ sym_recs, u64* __restrict__ nf_off, u64 expect_nf, Chain chain,
     u32* a_ro_copy, u32* __restrict__ verdict, u64* __restrict__ bytes_acc, u64 b_nnz)
 {
+    SPECK_POISON();
     constexpr int kAnThreads = NW * 64;
     constexpr int U = 4;   // entries per lane and tile: 256 entries cover most 32-row sub-chunks in ONE
                            //   round of the dependent chain A.col -> B.rowptr -> B.col
@@ -615,6 +616,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
     const u32* __restrict__ pred_off, u32* __restrict__ pred_off_out, u32* __restrict__ dev_ticket,
     u32* __restrict__ host_ticket, u64* __restrict__ bytes_acc)
 {
+    SPECK_POISON();
     constexpr int NW = kScanThreads / 64;
     constexpr u32 kSubRows = kScanThreads * ITEMS;
     __shared__ u32 s_mine[kChainWords];
@@ -891,6 +893,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
 __global__ __launch_bounds__(64) void done_kernel(u32* __restrict__ dev_ticket, u32* __restrict__ host_ticket,
                                                   const DeviceStats* __restrict__ st, DeviceStats* __restrict__ host_mirror)
 {
+    SPECK_POISON();
     const u64* src = reinterpret_cast<const u64*>(st);
     u64* dst = reinterpret_cast<u64*>(host_mirror);
     for (u32 i = threadIdx.x; i < sizeof(DeviceStats) / 8; i += 64)
@@ -910,6 +913,7 @@ constexpr u32 kValChunk = 8192;  // entries of B per workgroup and step: eight 1
 __global__ __launch_bounds__(256) void validate_b_kernel(const u32* __restrict__ b_ro, const u32* __restrict__ b_col, u32 b_rows,
                                                           u32 b_cols, u64 b_nnz, u32* __restrict__ verdict)
 {
+    SPECK_POISON();
     // O(nnz + rows), streaming: a workgroup owns a contiguous span of entries and walks the row offsets alongside it.  Per
     // chunk of 8192 entries: the row STARTS inside the chunk as a bitmap in LDS (a pair of neighbours that does not ascend
     // is fine exactly where a row starts), then the entries as 16-byte loads.  (Round 4 looked every such pair up by binary
@@ -1008,6 +1012,7 @@ void launch_validate_b(hipStream_t s, const u32* b_ro, const u32* b_col, u32 b_r
 // verdict (system-scope atomics on pinned memory) before the ticket
 __global__ __launch_bounds__(64) void ticket_kernel(u32* __restrict__ dev_ticket, u32* __restrict__ host_ticket)
 {
+    SPECK_POISON();
     if (threadIdx.x == 0) {
         const u32 t = *dev_ticket + 1u;
         *dev_ticket = t;
@@ -1026,6 +1031,7 @@ __global__ __launch_bounds__(256) void snapshot_inputs_kernel(const u32* __restr
                                                                const u32* __restrict__ b_ro, const u32* __restrict__ b_col,
                                                                u32 b_rows, u32* __restrict__ b_snap)
 {
+    SPECK_POISON();
     const u32 e_base = a_ro[0];  // (A may be a row-range view with absolute offsets)
     const u64 tid = u64(blockIdx.x) * 256 + threadIdx.x, nthreads = u64(gridDim.x) * 256;
     for (u64 i = tid; i < nnz_a; i += nthreads) a_col_copy[i] = a_col[e_base + i];
@@ -1045,6 +1051,7 @@ __global__ __launch_bounds__(256) void verify_inputs_kernel(const u32* __restric
                                                              const u32* __restrict__ b_ro, const u32* __restrict__ b_col,
                                                              u32 b_rows, const u32* __restrict__ b_snap, u32* __restrict__ verdict)
 {
+    SPECK_POISON();
     const u32 e_base = a_ro[0];
     const u64 tid = u64(blockIdx.x) * 256 + threadIdx.x, nthreads = u64(gridDim.x) * 256;
     bool bad = e_base != a_ro_copy[0];
@@ -1113,6 +1120,7 @@ void launch_done(hipStream_t s, u32* dev_ticket, u32* host_ticket, const DeviceS
 __global__ __launch_bounds__(256) void copy_offsets_kernel(const u32* __restrict__ src, u32* __restrict__ dst, u32 n,
                                                             const DeviceStats* __restrict__ st)
 {
+    SPECK_POISON();
     if (st->capacity_miss) return;
     for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
 }

@@ -234,6 +234,7 @@ constexpr int kGhThreads = 1024;
 __global__ __launch_bounds__(kGhThreads) void sym_global_hash_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
                                                                       u32* __restrict__ counts)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // a replayed sequence whose scratch pool no longer holds the key sets (sym_scatter_kernel raised the flag)
     // must not clear or probe them: the eager path re-runs with a pool of the right size
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(THREADS) void sym_hash_kernel(ProductSrc<float> src
                                                            RowWork w, u32* __restrict__ counts,
                                                            int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     sym_hash_body<G, CAP, THREADS>(smem, src, w, counts, cls, blockIdx.x, gridDim.x);
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(THREADS) void sym_bitmap_kernel(ProductSrc<float> s
                                                              RowWork w, u32* __restrict__ counts,
                                                              int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     sym_bitmap_body<WORDS, THREADS>(smem, src, w, counts, cls, blockIdx.x, gridDim.x);
@@ -296,6 +299,7 @@ template <u32 L>
 __global__ __launch_bounds__(256) void sym_escw_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
                                                        u32* __restrict__ counts, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     sym_escw_body<L, 256>(smem, src, w, counts, cls, blockIdx.x, gridDim.x);
@@ -305,6 +309,7 @@ template <u32 L>
 __global__ __launch_bounds__(256) void sym_esc_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
                                                       u32* __restrict__ counts, int cls)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     sym_esc_body<L, 256>(smem, src, w, counts, cls, blockIdx.x, gridDim.x);
@@ -313,6 +318,7 @@ __global__ __launch_bounds__(256) void sym_esc_kernel(ProductSrc<float> src, con
 __global__ __launch_bounds__(256) void sym_light_kernel(ProductSrc<float> src, const u32* a_ro, RowWork w,
                                                         u32* __restrict__ counts, ClassGrid cg)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     src.rebase(a_ro);
     const u32 b = blockIdx.x;
@@ -345,6 +351,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void sym_light_fused_kernel(ProductSrc<T> nsrc, const u32* a_ro, RowWork w,
                                                               u32* __restrict__ counts, ClassGrid cg)
 {
+    SPECK_POISON();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     nsrc.rebase(a_ro);
     const ProductSrc<float> src{nsrc.b_sl, nullptr, nsrc.b_col, nullptr, nsrc.w_sl};

@@ -81,6 +81,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char walk_lds[];  // kWa
 template <typename T, int ITEMS>
 __global__ __launch_bounds__(kWalkThreads, 7) void walk_kernel(ProductSrc<T> src, WalkArgs a, Chain chain)
 {
+    SPECK_POISON();
     constexpr u32 TRMAX = kWalkThreads * ITEMS;
     constexpr int NW = kWalkWaves;
     __shared__ u32 s_a0[TRMAX + 1], s_cmin[TRMAX], s_nnz[TRMAX], s_off[TRMAX];
