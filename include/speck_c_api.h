@@ -99,6 +99,11 @@ typedef struct speck_stats {
                                                   * rows -- no symbolic pass for them, no scan kernel; scan_ms is that kernel */
     int32_t walk_misses;                         /* one-walk calls the device-side checks declared void (cumulative; the
                                                   * two-phase call re-ran) */
+    int32_t eager_through;                       /* 1: the last multiply was a complete two-phase call enqueued as ONE batch --
+                                                  * the numeric launches queued behind the scan, into the buffers matOut already
+                                                  * had, everything the host checks between the phases checked by the scan
+                                                  * (option eager_through; eager_speculated is 1 as well); -1: attempted, the
+                                                  * device-side checks did not hold, nothing of C was written, the call re-ran */
 } speck_stats;
 
 typedef struct speck_config speck_config; /* opaque; reference: spECKConfig, include/spECKConfig.h:8-53 */

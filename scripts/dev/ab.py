@@ -25,7 +25,7 @@ def run(kind, scale, opts, steps=40, warm=10, dtype=np.float64):
             sa.MultiplyspECK(dA, dA, dC, cfg)
         best = min(best, (time.perf_counter() - t0) / steps * 1e3)
     st = cfg.last_stats()
-    print("%-9s %-28s %.4f ms  walk %d misses %d spec %d  %.1f GF" % (kind, opts, best, st["one_walk"], st["walk_misses"], st["eager_speculated"],
+    print("%-9s %-28s %.4f ms  walk %d misses %d spec %d through %d  %.1f GF" % (kind, opts, best, st["one_walk"], st["walk_misses"], st["eager_speculated"], st["eager_through"],
           2.0 * st["sum_products"] / best / 1e6), flush=True)
     cfg.cleanup()
 

@@ -39,7 +39,7 @@ class CStats(C.Structure):
                 ("replayed", C.c_int32), ("nf_direct", C.c_int32), ("pool_fallbacks", C.c_int32),
                 ("esc_fused", C.c_int32), ("scratch_pool_bytes", C.c_uint64),
                 ("pred_stages", C.c_int32), ("eager_speculated", C.c_int32), ("one_walk", C.c_int32),
-                ("walk_misses", C.c_int32)]
+                ("walk_misses", C.c_int32), ("eager_through", C.c_int32)]
 
 
 # every symbol include/speck_c_api.h declares, with its ctypes signature

@@ -300,7 +300,8 @@ class spECKConfig:
             sym_phase_ms=float(s.sym_phase_ms), num_phase_ms=float(s.num_phase_ms),
             replayed=bool(s.replayed), nf_direct=bool(s.nf_direct), esc_fused=bool(s.esc_fused), pool_fallbacks=int(s.pool_fallbacks),
             scratch_pool_bytes=int(s.scratch_pool_bytes), pred_stages=int(s.pred_stages),
-            eager_speculated=int(s.eager_speculated), one_walk=int(s.one_walk), walk_misses=int(s.walk_misses))
+            eager_speculated=int(s.eager_speculated), one_walk=int(s.one_walk), walk_misses=int(s.walk_misses),
+            eager_through=int(s.eager_through))
 
 
 _NO_TIMINGS = CTimings()  # scratch for calls that do not ask for stage times

@@ -298,6 +298,10 @@ struct DeviceStats {
     u32 nf_max_range;        // widest column range among the SYM_NF rows (sizes the LDS window of their kernel)
     u32 a_invalid;           // a column id of A is >= rows(B) (the analysis clamps it, so nothing reads out of bounds)
     u32 chain_error;         // a workgroup of the analysis / scan waited in vain for the workgroups before it (chain.hpp)
+    u32 front_miss;          // capacity_miss as the scan FOUND it: raised by the analysis / symbolic side of the call.  0 with
+                             //   capacity_miss = 1: only the scan's own checks objected (nnz(C), numeric classes, spill pool,
+                             //   input check) -- its offsets, counts and class lists stand (the through call, pipeline.hip)
+    u32 pad_;
 };
 static_assert(sizeof(DeviceStats) % 8 == 0, "mirrored to the host in 8-byte words");
 

@@ -67,7 +67,9 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
                  const u32* row_col_min, const u32* row_col_max, RowRec* num_recs, DeviceStats* st,
                  const ClassifyParams& cp, u32 vsize, u64 exact_nnz, const Chain& chain, DeviceStats* host_mirror = nullptr,
                  u64 expect_g = ~0ull, u32 expect_g_rows = ~0u, const u32* pred_off = nullptr, u32* pred_off_out = nullptr,
-                 u32* dev_ticket = nullptr, u32* host_ticket = nullptr, u64* bytes_acc = nullptr);
+                 u32* dev_ticket = nullptr, u32* host_ticket = nullptr, u64* bytes_acc = nullptr,
+                 const u32* gate = nullptr /* verdict word of the input check: a violation (bit 2) voids what follows */,
+                 u32 gate_ticket = 0 /* != 0: ... and so does a check that has not stored this ticket at gate[16] yet */);
 
 template <typename T>
 struct ProductSrc;  // row_groups.hpp

@@ -150,6 +150,15 @@ struct speck_config {
                                   //   THAT call and runs analysis .. scan as one batch -- one read-back instead of two; the
                                   //   device checks every assumption (capacity_miss: the two-read-back sequence re-runs)
     bool spec_valid = false;      // such a call has completed (last_sym_* describe it)
+    // option eager_through: ... and when matOut already holds buffers of the size that call produced, the numeric launches are
+    // queued right behind the scan -- no read-back in the middle of the call.  The scan checks on the device what the host
+    // would have (nnz(C) = what the buffers hold, the classes with rows, the spill pool, the verdict of the input check: its
+    // stream is joined in front of the scan); on a miss nothing of C is written and the call re-runs with its read-back.
+    bool eager_through = true;
+    const u32* through_gate = nullptr;  // (set around enqueue_front: the verdict word the scan looks at)
+    u32 through_ticket = 0;             // != 0: ... and the ticket the check stores when it is done (its stream is not joined)
+    hipEvent_t vdone = nullptr;         // the input check's stream, joined in front of that scan
+    u64 through_hits = 0, through_misses = 0;
     u64 spec_rows_a = 0, spec_rows_b = 0;
     int eager_spec_hits = 0, eager_spec_misses = 0;
     const u32* stage_off_src = nullptr;  // call in flight: the staged row offsets ride to C in the numeric light
@@ -826,10 +835,17 @@ int enqueue_front(speck_config* c, hipStream_t s, const speck_dcsr* A_in, const 
         Chain chain;
         const int crc = next_chain(c, s, &chain);
         if (crc != SPECK_OK) return crc;
+        // (through call: the input check finished long ago, or at least before this scan.  A LARGE B: its stream is joined;
+        //  else the scan looks for the check's ticket -- a join costs ~6 us of this short call even on a finished branch)
+        if (c->through_gate && !c->through_ticket) {
+            HIP_TRY(hipEventRecord(c->vdone, c->vstream));
+            HIP_TRY(hipStreamWaitEvent(s, c->vdone, 0));
+        }
         launch_scan(s, c_ro, sc.offsets, m, A->row_offsets, sc.row_ops, sc.row_col_min, sc.row_col_max,
                     classify_numeric ? sc.num_recs : nullptr, c->d_stats, cp, vsize, exact_nnz, chain, host_mirror,
                     expect_g, expect_g_rows, c->capture_direct ? c->gpred.off : nullptr, pred_off_out,
-                    host_mirror ? c->d_ticket : nullptr, host_mirror ? c->h_ticket_dev : nullptr, bytes);
+                    host_mirror ? c->d_ticket : nullptr, host_mirror ? c->h_ticket_dev : nullptr, bytes, c->through_gate,
+                    c->through_ticket);
     }
     if (timed) (void)hipEventRecord(kernel_event(c, tm->ev++), s);
     LAUNCHES_OK();
@@ -1552,10 +1568,78 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
             }
         }
     }
-    if (!walked) {
-    bool speculated = false;
+    // ---- THROUGH call: a complete two-phase call enqueued in ONE batch -- analysis, symbolic, scan AND the numeric launches,
+    // sized from the previous complete call on this config, into the buffers matOut already has.  What the host checks between
+    // the two phases of the call below is checked by the scan on the device; a miss leaves C untouched and falls through.
+    bool through_ok = false, through_missed = false, through_front = false;
+    if (!walked && c->eager_through && c->eager_speculate && c->spec_valid && c->spec_rows_a == A->rows && c->spec_rows_b == B->rows &&
+        c_ready && C->nnz <= 0xFFFFFFFFull && C->nnz == c->last_eager_stats.nnz_c && c->last_num_mask && !c->last_was_walk &&
+        !c->profile_kernels && !t->measureAll && c->spin_wait && !c->cp.want_bytes &&
+        (!(c->last_num_mask >> NUM_G & 1u) || c->spill.plan != nullptr)) {
+        u32 hints[kMaxClasses], mask = kSymLightMask;
+        for (int k = 0; k < kMaxClasses; ++k) {
+            hints[k] = c->last_sym_counts[k];
+            if (hints[k]) mask |= 1u << k;
+            if ((kSymLightMask >> k & 1u) && !hints[k]) hints[k] = 256;
+        }
+        struct ThroughFlags {
+            speck_config* c;
+            ~ThroughFlags()
+            {
+                c->through_gate = nullptr, c->through_ticket = 0;
+                c->stage_off_src = nullptr, c->stage_off_dst = nullptr, c->stage_off_n = 0;
+            }
+        } through_flags{c};
+        c->through_gate = c->validate_inputs ? c->h_verify_dev : nullptr;
+        // (the ticket the check of THIS call will store: wait_verifier counts them)
+        c->through_ticket = (c->validate_inputs && B->nnz < c->validate_after_nnz) ? c->vticket_expected + 1u : 0u;
+        c->stage_off_src = sc.offsets;
+        c->stage_off_dst = C->row_offsets;  // (c_ready: c_ro IS C's array)
+        c->stage_off_n = m + 1;
+        const bool has_g = (c->last_num_mask >> NUM_G & 1u) != 0;
+        rc = enqueue_front(c, s, A, B, sc, (u32)sizeof(T), C->nnz, mask, c->last_num_mask, true, &tm, hints, nullptr,
+                           has_g ? c->last_g_products : ~0ull, has_g ? c->last_num_counts[NUM_G] : ~0u, 3u, c->nf_cap_entries,
+                           keep_pred ? c->pred.off : nullptr, true);
+        if (rc != SPECK_OK) return fail(rc);
+        rc = enqueue_back<T>(c, s, A, B, sc, C->col_ids, static_cast<T*>(C->data), c->last_num_mask, c->last_num_counts, &tm);
+        if (rc != SPECK_OK) return fail(rc);
+        rc = read_stats(c, s);  // (done_kernel + ticket: the one wait of the call)
+        if (rc != SPECK_OK) return fail(rc);
+        if (c->h_stats->a_invalid) return fail(SPECK_ERR_INVALID);
+        bool b_bad = false;
+        rc = b_is_invalid(&b_bad);
+        if (rc != SPECK_OK) return fail(rc);
+        if (b_bad) return fail(SPECK_ERR_UNSORTED);  // (the scan saw the verdict: nothing of C was written)
+        through_ok = !c->h_stats->capacity_miss && !c->h_stats->nnz_overflow && c->h_stats->nnz_c == C->nnz &&
+                     c->h_stats->sum_products != 0;
+        ++(through_ok ? c->through_hits : c->through_misses);
+        if (through_ok) {
+            publish_counts(c, s);
+            num_mask = mask_of(c->h_stats->num.count, NUM_CLASSES);
+            c->last_g_products = c->h_stats->g_products;
+            c->last.eager_speculated = 1;
+            c->last.eager_through = 1;
+            t->countProducts = t->loadBalanceCounting = t->globalMapsCounting = t->globalMapsNumeric = t->allocC = t->loadBalanceNumeric = 0.f;
+            t->spGEMMCounting = 0.f;
+            t->spGEMMNumeric = st.lap();
+        } else if (!c->h_stats->front_miss && !c->h_stats->nnz_overflow) {
+            // only the scan objected (another nnz(C), a numeric class without a launch, the spill pool): its offsets, counts
+            // and class lists stand -- the call goes on behind its ONE read-back like a speculated call whose checks held;
+            // the numeric launches queued above found the flag and wrote nothing
+            HIP_TRY(hipMemsetAsync(&c->d_stats->capacity_miss, 0, sizeof(u32), s));
+            c->h_stats->capacity_miss = 0;
+            through_missed = through_front = true;
+        } else {
+            validate_started = false;  // (the call below checks B again: the verdict word was consumed)
+            tm = Timing{};
+            through_missed = true;
+        }
+    }
+    if (!walked && !through_ok) {
+    bool speculated = through_front;
+    if (through_front) c->last.eager_speculated = 1;
     u32 spec_counts[kMaxClasses];
-    if (c->eager_speculate && c->spec_valid && c->spec_rows_a == A->rows && c->spec_rows_b == B->rows) {
+    if (c->eager_speculate && !through_missed && c->spec_valid && c->spec_rows_a == A->rows && c->spec_rows_b == B->rows) {
         u32 mask = 0;
         for (int k = 0; k < kMaxClasses; ++k) {
             spec_counts[k] = c->last_sym_counts[k];
@@ -1785,6 +1869,10 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
     // ... and where every row went: the scan kernel wrote the config's copy of the offsets as it went
     c->pred_valid = keep_pred;
     c->last_eager_stats = *c->h_stats;
+    if (through_missed) {
+        c->last.eager_through = -1;
+        if (!through_front) c->last.eager_speculated = -1;  // (what the batch was sized from did not hold)
+    }
 
     rc = finish_complete();
     if (rc != SPECK_OK) return rc;
@@ -1868,6 +1956,7 @@ int speck_config_create(int device, speck_config** out)
     }
     HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->vgate, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->vdone, hipEventDisableTiming));
     {
         // the verifier yields to the sequence it runs beside: lowest stream priority (the sequence's light launches
         // lost 5-8 % to it at equal priority)
@@ -1929,6 +2018,7 @@ int speck_config_destroy(speck_config* c)
     for (auto e : c->aux_done) (void)hipEventDestroy(e);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->vgate) (void)hipEventDestroy(c->vgate);
+    if (c->vdone) (void)hipEventDestroy(c->vdone);
     if (c->vstream) (void)hipStreamDestroy(c->vstream);
     if (c->h_verify) (void)hipHostFree(c->h_verify);
     if (c->d_vticket) (void)hipFree(c->d_vticket);
@@ -1999,6 +2089,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "nf_pool_max_mb") c->nf_pool_max_bytes = size_t(value) << 20;
     else if (n == "analysis_wide_rows") set_analysis_wide_rows((u32)value), forget(true);
     else if (n == "eager_speculate") c->eager_speculate = value != 0;
+    else if (n == "eager_through") c->eager_through = value != 0;
     else if (n == "one_walk") c->one_walk = (int)value;
     else if (n == "one_walk_hash") c->one_walk_hash = (int)value;
     else if (n == "walk_hash_debug") c->walk_hash_debug = (u32)value;

@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
     const u32* __restrict__ row_col_max, RowRec* __restrict__ recs /* numeric class lists; nullptr: offsets only */,
     ClassifyParams cp, u32 vsize, u64 exact_nnz, u64 expect_g, u32 expect_g_rows, DeviceStats* __restrict__ host_mirror,
     const u32* __restrict__ pred_off, u32* __restrict__ pred_off_out, u32* __restrict__ dev_ticket,
-    u32* __restrict__ host_ticket, u64* __restrict__ bytes_acc)
+    u32* __restrict__ host_ticket, u64* __restrict__ bytes_acc, const u32* __restrict__ gate, u32 gate_ticket)
 {
     SPECK_POISON();
     constexpr int NW = kScanThreads / 64;
@@ -732,6 +732,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
     // ---- the LAST tile has the totals: statistics, the checks of a sequence sized from an earlier call, and -- eager
     // call -- the mirror + ticket for the host, NOW: nothing the writes below do changes what the host needs
     if (last) {
+        u32 front_miss = 0;
+        if (t == 0) front_miss = st->capacity_miss;  // (before this kernel's own checks below)
+        __syncthreads();
             const u64 nnz_c = nnz_before + (u64(s_mine[kCwPfxHi]) << 32) + s_mine[kCwPfxLo];
         const u64 g_total = chain_u64(s_pref, kCwTotLo, kCwTotHi) + (u64(s_mine[kCwTotHi]) << 32) + s_mine[kCwTotLo];
         if (t < kMaxClasses && recs) {
@@ -749,7 +752,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
             if (exact_nnz != ~0ull && nnz_c != exact_nnz) st->capacity_miss = 1;
             // ... and so was the spill pool of the NUM_G rows
             st->g_products = g_total;
+            st->front_miss = front_miss;
             if (expect_g != ~0ull && g_total != expect_g) st->capacity_miss = 1;
+            // a call whose numeric launches are already queued behind this kernel (pipeline.hip, the through call): the
+            // input check of B has finished (the stream waited for it) -- a violation voids them, C stays as it is
+            // (gate_ticket: the check's stream was NOT joined -- a cross-queue wait costs ~6 us even on a finished branch --
+            //  the check counts as done only if its ticket kernel has stored this call's ticket; else: void, the call re-runs)
+            if (gate) {
+                const u32 ticket = gate_ticket ? __hip_atomic_load(gate + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                const u32 verdict = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((verdict & 4u) || ticket != gate_ticket) st->capacity_miss = 1;
+            }
             if (!chain_ok || chain_error(chain)) {
                 st->chain_error = 1;
                 st->capacity_miss = 1;
@@ -1169,7 +1182,8 @@ void launch_analysis(hipStream_t s, const u32* a_ro, const u32* a_col, const u32
 void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, const u32* a_ro, const u32* row_ops,
                  const u32* row_col_min, const u32* row_col_max, RowRec* num_recs, DeviceStats* st,
                  const ClassifyParams& cp, u32 vsize, u64 exact_nnz, const Chain& chain, DeviceStats* host_mirror, u64 expect_g,
-                 u32 expect_g_rows, const u32* pred_off, u32* pred_off_out, u32* dev_ticket, u32* host_ticket, u64* bytes_acc)
+                 u32 expect_g_rows, const u32* pred_off, u32* pred_off_out, u32* dev_ticket, u32* host_ticket, u64* bytes_acc,
+                 const u32* gate, u32 gate_ticket)
 {
     const u32 tiles = scan_tiles(m), sub = scan_subtiles(m);
     auto go = [&](auto items) {
@@ -1177,11 +1191,11 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
         if (sub > 1)
             SPECK_LAUNCH((scan_kernel<32, true>), dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, sub, st, chain, a_ro,
                                row_ops, row_col_min, row_col_max, num_recs, cp, vsize, exact_nnz, expect_g, expect_g_rows,
-                               host_mirror, pred_off, pred_off_out, dev_ticket, host_ticket, bytes_acc);
+                               host_mirror, pred_off, pred_off_out, dev_ticket, host_ticket, bytes_acc, gate, gate_ticket);
         else
         SPECK_LAUNCH((scan_kernel<I, false>), dim3(tiles), dim3(kScanThreads), 0, s, counts, offsets_out, m, sub, st, chain, a_ro,
                            row_ops, row_col_min, row_col_max, num_recs, cp, vsize, exact_nnz, expect_g, expect_g_rows,
-                           host_mirror, pred_off, pred_off_out, dev_ticket, host_ticket, bytes_acc);
+                           host_mirror, pred_off, pred_off_out, dev_ticket, host_ticket, bytes_acc, gate, gate_ticket);
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;
