@@ -29,6 +29,8 @@ done
 rm -rf gpurun_out/_ow
 bash scripts/timeline.sh ${ROUND}_onewalk_scircuit scircuit 12 --no-reuse --no-lib-baseline --opt one_walk=2 > /dev/null 2>&1; cp gpurun_out/timeline/${ROUND}_onewalk_scircuit.txt $OUT/
 bash scripts/timeline.sh ${ROUND}_complete_scircuit scircuit 10 --no-reuse --no-lib-baseline > /dev/null 2>&1; cp gpurun_out/timeline/${ROUND}_complete_scircuit.txt $OUT/
+# ... and with the through call off (option eager_through=0: the read-back between scan and numeric launches)
+bash scripts/timeline.sh ${ROUND}_complete_nothrough_scircuit scircuit 10 --no-reuse --no-lib-baseline --opt eager_through=0 > /dev/null 2>&1; cp gpurun_out/timeline/${ROUND}_complete_nothrough_scircuit.txt $OUT/
 timeout 300 python scripts/multiwindow_time.py 2>&1 | grep windows > $OUT/${ROUND}_multiwindow_now.txt
 python - <<'PY'
 import json, glob
