@@ -1864,6 +1864,8 @@ static void launch_num_hash(hipStream_t s, int cls, u32 count, const ProductSrc<
                        dim3(THREADS), lds, s, A, B, w, c_col, c_val, cls);
 }
 
+static u32 g_b8k_full_first = 1;  // bit 0: complete calls, bit 1: the verifying launches of a reuse sequence
+void set_b8k_full_first(u32 mask) { g_b8k_full_first = mask; }
 static u32 g_spill_big_grid = 256;
 void set_spill_big_grid(u32 blocks) { g_spill_big_grid = blocks ? blocks : 256u; }
 
@@ -2005,10 +2007,14 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                         s, cls, count, A, B, w, c_col, c_val, cu_count);
                     break;
                 }
-                launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KHalfMaxNnz, true>(
-                    s, cls, count, A, B, w, c_col, c_val, cu_count);
+                if (g_b8k_full_first & 2u)
+                    launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KHalfMaxNnz, true>(
+                        s, cls, count, A, B, w, c_col, c_val, cu_count);
                 launch_num_hash<Block<512>, T, kNumB8KCap / 2, kB8KW1, kNumB8KHalfMaxNnz, SORT_BITMAP, 512, 0, true>(
                     s, cls, count, A, B, w, c_col, c_val, cu_count);
+                if (!(g_b8k_full_first & 2u))
+                    launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KHalfMaxNnz, true>(
+                        s, cls, count, A, B, w, c_col, c_val, cu_count);
                 break;
             }
             if (count * 2 < (u32)cu_count) {
@@ -2017,11 +2023,16 @@ void launch_numeric(hipStream_t s, int cls, u32 count, const CsrView<T>& Av, con
                 break;
             }
             // (the full table first: a workgroup of 106 KiB finds room on a CU only while the light launch beside it has
-            //  not filled the chip -- webbase stand-in 1.201 -> 1.189 ms, three A/B pairs)
-            launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KHalfMaxNnz>(
-                s, cls, count, A, B, w, c_col, c_val, cu_count);
+            //  not filled the chip -- webbase stand-in 1.176 -> 1.158 ms complete, three alternating pairs; the verifying
+            //  launches of a reuse sequence keep the half table first: 0.788 against 0.868 ms.  Option b8k_full_first)
+            if (g_b8k_full_first & 1u)
+                launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KHalfMaxNnz>(
+                    s, cls, count, A, B, w, c_col, c_val, cu_count);
             launch_num_hash<Block<512>, T, kNumB8KCap / 2, kB8KW1, kNumB8KHalfMaxNnz, SORT_BITMAP, 512>(
                 s, cls, count, A, B, w, c_col, c_val, cu_count);
+            if (!(g_b8k_full_first & 1u))
+                launch_num_hash<Block<512>, T, kNumB8KCap, kB8KW1, kNumB8KMaxNnz, SORT_BITMAP, 512, kNumB8KHalfMaxNnz>(
+                    s, cls, count, A, B, w, c_col, c_val, cu_count);
             break;
         case NUM_D1: {
             auto k = num_dense_kernel<T, kNumD1Win, 256>;
