@@ -139,10 +139,12 @@ int speck_last_stats(const speck_config *cfg, speck_stats *out);
  * straight into C->col_ids / C->data (options nf_direct / esc_fused, both on by default) before the device-side
  * checks of that sequence can reject it; if the eager re-run that follows then fails as well (inputs changed in
  * place into something invalid, out of memory for a grown C), the call returns the error with the contents of
- * col_ids / data unspecified.  The same holds for a ONE-WALK complete call (option one_walk, on by default: a complete
+ * col_ids / data unspecified.  The same holds for a ONE-WALK complete call (option one_walk, OFF by default: a complete
  * call on a matOut that is already allocated finishes short rows straight into C->col_ids / C->data before the input
  * check of B and its own device-side checks have spoken; a miss re-runs the two-phase call, an invalid input returns its
- * error with the contents unspecified).  row_offsets is rewritten only by a call that completes. */
+ * error with the contents unspecified).  A complete call enqueued as one batch (option eager_through, on by default) keeps
+ * the rule: its scan looks at the verdict of the input check and at its own checks before any numeric kernel starts, and a
+ * voided batch writes nothing.  row_offsets is rewritten only by a call that completes. */
 int speck_multiply_f64(speck_config *cfg, const speck_dcsr *A, const speck_dcsr *B, speck_dcsr *C,
                        speck_timings *timings);
 /* the <float,...> instantiation, source/GPU/Multiply.cu:1130 */
