@@ -488,6 +488,7 @@ def measure(env, A, steps, warmup, gather, profile, verify=None, reuse=False):
         job.step()
     elapsed = job.timed(steps)
     out["speculated"] = job.cfg.last_stats()["eager_speculated"]
+    out["through"] = job.cfg.last_stats().get("eager_through", 0)  # 1: the timed complete calls were enqueued as one batch
     cache = {}
     out["verify"] = None
     if verify:
@@ -555,7 +556,8 @@ def config_objects(workload, wl_name, data_label, A, res, steps):
                 kernels_ms={k: round(v, 5) for k, v in res["kernel_ms"].items() if v > 0},
                 rows_per_class={k: v for k, v in st["num_bin_rows"].items() if v},
                 sym_rows_per_class={k: v for k, v in st["sym_bin_rows"].items() if v},
-                eager_speculated=res["speculated"], graph_replays=res["replays"], verify=res["verify"],
+                eager_speculated=res["speculated"], eager_through=res.get("through", 0), graph_replays=res["replays"],
+                verify=res["verify"],
                 verify_reuse=res["verify_reuse"])
     return short, full, compact_roof
 
