@@ -270,6 +270,7 @@ u32 grid_for(u32 count, u32 lds, int threads, int cu_count, u32 rows_per_block);
 // resident-set multiples a class grid may reach before its workgroups start striding over rows
 void set_grid_rounds(u32 block_classes, u32 subwave_classes);
 void set_b8k_full_first(u32 mask);  // NUM_B8K: the full-table launch in front of the half-table one (bit 0 complete calls, bit 1 reuse)
+void set_scan_small_items(int items);
 void set_spill_big_grid(u32 blocks);  // workgroups of the NUM_G launch that reduces the oversized buckets
 
 // LDS bytes a class needs (for occupancy-aware grid sizing and DESIGN.md tables)

@@ -2138,6 +2138,7 @@ int speck_config_set_option(speck_config* c, const char* name, int64_t value)
     else if (n == "grid_rounds_block") set_grid_rounds((u32)value, 0), forget(false);
     else if (n == "grid_rounds_sub") set_grid_rounds(0, (u32)value), forget(false);
     else if (n == "spill_big_grid") set_spill_big_grid((u32)value), forget(false);
+    else if (n == "scan_small_items") set_scan_small_items((int)value), forget(true);
     else if (n == "b8k_full_first") set_b8k_full_first((u32)value), forget(false);
     else if (n == "xcd_aware") c->xcd_aware = (u32)value, forget(false);
     else return SPECK_ERR_INVALID;

@@ -580,7 +580,12 @@ __global__ __launch_bounds__(NW * 64) void analysis_kernel(
 constexpr int kScanThreads = 256;
 // rows per thread: small inputs still get >= ~300 tiles, big ones at most kChainMaxBlocks.  32 rows per thread are a
 // last resort: a thread's rows are contiguous, so every load instruction of a wave touches 64 cache lines.
-static inline int scan_items(u32 m) { return m <= (1u << 19) ? 2 : (m <= (1u << 23) ? 8 : 32); }
+// (rows per tile for rows(A) <= 2^19: 256 x 3 -- 223 tiles for the 171 k rows of the scircuit stand-in, one per CU, instead of 334
+//  with 256 x 2: complete call 0.1363 -> 0.1345 ms, uniform 0.1257 -> 0.1238, mac_econ +-0, two alternating pairs; 256 x 4: +-0.
+//  Option scan_small_items)
+static int g_scan_small = 3;
+void set_scan_small_items(int i) { g_scan_small = (i == 4 || i == 2) ? i : 3; }
+static inline int scan_items(u32 m) { return m <= (1u << 19) ? g_scan_small : (m <= (1u << 23) ? 8 : 32); }
 static inline u32 scan_subtiles(u32 m) { return m <= (1u << 25) ? 1u : cdiv(m, (1u << 25)); }
 // One 16-bit counter per numeric class, four per u64: a count never exceeds the rows of a sub-tile
 // (256 threads x 32 items = 8192), and sums of whole structs are plain u64 additions.
@@ -1199,6 +1204,8 @@ void launch_scan(hipStream_t s, const u32* counts, u32* offsets_out, u32 m, cons
     };
     switch (scan_items(m)) {
         case 2: go(std::integral_constant<int, 2>{}); break;
+        case 3: go(std::integral_constant<int, 3>{}); break;
+        case 4: go(std::integral_constant<int, 4>{}); break;
         case 8: go(std::integral_constant<int, 8>{}); break;
         default: go(std::integral_constant<int, 32>{}); break;
     }
