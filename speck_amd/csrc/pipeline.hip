@@ -5,7 +5,9 @@
 //     scratch buffer inside each call, Multiply.cu:202-225,1056-1070)
 //   * the launch sequence is STATIC: every kernel takes its row list and counts from a
 //     device-side stats block and its grid depends only on rows(A), so a call needs ONE read-back
-//     (nnz(C), to allocate C) instead of the reference's 5-8;
+//     (nnz(C), to allocate C) instead of the reference's 5-8 -- and NONE in the middle of the call when matOut already
+//     holds buffers of the size the previous complete call produced (the through call, option eager_through: the scan
+//     checks on the device what the host would have);
 //   * a repeated call with the same buffers (the benchmark loop, Executor.cpp:59-72) may REUSE the placement of the
 //     previous identical call (option "reuse"; the sequence is enqueued launch by launch -- no executable graph
 //     since round 5) -- verified on the device, never trusted; the complete call is what every measurement
@@ -1845,7 +1847,7 @@ int multiply_impl(speck_config* c, const speck_dcsr* A, const speck_dcsr* B, spe
         HIP_TRY(hipStreamSynchronize(s));
     }
     t->spGEMMNumeric = st.lap();
-    }  // !walked
+    }  // !walked && !through_ok
     t->sorting = 0.f;  // sorting is fused into the numeric kernels
     t->cleanup = 0.f;  // nothing to free: the arena persists
 
